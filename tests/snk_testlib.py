@@ -1,0 +1,141 @@
+"""Shared helpers for the test-suite: loaders for the oracle (our C restatement),
+the compiled reference shim (oracle/_ref, optional) and the HIP library, plus
+batch marshalling.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg are allowed to touch oracle/."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from soapnuke_amd import abi  # noqa: E402
+
+ORACLE_SO = os.path.join(ROOT, "oracle", "libsnk_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libsnkref.so")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "SOAPnuke")
+
+
+def build_oracle():
+    src = os.path.join(ROOT, "oracle", "snk_oracle.c")
+    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    return ORACLE_SO
+
+
+_oracle = None
+_ref = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        lib = C.CDLL(build_oracle())
+        lib.snk_oracle_adapter_pos.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_int]
+        lib.snk_oracle_filter_batch.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Batch), C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.POINTER(abi.Error)]
+        _oracle = lib
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        lib = C.CDLL(REF_SO)
+        lib.snkref_adapter_pos.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_int]
+        lib.snkref_filter_batch.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Batch), C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+        _ref = lib
+    return _ref
+
+
+def host_batch(data, first_index=0, dup=None, n=None):
+    """abi.Batch over the numpy arrays of soapnuke_amd.synth.make_batch()."""
+    b = abi.Batch()
+    b.n = data["n"] if n is None else n
+    b.pitch = data["pitch"]
+    keep = []
+    for m in range(len(data["seq"])):
+        b.fixed_len[m] = data["L"]
+        s = np.ascontiguousarray(data["seq"][m])
+        q = np.ascontiguousarray(data["qual"][m])
+        keep += [s, q]
+        b.seq[m] = s.ctypes.data
+        b.qual[m] = q.ctypes.data
+        if data["len"][m] is not None:
+            ln = np.ascontiguousarray(data["len"][m], dtype=np.uint16)
+            keep.append(ln)
+            b.len[m] = ln.ctypes.data
+    if dup is not None:
+        d = np.ascontiguousarray(dup, dtype=np.uint8)
+        keep.append(d)
+        b.dup = d.ctypes.data
+    b.first_index = first_index
+    b._keep = keep
+    return b
+
+
+def new_stats(params):
+    lcap, nq = params.max_read_len, params.max_base_quality + 1
+    return (np.zeros(abi.stats_u64(lcap, nq), dtype=np.uint64), np.zeros(abi.SNK_MAX_N, dtype=np.uint64))
+
+
+def run_oracle(params, data, first_index=0, dup=None, stats=None):
+    lib = oracle_lib()
+    b = host_batch(data, first_index, dup)
+    n = b.n
+    r1 = np.zeros(n, dtype=abi.record_dtype())
+    r2 = np.zeros(n, dtype=abi.record_dtype())
+    s, mx = stats if stats is not None else new_stats(params)
+    err = abi.Error()
+    rc = lib.snk_oracle_filter_batch(C.byref(params), C.byref(b), r1.ctypes.data, r2.ctypes.data,
+                                     s.ctypes.data, mx.ctypes.data, C.byref(err))
+    return dict(rc=rc, rec=[r1, r2], sum=s, max=mx, err=(err.code, err.mate, err.index))
+
+
+def run_ref(params, data, first_index=0, stats=None):
+    lib = ref_lib()
+    b = host_batch(data, first_index)
+    n = b.n
+    r1 = np.zeros(n, dtype=abi.record_dtype())
+    r2 = np.zeros(n, dtype=abi.record_dtype())
+    s, mx = stats if stats is not None else new_stats(params)
+    rc = lib.snkref_filter_batch(C.byref(params), C.byref(b), r1.ctypes.data, r2.ctypes.data,
+                                 s.ctypes.data, mx.ctypes.data)
+    return dict(rc=rc, rec=[r1, r2], sum=s, max=mx)
+
+
+def describe_stats_diff(params, a, b, limit=10):
+    """Human-readable location of the first differences between two sum blocks."""
+    lcap, nq = params.max_read_len, params.max_base_quality + 1
+    idx = np.nonzero(a != b)[0]
+    out = []
+    names = ["raw1", "raw2", "clean1", "clean2"]
+    fb = abi.file_block_u64(lcap, nq)
+    for i in idx[:limit]:
+        i = int(i)
+        if i < abi.SNK_FS_N:
+            out.append(f"fs[{i}]: {a[i]} vs {b[i]}")
+            continue
+        k, r = divmod(i - abi.SNK_FS_N, fb)
+        if r < abi.SNK_GS_N:
+            where = f"gs[{r}]"
+        elif r < abi.qs_off(lcap, nq):
+            p, j = divmod(r - abi.bs_off(lcap, nq), 5)
+            where = f"bs[{p}][{j}]"
+        elif r < abi.ts_off(lcap, nq):
+            p, j = divmod(r - abi.qs_off(lcap, nq), nq)
+            where = f"qs[{p}][{j}]"
+        else:
+            t = r - abi.ts_off(lcap, nq)
+            where = f"ts[{['hlq', 'ht', 'ta', 'tlq', 'tt'][t // 1000]}][{t % 1000}]"
+        out.append(f"{names[k]}.{where}: {a[i]} vs {b[i]}")
+    return f"{len(idx)} differing u64; " + "; ".join(out)

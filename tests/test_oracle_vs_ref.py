@@ -1,0 +1,73 @@
+"""Pins the oracle (our C restatement) against the compiled reference itself
+(oracle/_ref/libsnkref.so = /root/reference/src objects + oracle/ref_shim.cpp).
+Runs wherever the prebuilt shim exists (it travels to the GPU box); never reads
+/root/reference at run time."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import snk_testlib as T
+from cases import PE_CASES, se_kwargs
+from soapnuke_amd import abi, synth
+
+pytestmark = pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref/libsnkref.so not built (make -C oracle ref)")
+
+
+def _compare(p, d, paired):
+    o, r = T.run_oracle(p, d), T.run_ref(p, d)
+    assert o["rc"] == 0 and r["rc"] == 0
+    for m in range(2 if paired else 1):
+        bad = np.nonzero(o["rec"][m] != r["rec"][m])[0]
+        assert len(bad) == 0, (m, bad[:5], o["rec"][m][bad[:3]], r["rec"][m][bad[:3]])
+    assert np.array_equal(o["sum"], r["sum"]), T.describe_stats_diff(p, o["sum"], r["sum"])
+    assert np.array_equal(o["max"], r["max"])
+
+
+@pytest.mark.parametrize("name", sorted(PE_CASES))
+@pytest.mark.parametrize("var_len", [False, True])
+def test_pe_batch(name, var_len):
+    d = synth.make_batch(6000, 150, paired=True, var_len=var_len, seed=11)
+    _compare(abi.default_params(paired=True, max_read_len=150, **PE_CASES[name]), d, True)
+
+
+@pytest.mark.parametrize("name", sorted(PE_CASES))
+def test_se_batch(name):
+    d = synth.make_batch(6000, 100, paired=False, var_len=(len(name) % 2 == 0), seed=12)
+    _compare(abi.default_params(paired=False, max_read_len=100, **se_kwargs(PE_CASES[name])), d, False)
+
+
+def test_pe250():
+    d = synth.make_batch(3000, 250, paired=True, seed=13)
+    _compare(abi.default_params(paired=True, max_read_len=250, **PE_CASES["C3_full"]), d, True)
+
+
+def test_adapter_pos_fuzz():
+    """adapter_pos() on planted/mutated/truncated adapters and random parameters."""
+    rng = np.random.default_rng(5)
+    olib, rlib = T.oracle_lib(), T.ref_lib()
+    bases = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    n_hit = 0
+    for it in range(30000):
+        alen = int(rng.integers(6, 64))
+        rlen = int(rng.integers(alen + 2, 200))
+        ada = bases[rng.integers(0, 4, alen)].copy()
+        read = bases[rng.choice(5, rlen, p=[.245, .245, .245, .245, .02])].copy()
+        mode = it % 4
+        if mode == 1:      # full adapter inside
+            p = int(rng.integers(0, rlen - alen + 1)); read[p:p + alen] = ada
+        elif mode == 2:    # adapter prefix at the tail
+            k = int(rng.integers(1, alen)); read[rlen - k:] = ada[:k]
+        elif mode == 3:    # adapter suffix at the head (phase A)
+            k = int(rng.integers(1, 8)); read[:alen - k] = ada[k:]
+        if mode and rng.random() < 0.7:   # substitutions
+            for _ in range(int(rng.integers(1, 5))):
+                read[int(rng.integers(0, rlen))] = bases[int(rng.integers(0, 4))]
+        mis = int(rng.integers(0, 5)); mr = float(rng.choice([0.3, 0.5, 0.7, 1.0])); edge = int(rng.integers(3, 8))
+        # (alen-edge)/(mis+1) == 0 cases stay in: float->int of inf/NaN is UB in C++ but the
+        # x86-64 reference build yields INT_MIN (cvttss2si), which the oracle restates.
+        a = olib.snk_oracle_adapter_pos(read.tobytes(), rlen, ada.tobytes(), alen, mis, mr, edge)
+        b = rlib.snkref_adapter_pos(read.tobytes(), rlen, ada.tobytes(), alen, mis, mr, edge)
+        assert a == b, (it, read.tobytes(), ada.tobytes(), mis, mr, edge, a, b)
+        n_hit += a >= 0
+    assert n_hit > 5000
