@@ -59,7 +59,7 @@ def test_adapter_pos_fuzz():
         elif mode == 2:    # adapter prefix at the tail
             k = int(rng.integers(1, alen)); read[rlen - k:] = ada[:k]
         elif mode == 3:    # adapter suffix at the head (phase A)
-            k = int(rng.integers(1, 8)); read[:alen - k] = ada[k:]
+            k = int(rng.integers(1, min(8, alen))); read[:alen - k] = ada[k:]
         if mode and rng.random() < 0.7:   # substitutions
             for _ in range(int(rng.integers(1, 5))):
                 read[int(rng.integers(0, rlen))] = bases[int(rng.integers(0, 4))]
