@@ -241,8 +241,8 @@ static void fastq_trim(const snk_params *P, int mate, const uint8_t *seq,
         r->start = 0;
         r->clen = 0;
     } else {
-        r->start = head_cut;
         r->clen = len - head_cut - tail_cut;
+        r->start = r->clen ? head_cut : 0;   /* record convention: empty view starts at 0 */
     }
 }
 

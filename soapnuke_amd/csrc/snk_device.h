@@ -1,0 +1,74 @@
+// snk_device.h -- structures shared by the host side of the C ABI (snk_filter.cpp)
+// and the gfx950 kernels (snk_kernels.hip).  Internal; the public surface is
+// include/snk_filter.h.
+#pragma once
+#include <stdint.h>
+#include "../../include/snk_filter.h"
+
+#define SNK_DEV_MAX_ADA_LEN 256
+
+// One adapter with everything adapter_pos() (src/read_filter.cpp:707-790) derives
+// from (adptLen, adaMis, adaMR, adaEdge) precomputed on the host with the
+// reference's own int->float->int arithmetic, so the GPU does integer work only
+// (SURVEY H1).
+struct DevAdapter {
+    int32_t len;            // adptLen
+    int32_t S;              // segMatchThr = (int)ceil(adptLen*adaMR), src/read_filter.cpp:717
+    int32_t mis;            // adaMis (phase B budget)
+    int32_t edge;           // adaEdge
+    int32_t nC;             // adptLen - adaEdge (phase C trip count, may be <= 0)
+    int32_t budgetA[6];     // [r1] = (int)((adptLen-r1)/misGrad5), r1 = 1..5   (:724)
+    int32_t budgetC[SNK_DEV_MAX_ADA_LEN]; // [r1] = (int)(r1/misGrad)           (:769)
+    uint8_t seq[SNK_DEV_MAX_ADA_LEN];
+    // ---- bit-parallel view used by the wave-tiled kernel (adapters <= 64 nt) ----
+    uint64_t cmask[4];      // cmask[k] bit c = adapter[c] == "ACGT"[k] (exact, upper case)
+    uint8_t  code[SNK_DEV_MAX_ADA_LEN]; // 0..3 = ACGT, 4 = can never match a valid read base
+    int32_t  tile_ok;       // 1 when the tiled kernel can handle this adapter
+    int32_t  maxBudget;     // max over all phases of max(budget,0)
+};
+
+struct DevParams {
+    int32_t paired, phred, nq, low_qual;
+    int32_t polyX_num;                 // -1 off
+    uint32_t min_len_u, max_len_u;     // unsigned compares as in src/sequence.cpp:233,251
+    int32_t has_min, has_max, has_n, has_highA, has_lowq, has_meanq;
+    int32_t ada_trim, copy_back, trim_on, has_hard, has_lq, has_polyG, rmdup;
+    int32_t hard[4];
+    int32_t lq_head_q, lq_head_len, lq_tail_q, lq_tail_len;
+    int32_t polyG_thr;                 // min n with (float)n >= polyG_tail  (:456)
+    int32_t lcap;                      // positions per histogram row block
+    int32_t n_ada[2];
+    // per-length integer thresholds replacing the fp32 ratio compares:
+    //   discard iff count >= thr_x[len]            (n_ratio, highA, low-quality ratio)
+    //   discard iff sumq  <  thr_meanq[len]        (mean quality)
+    const int32_t *thr_n, *thr_a, *thr_lowq, *thr_meanq;
+    const DevAdapter *ada;             // [2][SNK_MAX_ADAPTERS]
+};
+
+// device view of one patch (see snk_batch)
+struct DevBatch {
+    int64_t n;
+    int32_t pitch;
+    int32_t fixed_len[2];
+    const uint8_t *seq[2];
+    const uint8_t *qual[2];
+    const uint16_t *len[2];
+    const uint8_t *dup;
+    uint64_t first_index;
+    snk_read_result *out[2];
+};
+
+struct DevStats {
+    unsigned long long *sum;   // snk_stats_u64(lcap,nq)
+    unsigned long long *maxb;  // SNK_MAX_N
+    unsigned long long *err;   // 1 word: min over offending reads of (index<<8 | mate<<4 | code)
+};
+
+#define SNK_ERR_NONE 0xFFFFFFFFFFFFFFFFull
+
+void snk_launch_generic(const DevParams *dp, const DevBatch &b, const DevStats &st, int lcap,
+                        int nq, void *stream);
+// returns 0 when the tiled kernel cannot run this configuration
+int snk_launch_tiled(const DevParams *dp_dev, const DevParams &dp_host, const DevBatch &b,
+                     const DevStats &st, int lcap, int nq, int n_cu, void *stream);
+void snk_launch_finalize(const DevStats &st, int lcap, int nq, void *stream);

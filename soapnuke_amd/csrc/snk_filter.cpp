@@ -1,0 +1,484 @@
+// snk_filter.cpp -- host side of the C ABI declared in include/snk_filter.h.
+//
+// Plays the role thread_process_reads() plays around filter_pe_fqs/stat_pe_fqs
+// in the reference (src/peprocess.cpp:1862-1992): owns the accumulators, turns
+// the float/str parameters of C_global_parameter into integer tables once
+//  and launches the gfx950 kernels.  No CPU fallback exists: every
+// entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "snk_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+void set_err(const std::string &s) { g_err = s; }
+
+#define HIP_OK(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_err(std::string(#call) + ": " + hipGetErrorString(e_));                \
+            return SNK_E_HIP;                                                          \
+        }                                                                              \
+    } while (0)
+
+// float -> int as the x86-64 reference build does it (cvttss2si): NaN/overflow -> INT_MIN
+int f2i_x86(float f) {
+    if (!(f == f)) return INT_MIN;
+    if (f >= 2147483648.0f || f < -2147483648.0f) return INT_MIN;
+    return (int)f;
+}
+
+// min count c in [0,len] with float(c)/size_t(len) >= ratio  (src/read_filter.cpp:290-295,310
+// feeding src/sequence.cpp:292,306,333); INT_MAX when no count trips it.
+int32_t thr_ratio(int len, float ratio) {
+    if (len <= 0) return INT_MAX;
+    for (int c = 0; c <= len; ++c)
+        if ((float)c / (float)(size_t)len >= ratio) return c;
+    return INT_MAX;
+}
+
+// min total T with !(float(T)/size_t(len) < float(mq))  (src/read_filter.cpp:311, src/sequence.cpp:352)
+int32_t thr_meanq(int len, int mq) {
+    if (len <= 0) return INT_MIN;
+    long lo = -300L * len, hi = 300L * len;          // quality bytes are 0..255
+    auto below = [&](long t) { return (float)(int)t / (float)(size_t)len < (float)mq; };
+    if (!below(lo)) return (int32_t)lo;
+    if (below(hi)) return INT_MAX;
+    while (hi - lo > 1) {                            // below(lo) && !below(hi), monotone
+        long mid = lo + (hi - lo) / 2;
+        if (below(mid)) lo = mid; else hi = mid;
+    }
+    return (int32_t)hi;
+}
+
+void build_adapter(DevAdapter &A, const char *seq, int mis, float mr, int edge) {
+    memset(&A, 0, sizeof(A));
+    const int al = (int)strlen(seq);
+    A.len = al;
+    A.mis = mis;
+    A.edge = edge;
+    A.nC = al - edge;
+    memcpy(A.seq, seq, al);
+    // src/read_filter.cpp:714-717 : integer division, then float
+    const float misGrad5 = (float)((al - 5) / (mis + 1));
+    const float misGrad = (float)((al - edge) / (mis + 1));
+    A.S = (int)ceilf((float)al * mr);
+    int maxb = mis > 0 ? mis : 0;
+    for (int r1 = 1; r1 <= 5; ++r1) {
+        A.budgetA[r1] = f2i_x86((float)(al - r1) / misGrad5);
+        if (A.budgetA[r1] > maxb) maxb = A.budgetA[r1];
+    }
+    for (int r1 = 0; r1 < A.nC && r1 < SNK_DEV_MAX_ADA_LEN; ++r1) {
+        A.budgetC[r1] = f2i_x86((float)r1 / misGrad);
+        if (A.budgetC[r1] > maxb) maxb = A.budgetC[r1];
+    }
+    A.maxBudget = maxb;
+    // bit-parallel view for the tiled kernel
+    A.tile_ok = (al >= 1 && al <= 64 && edge >= 1 && A.nC <= 64) ? 1 : 0;
+    for (int c = 0; c < al; ++c) {
+        int k = 4;
+        switch (seq[c]) { case 'A': k = 0; break; case 'C': k = 1; break; case 'G': k = 2; break; case 'T': k = 3; break; default: break; }
+        A.code[c] = (uint8_t)k;
+        if (k < 4 && c < 64) A.cmask[k] |= 1ull << c;
+        // lower-case / N adapter characters would need the case-exact planes: generic kernel only
+        if (k == 4 && (seq[c] == 'a' || seq[c] == 'c' || seq[c] == 'g' || seq[c] == 't' || seq[c] == 'n' || seq[c] == 'N'))
+            A.tile_ok = 0;
+    }
+}
+
+}  // namespace
+
+struct snk_ctx {
+    snk_params p;
+    std::vector<std::string> ada_store[2];
+    int device = 0;
+    int n_cu = 256;
+    int lcap = 0, nq = 0;
+    int64_t sum_u64 = 0;
+    DevParams hp;                 // host copy (device pointers inside)
+    DevParams *d_params = nullptr;
+    DevAdapter *d_ada = nullptr;
+    int32_t *d_tables = nullptr;
+    unsigned long long *d_sum = nullptr, *d_max = nullptr, *d_err = nullptr;
+    bool own_stats = false;
+    // staging for the host-pointer entry point
+    uint8_t *st_buf = nullptr;
+    size_t st_cap = 0;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    bool last_timed = false;
+};
+
+extern "C" {
+
+const char *snk_last_error(void) { return g_err.c_str(); }
+
+void snk_params_default(snk_params *p) {            // src/global_parameter.h:20-83
+    memset(p, 0, sizeof(*p));
+    p->struct_size = (int32_t)sizeof(*p);
+    p->paired = 1;
+    p->quality_phred = 33;
+    p->output_quality_phred = 33;
+    p->max_base_quality = 42;
+    p->low_qual = 5;
+    p->low_qual_ratio = 0.5f;
+    p->n_ratio = 0.05f;
+    p->highA_ratio = -1;
+    p->polyG_tail = -1;
+    p->polyX_num = -1;
+    p->mean_quality = -1;
+    p->min_read_length = 30;
+    p->max_read_length = -1;
+    p->ada_mis[0] = p->ada_mis[1] = 2;
+    p->ada_mr[0] = p->ada_mr[1] = 0.5f;
+    p->ada_edge[0] = p->ada_edge[1] = 6;
+    p->max_read_len = 150;
+}
+
+static int ctx_fail(snk_ctx *c, int rc) { snk_destroy(c); return rc; }
+
+static int build_ctx(snk_ctx *c) {
+    const snk_params &P = c->p;
+    HIP_OK(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, c->device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->lcap = P.max_read_len;
+    c->nq = P.max_base_quality + 1;
+    c->sum_u64 = snk_stats_u64(c->lcap, c->nq);
+
+    // ---- adapters
+    std::vector<DevAdapter> ada(2 * SNK_MAX_ADAPTERS);
+    for (int m = 0; m < 2; ++m)
+        for (int i = 0; i < P.n_adapters[m]; ++i)
+            build_adapter(ada[m * SNK_MAX_ADAPTERS + i], c->ada_store[m][i].c_str(), P.ada_mis[m],
+                          P.ada_mr[m], P.ada_edge[m]);
+    HIP_OK(hipMalloc(&c->d_ada, ada.size() * sizeof(DevAdapter)));
+    HIP_OK(hipMemcpy(c->d_ada, ada.data(), ada.size() * sizeof(DevAdapter), hipMemcpyHostToDevice));
+
+    // ---- per-length thresholds
+    const int L1 = c->lcap + 1;
+    std::vector<int32_t> tab(4 * (size_t)L1);
+    for (int len = 0; len <= c->lcap; ++len) {
+        tab[0 * L1 + len] = thr_ratio(len, P.n_ratio);
+        tab[1 * L1 + len] = thr_ratio(len, P.highA_ratio);
+        tab[2 * L1 + len] = thr_ratio(len, P.low_qual_ratio);
+        tab[3 * L1 + len] = thr_meanq(len, P.mean_quality);
+    }
+    HIP_OK(hipMalloc(&c->d_tables, tab.size() * sizeof(int32_t)));
+    HIP_OK(hipMemcpy(c->d_tables, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+
+    // ---- scalar parameters
+    DevParams &D = c->hp;
+    memset(&D, 0, sizeof(D));
+    D.paired = P.paired ? 1 : 0;
+    D.phred = P.quality_phred;
+    D.nq = c->nq;
+    D.low_qual = P.low_qual;
+    D.polyX_num = P.polyX_num;
+    D.has_min = P.min_read_length != -1;
+    D.has_max = P.max_read_length != -1;
+    D.min_len_u = (uint32_t)P.min_read_length;
+    D.max_len_u = (uint32_t)P.max_read_length;
+    D.has_n = P.n_ratio != -1;                       // float != int, as in src/sequence.cpp:291
+    D.has_highA = P.highA_ratio != -1;
+    D.has_lowq = P.low_qual_ratio != -1;
+    D.has_meanq = P.mean_quality != -1;
+    D.ada_trim = P.ada_trim ? 1 : 0;
+    D.has_hard = P.has_hard_trim ? 1 : 0;
+    D.has_lq = P.has_lq_trim ? 1 : 0;
+    D.has_polyG = P.polyG_tail != -1;
+    D.copy_back = (P.ada_trim || P.contam_trim || P.has_hard_trim || P.has_lq_trim) ? 1 : 0;  // src/peprocess.cpp:1441
+    D.trim_on = (P.has_hard_trim || P.has_lq_trim || P.ada_trim || P.contam_trim || D.has_polyG) ? 1 : 0; // src/read_filter.cpp:354
+    D.rmdup = P.rmdup ? 1 : 0;
+    for (int i = 0; i < 4; ++i) D.hard[i] = P.hard_trim[i];
+    D.lq_head_q = P.lq_head_qual; D.lq_head_len = P.lq_head_len;
+    D.lq_tail_q = P.lq_tail_qual; D.lq_tail_len = P.lq_tail_len;
+    D.polyG_thr = INT_MAX;
+    if (D.has_polyG)
+        for (int n = 0; n <= SNK_READ_MAX_LEN + 1; ++n)
+            if ((float)n >= P.polyG_tail) { D.polyG_thr = n; break; }   // src/read_filter.cpp:456
+    D.lcap = c->lcap;
+    D.n_ada[0] = P.n_adapters[0];
+    D.n_ada[1] = P.n_adapters[1];
+    D.thr_n = c->d_tables;
+    D.thr_a = c->d_tables + L1;
+    D.thr_lowq = c->d_tables + 2 * L1;
+    D.thr_meanq = c->d_tables + 3 * L1;
+    D.ada = c->d_ada;
+    HIP_OK(hipMalloc(&c->d_params, sizeof(DevParams)));
+    HIP_OK(hipMemcpy(c->d_params, &D, sizeof(DevParams), hipMemcpyHostToDevice));
+
+    // ---- accumulators
+    HIP_OK(hipMalloc(&c->d_sum, c->sum_u64 * sizeof(uint64_t)));
+    HIP_OK(hipMalloc(&c->d_max, SNK_MAX_N * sizeof(uint64_t)));
+    HIP_OK(hipMalloc(&c->d_err, sizeof(uint64_t)));
+    c->own_stats = true;
+    HIP_OK(hipMemset(c->d_sum, 0, c->sum_u64 * sizeof(uint64_t)));
+    HIP_OK(hipMemset(c->d_max, 0, SNK_MAX_N * sizeof(uint64_t)));
+    HIP_OK(hipMemset(c->d_err, 0xFF, sizeof(uint64_t)));
+    HIP_OK(hipEventCreate(&c->ev0));
+    HIP_OK(hipEventCreate(&c->ev1));
+    return SNK_OK;
+}
+
+snk_ctx *snk_create(const snk_params *params, int device) {
+    if (!params || params->struct_size != (int32_t)sizeof(snk_params)) {
+        set_err("snk_create: snk_params.struct_size mismatch (ABI version)");
+        return nullptr;
+    }
+    if (params->max_read_len < 1 || params->max_read_len > SNK_READ_MAX_LEN) {
+        set_err("snk_create: max_read_len must be in [1,1000]");
+        return nullptr;
+    }
+    if (params->max_base_quality < 1 || params->max_base_quality > 93) {
+        set_err("snk_create: max_base_quality out of range");
+        return nullptr;
+    }
+    for (int m = 0; m < 2; ++m) {
+        if (params->n_adapters[m] < 0 || params->n_adapters[m] > SNK_MAX_ADAPTERS) {
+            set_err("snk_create: too many adapters");
+            return nullptr;
+        }
+        if (params->n_adapters[m] && params->ada_mis[m] + 1 == 0) {
+            set_err("snk_create: adaMis == -1 divides by zero in the reference (src/read_filter.cpp:714)");
+            return nullptr;
+        }
+        for (int i = 0; i < params->n_adapters[m]; ++i) {
+            const char *a = params->adapters[m][i];
+            if (!a || strlen(a) >= SNK_DEV_MAX_ADA_LEN) {
+                set_err("snk_create: adapter missing or longer than 255");
+                return nullptr;
+            }
+        }
+    }
+    snk_ctx *c = new snk_ctx();
+    c->p = *params;
+    c->device = device;
+    for (int m = 0; m < 2; ++m)
+        for (int i = 0; i < params->n_adapters[m]; ++i) {
+            c->ada_store[m].push_back(params->adapters[m][i]);
+        }
+    for (int m = 0; m < 2; ++m)
+        for (int i = 0; i < SNK_MAX_ADAPTERS; ++i)
+            c->p.adapters[m][i] = i < params->n_adapters[m] ? c->ada_store[m][i].c_str() : nullptr;
+    if (build_ctx(c) != SNK_OK) { std::string keep = g_err; snk_destroy(c); g_err = keep; return nullptr; }
+    return c;
+}
+
+void snk_destroy(snk_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_params) (void)hipFree(c->d_params);
+    if (c->d_ada) (void)hipFree(c->d_ada);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->own_stats) {
+        if (c->d_sum) (void)hipFree(c->d_sum);
+        if (c->d_max) (void)hipFree(c->d_max);
+    }
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->st_buf) (void)hipFree(c->st_buf);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+int snk_stats_geometry(const snk_ctx *c, int32_t *lcap, int32_t *nq, int64_t *sum_u64) {
+    if (!c) return SNK_E_PARAM;
+    if (lcap) *lcap = c->lcap;
+    if (nq) *nq = c->nq;
+    if (sum_u64) *sum_u64 = c->sum_u64;
+    return SNK_OK;
+}
+
+int snk_bind_stats(snk_ctx *c, void *d_sum, void *d_max) {
+    if (!c || !d_sum || !d_max) { set_err("snk_bind_stats: null argument"); return SNK_E_PARAM; }
+    if (c->own_stats) {
+        (void)hipFree(c->d_sum);
+        (void)hipFree(c->d_max);
+        c->own_stats = false;
+    }
+    c->d_sum = (unsigned long long *)d_sum;
+    c->d_max = (unsigned long long *)d_max;
+    return SNK_OK;
+}
+
+int snk_stats_clear(snk_ctx *c, void *stream) {
+    if (!c) return SNK_E_PARAM;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_OK(hipMemsetAsync(c->d_sum, 0, c->sum_u64 * sizeof(uint64_t), s));
+    HIP_OK(hipMemsetAsync(c->d_max, 0, SNK_MAX_N * sizeof(uint64_t), s));
+    HIP_OK(hipMemsetAsync(c->d_err, 0xFF, sizeof(uint64_t), s));
+    return SNK_OK;
+}
+
+int snk_set_timing(snk_ctx *c, int enabled) {
+    if (!c) return SNK_E_PARAM;
+    c->timing = enabled != 0;
+    return SNK_OK;
+}
+
+int snk_last_kernel_ms(snk_ctx *c, float *ms) {
+    if (!c || !ms) return SNK_E_PARAM;
+    if (c->last_timed) {
+        HIP_OK(hipEventSynchronize(c->ev1));
+        HIP_OK(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+        c->last_timed = false;
+    }
+    *ms = c->last_ms;
+    return SNK_OK;
+}
+
+int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_out1,
+                            snk_read_result *d_out2, void *stream, int kernel) {
+    if (!c || !b) { set_err("snk_filter_batch_device: null argument"); return SNK_E_PARAM; }
+    if (b->n < 0 || b->pitch <= 0 || (b->pitch & 3)) { set_err("snk_filter_batch_device: bad n/pitch (pitch must be a positive multiple of 4)"); return SNK_E_PARAM; }
+    const int mates = c->p.paired ? 2 : 1;
+    for (int m = 0; m < mates; ++m) {
+        if (!b->seq[m] || !b->qual[m]) { set_err("snk_filter_batch_device: missing seq/qual"); return SNK_E_PARAM; }
+        if (!b->len[m] && (b->fixed_len[m] < 0 || b->fixed_len[m] > b->pitch)) { set_err("snk_filter_batch_device: fixed_len exceeds pitch"); return SNK_E_PARAM; }
+    }
+    if (!d_out1 || (mates == 2 && !d_out2)) { set_err("snk_filter_batch_device: missing output"); return SNK_E_PARAM; }
+    if (b->n == 0) return SNK_OK;
+    DevBatch D;
+    memset(&D, 0, sizeof(D));
+    D.n = b->n;
+    D.pitch = b->pitch;
+    for (int m = 0; m < 2; ++m) {
+        D.fixed_len[m] = b->fixed_len[m];
+        D.seq[m] = m < mates ? b->seq[m] : nullptr;
+        D.qual[m] = m < mates ? b->qual[m] : nullptr;
+        D.len[m] = m < mates ? b->len[m] : nullptr;
+    }
+    D.dup = c->p.rmdup ? b->dup : nullptr;
+    D.first_index = b->first_index;
+    D.out[0] = d_out1;
+    D.out[1] = d_out2;
+    DevStats st{c->d_sum, c->d_max, c->d_err};
+    hipStream_t s = (hipStream_t)stream;
+    if (c->timing) HIP_OK(hipEventRecord(c->ev0, s));
+    int done = 0;
+    if (kernel == 0 || kernel == 2) {
+        done = snk_launch_tiled(c->d_params, c->hp, D, st, c->lcap, c->nq, c->n_cu, stream);
+        if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return SNK_E_UNSUPPORTED; }
+    }
+    if (!done) snk_launch_generic(c->d_params, D, st, c->lcap, c->nq, stream);
+    if (c->timing) { HIP_OK(hipEventRecord(c->ev1, s)); c->last_timed = true; }
+    HIP_OK(hipGetLastError());
+    return SNK_OK;
+}
+
+int snk_filter_batch(snk_ctx *c, const snk_batch *b, snk_read_result *out1, snk_read_result *out2) {
+    if (!c || !b) { set_err("snk_filter_batch: null argument"); return SNK_E_PARAM; }
+    if (b->n == 0) return SNK_OK;
+    HIP_OK(hipSetDevice(c->device));
+    const int mates = c->p.paired ? 2 : 1;
+    const size_t n = (size_t)b->n, plane = n * (size_t)b->pitch;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t need = 0;
+    const size_t o_seq[2] = {need, need + al(plane)};
+    need += 2 * al(plane);
+    const size_t o_qual[2] = {need, need + al(plane)};
+    need += 2 * al(plane);
+    const size_t o_len[2] = {need, need + al(n * 2)};
+    need += 2 * al(n * 2);
+    const size_t o_dup = need;
+    need += al(n);
+    const size_t o_out[2] = {need, need + al(n * sizeof(snk_read_result))};
+    need += 2 * al(n * sizeof(snk_read_result));
+    if (need > c->st_cap) {
+        if (c->st_buf) (void)hipFree(c->st_buf);
+        c->st_buf = nullptr;
+        c->st_cap = 0;
+        HIP_OK(hipMalloc(&c->st_buf, need));
+        c->st_cap = need;
+    }
+    snk_batch d = *b;
+    for (int m = 0; m < 2; ++m) { d.seq[m] = d.qual[m] = nullptr; d.len[m] = nullptr; }
+    d.dup = nullptr;
+    for (int m = 0; m < mates; ++m) {
+        if (!b->seq[m] || !b->qual[m]) { set_err("snk_filter_batch: missing seq/qual"); return SNK_E_PARAM; }
+        HIP_OK(hipMemcpyAsync(c->st_buf + o_seq[m], b->seq[m], plane, hipMemcpyHostToDevice, 0));
+        HIP_OK(hipMemcpyAsync(c->st_buf + o_qual[m], b->qual[m], plane, hipMemcpyHostToDevice, 0));
+        d.seq[m] = c->st_buf + o_seq[m];
+        d.qual[m] = c->st_buf + o_qual[m];
+        if (b->len[m]) {
+            HIP_OK(hipMemcpyAsync(c->st_buf + o_len[m], b->len[m], n * 2, hipMemcpyHostToDevice, 0));
+            d.len[m] = (const uint16_t *)(c->st_buf + o_len[m]);
+        }
+    }
+    if (b->dup && c->p.rmdup) {
+        HIP_OK(hipMemcpyAsync(c->st_buf + o_dup, b->dup, n, hipMemcpyHostToDevice, 0));
+        d.dup = c->st_buf + o_dup;
+    }
+    int rc = snk_filter_batch_device(c, &d, (snk_read_result *)(c->st_buf + o_out[0]),
+                                     (snk_read_result *)(c->st_buf + o_out[1]), nullptr, 0);
+    if (rc) return rc;
+    if (out1) HIP_OK(hipMemcpyAsync(out1, c->st_buf + o_out[0], n * sizeof(snk_read_result), hipMemcpyDeviceToHost, 0));
+    if (out2 && mates == 2) HIP_OK(hipMemcpyAsync(out2, c->st_buf + o_out[1], n * sizeof(snk_read_result), hipMemcpyDeviceToHost, 0));
+    HIP_OK(hipStreamSynchronize(0));
+    return SNK_OK;
+}
+
+int snk_stats_finalize(snk_ctx *c, void *stream) {
+    if (!c) return SNK_E_PARAM;
+    DevStats st{c->d_sum, c->d_max, c->d_err};
+    snk_launch_finalize(st, c->lcap, c->nq, stream);
+    HIP_OK(hipGetLastError());
+    return SNK_OK;
+}
+
+int snk_stats_fetch(snk_ctx *c, uint64_t *sum, uint64_t *maxb, snk_error *err, void *stream) {
+    if (!c) return SNK_E_PARAM;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = snk_stats_finalize(c, stream);
+    if (rc) return rc;
+    uint64_t e = SNK_ERR_NONE;
+    if (sum) HIP_OK(hipMemcpyAsync(sum, c->d_sum, c->sum_u64 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    if (maxb) HIP_OK(hipMemcpyAsync(maxb, c->d_max, SNK_MAX_N * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    if (err) {
+        if (e == SNK_ERR_NONE) { err->code = SNK_OK; err->mate = 0; err->index = 0; }
+        else { err->code = (int32_t)(e & 0xF); err->mate = (int32_t)((e >> 4) & 0xF); err->index = e >> 8; }
+    }
+    return SNK_OK;
+}
+
+// RCCL is resolved lazily so that the library has no link-time dependency on it:
+// inside a torch process the already-loaded librccl.so.1 is reused.
+int snk_stats_allreduce(snk_ctx *c, void *comm, void *stream) {
+    if (!c || !comm) { set_err("snk_stats_allreduce: null argument"); return SNK_E_PARAM; }
+    typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    static allreduce_fn fn = nullptr;
+    if (!fn) {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { set_err(std::string("snk_stats_allreduce: cannot load RCCL: ") + dlerror()); return SNK_E_UNSUPPORTED; }
+        fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+        if (!fn) { set_err("snk_stats_allreduce: ncclAllReduce not found"); return SNK_E_UNSUPPORTED; }
+    }
+    int rc = snk_stats_finalize(c, stream);
+    if (rc) return rc;
+    const int ncclUint64 = 5, ncclSum = 0, ncclMax = 2, ncclMin = 3;   // rccl.h enums
+    hipStream_t s = (hipStream_t)stream;
+    if (fn(c->d_sum, c->d_sum, (size_t)c->sum_u64, ncclUint64, ncclSum, comm, s) != 0 ||
+        fn(c->d_max, c->d_max, (size_t)SNK_MAX_N, ncclUint64, ncclMax, comm, s) != 0 ||
+        fn(c->d_err, c->d_err, 1, ncclUint64, ncclMin, comm, s) != 0) {
+        set_err("snk_stats_allreduce: ncclAllReduce failed");
+        return SNK_E_HIP;
+    }
+    return SNK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,204 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the
+oracle on the same seeded inputs -- bit-exact on per-read records, every stats
+counter and the max block."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import snk_testlib as T
+from cases import PE_CASES, se_kwargs
+from soapnuke_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = [1, 0]   # generic, auto (tiled where supported)
+
+
+def run_hip_host(lib, p, d, first_index=0, dup=None):
+    """through snk_filter_batch(): host pointers in, host records out"""
+    ctx = lib.snk_create(C.byref(p), 0)
+    assert ctx, lib.snk_last_error()
+    try:
+        b = T.host_batch(d, first_index, dup)
+        r1 = np.zeros(b.n, dtype=abi.record_dtype())
+        r2 = np.zeros(b.n, dtype=abi.record_dtype())
+        rc = lib.snk_filter_batch(ctx, C.byref(b), r1.ctypes.data, r2.ctypes.data)
+        assert rc == 0, lib.snk_last_error()
+        s, mx = T.new_stats(p)
+        err = abi.Error()
+        assert lib.snk_stats_fetch(ctx, s.ctypes.data, mx.ctypes.data, C.byref(err), None) == 0
+        return dict(rec=[r1, r2], sum=s, max=mx, err=(err.code, err.mate, err.index))
+    finally:
+        lib.snk_destroy(ctx)
+
+
+def run_hip_device(p, d, kernel, first_index=0, dup=None, chunks=1):
+    """through snk_filter_batch_device(): torch-owned device memory, current stream"""
+    import torch
+    from soapnuke_amd.filter import FilterContext, records_to_numpy
+    ctx = FilterContext(p, device=0)
+    dev = ctx.upload(d)
+    n = d["n"]
+    rec = ctx.alloc_records(n)
+    dupt = None if dup is None else torch.from_numpy(np.ascontiguousarray(dup, dtype=np.uint8)).cuda()
+    edges = np.linspace(0, n, chunks + 1).astype(int)
+    for a, z in zip(edges[:-1], edges[1:]):
+        if z == a:
+            continue
+        sub = {"n": int(z - a), "L": dev["L"], "pitch": dev["pitch"],
+               "seq": [x[a:z] for x in dev["seq"]], "qual": [x[a:z] for x in dev["qual"]],
+               "len": [None if x is None else x[a:z] for x in dev["len"]]}
+        b = ctx.make_batch(sub, first_index + int(a), None if dupt is None else dupt[a:z])
+        ctx.filter_batch(b, [rec[0][a:z], rec[1][a:z]], kernel=kernel)
+    s, mx, err = ctx.fetch()
+    out = dict(rec=[records_to_numpy(rec[0]), records_to_numpy(rec[1])], sum=s, max=mx, err=err)
+    ctx.close()
+    return out
+
+
+def assert_same(p, got, want, paired):
+    assert got["err"][0] == 0, got["err"]
+    for m in range(2 if paired else 1):
+        bad = np.nonzero(got["rec"][m] != want["rec"][m])[0]
+        assert len(bad) == 0, (m, len(bad), bad[:5], got["rec"][m][bad[:3]], want["rec"][m][bad[:3]])
+    assert np.array_equal(got["sum"], want["sum"]), T.describe_stats_diff(p, got["sum"], want["sum"])
+    assert np.array_equal(got["max"], want["max"]), (got["max"], want["max"])
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", sorted(PE_CASES))
+def test_pe150_cases(name, kernel):
+    d = synth.make_batch(20000, 150, paired=True, var_len=(name in ("hard_lq_trim", "C3_full")), seed=21)
+    p = abi.default_params(paired=True, max_read_len=150, **PE_CASES[name])
+    assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), True)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", ["defaults", "C2_adatrim_lowq", "C3_full", "hard_lq_trim", "short_adapter_edge"])
+def test_se100_cases(name, kernel):
+    d = synth.make_batch(20000, 100, paired=False, var_len=(name == "C3_full"), seed=22)
+    p = abi.default_params(paired=False, max_read_len=100, **se_kwargs(PE_CASES[name]))
+    assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), False)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_pe250_full(kernel):
+    d = synth.make_batch(8000, 250, paired=True, seed=23)
+    p = abi.default_params(paired=True, max_read_len=250, **PE_CASES["C3_full"])
+    assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), True)
+
+
+def test_host_pointer_entry(snk_lib):
+    d = synth.make_batch(5000, 150, paired=True, seed=24)
+    p = abi.default_params(paired=True, max_read_len=150, **PE_CASES["C2_adatrim_lowq"])
+    assert_same(p, run_hip_host(snk_lib, p, d), T.run_oracle(p, d), True)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_ragged_and_chunked(kernel):
+    """n not a multiple of anything, several calls accumulating into one stats block,
+    non-zero first_index, reads much shorter than the capacity."""
+    d = synth.make_batch(7777, 120, paired=True, var_len=True, seed=25)
+    p = abi.default_params(paired=True, max_read_len=150, **PE_CASES["C3_full"])
+    want = T.run_oracle(p, d, first_index=123456789)
+    assert_same(p, run_hip_device(p, d, kernel, first_index=123456789, chunks=5), want, True)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_tiny_batches(kernel):
+    for n in (1, 2, 63, 64, 65):
+        d = synth.make_batch(n, 150, paired=True, seed=26 + n)
+        p = abi.default_params(paired=True, max_read_len=150, **PE_CASES["C2_adatrim_lowq"])
+        assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), True)
+
+
+def test_empty_batch(snk_lib):
+    p = abi.default_params()
+    ctx = snk_lib.snk_create(C.byref(p), 0)
+    assert ctx
+    b = abi.Batch()
+    b.n, b.pitch = 0, 160
+    assert snk_lib.snk_filter_batch(ctx, C.byref(b), None, None) == 0
+    s, mx = T.new_stats(p)
+    err = abi.Error()
+    assert snk_lib.snk_stats_fetch(ctx, s.ctypes.data, mx.ctypes.data, C.byref(err), None) == 0
+    assert not s.any() and not mx.any() and err.code == 0
+    snk_lib.snk_destroy(ctx)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_rmdup_flags(kernel):
+    d = synth.make_batch(5000, 150, paired=True, seed=27)
+    dup = (np.random.default_rng(1).random(5000) < 0.05).astype(np.uint8)
+    p = abi.default_params(paired=True, max_read_len=150, rmdup=1, **PE_CASES["C2_adatrim_lowq"])
+    assert_same(p, run_hip_device(p, d, kernel, dup=dup), T.run_oracle(p, d, dup=dup), True)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_error_reporting(kernel):
+    """unrecognized base / quality out of range: same first-offender as the oracle
+    (the reference exit(1)s: src/read_filter.cpp:283)."""
+    d = synth.make_batch(3000, 150, paired=True, seed=28)
+    d["seq"][1][1234, 77] = ord("X")
+    d["seq"][0][2000, 3] = ord("#")
+    p = abi.default_params(paired=True, max_read_len=150)
+    got = run_hip_device(p, d, kernel)
+    want = T.run_oracle(p, d)
+    assert want["err"] == (abi.E_BAD_BASE, 1, 1234)
+    assert got["err"] == want["err"]
+    d = synth.make_batch(3000, 150, paired=True, seed=29)
+    d["qual"][0][17, 5] = 33 + 60
+    got = run_hip_device(p, d, kernel)
+    assert got["err"] == (abi.E_QUAL_RANGE, 0, 17)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_lowercase_and_N_reads(kernel):
+    """case-insensitive counting but case-sensitive adapter/polyX compares
+    (src/read_filter.cpp:261,270-281,728)."""
+    d = synth.make_batch(4000, 150, paired=True, seed=30)
+    rng = np.random.default_rng(2)
+    rows = rng.choice(4000, 400, replace=False)
+    for m in range(2):
+        blk = d["seq"][m][rows, :150]
+        low = rng.random(blk.shape) < 0.3
+        d["seq"][m][rows, :150] = np.where(low, blk | 0x20, blk)
+    p = abi.default_params(paired=True, max_read_len=150, **PE_CASES["C3_full"])
+    assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), True)
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] shape (PE150, adapter-trim + lowQual) at a size the oracle
+    cannot follow in seconds: size-independent invariants instead.  Stats are a pure
+    sum over reads, so 4 chunks accumulated == the whole, the generic and the auto
+    kernel agree on a checksum of the records, and gs totals equal histogram totals."""
+    n = 1 << 20
+    d = synth.make_batch(n, 150, paired=True, seed=31)
+    p = abi.default_params(paired=True, max_read_len=150, **PE_CASES["C2_adatrim_lowq"])
+    a = run_hip_device(p, d, 0, chunks=1)
+    b = run_hip_device(p, d, 0, chunks=4)
+    c = run_hip_device(p, d, 1, chunks=3)
+    for other in (b, c):
+        assert np.array_equal(a["sum"], other["sum"]) and np.array_equal(a["max"], other["max"])
+        for m in range(2):
+            assert np.array_equal(a["rec"][m], other["rec"][m])
+    lcap, nq = 150, 43
+    for k in range(4):
+        f = a["sum"][abi.file_off(lcap, nq, k):][:abi.file_block_u64(lcap, nq)]
+        bs = f[abi.bs_off(lcap, nq):abi.qs_off(lcap, nq)].reshape(lcap, 5)
+        qs = f[abi.qs_off(lcap, nq):abi.ts_off(lcap, nq)].reshape(lcap, nq)
+        assert f[abi.GS_BASES] == bs.sum() == qs.sum()
+        assert f[abi.GS_READS] == bs[0].sum()
+        assert f[abi.GS_Q20] == qs[:, 20:].sum() and f[abi.GS_Q30] == qs[:, 30:].sum()
+    kept = int((a["rec"][0]["reason"] == 0).sum())
+    raw1 = a["sum"][abi.file_off(lcap, nq, 0):]
+    clean1 = a["sum"][abi.file_off(lcap, nq, 2):]
+    assert raw1[abi.GS_READS] == n and clean1[abi.GS_READS] == kept
+    assert int(a["sum"][:abi.SNK_FS_N][[abi.FS_SHORT, abi.FS_NRATE, abi.FS_LOWQUAL]].sum()) == n - kept
+    # and a slice of it against the oracle
+    sub = {"n": 20000, "L": 150, "pitch": d["pitch"], "paired": True,
+           "seq": [x[:20000] for x in d["seq"]], "qual": [x[:20000] for x in d["qual"]], "len": [None, None]}
+    o = T.run_oracle(p, sub)
+    for m in range(2):
+        assert np.array_equal(a["rec"][m][:20000], o["rec"][m])
