@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the SOAPnuke-filter hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (filter + raw stats + clean stats, i.e. one
+reference patch: filter_pe_fqs + stat_pe_fqs x2) over one device-resident batch of
+synthetic PE150 reads, followed by the stats all-reduce (RCCL) when N > 1.
+Workload = BASELINE.json configs[1]: PE 10M x 150 bp, adapter-trim + lowQual
+(`-f A1 -r A2 -J -l 10 -q 0.1`), inputs resident in HBM when the timed region
+starts.  Every rank processes its own 10M-pair shard (weak scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against the
+8 TB/s HBM peak with the algorithmic bytes of SURVEY 8(d): 2*L + 16 per read =
+632 B per PE150 pair, timed with hipEvents on the launch stream inside the C ABI.
+`cpu_baseline` times the compiled reference (oracle/_ref/SOAPnuke) on the host
+cores on a bounded sample of the same workload (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PAIRS_TOTAL = 10_000_000
+PAIRS_UNIQUE = 1_000_000
+L = 150
+BYTES_PER_PAIR = 2 * (2 * L + 16)      # bases + qualities read once + 16 B record, per mate
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def bench_params():
+    from soapnuke_amd import abi, synth
+    return abi.default_params(paired=True, max_read_len=L, adapters1=[synth.ADAPTER1],
+                              adapters2=[synth.ADAPTER2], ada_trim=1, low_qual=10, low_qual_ratio=0.1)
+
+
+def cpu_baseline(data, n_sample):
+    """The reference binary itself on the host cores (kind 'reference'), or the C port."""
+    from soapnuke_amd import synth
+    cores = min(16, os.cpu_count() or 1)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "SOAPnuke")
+    tmp = tempfile.mkdtemp(prefix="snkbench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        if os.path.exists(ref_bin):
+            f1, f2 = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
+            synth.write_fastq(f1, data["seq"][0][:n_sample], data["qual"][0][:n_sample], L, 1)
+            synth.write_fastq(f2, data["seq"][1][:n_sample], data["qual"][1][:n_sample], L, 2)
+            cmd = [ref_bin, "filter", "-1", f1, "-2", f2, "-C", "c1.fq", "-D", "c2.fq", "-o", os.path.join(tmp, "out"),
+                   "-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-l", "10", "-q", "0.1", "-T", str(cores)]
+            t0 = time.time()
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            wall = time.time() - t0
+            if r.returncode == 0:
+                return {"value": round(2 * n_sample / wall / 1e6, 4), "unit": "Mreads/s", "cores": cores,
+                        "kind": "reference",
+                        "sample": f"{n_sample} PE150 pairs, plain FASTQ in /dev/shm, `SOAPnuke filter -J -l 10 -q 0.1 -T {cores}`, "
+                                  f"whole-process wall {wall:.1f}s (includes its 5 s merge-poll quantum)"}
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import snk_testlib as T
+        n = min(n_sample, 200_000)
+        sub = {"n": n, "L": L, "pitch": data["pitch"], "paired": True,
+               "seq": [x[:n] for x in data["seq"]], "qual": [x[:n] for x in data["qual"]], "len": [None, None]}
+        t0 = time.time()
+        T.run_oracle(bench_params(), sub)
+        wall = time.time() - t0
+        return {"value": round(2 * n / wall / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
+                "sample": f"{n} PE150 pairs through oracle/snk_oracle.c (hot path only, no I/O), {wall:.1f}s"}
+    finally:
+        subprocess.call(["rm", "-rf", tmp])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=PAIRS_TOTAL, help="pairs per GPU per step")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 tiled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from soapnuke_amd import synth
+    from soapnuke_amd.filter import FilterContext
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    n_unique = min(PAIRS_UNIQUE, args.pairs)
+    reps = max(1, args.pairs // n_unique)
+    n = n_unique * reps
+    data = synth.make_batch(n_unique, L, paired=True, seed=synth.SEED + rank)
+    ctx = FilterContext(bench_params(), device=local_rank)
+    dev = ctx.upload(data)
+    if reps > 1:   # distinct HBM copies: no cache reuse between replicas (6.4 GB >> 256 MB L3)
+        dev["seq"] = [x.repeat(reps, 1) for x in dev["seq"]]
+        dev["qual"] = [x.repeat(reps, 1) for x in dev["qual"]]
+        dev["n"] = n
+    rec = ctx.alloc_records(n)
+    batch = ctx.make_batch(dev, first_index=rank * n)
+    ctx.set_timing(True)
+
+    def step():
+        ctx.filter_batch(batch, rec, kernel=args.kernel)
+        if world > 1:
+            ctx.allreduce()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.clear()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if world == 1:
+            pass
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # per-launch kernel time: hipEvents recorded on the launch stream inside the C ABI
+    # (the last launch's pair; all launches are identical and back-to-back)
+    kernel_ms.append(ctx.last_kernel_ms())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    s, mx, err = ctx.fetch()
+    assert err[0] == 0, err
+    kept = int(s[(64 + 2 * (16 + L * 5 + L * 43 + 5000))])   # clean fq1 reads_number
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = 2.0 * n * world * args.steps / elapsed / 1e6
+        k_ms = float(np.mean(kernel_ms))
+        achieved = BYTES_PER_PAIR * n / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "Mreads/s PE150 `filter` (adapter+qual), bit-exact vs ref",
+            "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": f"synthetic PE150 (seed {synth.SEED}+rank): {n_unique} unique pairs x{reps} distinct HBM copies per GPU",
+            "config": {"workload": "BASELINE configs[1]: PE 10Mx150bp, adapter-trim + lowQual (-f/-r README adapters, -J -l 10 -q 0.1)",
+                       "pairs_per_gpu_per_step": n, "read_len": L, "Mpairs_per_s": round(value / 2, 3),
+                       "kernel": {0: "auto", 1: "generic", 2: "tiled"}[args.kernel],
+                       "parallelism": f"shard{world}" if world > 1 else "single",
+                       "clean_pairs_per_step_per_gpu": kept // args.steps},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(k_ms, 4), "bytes_per_launch": BYTES_PER_PAIR * n},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data, min(n_unique, 1_000_000))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

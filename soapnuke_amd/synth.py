@@ -26,33 +26,44 @@ def _mate(rng, n, L, pitch, ins, adapter, polyg_frac, var_len):
     seq = _BASES[rng.integers(0, 4, size=(n, L), dtype=np.uint8)]
     ada = np.frombuffer(adapter.encode(), dtype=np.uint8)
     pos = np.arange(L, dtype=np.int32)[None, :]
-    j = pos - ins[:, None]                       # index into the adapter
-    inside = (j >= 0) & (j < len(ada))
-    a_chars = ada[np.clip(j, 0, len(ada) - 1)]
-    # substitutions inside the adapter for ~30 % of read-through reads
-    mut = inside & (rng.random((n, L)) < 0.04) & (rng.random(n) < 0.3)[:, None]
-    a_chars = np.where(mut, _BASES[rng.integers(0, 4, size=(n, L), dtype=np.uint8)], a_chars)
-    seq = np.where(inside, a_chars, seq)
-    # N-rich reads
-    nrich = rng.random(n) < 0.01
-    seq = np.where(nrich[:, None] & (rng.random((n, L)) < 0.10), np.uint8(ord("N")), seq)
+    # read-through rows only: adapter (+ substitutions for ~30 % of them) then random tail
+    rt = np.nonzero(ins < L)[0]
+    if len(rt):
+        j = pos - ins[rt, None]
+        inside = (j >= 0) & (j < len(ada))
+        a_chars = ada[np.clip(j, 0, len(ada) - 1)]
+        mut = inside & (rng.random((len(rt), L), dtype=np.float32) < 0.04) & (rng.random(len(rt)) < 0.3)[:, None]
+        a_chars = np.where(mut, _BASES[rng.integers(0, 4, size=(len(rt), L), dtype=np.uint8)], a_chars)
+        seq[rt] = np.where(inside, a_chars, seq[rt])
+    # N-rich reads (1 %, 10 % N)
+    nr = np.nonzero(rng.random(n) < 0.01)[0]
+    if len(nr):
+        seq[nr] = np.where(rng.random((len(nr), L), dtype=np.float32) < 0.10, np.uint8(ord("N")), seq[nr])
     # poly-G tails
     if polyg_frac > 0:
-        pg = rng.random(n) < polyg_frac
-        glen = rng.integers(30, 61, size=n)
-        seq = np.where(pg[:, None] & (pos >= (L - glen)[:, None]), np.uint8(ord("G")), seq)
-    # qualities
+        pg = np.nonzero(rng.random(n) < polyg_frac)[0]
+        if len(pg):
+            glen = rng.integers(30, 61, size=len(pg))
+            seq[pg] = np.where(pos >= (L - glen)[:, None], np.uint8(ord("G")), seq[pg])
+    # qualities: per-read profile
     prof = rng.random(n)
-    mean = np.where(prof < 0.85, 36.0, np.where(prof < 0.90, 30.0, np.where(prof < 0.95, 12.0, 4.0)))
-    q = np.rint(rng.normal(mean[:, None], 4.0, size=(n, L))).astype(np.int32)
+    mean = np.where(prof < 0.85, 36.0, np.where(prof < 0.90, 30.0, np.where(prof < 0.95, 12.0, 4.0))).astype(np.float32)
+    q = rng.standard_normal((n, L), dtype=np.float32)
+    q *= 4.0
+    q += mean[:, None]
+    np.rint(q, out=q)
     # a few reads with bad ends (exercise trimBadHead/Tail)
-    bad_tail = rng.random(n) < 0.05
-    tl = rng.integers(1, 25, size=n)
-    q = np.where(bad_tail[:, None] & (pos >= (L - tl)[:, None]), q - 25, q)
-    bad_head = rng.random(n) < 0.02
-    hl = rng.integers(1, 12, size=n)
-    q = np.where(bad_head[:, None] & (pos < hl[:, None]), q - 25, q)
-    q = np.clip(q, 2, 41).astype(np.uint8) + 33
+    bt = np.nonzero(rng.random(n) < 0.05)[0]
+    if len(bt):
+        tl = rng.integers(1, 25, size=len(bt))
+        q[bt] -= np.where(pos >= (L - tl)[:, None], np.float32(25), np.float32(0))
+    bh = np.nonzero(rng.random(n) < 0.02)[0]
+    if len(bh):
+        hl = rng.integers(1, 12, size=len(bh))
+        q[bh] -= np.where(pos < hl[:, None], np.float32(25), np.float32(0))
+    np.clip(q, 2, 41, out=q)
+    q = q.astype(np.uint8)
+    q += 33
     lens = None
     if var_len:
         lens = rng.integers(max(len(ada) + 8, L // 2), L + 1, size=n).astype(np.uint16)
@@ -82,3 +93,28 @@ def make_batch(n, L=150, paired=True, seed=SEED, adapters=(ADAPTER1, ADAPTER2),
         out["qual"].append(Q)
         out["len"].append(lens)
     return out
+
+
+def write_fastq(path, S, Q, L, mate, lens=None, first_index=0):
+    """Plain 4-line FASTQ with fixed-width IDs `@SNK:1:1101:<idx>/<mate>` (vectorised)."""
+    n = S.shape[0]
+    if lens is not None:
+        with open(path, "wb") as f:
+            for i in range(n):
+                f.write(b"@SNK:1:1101:%09d/%d\n" % (first_index + i, mate))
+                f.write(S[i, :lens[i]].tobytes() + b"\n+\n" + Q[i, :lens[i]].tobytes() + b"\n")
+        return
+    idw = len(b"@SNK:1:1101:000000000/1\n")
+    rec = np.empty((n, idw + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, :12] = np.frombuffer(b"@SNK:1:1101:", dtype=np.uint8)
+    idx = np.arange(first_index, first_index + n, dtype=np.int64)
+    for k in range(9):
+        rec[:, 12 + 8 - k] = (idx // 10 ** k % 10 + 48).astype(np.uint8)
+    rec[:, 21] = ord("/")
+    rec[:, 22] = 48 + mate
+    rec[:, 23] = 10
+    rec[:, idw:idw + L] = S[:, :L]
+    rec[:, idw + L:idw + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, idw + L + 3:idw + 2 * L + 3] = Q[:, :L]
+    rec[:, -1] = 10
+    rec.tofile(path)
