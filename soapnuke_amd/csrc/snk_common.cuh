@@ -1,0 +1,182 @@
+// snk_common.cuh -- device code shared by the generic and the wave-tiled kernels:
+// the per-read state, the sequential adapter matcher (also the in-kernel fallback
+// for reads shorter than the adapter), the discard cascade and the trimming-
+// position bookkeeping.  Reference rows: SURVEY.md 8(a) A2/A3/A6/A8.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "snk_device.h"
+
+namespace snk {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+struct ReadState {
+    int len;
+    int n_a, n_n, lowq, sumq;
+    int polyx;                         // contig_base >= polyX_num
+    int inc_ada;                       // include_adapter_seq == 1
+    int hd_h, lq_h, hd_t, lq_t, adacut;
+    int start, clen;
+};
+
+__device__ __forceinline__ void rs_init(ReadState &r, int len) {
+    r.len = len;
+    r.n_a = r.n_n = r.lowq = r.sumq = 0;
+    r.polyx = 0;
+    r.inc_ada = 0;
+    r.hd_h = r.lq_h = r.hd_t = r.lq_t = r.adacut = -1;   // C_fastq_init, src/peprocess.cpp:1674
+    r.start = 0;
+    r.clen = len;
+}
+
+__device__ __forceinline__ int rdc(const uint8_t *s, int len, int i) {
+    return (i >= 0 && i < len) ? (int)s[i] : 0;   // outside the read: '\0' 
+}
+
+// A2 adapter_pos(), src/read_filter.cpp:707-790, one read, sequential.
+__device__ inline int adapter_pos_seq(const uint8_t *s, int len, const DevAdapter &A) {
+    const int al = A.len;
+    if (al == 0) return -1;
+    for (int r1 = 1; r1 <= 5; ++r1) {                       // phase A, :720-742
+        int mis = 0, run = 0;
+        const int budget = A.budgetA[r1];
+        for (int c = 0; c < al - r1; ++c) {
+            if ((int)A.seq[r1 + c] == rdc(s, len, c)) { if (++run >= A.S) return 0; }
+            else { ++mis; run = 0; if (mis > budget) break; }
+        }
+        if (mis <= budget) return 0;
+    }
+    for (int r1 = 0; r1 <= len - al; ++r1) {                // phase B, :743-764
+        int mis = 0, run = 0;
+        for (int c = 0; c < al; ++c) {
+            if (A.seq[c] == s[r1 + c]) { if (++run >= A.S) return r1; }
+            else { ++mis; run = 0; if (mis > A.mis) break; }
+        }
+        if (mis <= A.mis) return r1;
+    }
+    for (int r1 = 0; r1 < A.nC; ++r1) {                     // phase C, :765-788
+        int mis = 0, run = 0;
+        const int budget = A.budgetC[r1];
+        const int st = len - r1 - A.edge;
+        for (int c = 0; c < r1 + A.edge; ++c) {
+            if ((int)A.seq[c] == rdc(s, len, st + c)) { if (++run >= A.S) return st; }
+            else { ++mis; run = 0; if (mis > budget) break; }
+        }
+        if (mis <= budget) return st;
+    }
+    return -1;
+}
+
+// A3 fastq_trim() arithmetic once the per-read scan results are known
+// (src/read_filter.cpp:383-468).  lq_hix/lq_tix/polyg: the three run lengths.
+__device__ __forceinline__ void trim_finish(const DevParams &P, int mate, ReadState &r, int lq_hix,
+                                            int lq_tix, int polyg) {
+    const int len = r.len;
+    int head_cut = 0, tail_cut = 0;
+    if (P.has_hard) {
+        r.hd_h = P.hard[P.paired ? 2 * mate : 0];
+        r.hd_t = P.hard[P.paired ? 2 * mate + 1 : 1];
+        head_cut = r.hd_h;
+        tail_cut = r.hd_t;
+    }
+    if (P.has_lq) {
+        r.lq_h = lq_hix;
+        r.lq_t = lq_tix;
+        head_cut = max(head_cut, lq_hix);
+        tail_cut = max(tail_cut, lq_tix);
+    }
+    if (P.ada_trim && r.adacut > 0) tail_cut = max(tail_cut, r.adacut);
+    if (P.has_polyG && polyg >= P.polyG_thr && polyg > tail_cut) tail_cut = polyg;
+    if ((u64)(long long)(head_cut + tail_cut) > (u64)len) {       // int sum compared as size_t, :462
+        r.start = 0;
+        r.clen = 0;
+    } else {
+        r.clen = len - head_cut - tail_cut;
+        r.start = r.clen ? head_cut : 0;
+    }
+}
+
+__device__ __forceinline__ int pe_dis(bool a, bool b) { return (a ? 1 : 0) + (b ? 2 : 0); }
+
+// A6: the cascade (src/sequence.cpp:198-387 PE, :76-178 SE); returns the reason and
+// the pe_dis() code, counters are the caller's business.
+__device__ inline int discard_reason(const DevParams &P, const ReadState &a, const ReadState &b, int dup,
+                                     int &vout) {
+    const bool pe = P.paired;
+    int v;
+    vout = 0;
+#define SNK_TEST(COND_A, COND_B, REASON)                 \
+    v = pe_dis((COND_A), pe && (COND_B));                \
+    if (v > 0) { vout = pe ? v : 0; return REASON; }
+    if (P.rmdup && dup) return SNK_R_DUP;
+    if (P.has_min) {
+        SNK_TEST((u32)a.clen < P.min_len_u, (u32)b.clen < P.min_len_u, SNK_R_SHORT)
+    } else if (pe && (a.clen == 0 || b.clen == 0)) {
+        return SNK_R_EMPTY;
+    }
+    if (P.has_max) { SNK_TEST((u32)a.clen > P.max_len_u, (u32)b.clen > P.max_len_u, SNK_R_LONG) }
+    if (P.has_n) { SNK_TEST(a.n_n >= P.thr_n[a.len], b.n_n >= P.thr_n[b.len], SNK_R_NRATE) }
+    if (P.has_highA) { SNK_TEST(a.n_a >= P.thr_a[a.len], b.n_a >= P.thr_a[b.len], SNK_R_HIGHA) }
+    if (P.polyX_num != -1) { SNK_TEST(a.polyx, b.polyx, SNK_R_POLYX) }
+    if (P.has_lowq) { SNK_TEST(a.lowq >= P.thr_lowq[a.len], b.lowq >= P.thr_lowq[b.len], SNK_R_LOWQUAL) }
+    if (P.has_meanq) { SNK_TEST(a.sumq < P.thr_meanq[a.len], b.sumq < P.thr_meanq[b.len], SNK_R_MEANQ) }
+    if (!P.ada_trim) { SNK_TEST(a.inc_ada, b.inc_ada, SNK_R_ADAPTER) }
+#undef SNK_TEST
+    return SNK_KEEP;
+}
+
+__device__ __forceinline__ int reason_family(int reason) {
+    switch (reason) {
+    case SNK_R_SHORT: return SNK_FS_SHORT;
+    case SNK_R_LONG: return SNK_FS_LONG;
+    case SNK_R_NRATE: return SNK_FS_NRATE;
+    case SNK_R_HIGHA: return SNK_FS_HIGHA;
+    case SNK_R_POLYX: return SNK_FS_POLYX;
+    case SNK_R_LOWQUAL: return SNK_FS_LOWQUAL;
+    case SNK_R_MEANQ: return SNK_FS_MEANQ;
+    case SNK_R_ADAPTER: return SNK_FS_ADAPTER;
+    default: return -1;
+    }
+}
+
+__device__ __forceinline__ void ts_inc(u64 *ts, long idx) {
+    if (idx >= 0 && idx < SNK_TS_N) atomicAdd(&ts[idx], 1ull);   // outside the struct the reference is UB
+}
+
+// src/peprocess.cpp:1107-1143 (fq1) / :1325-1360 (fq2) / src/seprocess.cpp:647-682
+__device__ inline void ts_update(u64 *ts, int hd_h, int lq_h, int hd_t, int lq_t, int ada, long base_len,
+                                 bool se) {
+    if (hd_h > 0 || lq_h > 0) {
+        if (hd_h >= lq_h) ts_inc(ts, SNK_TS_HT + hd_h); else ts_inc(ts, SNK_TS_HLQ + lq_h);
+    }
+    if (hd_t > 0 || lq_t > 0 || (se ? ada >= 0 : ada > 0)) {
+        if (hd_t >= lq_t) {
+            if (hd_t >= ada) ts_inc(ts, SNK_TS_TT + base_len - hd_t + 1);
+            else ts_inc(ts, SNK_TS_TA + base_len - ada + 1);
+        } else {
+            if (lq_t >= ada) ts_inc(ts, SNK_TS_TLQ + base_len - lq_t + 1);
+            else ts_inc(ts, SNK_TS_TA + base_len - ada + 1);
+        }
+    }
+}
+
+__device__ __forceinline__ void report_err(const DevStats &st, u64 index, int mate, int code) {
+    atomicMin(st.err, (index << 8) | ((u64)mate << 4) | (u64)code);
+}
+
+__device__ __forceinline__ void store_rec(snk_read_result *out, long i, const ReadState &r, int reason, int v) {
+    snk_read_result o;
+    o.head_hdcut = (int16_t)r.hd_h; o.head_lqcut = (int16_t)r.lq_h;
+    o.tail_hdcut = (int16_t)r.hd_t; o.tail_lqcut = (int16_t)r.lq_t;
+    o.adacut_pos = (int16_t)r.adacut;
+    o.clean_start = (uint16_t)r.start; o.clean_len = (uint16_t)r.clen;
+    o.reason = (uint8_t)reason; o.flags = (uint8_t)v;
+    reinterpret_cast<uint4 *>(out)[i] = *reinterpret_cast<const uint4 *>(&o);
+}
+
+__device__ __forceinline__ long file_block(int lcap, int nq) {
+    return SNK_GS_N + (long)lcap * 5 + (long)lcap * nq + SNK_TS_N;
+}
+
+}  // namespace snk

@@ -25,6 +25,9 @@ struct DevAdapter {
     uint8_t  code[SNK_DEV_MAX_ADA_LEN]; // 0..3 = ACGT, 4 = can never match a valid read base
     int32_t  tile_ok;       // 1 when the tiled kernel can handle this adapter
     int32_t  maxBudget;     // max over all phases of max(budget,0)
+    int32_t  rk[4];         // rk[k] = smallest phase-C r1 with budgetC[r1] >= k (nC if none), k = 1..3
+    int32_t  negC;          // phase-C budgets are INT_MIN (misGrad == 0): only a run of S accepts
+    uint64_t nmask;         // bit c = adapter[c] == 'N' (matches a read 'N' exactly)
 };
 
 struct DevParams {
@@ -38,6 +41,8 @@ struct DevParams {
     int32_t polyG_thr;                 // min n with (float)n >= polyG_tail  (:456)
     int32_t lcap;                      // positions per histogram row block
     int32_t n_ada[2];
+    int32_t tile_ok;                   // every adapter can run in the wave-tiled kernel
+    int32_t need_n;                    // some adapter contains 'N' (needs the N plane)
     // per-length integer thresholds replacing the fp32 ratio compares:
     //   discard iff count >= thr_x[len]            (n_ratio, highA, low-quality ratio)
     //   discard iff sumq  <  thr_meanq[len]        (mean quality)

@@ -82,16 +82,22 @@ void build_adapter(DevAdapter &A, const char *seq, int mis, float mr, int edge) 
         if (A.budgetC[r1] > maxb) maxb = A.budgetC[r1];
     }
     A.maxBudget = maxb;
-    // bit-parallel view for the tiled kernel
-    A.tile_ok = (al >= 1 && al <= 64 && edge >= 1 && A.nC <= 64) ? 1 : 0;
+    A.negC = (misGrad == 0.0f) ? 1 : 0;
+    for (int k = 1; k <= 3; ++k) {
+        A.rk[k] = A.nC > 0 ? A.nC : 0;
+        for (int r1 = 0; r1 < A.nC && r1 < SNK_DEV_MAX_ADA_LEN; ++r1)
+            if (A.budgetC[r1] >= k) { A.rk[k] = r1; break; }
+    }
+    // bit-parallel view for the tiled kernel: code 0..3 = ACGT, 4 = matches no valid read base,
+    // 5 = 'N'.  Lower-case adapter characters would need case-exact planes: generic kernel only.
+    A.tile_ok = (al >= 6 && al <= 64 && edge >= 1 && edge <= al && mis >= 0 && maxb <= 3) ? 1 : 0;
     for (int c = 0; c < al; ++c) {
         int k = 4;
-        switch (seq[c]) { case 'A': k = 0; break; case 'C': k = 1; break; case 'G': k = 2; break; case 'T': k = 3; break; default: break; }
+        switch (seq[c]) { case 'A': k = 0; break; case 'C': k = 1; break; case 'G': k = 2; break; case 'T': k = 3; break; case 'N': k = 5; break; default: break; }
         A.code[c] = (uint8_t)k;
         if (k < 4 && c < 64) A.cmask[k] |= 1ull << c;
-        // lower-case / N adapter characters would need the case-exact planes: generic kernel only
-        if (k == 4 && (seq[c] == 'a' || seq[c] == 'c' || seq[c] == 'g' || seq[c] == 't' || seq[c] == 'n' || seq[c] == 'N'))
-            A.tile_ok = 0;
+        if (k == 5 && c < 64) A.nmask |= 1ull << c;
+        if (seq[c] == 'a' || seq[c] == 'c' || seq[c] == 'g' || seq[c] == 't' || seq[c] == 'n') A.tile_ok = 0;
     }
 }
 
@@ -211,6 +217,14 @@ static int build_ctx(snk_ctx *c) {
     D.lcap = c->lcap;
     D.n_ada[0] = P.n_adapters[0];
     D.n_ada[1] = P.n_adapters[1];
+    D.tile_ok = 1;
+    D.need_n = 0;
+    for (int m = 0; m < 2; ++m)
+        for (int i = 0; i < P.n_adapters[m]; ++i) {
+            const DevAdapter &A = ada[m * SNK_MAX_ADAPTERS + i];
+            if (!A.tile_ok) D.tile_ok = 0;
+            if (A.nmask) D.need_n = 1;
+        }
     D.thr_n = c->d_tables;
     D.thr_a = c->d_tables + L1;
     D.thr_lowq = c->d_tables + 2 * L1;

@@ -1,4 +1,650 @@
-// placeholder until the wave-tiled kernel lands
+// snk_tiled.hip -- the wave-tiled fast kernel of the SOAPnuke-filter hot path (gfx950).
+//
+// One wavefront owns a tile of 64 read pairs and walks it in three phases:
+//
+//  phase 1  lane = read POSITION.  For each of the tile's reads the wave loads the
+//           base and quality bytes with coalesced 64-byte strips, turns the per-base
+//           predicates (==A/C/G/T/N, Q<=lowQual, ...) into 64-bit ballots on the scalar
+//           unit, adds the raw per-position histograms into LDS (lane l owns positions
+//           l, l+64, ... so the adds of one instruction never collide), and *transposes*
+//           the ballots into the lane that owns the read with v_writelane.
+//  phase 2  lane = READ.  Each lane now holds its read as bit planes (one bit per
+//           position).  Adapter search (src/read_filter.cpp:707-790) runs bit-sliced over
+//           all candidate offsets at once: for the first S-1 adapter characters (S =
+//           segMatchThr) no run of S matches can complete, so the only possible event is
+//           "mismatch budget exceeded" -> a unary mismatch counter per candidate kept in
+//           bit planes, one funnel shift + a few logic ops per 32 candidates per step.
+//           The handful of survivors is decided exactly with the closed form of the
+//           reference's early-exit scan (first run of S ones vs (budget+1)-th zero, SURVEY
+//           appendix D).  Low-quality-end / polyG / polyX runs are ctz/clz on the planes;
+//           the discard cascade uses host-precomputed integer thresholds (no fp32 here).
+//  phase 3  lane = position again, only for reads that were discarded or trimmed: their
+//           (removed part of the) contribution goes to a second LDS histogram, so that
+//           clean = raw - removed needs no second pass over the surviving 80 %.
+//
+// LDS holds, per mate, raw and removed {base[pos][5], qual[pos][nq]} histograms as 16-bit
+// counters packed two per dword (positions p and p+Lh share a dword, so one strip never
+// hits a dword twice); the workgroup flushes them to the global uint64 block before a
+// counter can overflow.  Everything is integer/byte work: no MFMA, bound by HBM in theory
+// and by VALU issue in practice.
 #include <hip/hip_runtime.h>
-#include "snk_device.h"
-int snk_launch_tiled(const DevParams *, const DevParams &, const DevBatch &, const DevStats &, int, int, int, void *) { return 0; }
+#include "snk_common.cuh"
+
+using namespace snk;
+
+extern "C" __device__ int __snk_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+
+namespace {
+
+__device__ __forceinline__ u32 lowmask32(int n) { return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u)); }
+__device__ __forceinline__ u64 lowmask64(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); }
+
+// clang exposes readlane but not writelane as a builtin; the LLVM intrinsic is bound above
+// (v_writelane_b32: uniform value -> one lane of a VGPR, the transpose primitive of phase 1).
+__device__ __forceinline__ int wl(int dst, int val, int lane) { return __snk_writelane(val, lane, dst); }
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+__device__ __forceinline__ int wave_sum(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Exact outcome of one alignment of the reference's scan (src/read_filter.cpp:726-741 and
+// its two siblings): m bit c = adapter/read characters equal at step c, n steps.
+// accept <=> a run of S matches completes before the (budget+1)-th mismatch, or fewer than
+// budget+1 mismatches occur at all.  budget < 0 (INT_MIN): only the run can accept.
+__device__ inline bool accept_exact(u64 m, int n, int S, int budget) {
+    const u64 nm = lowmask64(n);
+    m &= nm;
+    const u64 z = ~m & nm;
+    if (budget < 0) return S <= n && (z & lowmask64(S)) == 0;
+    if (__popcll(z) <= budget) return true;
+    u64 t = z;
+    for (int i = 0; i < budget; ++i) t &= t - 1;
+    const int kz = __ffsll((long long)t) - 1;          // position of the (budget+1)-th mismatch
+    if (S > kz) return false;
+    u64 r = m & lowmask64(kz);
+    int have = 1;
+    while (have < S) {                                  // r bit i = ones at i..i+have-1
+        const int st = min(have, S - have);
+        r &= r >> st;
+        have += st;
+    }
+    return r != 0;
+}
+
+template <int NW>
+__device__ __forceinline__ int lowest_bit(const u32 (&w)[NW]) {
+    int p = -1;
+#pragma unroll
+    for (int j = NW - 1; j >= 0; --j) p = w[j] ? 32 * j + __ffs((int)w[j]) - 1 : p;
+    return p;
+}
+template <int NW>
+__device__ __forceinline__ int highest_bit(const u32 (&w)[NW]) {
+    int p = -1;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) p = w[j] ? 32 * j + 31 - __clz((int)w[j]) : p;
+    return p;
+}
+template <int NW>
+__device__ __forceinline__ void clear_bit(u32 (&w)[NW], int p) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) w[j] &= ~(((p >> 5) == j) ? (1u << (p & 31)) : 0u);
+}
+template <int NW>
+__device__ __forceinline__ bool any_bit(const u32 (&w)[NW]) {
+    u32 o = 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) o |= w[j];
+    return o != 0;
+}
+
+// bits [p, p+64) of a plane (per-lane p); bits past the plane read as `fill`
+template <int NW>
+__device__ __forceinline__ u64 window64(const u32 (&X)[NW], int p, u32 fill) {
+    const int q = p >> 5, sh = p & 31;
+    u32 w0 = fill, w1 = fill, w2 = fill;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        w0 = (q == j) ? X[j] : w0;
+        w1 = (q + 1 == j) ? X[j] : w1;
+        w2 = (q + 2 == j) ? X[j] : w2;
+    }
+    const u32 lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+    const u32 hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    return ((u64)hi << 32) | lo;
+}
+
+// number of consecutive set bits going DOWN from position len-1 (0 if bit len-1 is clear);
+// returns len when every bit below len is set.
+template <int NW>
+__device__ __forceinline__ int run_down(const u32 (&X)[NW], int len) {
+    int hz = -1;                                         // highest zero below len
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const u32 z = ~X[j] & lowmask32(len - 32 * j);
+        hz = z ? 32 * j + 31 - __clz((int)z) : hz;
+    }
+    return len - 1 - hz;
+}
+// number of consecutive set bits going UP from position 0; 32*NW when all are set
+template <int NW>
+__device__ __forceinline__ int run_up(const u32 (&X)[NW]) {
+    int p = 32 * NW;
+#pragma unroll
+    for (int j = NW - 1; j >= 0; --j) p = (~X[j]) ? 32 * j + __ffs((int)~X[j]) - 1 : p;
+    return p;
+}
+
+// plane >> st (uniform st), zero fill
+template <int NW>
+__device__ __forceinline__ void shr_plane(u32 (&R)[NW], int st) {
+    const int q = st >> 5, r = st & 31;
+    u32 T[NW + 1];
+#pragma unroll
+    for (int j = 0; j <= NW; ++j) T[j] = 0;
+#pragma unroll
+    for (int qq = 0; qq < NW; ++qq)
+        if (q == qq) {                                   // uniform branch, static indices inside
+#pragma unroll
+            for (int j = 0; j + qq < NW; ++j) T[j] = R[j + qq];
+        }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) R[j] = __builtin_amdgcn_alignbit(T[j + 1], T[j], r);
+}
+
+// one screening step: D = plane >> c (ones shifted in), C_k |= C_{k-1} & ~D
+template <int NW, int CQ>
+__device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C1)[NW], u32 (&C2)[NW],
+                                            u32 (&C3)[NW], u32 (&C4)[NW]) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const u32 lo = (j + CQ < NW) ? Pl[(j + CQ < NW) ? j + CQ : 0] : 0xFFFFFFFFu;
+        const u32 hi = (j + CQ + 1 < NW) ? Pl[(j + CQ + 1 < NW) ? j + CQ + 1 : 0] : 0xFFFFFFFFu;
+        const u32 x = ~__builtin_amdgcn_alignbit(hi, lo, cr);
+        C4[j] |= C3[j] & x;
+        C3[j] |= C2[j] & x;
+        C2[j] |= C1[j] & x;
+        C1[j] |= x;
+    }
+}
+
+struct Planes4 { };
+
+// Adapter search for the lanes with `todo`; returns the position or -1.
+// X[k] bit p = read[p] == "ACGT"[k] (exact), ones beyond the read; XN likewise for 'N'.
+template <int NW>
+__device__ int adapter_tile(const DevAdapter &A, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len,
+                            bool todo, const uint8_t *sptr) {
+    const int al = A.len, S = max(A.S, 1), edge = A.edge, mis = A.mis;
+    int result = -1;
+    bool done = !todo;
+    if (!done && len < al) {           // shorter than the adapter: negative offsets, rare -> sequential
+        result = adapter_pos_seq(sptr, len, A);
+        done = true;
+    }
+    const u64 cm0 = A.cmask[0], cm1 = A.cmask[1], cm2 = A.cmask[2], cm3 = A.cmask[3], cmn = A.nmask;
+    // ---------------- phase A (src/read_filter.cpp:720-742): adapter[r1..] on read[0..]
+    {
+        const u64 x0 = ((u64)X[0][1] << 32) | X[0][0], x1 = ((u64)X[1][1] << 32) | X[1][0];
+        const u64 x2 = ((u64)X[2][1] << 32) | X[2][0], x3 = ((u64)X[3][1] << 32) | X[3][0];
+        const u64 xn = ((u64)XN[1] << 32) | XN[0];
+        for (int r1 = 1; r1 <= 5; ++r1) {
+            const int n = al - r1, budget = A.budgetA[r1];
+            const u64 m = ((x0 & (cm0 >> r1)) | (x1 & (cm1 >> r1)) | (x2 & (cm2 >> r1)) | (x3 & (cm3 >> r1)) |
+                           (xn & (cmn >> r1))) & lowmask64(n);
+            const u64 zz = ~m & lowmask64(min(n, S - 1));
+            const bool maybe = __popcll(zz) <= max(budget, 0);
+            if (!done && maybe && accept_exact(m, n, S, budget)) { result = 0; done = true; }
+        }
+    }
+    if (!__any(!done)) return result;
+    // ---------------- phases B+C screening: candidates p = 0 .. len-edge, bit-sliced
+    u32 C1[NW], C2[NW], C3[NW], C4[NW], BY[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) { C1[j] = C2[j] = C3[j] = C4[j] = 0; BY[j] = ~lowmask32(len - 32 * j); }
+    const int steps = min(S - 1, al);
+    for (int c = 0; c < steps; ++c) {
+        const int code = A.code[c], cr = c & 31;
+#define SNK_STEP(PL)                                                         \
+    if (c < 32) screen_step<NW, 0>(PL, cr, C1, C2, C3, C4);                  \
+    else screen_step<NW, 1>(PL, cr, C1, C2, C3, C4);
+        switch (code) {
+        case 0: SNK_STEP(X[0]) break;
+        case 1: SNK_STEP(X[1]) break;
+        case 2: SNK_STEP(X[2]) break;
+        case 3: SNK_STEP(X[3]) break;
+        case 5: SNK_STEP(XN) break;
+        default: SNK_STEP(BY) break;       // matches nothing inside the read
+        }
+#undef SNK_STEP
+    }
+    // budgets as thermometer planes T_k = [budget >= k]; reject = mis count > budget
+    u32 aliveB[NW], aliveC[NW];
+    const int rk1 = A.rk[1], rk2 = A.rk[2], rk3 = A.rk[3];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const u32 valid = lowmask32(len - edge + 1 - 32 * j);
+        const u32 bm = lowmask32(len - al + 1 - 32 * j);                    // phase B region
+        const u32 t1 = lowmask32(len - edge - rk1 + 1 - 32 * j) & (mis >= 1 ? 0xFFFFFFFFu : ~bm);
+        const u32 t2 = lowmask32(len - edge - rk2 + 1 - 32 * j) & (mis >= 2 ? 0xFFFFFFFFu : ~bm);
+        const u32 t3 = lowmask32(len - edge - rk3 + 1 - 32 * j) & (mis >= 3 ? 0xFFFFFFFFu : ~bm);
+        const u32 rej = (C1[j] & ~t1) | (C2[j] & ~t2) | (C3[j] & ~t3) | C4[j];
+        const u32 alive = done ? 0u : (valid & ~rej);
+        aliveB[j] = alive & bm;
+        aliveC[j] = alive & ~bm;
+    }
+    // ---------------- phase B (:743-764): ascending offset, first accepted wins
+    while (__any(!done && any_bit(aliveB))) {
+        if (!done && any_bit(aliveB)) {
+            const int p = lowest_bit(aliveB);
+            const u64 m = (window64(X[0], p, ~0u) & cm0) | (window64(X[1], p, ~0u) & cm1) |
+                          (window64(X[2], p, ~0u) & cm2) | (window64(X[3], p, ~0u) & cm3) |
+                          (window64(XN, p, ~0u) & cmn);
+            if (accept_exact(m, al, S, mis)) { result = p; done = true; }
+            else clear_bit(aliveB, p);
+        }
+    }
+    // ---------------- phase C (:765-788): ascending r1 == descending offset
+    while (__any(!done && any_bit(aliveC))) {
+        if (!done && any_bit(aliveC)) {
+            const int p = highest_bit(aliveC);
+            const int n = len - p;                                   // compared length, edge <= n < al
+            bool ok;
+            if (n < S) {
+                ok = !A.negC;                                        // no run possible: survived <=> mis <= budget
+            } else {
+                const u64 m = (window64(X[0], p, ~0u) & cm0) | (window64(X[1], p, ~0u) & cm1) |
+                              (window64(X[2], p, ~0u) & cm2) | (window64(X[3], p, ~0u) & cm3) |
+                              (window64(XN, p, ~0u) & cmn);
+                ok = accept_exact(m, n, S, A.budgetC[n - edge]);
+            }
+            if (ok) { result = p; done = true; }
+            else clear_bit(aliveC, p);
+        }
+    }
+    return result;
+}
+
+struct TileGeom {
+    int lcap, nq, Lh, WB, WQ, SET;
+};
+
+// One tile = up to 64 pairs starting at t0, processed by one wave.
+template <int NS, bool FULL>
+__device__ void process_tile(const DevParams &P, const DevBatch &B, const DevStats &st, const TileGeom &G,
+                             u32 *lds, long t0, int cnt, const int (&wb)[NS], const int (&wq)[NS],
+                             const u32 (&inc)[NS]) {
+    constexpr int NW = 2 * NS;
+    const int lane = threadIdx.x & 63;
+    const int mates = P.paired ? 2 : 1;
+    const int phred = P.phred, nq = G.nq, lowQ = P.low_qual;
+    const bool lanev = lane < cnt;
+    const long fb = file_block(G.lcap, nq);
+    const long ts_off = SNK_GS_N + (long)G.lcap * 5 + (long)G.lcap * nq;
+    const u64 gidx = B.first_index + (u64)(t0 + lane);
+
+    ReadState rs[2];
+    int estat[2] = {0, 0}, equal[2] = {0, 0};
+    const bool oobH = (0 - phred) < P.lq_head_q, oobT = (0 - phred) < P.lq_tail_q;
+
+    for (int m = 0; m < mates; ++m) {
+        const uint8_t *seq = B.seq[m], *qual = B.qual[m];
+        u32 *rawB = lds + (m * 2 + 0) * G.SET, *rawQ = rawB + G.WB;
+        int mylen = 0;
+        if (lanev) mylen = B.len[m] ? (int)B.len[m][t0 + lane] : B.fixed_len[m];
+        // ------------------------------------------------------------ phase 1
+        u32 X[4][NW], XN[NW], FG[NW], EQ[NW], LQH[NW], LQT[NW];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            X[0][j] = X[1][j] = X[2][j] = X[3][j] = 0xFFFFFFFFu;
+            XN[j] = 0xFFFFFFFFu;
+            FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
+        }
+        int v_na = 0, v_nn = 0, v_lowq = 0, v_sumq = 0, v_err = 0;
+        for (int r = 0; r < cnt; ++r) {
+            int len_r = rl(mylen, r);
+            int e = 0, eq = 0;
+            if (len_r > G.lcap) { e = SNK_E_TOO_LONG; len_r = G.lcap; }
+            if (len_r == 0) e = SNK_E_EMPTY_SEQ;
+            const long base = (t0 + r) * (long)B.pitch;
+            int nA = 0, nN = 0, nLow = 0, qsum = 0;
+            u32 prev_last = 0xFFFFFFFFu;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int pos = 64 * s + lane;
+                const bool valid = pos < len_r;
+                const u64 vm = lowmask64(len_r - 64 * s);
+                u32 c = 0, qb = 0;
+                if (valid) { c = seq[base + pos]; qb = qual[base + pos]; }
+                const u64 bA = __ballot(c == 'A'), bC = __ballot(c == 'C'), bG = __ballot(c == 'G'),
+                          bT = __ballot(c == 'T'), bN = __ballot(c == 'N');
+                u64 fA = bA, fN = bN, fG = bG;
+                if ((bA | bC | bG | bT | bN) != vm) {       // lower case or garbage in this strip (rare)
+                    const u32 cu = c & 0xDFu;
+                    fA = __ballot(cu == 'A');
+                    fG = __ballot(cu == 'G');
+                    fN = __ballot(cu == 'N');
+                    const u64 fC = __ballot(cu == 'C'), fT = __ballot(cu == 'T');
+                    if ((fA | fC | fG | fT | fN) != vm && !e) e = SNK_E_BAD_BASE;
+                }
+                nA += __popcll(fA);
+                nN += __popcll(fN);
+                const u64 by = ~vm;                          // beyond the read: matches anything
+                X[0][2 * s] = wl(X[0][2 * s], (int)(u32)(bA | by), r);
+                X[0][2 * s + 1] = wl(X[0][2 * s + 1], (int)(u32)((bA | by) >> 32), r);
+                X[1][2 * s] = wl(X[1][2 * s], (int)(u32)(bC | by), r);
+                X[1][2 * s + 1] = wl(X[1][2 * s + 1], (int)(u32)((bC | by) >> 32), r);
+                X[2][2 * s] = wl(X[2][2 * s], (int)(u32)(bG | by), r);
+                X[2][2 * s + 1] = wl(X[2][2 * s + 1], (int)(u32)((bG | by) >> 32), r);
+                X[3][2 * s] = wl(X[3][2 * s], (int)(u32)(bT | by), r);
+                X[3][2 * s + 1] = wl(X[3][2 * s + 1], (int)(u32)((bT | by) >> 32), r);
+                const int q = (int)qb - phred;
+                const u64 low = __ballot(q <= lowQ) & vm;
+                nLow += __popcll(low);
+                const bool qok = (u32)q < (u32)nq;
+                if ((__ballot(!qok) & vm) != 0) eq = SNK_E_QUAL_RANGE;
+                if (P.has_meanq) qsum += valid ? q : 0;
+                if (FULL) {
+                    if (P.need_n) {
+                        XN[2 * s] = wl(XN[2 * s], (int)(u32)(bN | by), r);
+                        XN[2 * s + 1] = wl(XN[2 * s + 1], (int)(u32)((bN | by) >> 32), r);
+                    }
+                    if (P.has_polyG) {
+                        FG[2 * s] = wl(FG[2 * s], (int)(u32)fG, r);
+                        FG[2 * s + 1] = wl(FG[2 * s + 1], (int)(u32)(fG >> 32), r);
+                    }
+                    if (P.polyX_num != -1) {
+                        u32 pc = __shfl_up(c, 1);
+                        if (lane == 0) pc = prev_last;
+                        const u64 eqm = __ballot(c == pc) & vm;
+                        prev_last = (u32)rl((int)c, 63);
+                        EQ[2 * s] = wl(EQ[2 * s], (int)(u32)eqm, r);
+                        EQ[2 * s + 1] = wl(EQ[2 * s + 1], (int)(u32)(eqm >> 32), r);
+                    }
+                    if (P.has_lq) {
+                        const u64 h = __ballot(valid ? (q < P.lq_head_q) : oobH);
+                        const u64 t = __ballot(valid ? (q < P.lq_tail_q) : oobT);
+                        LQH[2 * s] = wl(LQH[2 * s], (int)(u32)h, r);
+                        LQH[2 * s + 1] = wl(LQH[2 * s + 1], (int)(u32)(h >> 32), r);
+                        LQT[2 * s] = wl(LQT[2 * s], (int)(u32)t, r);
+                        LQT[2 * s + 1] = wl(LQT[2 * s + 1], (int)(u32)(t >> 32), r);
+                    }
+                }
+                // raw per-position histograms (src/peprocess.cpp:1145-1201)
+                if (valid && qok) {
+                    const u32 t2 = (c >> 1) & 3u;
+                    const u32 cls = (c & 0xDFu) == 'N' ? 4u : (t2 ^ (t2 >> 1));
+                    atomicAdd(&rawB[wb[s] + cls], inc[s]);
+                    atomicAdd(&rawQ[wq[s] + q], inc[s]);
+                }
+            }
+            if (P.has_meanq) qsum = wave_sum(qsum);
+            v_na = wl(v_na, nA, r);
+            v_nn = wl(v_nn, nN, r);
+            v_lowq = wl(v_lowq, nLow, r);
+            v_sumq = wl(v_sumq, qsum, r);
+            v_err = wl(v_err, e | (eq << 8), r);
+        }
+        // ------------------------------------------------------------ phase 2 (this mate)
+        ReadState &R = rs[m];
+        rs_init(R, min(mylen, G.lcap));
+        R.n_a = v_na; R.n_n = v_nn; R.lowq = v_lowq; R.sumq = v_sumq;
+        estat[m] = v_err & 0xFF;
+        equal[m] = v_err >> 8;
+        int hix = 0, tix = 0, polyg = 0;
+        if (FULL) {
+            if (P.polyX_num != -1) {        // contig_base >= polyX_num  <=>  run of polyX_num-1 "same as previous"
+                const int need = P.polyX_num - 1;
+                if (need <= 0) R.polyx = 1;
+                else {
+                    int have = 1;
+                    while (have < need) {
+                        const int stp = min(have, need - have);
+                        u32 T[NW];
+#pragma unroll
+                        for (int j = 0; j < NW; ++j) T[j] = EQ[j];
+                        shr_plane<NW>(T, stp);
+#pragma unroll
+                        for (int j = 0; j < NW; ++j) EQ[j] &= T[j];
+                        have += stp;
+                    }
+                    R.polyx = any_bit(EQ) ? 1 : 0;
+                }
+            }
+            if (P.has_lq) {                  // src/read_filter.cpp:409-424
+                hix = min(run_up<NW>(LQH), P.lq_head_len);
+                hix = max(hix, 0);
+                int rd = run_down<NW>(LQT, R.len);
+                if (rd >= R.len && oobT) rd = 0x7FFFFFFF;           // runs off the front: reads '\0'
+                tix = max(min(rd, P.lq_tail_len), 0);
+                if (run_up<NW>(LQH) >= 32 * NW && oobH) hix = max(P.lq_head_len, 0);
+            }
+            if (P.has_polyG) polyg = run_down<NW>(FG, R.len);     // src/read_filter.cpp:472-482
+        }
+        const bool good = lanev && !estat[m];
+        int ada_pos = -1;
+        const int nada = P.n_ada[m];
+        for (int i = 0; i < nada; ++i) {                           // src/read_filter.cpp:175-188
+            const bool todo = good && ada_pos < 0;
+            if (!__any(todo)) break;
+            const int pp = adapter_tile<NW>(P.ada[m * SNK_MAX_ADAPTERS + i], X, XN, R.len, todo,
+                                            seq + (t0 + lane) * (long)B.pitch);
+            if (todo && pp >= 0) ada_pos = pp;
+        }
+        if (ada_pos >= 0) { R.inc_ada = 1; R.adacut = R.len - ada_pos; }
+        if (P.trim_on) trim_finish(P, m, R, hix, tix, polyg);
+    }
+
+    // ---------------------------------------------------------------- pair level
+    const int pe = mates - 1;
+    int ecode = 0, emate = 0;
+    if (estat[0]) { ecode = estat[0]; emate = 0; }
+    else if (pe && estat[1]) { ecode = estat[1]; emate = 1; }
+    else if (equal[0]) { ecode = equal[0]; emate = 0; }
+    else if (pe && equal[1]) { ecode = equal[1]; emate = 1; }
+    if (lanev && ecode) report_err(st, gidx, emate, ecode);
+    const bool live = lanev && !(estat[0] || (pe && estat[1]));
+    int v = 0, reason = SNK_KEEP;
+    if (live) {
+        const int dup = B.dup ? (int)B.dup[t0 + lane] : 0;
+        reason = discard_reason(P, rs[0], rs[pe], dup, v);
+        store_rec(B.out[0], t0 + lane, rs[0], reason, v);
+        if (pe) store_rec(B.out[1], t0 + lane, rs[1], reason, v);
+    }
+    // reason counters: one atomic per (family, tile)
+    {
+        u64 *fs = st.sum;
+        const u64 anyd = __ballot(live && reason != SNK_KEEP);
+        if (anyd) {
+            const int cd = __popcll(__ballot(live && reason == SNK_R_DUP));
+            if (cd && lane == 0) atomicAdd(&fs[SNK_FS_DUP], (u64)cd);
+            const int fam = reason_family(reason);
+#pragma unroll
+            for (int f = SNK_FS_SHORT; f <= SNK_FS_ADAPTER; f += 4) {
+                const u64 bm = __ballot(live && fam == f);
+                if (bm) {
+                    const int c0 = __popcll(bm), c1 = __popcll(__ballot(live && fam == f && (v & 1))),
+                              c2 = __popcll(__ballot(live && fam == f && (v & 2))),
+                              c3 = __popcll(__ballot(live && fam == f && v == 3));
+                    if (lane == 0) {
+                        atomicAdd(&fs[f], (u64)c0);
+                        if (c1) atomicAdd(&fs[f + 1], (u64)c1);
+                        if (c2) atomicAdd(&fs[f + 2], (u64)c2);
+                        if (c3) atomicAdd(&fs[f + 3], (u64)c3);
+                    }
+                }
+            }
+        }
+    }
+    // trimming-position counters (rare), reads_number, last-read key
+    const bool kept = live && reason == SNK_KEEP;
+    const u64 liveM = __ballot(live), keptM = __ballot(kept);
+    for (int m = 0; m < mates; ++m) {
+        u64 *fraw = st.sum + SNK_FS_N + m * fb, *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
+        const ReadState &R = rs[m];
+        if (live && P.copy_back)
+            ts_update(fraw + ts_off, R.hd_h, R.lq_h, R.hd_t, R.lq_t, R.adacut, (pe && m == 1) ? R.len : 0, !pe);
+        if (kept)
+            ts_update(fcl + ts_off, R.hd_h, R.lq_h, R.hd_t, R.lq_t, R.adacut, (pe && m == 1) ? R.clen : R.len, !pe);
+        if (liveM) {
+            const int last = 63 - __clzll((long long)liveM);
+            const int ll = rl(R.len, last);
+            if (lane == 0) {
+                atomicAdd(&fraw[SNK_GS_READS], (u64)__popcll(liveM));
+                atomicMax(&st.maxb[m], ((B.first_index + (u64)(t0 + last) + 1) << 16) | (u64)ll);
+            }
+        }
+        if (keptM) {
+            const int last = 63 - __clzll((long long)keptM);
+            const int ll = rl(R.clen, last);
+            if (lane == 0) {
+                atomicAdd(&fcl[SNK_GS_READS], (u64)__popcll(keptM));
+                atomicMax(&st.maxb[2 + m], ((B.first_index + (u64)(t0 + last) + 1) << 16) | (u64)ll);
+            }
+        }
+    }
+    // ---------------------------------------------------------------- phase 3
+    // clean = raw - removed: only discarded / trimmed reads are walked again
+    for (int m = 0; m < mates; ++m) {
+        const ReadState &R = rs[m];
+        const uint8_t *seq = B.seq[m], *qual = B.qual[m];
+        u32 *remB = lds + (m * 2 + 1) * G.SET, *remQ = remB + G.WB;
+        u64 *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
+        u64 *gbs = fcl + SNK_GS_N, *gqs = fcl + SNK_GS_N + (long)G.lcap * 5;
+        u64 mod = __ballot(live && (reason != SNK_KEEP || R.clen != R.len));
+        while (mod) {
+            const int r = __ffsll((long long)mod) - 1;
+            mod &= mod - 1;
+            const int len_r = rl(R.len, r), clen_r = rl(R.clen, r), start_r = rl(R.start, r);
+            const bool disc = rl(reason, r) != SNK_KEEP;
+            const bool shifted = !disc && start_r > 0;
+            const int rm_lo = (disc || shifted) ? 0 : clen_r;       // removed raw positions [rm_lo, len)
+            const long base = (t0 + r) * (long)B.pitch;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int pos = 64 * s + lane;
+                if (pos < len_r) {
+                    const u32 c = seq[base + pos];
+                    const int q = (int)qual[base + pos] - phred;
+                    const u32 t2 = (c >> 1) & 3u;
+                    const u32 cls = (c & 0xDFu) == 'N' ? 4u : (t2 ^ (t2 >> 1));
+                    if (pos >= rm_lo && (u32)q < (u32)nq) {
+                        atomicAdd(&remB[wb[s] + cls], inc[s]);
+                        atomicAdd(&remQ[wq[s] + q], inc[s]);
+                    }
+                    if (shifted && pos >= start_r && pos < start_r + clen_r && (u32)q < (u32)nq) {
+                        atomicAdd(&gbs[(pos - start_r) * 5 + cls], 1ull);     // head-trimmed survivor: rare
+                        atomicAdd(&gqs[(long)(pos - start_r) * nq + q], 1ull);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NS, bool FULL>
+__global__ void __launch_bounds__(1024)
+snk_tiled_kernel(const DevParams *Pp, DevBatch B, DevStats st, TileGeom G, int iters, int flush_every) {
+    extern __shared__ u32 lds[];
+    const DevParams &P = *Pp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    const int mates = P.paired ? 2 : 1;
+    const int nwords = mates * 2 * G.SET;
+    for (int i = threadIdx.x; i < nwords; i += blockDim.x) lds[i] = 0;
+    __syncthreads();
+    int wb[NS], wq[NS];
+    u32 inc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int p = 64 * s + lane, pm = p >= G.Lh ? p - G.Lh : p;
+        wb[s] = pm * 5;
+        wq[s] = pm * G.nq;
+        inc[s] = p >= G.Lh ? 0x10000u : 1u;
+    }
+    const long GW = (long)gridDim.x * W;
+    const long fb = file_block(G.lcap, G.nq);
+    for (int it = 0; it < iters; ++it) {
+        const long tile = (long)it * GW + (long)blockIdx.x * W + wave;
+        const long t0 = tile * 64;
+        long rem = B.n - t0;
+        const int cnt = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
+        if (cnt > 0) process_tile<NS, FULL>(P, B, st, G, lds, t0, cnt, wb, wq, inc);
+        if ((it + 1) % flush_every == 0 || it + 1 == iters) {
+            __syncthreads();
+            // flush: global raw += raw ; global clean += raw - removed
+            for (int m = 0; m < mates; ++m) {
+                u32 *raw = lds + (m * 2 + 0) * G.SET, *remv = lds + (m * 2 + 1) * G.SET;
+                u64 *fraw = st.sum + SNK_FS_N + m * fb, *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
+                for (int w = threadIdx.x; w < G.SET; w += blockDim.x) {
+                    const u32 a = raw[w], b = remv[w];
+                    if (a | b) {
+                        long off;
+                        int pm;
+                        if (w < G.WB) { pm = w / 5; off = SNK_GS_N + (long)(w - pm * 5); }
+                        else { const int ww = w - G.WB; pm = ww / G.nq; off = SNK_GS_N + (long)G.lcap * 5 + (ww - pm * G.nq); }
+                        const long stride = w < G.WB ? 5 : G.nq;
+                        const u32 alo = a & 0xFFFFu, blo = b & 0xFFFFu, ahi = a >> 16, bhi = b >> 16;
+                        if (alo) atomicAdd(&fraw[off + pm * stride], (u64)alo);
+                        if (alo != blo) atomicAdd(&fcl[off + pm * stride], (u64)alo - (u64)blo);
+                        if (ahi) atomicAdd(&fraw[off + (pm + G.Lh) * stride], (u64)ahi);
+                        if (ahi != bhi) atomicAdd(&fcl[off + (pm + G.Lh) * stride], (u64)ahi - (u64)bhi);
+                        raw[w] = 0;
+                        remv[w] = 0;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int NS, bool FULL>
+int launch(const DevParams *dp, const DevBatch &b, const DevStats &st, const TileGeom &G, int n_cu, void *stream) {
+    const size_t shmem = (size_t)2 * 2 * G.SET * sizeof(u32);
+    static bool attr_done = false;
+    auto kern = snk_tiled_kernel<NS, FULL>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        attr_done = true;
+    }
+    const int W = 16;
+    const long tiles = (b.n + 63) / 64;
+    long wgs = (tiles + W - 1) / W;
+    if (wgs > n_cu) wgs = n_cu;
+    const long GW = wgs * W;
+    const int iters = (int)((tiles + GW - 1) / GW);
+    const int flush_every = 65535 / (W * 64);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(W * 64), shmem, (hipStream_t)stream, dp, b, st, G, iters,
+                       flush_every);
+    return 1;
+}
+
+}  // namespace
+
+int snk_launch_tiled(const DevParams *dp_dev, const DevParams &hp, const DevBatch &b, const DevStats &st,
+                     int lcap, int nq, int n_cu, void *stream) {
+    if (!hp.tile_ok || lcap > 256 || b.n <= 0) return 0;
+    TileGeom G;
+    G.lcap = lcap;
+    G.nq = nq;
+    G.Lh = (lcap + 1) / 2 < 64 ? 64 : (lcap + 1) / 2;
+    G.WB = G.Lh * 5;
+    G.WQ = G.Lh * nq;
+    G.SET = G.WB + G.WQ;
+    if ((size_t)2 * 2 * G.SET * sizeof(u32) > 160 * 1024) return 0;
+    const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq;
+    const int ns = (lcap + 63) / 64;
+#define SNK_GO(NS_)                                                                    \
+    return full ? launch<NS_, true>(dp_dev, b, st, G, n_cu, stream)                    \
+                : launch<NS_, false>(dp_dev, b, st, G, n_cu, stream);
+    switch (ns) {
+    case 1: SNK_GO(1)
+    case 2: SNK_GO(2)
+    case 3: SNK_GO(3)
+    default: SNK_GO(4)
+    }
+#undef SNK_GO
+}
