@@ -116,10 +116,9 @@ class FilterContext:
     def allreduce(self):
         """Sum/max all-reduce of the accumulators over torch.distributed (RCCL on GPUs):
         the only collective of this path."""
-        import torch.distributed as dist
+        from .shard import allreduce_stats
         self.finalize()
-        dist.all_reduce(self.sum, op=dist.ReduceOp.SUM)
-        dist.all_reduce(self.max, op=dist.ReduceOp.MAX)
+        allreduce_stats(self.sum, self.max)
 
 
 def records_to_numpy(rec):

@@ -71,3 +71,20 @@ def test_adapter_pos_fuzz():
         assert a == b, (it, read.tobytes(), ada.tobytes(), mis, mr, edge, a, b)
         n_hit += a >= 0
     assert n_hit > 5000
+
+
+def test_lowercase_reads():
+    """a/c/g/t/n count like upper case (src/read_filter.cpp:272-281) but never match an
+    upper-case adapter character nor extend a polyX run of the other case (:261,:728)."""
+    d = synth.make_batch(3000, 150, paired=True, seed=14)
+    rng = np.random.default_rng(3)
+    rows = rng.choice(3000, 500, replace=False)
+    for m in range(2):
+        blk = d["seq"][m][rows, :150]
+        d["seq"][m][rows, :150] = np.where(rng.random(blk.shape) < 0.3, blk | 0x20, blk)
+    _compare(abi.default_params(paired=True, max_read_len=150, **PE_CASES["C3_full"]), d, True)
+
+
+def test_capacity_larger_than_reads():
+    d = synth.make_batch(2000, 100, paired=True, var_len=True, seed=15)
+    _compare(abi.default_params(paired=True, max_read_len=300, **PE_CASES["hard_lq_trim"]), d, True)
