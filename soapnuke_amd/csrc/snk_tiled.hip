@@ -174,7 +174,7 @@ struct Planes4 { };
 
 // Adapter search for the lanes with `todo`; returns the position or -1.
 // X[k] bit p = read[p] == "ACGT"[k] (exact), ones beyond the read; XN likewise for 'N'.
-template <int NW>
+template <int NW, bool FULL>
 __device__ int adapter_tile(const DevAdapter &A, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len,
                             bool todo, const uint8_t *sptr) {
     const int al = A.len, S = max(A.S, 1), edge = A.edge, mis = A.mis;
@@ -184,84 +184,104 @@ __device__ int adapter_tile(const DevAdapter &A, const u32 (&X)[4][NW], const u3
         result = adapter_pos_seq(sptr, len, A);
         done = true;
     }
-    const u64 cm0 = A.cmask[0], cm1 = A.cmask[1], cm2 = A.cmask[2], cm3 = A.cmask[3], cmn = A.nmask;
-    // ---------------- phase A (src/read_filter.cpp:720-742): adapter[r1..] on read[0..]
+    const u64 cm0 = A.cmask[0], cm1 = A.cmask[1], cm2 = A.cmask[2], cm3 = A.cmask[3];
+    const u64 cmn = FULL ? A.nmask : 0ull;
+    // ---------------- phase A (src/read_filter.cpp:720-742): adapter[r1..] on read[0..].
+    // Quick screen only (mismatches inside the first S-1 steps); survivors are queued in `pa`.
+    u32 pa = 0;
     {
         const u64 x0 = ((u64)X[0][1] << 32) | X[0][0], x1 = ((u64)X[1][1] << 32) | X[1][0];
         const u64 x2 = ((u64)X[2][1] << 32) | X[2][0], x3 = ((u64)X[3][1] << 32) | X[3][0];
-        const u64 xn = ((u64)XN[1] << 32) | XN[0];
+        const u64 xn = FULL ? (((u64)XN[1] << 32) | XN[0]) : 0ull;
         for (int r1 = 1; r1 <= 5; ++r1) {
             const int n = al - r1, budget = A.budgetA[r1];
             const u64 m = ((x0 & (cm0 >> r1)) | (x1 & (cm1 >> r1)) | (x2 & (cm2 >> r1)) | (x3 & (cm3 >> r1)) |
-                           (xn & (cmn >> r1))) & lowmask64(n);
+                           (xn & (cmn >> r1)));
             const u64 zz = ~m & lowmask64(min(n, S - 1));
-            const bool maybe = __popcll(zz) <= max(budget, 0);
-            if (!done && maybe && accept_exact(m, n, S, budget)) { result = 0; done = true; }
+            if (__popcll(zz) <= max(budget, 0)) pa |= 1u << r1;
         }
+        if (done) pa = 0;
     }
-    if (!__any(!done)) return result;
     // ---------------- phases B+C screening: candidates p = 0 .. len-edge, bit-sliced
-    u32 C1[NW], C2[NW], C3[NW], C4[NW], BY[NW];
+    u32 aliveB[NW], aliveC[NW];
+    if (__any(!done)) {
+        u32 C1[NW], C2[NW], C3[NW], C4[NW], BY[NW];
 #pragma unroll
-    for (int j = 0; j < NW; ++j) { C1[j] = C2[j] = C3[j] = C4[j] = 0; BY[j] = ~lowmask32(len - 32 * j); }
-    const int steps = min(S - 1, al);
-    for (int c = 0; c < steps; ++c) {
-        const int code = A.code[c], cr = c & 31;
+        for (int j = 0; j < NW; ++j) { C1[j] = C2[j] = C3[j] = C4[j] = 0; BY[j] = ~lowmask32(len - 32 * j); }
+        const int steps = min(S - 1, al);
+        for (int c = 0; c < steps; ++c) {
+            const int code = A.code[c], cr = c & 31;
 #define SNK_STEP(PL)                                                         \
     if (c < 32) screen_step<NW, 0>(PL, cr, C1, C2, C3, C4);                  \
     else screen_step<NW, 1>(PL, cr, C1, C2, C3, C4);
-        switch (code) {
-        case 0: SNK_STEP(X[0]) break;
-        case 1: SNK_STEP(X[1]) break;
-        case 2: SNK_STEP(X[2]) break;
-        case 3: SNK_STEP(X[3]) break;
-        case 5: SNK_STEP(XN) break;
-        default: SNK_STEP(BY) break;       // matches nothing inside the read
-        }
-#undef SNK_STEP
-    }
-    // budgets as thermometer planes T_k = [budget >= k]; reject = mis count > budget
-    u32 aliveB[NW], aliveC[NW];
-    const int rk1 = A.rk[1], rk2 = A.rk[2], rk3 = A.rk[3];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-        const u32 valid = lowmask32(len - edge + 1 - 32 * j);
-        const u32 bm = lowmask32(len - al + 1 - 32 * j);                    // phase B region
-        const u32 t1 = lowmask32(len - edge - rk1 + 1 - 32 * j) & (mis >= 1 ? 0xFFFFFFFFu : ~bm);
-        const u32 t2 = lowmask32(len - edge - rk2 + 1 - 32 * j) & (mis >= 2 ? 0xFFFFFFFFu : ~bm);
-        const u32 t3 = lowmask32(len - edge - rk3 + 1 - 32 * j) & (mis >= 3 ? 0xFFFFFFFFu : ~bm);
-        const u32 rej = (C1[j] & ~t1) | (C2[j] & ~t2) | (C3[j] & ~t3) | C4[j];
-        const u32 alive = done ? 0u : (valid & ~rej);
-        aliveB[j] = alive & bm;
-        aliveC[j] = alive & ~bm;
-    }
-    // ---------------- phase B (:743-764): ascending offset, first accepted wins
-    while (__any(!done && any_bit(aliveB))) {
-        if (!done && any_bit(aliveB)) {
-            const int p = lowest_bit(aliveB);
-            const u64 m = (window64(X[0], p, ~0u) & cm0) | (window64(X[1], p, ~0u) & cm1) |
-                          (window64(X[2], p, ~0u) & cm2) | (window64(X[3], p, ~0u) & cm3) |
-                          (window64(XN, p, ~0u) & cmn);
-            if (accept_exact(m, al, S, mis)) { result = p; done = true; }
-            else clear_bit(aliveB, p);
-        }
-    }
-    // ---------------- phase C (:765-788): ascending r1 == descending offset
-    while (__any(!done && any_bit(aliveC))) {
-        if (!done && any_bit(aliveC)) {
-            const int p = highest_bit(aliveC);
-            const int n = len - p;                                   // compared length, edge <= n < al
-            bool ok;
-            if (n < S) {
-                ok = !A.negC;                                        // no run possible: survived <=> mis <= budget
-            } else {
-                const u64 m = (window64(X[0], p, ~0u) & cm0) | (window64(X[1], p, ~0u) & cm1) |
-                              (window64(X[2], p, ~0u) & cm2) | (window64(X[3], p, ~0u) & cm3) |
-                              (window64(XN, p, ~0u) & cmn);
-                ok = accept_exact(m, n, S, A.budgetC[n - edge]);
+            switch (code) {
+            case 0: SNK_STEP(X[0]) break;
+            case 1: SNK_STEP(X[1]) break;
+            case 2: SNK_STEP(X[2]) break;
+            case 3: SNK_STEP(X[3]) break;
+            case 5: if (FULL) { SNK_STEP(XN) } else { SNK_STEP(BY) } break;
+            default: SNK_STEP(BY) break;       // matches nothing inside the read
             }
-            if (ok) { result = p; done = true; }
-            else clear_bit(aliveC, p);
+#undef SNK_STEP
+        }
+        // budgets as thermometer planes T_k = [budget >= k]; reject = mis count > budget
+        const int rk1 = A.rk[1], rk2 = A.rk[2], rk3 = A.rk[3];
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const u32 valid = lowmask32(len - edge + 1 - 32 * j);
+            const u32 bm = lowmask32(len - al + 1 - 32 * j);                    // phase B region
+            const u32 t1 = lowmask32(len - edge - rk1 + 1 - 32 * j) & (mis >= 1 ? 0xFFFFFFFFu : ~bm);
+            const u32 t2 = lowmask32(len - edge - rk2 + 1 - 32 * j) & (mis >= 2 ? 0xFFFFFFFFu : ~bm);
+            const u32 t3 = lowmask32(len - edge - rk3 + 1 - 32 * j) & (mis >= 3 ? 0xFFFFFFFFu : ~bm);
+            const u32 rej = (C1[j] & ~t1) | (C2[j] & ~t2) | (C3[j] & ~t3) | C4[j];
+            const u32 alive = done ? 0u : (valid & ~rej);
+            aliveB[j] = alive & bm;
+            aliveC[j] = alive & ~bm;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) aliveB[j] = aliveC[j] = 0;
+    }
+    // ---------------- exact decision of the survivors, in the reference's order:
+    // phase A r1 = 1..5 (-> 0), phase B ascending offset (:743-764), phase C ascending r1 ==
+    // descending offset (:765-788).  One candidate per lane per trip; trips are rare.
+    while (__any(!done && (pa != 0 || any_bit(aliveB) || any_bit(aliveC)))) {
+        if (!done) {
+            int p = 0, sh = 0, n = 0, budget = 0, res = 0;
+            bool have = true, skip_eval = false, skip_ok = false;
+            if (pa) {
+                sh = __ffs((int)pa) - 1;
+                pa &= pa - 1;
+                n = al - sh;
+                budget = sh == 1 ? A.budgetA[1] : sh == 2 ? A.budgetA[2] : sh == 3 ? A.budgetA[3]
+                         : sh == 4 ? A.budgetA[4] : A.budgetA[5];
+                res = 0;
+            } else if (any_bit(aliveB)) {
+                p = lowest_bit(aliveB);
+                clear_bit(aliveB, p);
+                n = al;
+                budget = mis;
+                res = p;
+            } else if (any_bit(aliveC)) {
+                p = highest_bit(aliveC);
+                clear_bit(aliveC, p);
+                n = len - p;                                         // compared length, edge <= n < al
+                res = p;
+                if (n < S) { skip_eval = true; skip_ok = !A.negC; }  // no run possible: survived <=> mis <= budget
+                else budget = A.budgetC[n - edge];
+            } else {
+                have = false;
+            }
+            if (have) {
+                bool ok = skip_ok;
+                if (!skip_eval) {
+                    u64 m = (window64(X[0], p, ~0u) & (cm0 >> sh)) | (window64(X[1], p, ~0u) & (cm1 >> sh)) |
+                            (window64(X[2], p, ~0u) & (cm2 >> sh)) | (window64(X[3], p, ~0u) & (cm3 >> sh));
+                    if (FULL) m |= window64(XN, p, ~0u) & (cmn >> sh);
+                    ok = accept_exact(m, n, S, budget);
+                }
+                if (ok) { result = res; done = true; }
+            }
         }
     }
     return result;
@@ -272,11 +292,10 @@ struct TileGeom {
 };
 
 // One tile = up to 64 pairs starting at t0, processed by one wave.
-template <int NS, bool FULL>
+template <int NW, bool FULL>
 __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevStats &st, const TileGeom &G,
-                             u32 *lds, long t0, int cnt, const int (&wb)[NS], const int (&wq)[NS],
-                             const u32 (&inc)[NS]) {
-    constexpr int NW = 2 * NS;
+                             u32 *lds, long t0, int cnt, const int (&pmv)[(NW + 1) / 2], const u32 (&inc)[(NW + 1) / 2]) {
+    constexpr int NS = (NW + 1) / 2;
     const int lane = threadIdx.x & 63;
     const int mates = P.paired ? 2 : 1;
     const int phred = P.phred, nq = G.nq, lowQ = P.low_qual;
@@ -289,7 +308,9 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
     int estat[2] = {0, 0}, equal[2] = {0, 0};
     const bool oobH = (0 - phred) < P.lq_head_q, oobT = (0 - phred) < P.lq_tail_q;
 
-    for (int m = 0; m < mates; ++m) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {       // static mate index: rs[]/estat[] must stay in registers
+        if (m >= mates) continue;
         const uint8_t *seq = B.seq[m], *qual = B.qual[m];
         u32 *rawB = lds + (m * 2 + 0) * G.SET, *rawQ = rawB + G.WB;
         int mylen = 0;
@@ -303,12 +324,29 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
             FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
         }
         int v_na = 0, v_nn = 0, v_lowq = 0, v_sumq = 0, v_err = 0;
+        // strip loads run one read ahead of the ballots (the whole tile is a dependent chain
+        // otherwise); addresses are clamped into the read's pitch slot instead of predicated
+        u32 offc[NS], nc[NS], nqb[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) offc[s] = (u32)min(64 * s + lane, B.pitch - 1);
+        {
+            const uint8_t *sp = seq + t0 * (long)B.pitch, *qp = qual + t0 * (long)B.pitch;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
+        }
         for (int r = 0; r < cnt; ++r) {
+            u32 cc[NS], cq[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { cc[s] = nc[s]; cq[s] = nqb[s]; }
+            if (r + 1 < cnt) {
+                const uint8_t *sp = seq + (t0 + r + 1) * (long)B.pitch, *qp = qual + (t0 + r + 1) * (long)B.pitch;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
+            }
             int len_r = rl(mylen, r);
             int e = 0, eq = 0;
             if (len_r > G.lcap) { e = SNK_E_TOO_LONG; len_r = G.lcap; }
             if (len_r == 0) e = SNK_E_EMPTY_SEQ;
-            const long base = (t0 + r) * (long)B.pitch;
             int nA = 0, nN = 0, nLow = 0, qsum = 0;
             u32 prev_last = 0xFFFFFFFFu;
 #pragma unroll
@@ -316,8 +354,7 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
                 const int pos = 64 * s + lane;
                 const bool valid = pos < len_r;
                 const u64 vm = lowmask64(len_r - 64 * s);
-                u32 c = 0, qb = 0;
-                if (valid) { c = seq[base + pos]; qb = qual[base + pos]; }
+                const u32 c = valid ? cc[s] : 0u, qb = valid ? cq[s] : 0u;
                 const u64 bA = __ballot(c == 'A'), bC = __ballot(c == 'C'), bG = __ballot(c == 'G'),
                           bT = __ballot(c == 'T'), bN = __ballot(c == 'N');
                 u64 fA = bA, fN = bN, fG = bG;
@@ -332,14 +369,16 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
                 nA += __popcll(fA);
                 nN += __popcll(fN);
                 const u64 by = ~vm;                          // beyond the read: matches anything
-                X[0][2 * s] = wl(X[0][2 * s], (int)(u32)(bA | by), r);
-                X[0][2 * s + 1] = wl(X[0][2 * s + 1], (int)(u32)((bA | by) >> 32), r);
-                X[1][2 * s] = wl(X[1][2 * s], (int)(u32)(bC | by), r);
-                X[1][2 * s + 1] = wl(X[1][2 * s + 1], (int)(u32)((bC | by) >> 32), r);
-                X[2][2 * s] = wl(X[2][2 * s], (int)(u32)(bG | by), r);
-                X[2][2 * s + 1] = wl(X[2][2 * s + 1], (int)(u32)((bG | by) >> 32), r);
-                X[3][2 * s] = wl(X[3][2 * s], (int)(u32)(bT | by), r);
-                X[3][2 * s + 1] = wl(X[3][2 * s + 1], (int)(u32)((bT | by) >> 32), r);
+#define SNK_PUT(PL, VAL)                                                                   \
+    {                                                                                      \
+        const u64 val_ = (VAL);                                                            \
+        PL[2 * s] = wl(PL[2 * s], (int)(u32)val_, r);                                      \
+        if (2 * s + 1 < NW) PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = wl(PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0], (int)(u32)(val_ >> 32), r); \
+    }
+                SNK_PUT(X[0], bA | by)
+                SNK_PUT(X[1], bC | by)
+                SNK_PUT(X[2], bG | by)
+                SNK_PUT(X[3], bT | by)
                 const int q = (int)qb - phred;
                 const u64 low = __ballot(q <= lowQ) & vm;
                 nLow += __popcll(low);
@@ -347,37 +386,28 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
                 if ((__ballot(!qok) & vm) != 0) eq = SNK_E_QUAL_RANGE;
                 if (P.has_meanq) qsum += valid ? q : 0;
                 if (FULL) {
-                    if (P.need_n) {
-                        XN[2 * s] = wl(XN[2 * s], (int)(u32)(bN | by), r);
-                        XN[2 * s + 1] = wl(XN[2 * s + 1], (int)(u32)((bN | by) >> 32), r);
-                    }
-                    if (P.has_polyG) {
-                        FG[2 * s] = wl(FG[2 * s], (int)(u32)fG, r);
-                        FG[2 * s + 1] = wl(FG[2 * s + 1], (int)(u32)(fG >> 32), r);
-                    }
+                    if (P.need_n) SNK_PUT(XN, bN | by)
+                    if (P.has_polyG) SNK_PUT(FG, fG)
                     if (P.polyX_num != -1) {
                         u32 pc = __shfl_up(c, 1);
                         if (lane == 0) pc = prev_last;
                         const u64 eqm = __ballot(c == pc) & vm;
                         prev_last = (u32)rl((int)c, 63);
-                        EQ[2 * s] = wl(EQ[2 * s], (int)(u32)eqm, r);
-                        EQ[2 * s + 1] = wl(EQ[2 * s + 1], (int)(u32)(eqm >> 32), r);
+                        SNK_PUT(EQ, eqm)
                     }
                     if (P.has_lq) {
                         const u64 h = __ballot(valid ? (q < P.lq_head_q) : oobH);
                         const u64 t = __ballot(valid ? (q < P.lq_tail_q) : oobT);
-                        LQH[2 * s] = wl(LQH[2 * s], (int)(u32)h, r);
-                        LQH[2 * s + 1] = wl(LQH[2 * s + 1], (int)(u32)(h >> 32), r);
-                        LQT[2 * s] = wl(LQT[2 * s], (int)(u32)t, r);
-                        LQT[2 * s + 1] = wl(LQT[2 * s + 1], (int)(u32)(t >> 32), r);
+                        SNK_PUT(LQH, h)
+                        SNK_PUT(LQT, t)
                     }
                 }
                 // raw per-position histograms (src/peprocess.cpp:1145-1201)
                 if (valid && qok) {
                     const u32 t2 = (c >> 1) & 3u;
                     const u32 cls = (c & 0xDFu) == 'N' ? 4u : (t2 ^ (t2 >> 1));
-                    atomicAdd(&rawB[wb[s] + cls], inc[s]);
-                    atomicAdd(&rawQ[wq[s] + q], inc[s]);
+                    atomicAdd(&rawB[cls * G.Lh + pmv[s]], inc[s]);
+                    atomicAdd(&rawQ[q * G.Lh + pmv[s]], inc[s]);
                 }
             }
             if (P.has_meanq) qsum = wave_sum(qsum);
@@ -429,7 +459,7 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
         for (int i = 0; i < nada; ++i) {                           // src/read_filter.cpp:175-188
             const bool todo = good && ada_pos < 0;
             if (!__any(todo)) break;
-            const int pp = adapter_tile<NW>(P.ada[m * SNK_MAX_ADAPTERS + i], X, XN, R.len, todo,
+            const int pp = adapter_tile<NW, FULL>(P.ada[m * SNK_MAX_ADAPTERS + i], X, XN, R.len, todo,
                                             seq + (t0 + lane) * (long)B.pitch);
             if (todo && pp >= 0) ada_pos = pp;
         }
@@ -449,7 +479,7 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
     int v = 0, reason = SNK_KEEP;
     if (live) {
         const int dup = B.dup ? (int)B.dup[t0 + lane] : 0;
-        reason = discard_reason(P, rs[0], rs[pe], dup, v);
+        reason = pe ? discard_reason(P, rs[0], rs[1], dup, v) : discard_reason(P, rs[0], rs[0], dup, v);
         store_rec(B.out[0], t0 + lane, rs[0], reason, v);
         if (pe) store_rec(B.out[1], t0 + lane, rs[1], reason, v);
     }
@@ -481,7 +511,9 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
     // trimming-position counters (rare), reads_number, last-read key
     const bool kept = live && reason == SNK_KEEP;
     const u64 liveM = __ballot(live), keptM = __ballot(kept);
-    for (int m = 0; m < mates; ++m) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (m >= mates) continue;
         u64 *fraw = st.sum + SNK_FS_N + m * fb, *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
         const ReadState &R = rs[m];
         if (live && P.copy_back)
@@ -507,7 +539,9 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
     }
     // ---------------------------------------------------------------- phase 3
     // clean = raw - removed: only discarded / trimmed reads are walked again
-    for (int m = 0; m < mates; ++m) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (m >= mates) continue;
         const ReadState &R = rs[m];
         const uint8_t *seq = B.seq[m], *qual = B.qual[m];
         u32 *remB = lds + (m * 2 + 1) * G.SET, *remQ = remB + G.WB;
@@ -531,8 +565,8 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
                     const u32 t2 = (c >> 1) & 3u;
                     const u32 cls = (c & 0xDFu) == 'N' ? 4u : (t2 ^ (t2 >> 1));
                     if (pos >= rm_lo && (u32)q < (u32)nq) {
-                        atomicAdd(&remB[wb[s] + cls], inc[s]);
-                        atomicAdd(&remQ[wq[s] + q], inc[s]);
+                        atomicAdd(&remB[cls * G.Lh + pmv[s]], inc[s]);
+                        atomicAdd(&remQ[q * G.Lh + pmv[s]], inc[s]);
                     }
                     if (shifted && pos >= start_r && pos < start_r + clen_r && (u32)q < (u32)nq) {
                         atomicAdd(&gbs[(pos - start_r) * 5 + cls], 1ull);     // head-trimmed survivor: rare
@@ -544,23 +578,25 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
     }
 }
 
-template <int NS, bool FULL>
+template <int NW, bool FULL>
 __global__ void __launch_bounds__(1024)
 snk_tiled_kernel(const DevParams *Pp, DevBatch B, DevStats st, TileGeom G, int iters, int flush_every) {
     extern __shared__ u32 lds[];
     const DevParams &P = *Pp;
+    constexpr int NS = (NW + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
     const int mates = P.paired ? 2 : 1;
     const int nwords = mates * 2 * G.SET;
     for (int i = threadIdx.x; i < nwords; i += blockDim.x) lds[i] = 0;
     __syncthreads();
-    int wb[NS], wq[NS];
+    // LDS histogram word of (position p, bin b) = b*Lh + (p mod Lh); high half-word when p >= Lh.
+    // Lh is a multiple of 32, so the 32 lanes of one ds_add group always hit 32 different banks.
+    int pmv[NS];
     u32 inc[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int p = 64 * s + lane, pm = p >= G.Lh ? p - G.Lh : p;
-        wb[s] = pm * 5;
-        wq[s] = pm * G.nq;
+        const int p = 64 * s + lane;
+        pmv[s] = p >= G.Lh ? p - G.Lh : p;
         inc[s] = p >= G.Lh ? 0x10000u : 1u;
     }
     const long GW = (long)gridDim.x * W;
@@ -570,7 +606,7 @@ snk_tiled_kernel(const DevParams *Pp, DevBatch B, DevStats st, TileGeom G, int i
         const long t0 = tile * 64;
         long rem = B.n - t0;
         const int cnt = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-        if (cnt > 0) process_tile<NS, FULL>(P, B, st, G, lds, t0, cnt, wb, wq, inc);
+        if (cnt > 0) process_tile<NW, FULL>(P, B, st, G, lds, t0, cnt, pmv, inc);
         if ((it + 1) % flush_every == 0 || it + 1 == iters) {
             __syncthreads();
             // flush: global raw += raw ; global clean += raw - removed
@@ -582,8 +618,8 @@ snk_tiled_kernel(const DevParams *Pp, DevBatch B, DevStats st, TileGeom G, int i
                     if (a | b) {
                         long off;
                         int pm;
-                        if (w < G.WB) { pm = w / 5; off = SNK_GS_N + (long)(w - pm * 5); }
-                        else { const int ww = w - G.WB; pm = ww / G.nq; off = SNK_GS_N + (long)G.lcap * 5 + (ww - pm * G.nq); }
+                        if (w < G.WB) { const int bin = w / G.Lh; pm = w - bin * G.Lh; off = SNK_GS_N + (long)bin; }
+                        else { const int ww = w - G.WB, bin = ww / G.Lh; pm = ww - bin * G.Lh; off = SNK_GS_N + (long)G.lcap * 5 + bin; }
                         const long stride = w < G.WB ? 5 : G.nq;
                         const u32 alo = a & 0xFFFFu, blo = b & 0xFFFFu, ahi = a >> 16, bhi = b >> 16;
                         if (alo) atomicAdd(&fraw[off + pm * stride], (u64)alo);
@@ -600,11 +636,11 @@ snk_tiled_kernel(const DevParams *Pp, DevBatch B, DevStats st, TileGeom G, int i
     }
 }
 
-template <int NS, bool FULL>
+template <int NW, bool FULL>
 int launch(const DevParams *dp, const DevBatch &b, const DevStats &st, const TileGeom &G, int n_cu, void *stream) {
     const size_t shmem = (size_t)2 * 2 * G.SET * sizeof(u32);
     static bool attr_done = false;
-    auto kern = snk_tiled_kernel<NS, FULL>;
+    auto kern = snk_tiled_kernel<NW, FULL>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
@@ -630,21 +666,20 @@ int snk_launch_tiled(const DevParams *dp_dev, const DevParams &hp, const DevBatc
     TileGeom G;
     G.lcap = lcap;
     G.nq = nq;
-    G.Lh = (lcap + 1) / 2 < 64 ? 64 : (lcap + 1) / 2;
+    G.Lh = (lcap + 1) / 2 < 64 ? 64 : ((lcap + 1) / 2 + 31) / 32 * 32;
     G.WB = G.Lh * 5;
     G.WQ = G.Lh * nq;
     G.SET = G.WB + G.WQ;
     if ((size_t)2 * 2 * G.SET * sizeof(u32) > 160 * 1024) return 0;
     const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq;
-    const int ns = (lcap + 63) / 64;
-#define SNK_GO(NS_)                                                                    \
-    return full ? launch<NS_, true>(dp_dev, b, st, G, n_cu, stream)                    \
-                : launch<NS_, false>(dp_dev, b, st, G, n_cu, stream);
-    switch (ns) {
-    case 1: SNK_GO(1)
-    case 2: SNK_GO(2)
-    case 3: SNK_GO(3)
-    default: SNK_GO(4)
-    }
+    const int nw = (lcap + 31) / 32;        // dwords per bit plane
+#define SNK_GO(NW_)                                                                    \
+    return full ? launch<NW_, true>(dp_dev, b, st, G, n_cu, stream)                    \
+                : launch<NW_, false>(dp_dev, b, st, G, n_cu, stream);
+    if (nw <= 2) { SNK_GO(2) }
+    else if (nw <= 4) { SNK_GO(4) }
+    else if (nw <= 5) { SNK_GO(5) }
+    else if (nw <= 6) { SNK_GO(6) }
+    else { SNK_GO(8) }
 #undef SNK_GO
 }
