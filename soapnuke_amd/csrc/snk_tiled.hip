@@ -289,7 +289,13 @@ __device__ int adapter_tile(const DevAdapter &A, const u32 (&X)[4][NW], const u3
 
 struct TileGeom {
     int lcap, nq, Lh, WB, WQ, SET;
+    // LDS staging of the read bytes (global_load_lds, 16 B/lane): per wave 2 buffers x
+    // {bases, qualities} x cba bytes, a chunk = rb consecutive reads.  rb == 0: disabled.
+    int rb, nd, cba, stg_off, stg_wave;
 };
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
 // One tile = up to 64 pairs starting at t0, processed by one wave.
 template <int NW, bool FULL>
@@ -315,114 +321,199 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
         u32 *rawB = lds + (m * 2 + 0) * G.SET, *rawQ = rawB + G.WB;
         int mylen = 0;
         if (lanev) mylen = B.len[m] ? (int)B.len[m][t0 + lane] : B.fixed_len[m];
+        const int clen_v = min(mylen, G.lcap);
         // ------------------------------------------------------------ phase 1
-        u32 X[4][NW], XN[NW], FG[NW], EQ[NW], LQH[NW], LQT[NW];
+        // Raw ballots go straight into the planes (bits beyond a read's length are garbage
+        // and are masked per lane in phase 2); everything per-read that can be derived from
+        // the planes later (base counts, low-quality count, error checks) is NOT done on the
+        // scalar unit here -- phase 1 is scalar-issue bound otherwise.
+        u32 X[4][NW], LQ[NW], XN[NW], FG[NW], EQ[NW], LQH[NW], LQT[NW];
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            X[0][j] = X[1][j] = X[2][j] = X[3][j] = 0xFFFFFFFFu;
-            XN[j] = 0xFFFFFFFFu;
-            FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
+            X[0][j] = X[1][j] = X[2][j] = X[3][j] = 0;
+            LQ[j] = XN[j] = FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
         }
-        int v_na = 0, v_nn = 0, v_lowq = 0, v_sumq = 0, v_err = 0;
-        // strip loads run one read ahead of the ballots (the whole tile is a dependent chain
-        // otherwise); addresses are clamped into the read's pitch slot instead of predicated
-        u32 offc[NS], nc[NS], nqb[NS];
+        int v_adja = 0, v_nn = 0, v_bad = 0, v_sumq = 0;
+        u32 qmax = 0;                                 // sticky max of the quality values this lane saw
+        const int len0 = rl(clen_v, 0);
+        const bool fixed = __all(!lanev || clen_v == len0);
+        u64 vmf[NS];
+        u32 offc[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) offc[s] = (u32)min(64 * s + lane, B.pitch - 1);
-        {
-            const uint8_t *sp = seq + t0 * (long)B.pitch, *qp = qual + t0 * (long)B.pitch;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
+        for (int s = 0; s < NS; ++s) {
+            offc[s] = (u32)min(64 * s + lane, B.pitch - 1);
+            vmf[s] = lowmask64(len0 - 64 * s);
         }
-        for (int r = 0; r < cnt; ++r) {
-            u32 cc[NS], cq[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) { cc[s] = nc[s]; cq[s] = nqb[s]; }
-            if (r + 1 < cnt) {
-                const uint8_t *sp = seq + (t0 + r + 1) * (long)B.pitch, *qp = qual + (t0 + r + 1) * (long)B.pitch;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
-            }
-            int len_r = rl(mylen, r);
-            int e = 0, eq = 0;
-            if (len_r > G.lcap) { e = SNK_E_TOO_LONG; len_r = G.lcap; }
-            if (len_r == 0) e = SNK_E_EMPTY_SEQ;
-            int nA = 0, nN = 0, nLow = 0, qsum = 0;
+        const u32 rawBw = (u32)((m * 2 + 0) * G.SET), rawQw = rawBw + (u32)G.WB;
+        const u32 dumW = (u32)(4 * G.SET) + (u32)lane;   // per-lane scratch word for lanes past the read end
+        const u32 nqm1 = (u32)(nq - 1);
+        auto do_read = [&](const int r, const u32 (&cc)[NS], const u32 (&cq)[NS]) {
+            const int len_r = fixed ? len0 : rl(clen_v, r);
+            int qsum = 0;
+            int adjA = 0, nN = 0, bad = 0;
+            bool slow = false;
             u32 prev_last = 0xFFFFFFFFu;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int pos = 64 * s + lane;
                 const bool valid = pos < len_r;
-                const u64 vm = lowmask64(len_r - 64 * s);
-                const u32 c = valid ? cc[s] : 0u, qb = valid ? cq[s] : 0u;
+                const u64 vm = fixed ? vmf[s] : lowmask64(len_r - 64 * s);
+                const u32 c = cc[s];
                 const u64 bA = __ballot(c == 'A'), bC = __ballot(c == 'C'), bG = __ballot(c == 'G'),
-                          bT = __ballot(c == 'T'), bN = __ballot(c == 'N');
-                u64 fA = bA, fN = bN, fG = bG;
-                if ((bA | bC | bG | bT | bN) != vm) {       // lower case or garbage in this strip (rare)
+                          bT = __ballot(c == 'T');
+                u64 fG = bG, bN = 0;
+                bool strip_slow = false;
+                if ((vm & ~(bA | bC | bG | bT)) != 0) {      // N, lower case or garbage inside the read (rare)
                     const u32 cu = c & 0xDFu;
-                    fA = __ballot(cu == 'A');
-                    fG = __ballot(cu == 'G');
-                    fN = __ballot(cu == 'N');
-                    const u64 fC = __ballot(cu == 'C'), fT = __ballot(cu == 'T');
-                    if ((fA | fC | fG | fT | fN) != vm && !e) e = SNK_E_BAD_BASE;
+                    const u64 fA = __ballot(cu == 'A') & vm, fC = __ballot(cu == 'C') & vm,
+                              fT = __ballot(cu == 'T') & vm, fN = __ballot(cu == 'N') & vm;
+                    fG = __ballot(cu == 'G') & vm;
+                    bN = __ballot(c == 'N');
+                    if ((fA | fC | fG | fT | fN) != vm) bad = 1;
+                    adjA += __popcll(fA) - __popcll(bA & vm);
+                    nN += __popcll(fN);
+                    slow = true;
+                    strip_slow = true;
                 }
-                nA += __popcll(fA);
-                nN += __popcll(fN);
-                const u64 by = ~vm;                          // beyond the read: matches anything
 #define SNK_PUT(PL, VAL)                                                                   \
     {                                                                                      \
         const u64 val_ = (VAL);                                                            \
         PL[2 * s] = wl(PL[2 * s], (int)(u32)val_, r);                                      \
         if (2 * s + 1 < NW) PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = wl(PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0], (int)(u32)(val_ >> 32), r); \
     }
-                SNK_PUT(X[0], bA | by)
-                SNK_PUT(X[1], bC | by)
-                SNK_PUT(X[2], bG | by)
-                SNK_PUT(X[3], bT | by)
-                const int q = (int)qb - phred;
-                const u64 low = __ballot(q <= lowQ) & vm;
-                nLow += __popcll(low);
-                const bool qok = (u32)q < (u32)nq;
-                if ((__ballot(!qok) & vm) != 0) eq = SNK_E_QUAL_RANGE;
+                SNK_PUT(X[0], bA)
+                SNK_PUT(X[1], bC)
+                SNK_PUT(X[2], bG)
+                SNK_PUT(X[3], bT)
+                const int q = (int)cq[s] - phred;
+                SNK_PUT(LQ, __ballot(q <= lowQ))
+                qmax = max(qmax, valid ? (u32)q : 0u);
                 if (P.has_meanq) qsum += valid ? q : 0;
                 if (FULL) {
-                    if (P.need_n) SNK_PUT(XN, bN | by)
+                    if (P.need_n) SNK_PUT(XN, bN)
                     if (P.has_polyG) SNK_PUT(FG, fG)
                     if (P.polyX_num != -1) {
                         u32 pc = __shfl_up(c, 1);
                         if (lane == 0) pc = prev_last;
-                        const u64 eqm = __ballot(c == pc) & vm;
                         prev_last = (u32)rl((int)c, 63);
-                        SNK_PUT(EQ, eqm)
+                        SNK_PUT(EQ, __ballot(c == pc))
                     }
                     if (P.has_lq) {
-                        const u64 h = __ballot(valid ? (q < P.lq_head_q) : oobH);
-                        const u64 t = __ballot(valid ? (q < P.lq_tail_q) : oobT);
-                        SNK_PUT(LQH, h)
-                        SNK_PUT(LQT, t)
+                        SNK_PUT(LQH, __ballot(q < P.lq_head_q))
+                        SNK_PUT(LQT, __ballot(q < P.lq_tail_q))
                     }
                 }
-                // raw per-position histograms (src/peprocess.cpp:1145-1201)
-                if (valid && qok) {
-                    const u32 t2 = (c >> 1) & 3u;
-                    const u32 cls = (c & 0xDFu) == 'N' ? 4u : (t2 ^ (t2 >> 1));
-                    atomicAdd(&rawB[cls * G.Lh + pmv[s]], inc[s]);
-                    atomicAdd(&rawQ[q * G.Lh + pmv[s]], inc[s]);
+                // raw per-position histograms (src/peprocess.cpp:1145-1201); lanes past the read end
+                // add into their private scratch word instead of branching around the ds_add
+                const u32 t2 = (c >> 1) & 3u;
+                u32 cls = t2 ^ (t2 >> 1);
+                if (strip_slow) cls = (c & 0xDFu) == 'N' ? 4u : cls;
+                const u32 wB = valid ? rawBw + cls * (u32)G.Lh + (u32)pmv[s] : dumW;
+                const u32 wQ = valid ? rawQw + min((u32)q, nqm1) * (u32)G.Lh + (u32)pmv[s] : dumW;
+                atomicAdd(&lds[wB], inc[s]);
+                atomicAdd(&lds[wQ], inc[s]);
+            }
+            if (P.has_meanq) v_sumq = wl(v_sumq, wave_sum(qsum), r);
+            if (slow) {
+                v_adja = wl(v_adja, adjA, r);
+                v_nn = wl(v_nn, nN, r);
+                v_bad = wl(v_bad, bad, r);
+            }
+        };
+        if (G.rb > 0) {
+            // bytes arrive in LDS by DMA, two chunks of rb reads in flight behind the ballots
+            uint8_t *stg = reinterpret_cast<uint8_t *>(lds) + G.stg_off + (threadIdx.x >> 6) * G.stg_wave;
+            const int rb = G.rb, nchunks = (cnt + rb - 1) / rb;
+            auto issue = [&](const int k) {
+                const long g0 = (t0 + (long)k * rb) * (long)B.pitch;
+                const int nbytes = min(rb, cnt - k * rb) * B.pitch;
+                uint8_t *dst = stg + (k & 1) * 2 * G.cba;
+                for (int i = 0; i < G.nd; ++i) {
+                    const int off = min(i * 1024 + lane * 16, nbytes - 16);
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(seq + g0 + off), (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(qual + g0 + off), (lds_ptr_t)(dst + G.cba + i * 1024), 16, 0, 0);
+                }
+            };
+            issue(0);
+            for (int k = 0; k < nchunks; ++k) {
+                if (k + 1 < nchunks) {
+                    issue(k + 1);
+                    if (G.nd == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                const uint8_t *cb = stg + (k & 1) * 2 * G.cba;
+                for (int rr = 0; rr < rb; ++rr) {
+                    const int r = k * rb + rr;
+                    if (r >= cnt) break;
+                    const uint8_t *sb = cb + rr * B.pitch, *qb = sb + G.cba;
+                    u32 cc[NS], cq[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { cc[s] = sb[offc[s]]; cq[s] = qb[offc[s]]; }
+                    do_read(r, cc, cq);
                 }
             }
-            if (P.has_meanq) qsum = wave_sum(qsum);
-            v_na = wl(v_na, nA, r);
-            v_nn = wl(v_nn, nN, r);
-            v_lowq = wl(v_lowq, nLow, r);
-            v_sumq = wl(v_sumq, qsum, r);
-            v_err = wl(v_err, e | (eq << 8), r);
+        } else {
+            // register path (pitch not a multiple of 16): strip loads run one read ahead
+            u32 nc[NS], nqb[NS];
+            {
+                const uint8_t *sp = seq + t0 * (long)B.pitch, *qp = qual + t0 * (long)B.pitch;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
+            }
+            for (int r = 0; r < cnt; ++r) {
+                u32 cc[NS], cq[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { cc[s] = nc[s]; cq[s] = nqb[s]; }
+                if (r + 1 < cnt) {
+                    const uint8_t *sp = seq + (t0 + r + 1) * (long)B.pitch, *qp = qual + (t0 + r + 1) * (long)B.pitch;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
+                }
+                do_read(r, cc, cq);
+            }
+        }
+        // a quality outside [0,nq) anywhere in the tile (error path, rare): find the first read
+        int v_eq = 0;
+        if (__any(lanev && qmax > nqm1)) {
+            for (int r = 0; r < cnt; ++r) {
+                const int len_r = rl(clen_v, r);
+                const uint8_t *qp = qual + (t0 + r) * (long)B.pitch;
+                bool bq = false;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int pos = 64 * s + lane;
+                    if (pos < len_r) bq = bq || (u32)((int)qp[pos] - phred) > nqm1;
+                }
+                if (__any(bq)) v_eq = wl(v_eq, SNK_E_QUAL_RANGE, r);
+            }
         }
         // ------------------------------------------------------------ phase 2 (this mate)
         ReadState &R = rs[m];
-        rs_init(R, min(mylen, G.lcap));
-        R.n_a = v_na; R.n_n = v_nn; R.lowq = v_lowq; R.sumq = v_sumq;
-        estat[m] = v_err & 0xFF;
-        equal[m] = v_err >> 8;
+        rs_init(R, clen_v);
+        estat[m] = !lanev ? 0 : (mylen > G.lcap ? SNK_E_TOO_LONG : (mylen == 0 ? SNK_E_EMPTY_SEQ : (v_bad ? SNK_E_BAD_BASE : 0)));
+        equal[m] = v_eq;
+        {   // mask the garbage past each read, derive the counts, then set "beyond = matches anything"
+            int na = 0, nl = 0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const u32 in = lowmask32(R.len - 32 * j);
+                na += __popc(X[0][j] & in);
+                nl += __popc(LQ[j] & in);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) X[k][j] = (X[k][j] & in) | ~in;
+                if (FULL) {
+                    XN[j] = (XN[j] & in) | ~in;
+                    EQ[j] &= in;
+                    LQH[j] = (LQH[j] & in) | (oobH ? ~in : 0u);
+                }
+            }
+            R.n_a = na + v_adja;
+            R.n_n = v_nn;
+            R.lowq = nl;
+            R.sumq = v_sumq;
+        }
         int hix = 0, tix = 0, polyg = 0;
         if (FULL) {
             if (P.polyX_num != -1) {        // contig_base >= polyX_num  <=>  run of polyX_num-1 "same as previous"
@@ -444,12 +535,12 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
                 }
             }
             if (P.has_lq) {                  // src/read_filter.cpp:409-424
-                hix = min(run_up<NW>(LQH), P.lq_head_len);
+                const int ru = run_up<NW>(LQH);
+                hix = (ru >= 32 * NW && oobH) ? P.lq_head_len : min(ru, P.lq_head_len);
                 hix = max(hix, 0);
                 int rd = run_down<NW>(LQT, R.len);
                 if (rd >= R.len && oobT) rd = 0x7FFFFFFF;           // runs off the front: reads '\0'
                 tix = max(min(rd, P.lq_tail_len), 0);
-                if (run_up<NW>(LQH) >= 32 * NW && oobH) hix = max(P.lq_head_len, 0);
             }
             if (P.has_polyG) polyg = run_down<NW>(FG, R.len);     // src/read_filter.cpp:472-482
         }
@@ -586,7 +677,7 @@ snk_tiled_kernel(const DevParams *Pp, DevBatch B, DevStats st, TileGeom G, int i
     constexpr int NS = (NW + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
     const int mates = P.paired ? 2 : 1;
-    const int nwords = mates * 2 * G.SET;
+    const int nwords = 4 * G.SET + 64;
     for (int i = threadIdx.x; i < nwords; i += blockDim.x) lds[i] = 0;
     __syncthreads();
     // LDS histogram word of (position p, bin b) = b*Lh + (p mod Lh); high half-word when p >= Lh.
@@ -637,8 +728,7 @@ snk_tiled_kernel(const DevParams *Pp, DevBatch B, DevStats st, TileGeom G, int i
 }
 
 template <int NW, bool FULL>
-int launch(const DevParams *dp, const DevBatch &b, const DevStats &st, const TileGeom &G, int n_cu, void *stream) {
-    const size_t shmem = (size_t)2 * 2 * G.SET * sizeof(u32);
+int launch(const DevParams *dp, const DevBatch &b, const DevStats &st, TileGeom G, int n_cu, void *stream) {
     static bool attr_done = false;
     auto kern = snk_tiled_kernel<NW, FULL>;
     if (!attr_done) {
@@ -646,7 +736,21 @@ int launch(const DevParams *dp, const DevBatch &b, const DevStats &st, const Til
             (void)hipGetLastError();
         attr_done = true;
     }
-    const int W = 16;
+    const size_t hist = ((size_t)2 * 2 * G.SET + 64) * sizeof(u32);
+    // staging needs 16-byte rows; otherwise the register path is used
+    const bool can_stage = (b.pitch % 16 == 0) && b.pitch <= 1024 &&
+                           (((uintptr_t)b.seq[0] | (uintptr_t)b.qual[0] | (uintptr_t)b.seq[1] | (uintptr_t)b.qual[1]) % 16 == 0);
+    int W = 16;
+    G.rb = 0; G.nd = 0; G.cba = 0; G.stg_off = (int)hist; G.stg_wave = 0;
+    if (can_stage) {
+        G.nd = 1;
+        G.cba = 1024 * G.nd;
+        G.rb = G.cba / b.pitch;
+        G.stg_wave = 2 * 2 * G.cba;
+        while (W > 4 && hist + (size_t)W * G.stg_wave > 160 * 1024) W -= 4;
+        if (hist + (size_t)W * G.stg_wave > 160 * 1024) { G.rb = 0; W = 16; }
+    }
+    const size_t shmem = hist + (G.rb ? (size_t)W * G.stg_wave : 0);
     const long tiles = (b.n + 63) / 64;
     long wgs = (tiles + W - 1) / W;
     if (wgs > n_cu) wgs = n_cu;
@@ -670,7 +774,8 @@ int snk_launch_tiled(const DevParams *dp_dev, const DevParams &hp, const DevBatc
     G.WB = G.Lh * 5;
     G.WQ = G.Lh * nq;
     G.SET = G.WB + G.WQ;
-    if ((size_t)2 * 2 * G.SET * sizeof(u32) > 160 * 1024) return 0;
+    if (((size_t)2 * 2 * G.SET + 64) * sizeof(u32) > 160 * 1024) return 0;
+    G.rb = G.nd = G.cba = G.stg_off = G.stg_wave = 0;
     const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq;
     const int nw = (lcap + 31) / 32;        // dwords per bit plane
 #define SNK_GO(NW_)                                                                    \
