@@ -671,9 +671,11 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
 
 template <int NW, bool FULL>
 __global__ void __launch_bounds__(1024)
-snk_tiled_kernel(const DevParams *Pp, DevBatch B, DevStats st, TileGeom G, int iters, int flush_every) {
+snk_tiled_kernel(const DevParams P, const DevBatch B, const DevStats st, const TileGeom G, const int iters,
+                 const int flush_every) {
+    // parameters travel by value in the kernarg segment: the compiler keeps them in SGPRs instead
+    // of re-loading them from global memory next to every atomic
     extern __shared__ u32 lds[];
-    const DevParams &P = *Pp;
     constexpr int NS = (NW + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
     const int mates = P.paired ? 2 : 1;
@@ -728,7 +730,7 @@ snk_tiled_kernel(const DevParams *Pp, DevBatch B, DevStats st, TileGeom G, int i
 }
 
 template <int NW, bool FULL>
-int launch(const DevParams *dp, const DevBatch &b, const DevStats &st, TileGeom G, int n_cu, void *stream) {
+int launch(const DevParams &hp, const DevBatch &b, const DevStats &st, TileGeom G, int n_cu, void *stream) {
     static bool attr_done = false;
     auto kern = snk_tiled_kernel<NW, FULL>;
     if (!attr_done) {
@@ -757,7 +759,7 @@ int launch(const DevParams *dp, const DevBatch &b, const DevStats &st, TileGeom 
     const long GW = wgs * W;
     const int iters = (int)((tiles + GW - 1) / GW);
     const int flush_every = 65535 / (W * 64);
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(W * 64), shmem, (hipStream_t)stream, dp, b, st, G, iters,
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(W * 64), shmem, (hipStream_t)stream, hp, b, st, G, iters,
                        flush_every);
     return 1;
 }
@@ -779,8 +781,8 @@ int snk_launch_tiled(const DevParams *dp_dev, const DevParams &hp, const DevBatc
     const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq;
     const int nw = (lcap + 31) / 32;        // dwords per bit plane
 #define SNK_GO(NW_)                                                                    \
-    return full ? launch<NW_, true>(dp_dev, b, st, G, n_cu, stream)                    \
-                : launch<NW_, false>(dp_dev, b, st, G, n_cu, stream);
+    return full ? launch<NW_, true>(hp, b, st, G, n_cu, stream)                        \
+                : launch<NW_, false>(hp, b, st, G, n_cu, stream);
     if (nw <= 2) { SNK_GO(2) }
     else if (nw <= 4) { SNK_GO(4) }
     else if (nw <= 5) { SNK_GO(5) }
