@@ -162,7 +162,9 @@ __device__ inline void ts_update(u64 *ts, int hd_h, int lq_h, int hd_t, int lq_t
 }
 
 __device__ __forceinline__ void report_err(const DevStats &st, u64 index, int mate, int code) {
-    atomicMin(st.err, (index << 8) | ((u64)mate << 4) | (u64)code);
+    // within one pair the reference meets stat_read() errors of either mate before the
+    // quality-range check of the raw-stats pass: class bit 5 orders them that way
+    atomicMin(st.err, (index << 8) | ((u64)(code == SNK_E_QUAL_RANGE) << 5) | ((u64)mate << 4) | (u64)code);
 }
 
 __device__ __forceinline__ void store_rec(snk_read_result *out, long i, const ReadState &r, int reason, int v) {

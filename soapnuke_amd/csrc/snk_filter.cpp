@@ -464,7 +464,7 @@ int snk_stats_fetch(snk_ctx *c, uint64_t *sum, uint64_t *maxb, snk_error *err, v
     HIP_OK(hipStreamSynchronize(s));
     if (err) {
         if (e == SNK_ERR_NONE) { err->code = SNK_OK; err->mate = 0; err->index = 0; }
-        else { err->code = (int32_t)(e & 0xF); err->mate = (int32_t)((e >> 4) & 0xF); err->index = e >> 8; }
+        else { err->code = (int32_t)(e & 0xF); err->mate = (int32_t)((e >> 4) & 0x1); err->index = e >> 8; }
     }
     return SNK_OK;
 }

@@ -28,6 +28,7 @@
 // counter can overflow.  Everything is integer/byte work: no MFMA, bound by HBM in theory
 // and by VALU issue in practice.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "snk_common.cuh"
 
 using namespace snk;
@@ -323,75 +324,50 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
         if (lanev) mylen = B.len[m] ? (int)B.len[m][t0 + lane] : B.fixed_len[m];
         const int clen_v = min(mylen, G.lcap);
         // ------------------------------------------------------------ phase 1
-        // Raw ballots go straight into the planes (bits beyond a read's length are garbage
-        // and are masked per lane in phase 2); everything per-read that can be derived from
-        // the planes later (base counts, low-quality count, error checks) is NOT done on the
-        // scalar unit here -- phase 1 is scalar-issue bound otherwise.
+        // Straight-line per strip: 4 base ballots + 1 quality ballot written into the owning
+        // lane with v_writelane, two LDS histogram adds.  Nothing else: bits past a read's end
+        // are masked per lane in phase 2, base/low-quality counts are popcounts of the planes
+        // there, reads containing anything but ACGT (N, lower case, garbage) are detected there
+        // and repaired in a rare fix-up pass, and an out-of-range quality lands in an overflow
+        // bin that the flush checks.  Phase 1 is VALU/SALU-issue bound, not HBM bound.
         u32 X[4][NW], LQ[NW], XN[NW], FG[NW], EQ[NW], LQH[NW], LQT[NW];
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             X[0][j] = X[1][j] = X[2][j] = X[3][j] = 0;
             LQ[j] = XN[j] = FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
         }
-        int v_adja = 0, v_nn = 0, v_bad = 0, v_sumq = 0;
-        u32 qmax = 0;                                 // sticky max of the quality values this lane saw
+        int v_sumq = 0;
         const int len0 = rl(clen_v, 0);
         const bool fixed = __all(!lanev || clen_v == len0);
-        u64 vmf[NS];
-        u32 offc[NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            offc[s] = (u32)min(64 * s + lane, B.pitch - 1);
-            vmf[s] = lowmask64(len0 - 64 * s);
-        }
+        // every read of the tile fills the whole capacity: lanes past the end fall into histogram
+        // slots of positions >= lcap, which are never flushed -> no validity masking at all
+        const bool fulllen = fixed && len0 == G.lcap;
         const u32 rawBw = (u32)((m * 2 + 0) * G.SET), rawQw = rawBw + (u32)G.WB;
-        const u32 dumW = (u32)(4 * G.SET) + (u32)lane;   // per-lane scratch word for lanes past the read end
-        const u32 nqm1 = (u32)(nq - 1);
-        auto do_read = [&](const int r, const u32 (&cc)[NS], const u32 (&cq)[NS]) {
-            const int len_r = fixed ? len0 : rl(clen_v, r);
+        const u32 dumW = (u32)(4 * G.SET) + (u32)lane;   // per-lane scratch word (variable-length tiles)
+        const u32 Lh = (u32)G.Lh, nqu = (u32)nq;
+        auto do_read = [&](auto FL, const int r, const u32 (&cc)[NS], const u32 (&cq)[NS]) {
+            constexpr bool FULLLEN = decltype(FL)::value;
+            const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
             int qsum = 0;
-            int adjA = 0, nN = 0, bad = 0;
-            bool slow = false;
             u32 prev_last = 0xFFFFFFFFu;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int pos = 64 * s + lane;
-                const bool valid = pos < len_r;
-                const u64 vm = fixed ? vmf[s] : lowmask64(len_r - 64 * s);
                 const u32 c = cc[s];
-                const u64 bA = __ballot(c == 'A'), bC = __ballot(c == 'C'), bG = __ballot(c == 'G'),
-                          bT = __ballot(c == 'T');
-                u64 fG = bG, bN = 0;
-                bool strip_slow = false;
-                if ((vm & ~(bA | bC | bG | bT)) != 0) {      // N, lower case or garbage inside the read (rare)
-                    const u32 cu = c & 0xDFu;
-                    const u64 fA = __ballot(cu == 'A') & vm, fC = __ballot(cu == 'C') & vm,
-                              fT = __ballot(cu == 'T') & vm, fN = __ballot(cu == 'N') & vm;
-                    fG = __ballot(cu == 'G') & vm;
-                    bN = __ballot(c == 'N');
-                    if ((fA | fC | fG | fT | fN) != vm) bad = 1;
-                    adjA += __popcll(fA) - __popcll(bA & vm);
-                    nN += __popcll(fN);
-                    slow = true;
-                    strip_slow = true;
-                }
 #define SNK_PUT(PL, VAL)                                                                   \
     {                                                                                      \
         const u64 val_ = (VAL);                                                            \
         PL[2 * s] = wl(PL[2 * s], (int)(u32)val_, r);                                      \
         if (2 * s + 1 < NW) PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = wl(PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0], (int)(u32)(val_ >> 32), r); \
     }
-                SNK_PUT(X[0], bA)
-                SNK_PUT(X[1], bC)
-                SNK_PUT(X[2], bG)
-                SNK_PUT(X[3], bT)
+                SNK_PUT(X[0], __ballot(c == 'A'))
+                SNK_PUT(X[1], __ballot(c == 'C'))
+                SNK_PUT(X[2], __ballot(c == 'G'))
+                SNK_PUT(X[3], __ballot(c == 'T'))
                 const int q = (int)cq[s] - phred;
                 SNK_PUT(LQ, __ballot(q <= lowQ))
-                qmax = max(qmax, valid ? (u32)q : 0u);
-                if (P.has_meanq) qsum += valid ? q : 0;
+                if (P.has_meanq) qsum += (pos < len_r) ? q : 0;
                 if (FULL) {
-                    if (P.need_n) SNK_PUT(XN, bN)
-                    if (P.has_polyG) SNK_PUT(FG, fG)
                     if (P.polyX_num != -1) {
                         u32 pc = __shfl_up(c, 1);
                         if (lane == 0) pc = prev_last;
@@ -403,111 +379,148 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
                         SNK_PUT(LQT, __ballot(q < P.lq_tail_q))
                     }
                 }
-                // raw per-position histograms (src/peprocess.cpp:1145-1201); lanes past the read end
-                // add into their private scratch word instead of branching around the ds_add
+                // raw per-position histograms (src/peprocess.cpp:1145-1201).  N / garbage land in a
+                // wrong base bin here and are moved by the fix-up pass; bin nq = quality overflow.
                 const u32 t2 = (c >> 1) & 3u;
-                u32 cls = t2 ^ (t2 >> 1);
-                if (strip_slow) cls = (c & 0xDFu) == 'N' ? 4u : cls;
-                const u32 wB = valid ? rawBw + cls * (u32)G.Lh + (u32)pmv[s] : dumW;
-                const u32 wQ = valid ? rawQw + min((u32)q, nqm1) * (u32)G.Lh + (u32)pmv[s] : dumW;
+                const u32 cls = t2 ^ (t2 >> 1);
+                const u32 qi = min((u32)q, nqu);
+                u32 wB = rawBw + cls * Lh + (u32)pmv[s], wQ = rawQw + qi * Lh + (u32)pmv[s];
+                if (!FULLLEN) {
+                    const bool valid = pos < len_r;
+                    wB = valid ? wB : dumW;
+                    wQ = valid ? wQ : dumW;
+                }
                 atomicAdd(&lds[wB], inc[s]);
                 atomicAdd(&lds[wQ], inc[s]);
             }
             if (P.has_meanq) v_sumq = wl(v_sumq, wave_sum(qsum), r);
-            if (slow) {
+        };
+        auto run_phase1 = [&](auto FL) {
+            if (G.rb > 0) {
+                // bytes arrive in LDS by DMA (16 B/lane), the next chunk of rb reads in flight
+                // behind the ballots of the current one
+                uint8_t *stg = reinterpret_cast<uint8_t *>(lds) + G.stg_off + (threadIdx.x >> 6) * G.stg_wave;
+                const int rb = G.rb, nchunks = (cnt + rb - 1) / rb;
+                auto issue = [&](const int k) {
+                    const long g0 = (t0 + (long)k * rb) * (long)B.pitch;
+                    const int nbytes = min(rb, cnt - k * rb) * B.pitch;
+                    uint8_t *dst = stg + (k & 1) * 2048;
+                    const int off = min(lane * 16, nbytes - 16);
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(seq + g0 + off), (lds_ptr_t)dst, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(qual + g0 + off), (lds_ptr_t)(dst + 1024), 16, 0, 0);
+                };
+                issue(0);
+                for (int k = 0; k < nchunks; ++k) {
+                    if (k + 1 < nchunks) {
+                        issue(k + 1);
+                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    const uint8_t *cb = stg + (k & 1) * 2048 + lane;
+                    for (int rr = 0; rr < rb; ++rr) {
+                        const int r = k * rb + rr;
+                        if (r >= cnt) break;
+                        const uint8_t *sb = cb + rr * B.pitch;
+                        u32 cc[NS], cq[NS];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) { cc[s] = sb[64 * s]; cq[s] = sb[1024 + 64 * s]; }
+                        do_read(FL, r, cc, cq);
+                    }
+                }
+            } else {
+                // register path (pitch not a multiple of 16): strip loads run one read ahead
+                u32 offc[NS], nc[NS], nqb[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) offc[s] = (u32)min(64 * s + lane, B.pitch - 1);
+                {
+                    const uint8_t *sp = seq + t0 * (long)B.pitch, *qp = qual + t0 * (long)B.pitch;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
+                }
+                for (int r = 0; r < cnt; ++r) {
+                    u32 cc[NS], cq[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { cc[s] = nc[s]; cq[s] = nqb[s]; }
+                    if (r + 1 < cnt) {
+                        const uint8_t *sp = seq + (t0 + r + 1) * (long)B.pitch, *qp = qual + (t0 + r + 1) * (long)B.pitch;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
+                    }
+                    do_read(FL, r, cc, cq);
+                }
+            }
+        };
+        if (fulllen) run_phase1(std::true_type{});
+        else run_phase1(std::false_type{});
+        // ------------------------------------------------------------ phase 2 (this mate)
+        ReadState &R = rs[m];
+        rs_init(R, clen_v);
+        int v_adja = 0, v_nn = 0, v_bad = 0;
+        bool needfix = false;
+        {   // mask the garbage past each read and look for anything that is not ACGT
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const u32 in = lowmask32(R.len - 32 * j);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) X[k][j] &= in;
+                LQ[j] &= in;
+                needfix = needfix || (in & ~(X[0][j] | X[1][j] | X[2][j] | X[3][j])) != 0;
+                if (FULL) {
+                    FG[j] = X[2][j];
+                    EQ[j] &= in;
+                    LQH[j] = (LQH[j] & in) | (oobH ? ~in : 0u);
+                }
+            }
+        }
+        // fix-up pass (rare): reads with N / lower case / garbage.  Exact counts, the N plane,
+        // the folded-G plane, and the histogram move "wrong base bin -> N bin".
+        {
+            u64 fix = __ballot(needfix && lanev);
+            while (fix) {
+                const int r = __ffsll((long long)fix) - 1;
+                fix &= fix - 1;
+                const int len_r = rl(clen_v, r);
+                const uint8_t *sp = seq + (t0 + r) * (long)B.pitch;
+                int adjA = 0, nN = 0, bad = 0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int pos = 64 * s + lane;
+                    const bool valid = pos < len_r;
+                    u32 c = 0;
+                    if (valid) c = sp[pos];
+                    const u32 cu = c & 0xDFu;
+                    adjA += __popcll(__ballot(valid && cu == 'A' && c != 'A'));
+                    const bool isn = valid && cu == 'N';
+                    nN += __popcll(__ballot(isn));
+                    if (__any(valid && !(cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T' || cu == 'N'))) bad = 1;
+                    if (isn) {
+                        const u32 t2 = (c >> 1) & 3u, clsw = t2 ^ (t2 >> 1);
+                        atomicSub(&lds[rawBw + clsw * Lh + (u32)pmv[s]], inc[s]);
+                        atomicAdd(&lds[rawBw + 4u * Lh + (u32)pmv[s]], inc[s]);
+                    }
+                    if (FULL) {
+                        SNK_PUT(XN, __ballot(valid && c == 'N'))
+                        SNK_PUT(FG, __ballot(valid && cu == 'G'))
+                    }
+                }
                 v_adja = wl(v_adja, adjA, r);
                 v_nn = wl(v_nn, nN, r);
                 v_bad = wl(v_bad, bad, r);
             }
-        };
-        if (G.rb > 0) {
-            // bytes arrive in LDS by DMA, two chunks of rb reads in flight behind the ballots
-            uint8_t *stg = reinterpret_cast<uint8_t *>(lds) + G.stg_off + (threadIdx.x >> 6) * G.stg_wave;
-            const int rb = G.rb, nchunks = (cnt + rb - 1) / rb;
-            auto issue = [&](const int k) {
-                const long g0 = (t0 + (long)k * rb) * (long)B.pitch;
-                const int nbytes = min(rb, cnt - k * rb) * B.pitch;
-                uint8_t *dst = stg + (k & 1) * 2 * G.cba;
-                for (int i = 0; i < G.nd; ++i) {
-                    const int off = min(i * 1024 + lane * 16, nbytes - 16);
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(seq + g0 + off), (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(qual + g0 + off), (lds_ptr_t)(dst + G.cba + i * 1024), 16, 0, 0);
-                }
-            };
-            issue(0);
-            for (int k = 0; k < nchunks; ++k) {
-                if (k + 1 < nchunks) {
-                    issue(k + 1);
-                    if (G.nd == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                const uint8_t *cb = stg + (k & 1) * 2 * G.cba;
-                for (int rr = 0; rr < rb; ++rr) {
-                    const int r = k * rb + rr;
-                    if (r >= cnt) break;
-                    const uint8_t *sb = cb + rr * B.pitch, *qb = sb + G.cba;
-                    u32 cc[NS], cq[NS];
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) { cc[s] = sb[offc[s]]; cq[s] = qb[offc[s]]; }
-                    do_read(r, cc, cq);
-                }
-            }
-        } else {
-            // register path (pitch not a multiple of 16): strip loads run one read ahead
-            u32 nc[NS], nqb[NS];
-            {
-                const uint8_t *sp = seq + t0 * (long)B.pitch, *qp = qual + t0 * (long)B.pitch;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
-            }
-            for (int r = 0; r < cnt; ++r) {
-                u32 cc[NS], cq[NS];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { cc[s] = nc[s]; cq[s] = nqb[s]; }
-                if (r + 1 < cnt) {
-                    const uint8_t *sp = seq + (t0 + r + 1) * (long)B.pitch, *qp = qual + (t0 + r + 1) * (long)B.pitch;
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
-                }
-                do_read(r, cc, cq);
-            }
         }
-        // a quality outside [0,nq) anywhere in the tile (error path, rare): find the first read
-        int v_eq = 0;
-        if (__any(lanev && qmax > nqm1)) {
-            for (int r = 0; r < cnt; ++r) {
-                const int len_r = rl(clen_v, r);
-                const uint8_t *qp = qual + (t0 + r) * (long)B.pitch;
-                bool bq = false;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const int pos = 64 * s + lane;
-                    if (pos < len_r) bq = bq || (u32)((int)qp[pos] - phred) > nqm1;
-                }
-                if (__any(bq)) v_eq = wl(v_eq, SNK_E_QUAL_RANGE, r);
-            }
-        }
-        // ------------------------------------------------------------ phase 2 (this mate)
-        ReadState &R = rs[m];
-        rs_init(R, clen_v);
         estat[m] = !lanev ? 0 : (mylen > G.lcap ? SNK_E_TOO_LONG : (mylen == 0 ? SNK_E_EMPTY_SEQ : (v_bad ? SNK_E_BAD_BASE : 0)));
-        equal[m] = v_eq;
-        {   // mask the garbage past each read, derive the counts, then set "beyond = matches anything"
+        equal[m] = 0;                     // quality-range errors are found by the flush (overflow bin)
+        {   // counts from the planes, then "beyond the read = matches anything" for the adapter search
             int na = 0, nl = 0;
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const u32 in = lowmask32(R.len - 32 * j);
-                na += __popc(X[0][j] & in);
-                nl += __popc(LQ[j] & in);
+                na += __popc(X[0][j]);
+                nl += __popc(LQ[j]);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) X[k][j] = (X[k][j] & in) | ~in;
-                if (FULL) {
-                    XN[j] = (XN[j] & in) | ~in;
-                    EQ[j] &= in;
-                    LQH[j] = (LQH[j] & in) | (oobH ? ~in : 0u);
-                }
+                for (int k = 0; k < 4; ++k) X[k][j] |= ~in;
+                if (FULL) XN[j] |= ~in;
             }
             R.n_a = na + v_adja;
             R.n_n = v_nn;
@@ -694,6 +707,7 @@ snk_tiled_kernel(const DevParams P, const DevBatch B, const DevStats st, const T
     }
     const long GW = (long)gridDim.x * W;
     const long fb = file_block(G.lcap, G.nq);
+    int flush_lo = 0;
     for (int it = 0; it < iters; ++it) {
         const long tile = (long)it * GW + (long)blockIdx.x * W + wave;
         const long t0 = tile * 64;
@@ -703,6 +717,7 @@ snk_tiled_kernel(const DevParams P, const DevBatch B, const DevStats st, const T
         if ((it + 1) % flush_every == 0 || it + 1 == iters) {
             __syncthreads();
             // flush: global raw += raw ; global clean += raw - removed
+            int ovf = 0;
             for (int m = 0; m < mates; ++m) {
                 u32 *raw = lds + (m * 2 + 0) * G.SET, *remv = lds + (m * 2 + 1) * G.SET;
                 u64 *fraw = st.sum + SNK_FS_N + m * fb, *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
@@ -710,21 +725,45 @@ snk_tiled_kernel(const DevParams P, const DevBatch B, const DevStats st, const T
                     const u32 a = raw[w], b = remv[w];
                     if (a | b) {
                         long off;
-                        int pm;
-                        if (w < G.WB) { const int bin = w / G.Lh; pm = w - bin * G.Lh; off = SNK_GS_N + (long)bin; }
-                        else { const int ww = w - G.WB, bin = ww / G.Lh; pm = ww - bin * G.Lh; off = SNK_GS_N + (long)G.lcap * 5 + bin; }
+                        int pm, bin;
+                        if (w < G.WB) { bin = w / G.Lh; pm = w - bin * G.Lh; off = SNK_GS_N + (long)bin; }
+                        else { const int ww = w - G.WB; bin = ww / G.Lh; pm = ww - bin * G.Lh; off = SNK_GS_N + (long)G.lcap * 5 + bin; }
                         const long stride = w < G.WB ? 5 : G.nq;
                         const u32 alo = a & 0xFFFFu, blo = b & 0xFFFFu, ahi = a >> 16, bhi = b >> 16;
-                        if (alo) atomicAdd(&fraw[off + pm * stride], (u64)alo);
-                        if (alo != blo) atomicAdd(&fcl[off + pm * stride], (u64)alo - (u64)blo);
-                        if (ahi) atomicAdd(&fraw[off + (pm + G.Lh) * stride], (u64)ahi);
-                        if (ahi != bhi) atomicAdd(&fcl[off + (pm + G.Lh) * stride], (u64)ahi - (u64)bhi);
+                        // slots of positions >= lcap hold the spill-over of lanes past the read end: dropped
+                        const bool lo_ok = pm < G.lcap, hi_ok = pm + G.Lh < G.lcap;
+                        if (w >= G.WB && bin == G.nq) {
+                            if ((alo && lo_ok) || (ahi && hi_ok)) ovf = 1;       // quality outside [0,nq)
+                        } else {
+                            if (alo && lo_ok) atomicAdd(&fraw[off + pm * stride], (u64)alo);
+                            if (alo != blo && lo_ok) atomicAdd(&fcl[off + pm * stride], (u64)alo - (u64)blo);
+                            if (ahi && hi_ok) atomicAdd(&fraw[off + (pm + G.Lh) * stride], (u64)ahi);
+                            if (ahi != bhi && hi_ok) atomicAdd(&fcl[off + (pm + G.Lh) * stride], (u64)ahi - (u64)bhi);
+                        }
                         raw[w] = 0;
                         remv[w] = 0;
                     }
                 }
             }
-            __syncthreads();
+            if (__syncthreads_or(ovf)) {
+                // error path: some quality since the last flush was out of range -> find the reads
+                // (the reference corrupts its heap here, src/peprocess.cpp:1196; we report the first)
+                for (int it2 = flush_lo; it2 <= it; ++it2) {
+                    const long t2 = ((long)it2 * GW + (long)blockIdx.x * W + wave) * 64;
+                    const long rem2 = B.n - t2;
+                    const int cnt2 = rem2 >= 64 ? 64 : (rem2 > 0 ? (int)rem2 : 0);
+                    for (int m = 0; m < mates; ++m)
+                        for (int r = 0; r < cnt2; ++r) {
+                            int len_r = B.len[m] ? (int)B.len[m][t2 + r] : B.fixed_len[m];
+                            len_r = min(len_r, G.lcap);
+                            const uint8_t *qp = B.qual[m] + (t2 + r) * (long)B.pitch;
+                            bool bq = false;
+                            for (int pos = lane; pos < len_r; pos += 64) bq = bq || (u32)((int)qp[pos] - P.phred) >= (u32)G.nq;
+                            if (__any(bq) && lane == 0) report_err(st, B.first_index + (u64)(t2 + r), m, SNK_E_QUAL_RANGE);
+                        }
+                }
+            }
+            flush_lo = it + 1;
         }
     }
 }
@@ -746,13 +785,13 @@ int launch(const DevParams &hp, const DevBatch &b, const DevStats &st, TileGeom 
     G.rb = 0; G.nd = 0; G.cba = 0; G.stg_off = (int)hist; G.stg_wave = 0;
     if (can_stage) {
         G.nd = 1;
-        G.cba = 1024 * G.nd;
+        G.cba = 1024;                      // bytes per array per buffer: one 64-lane x 16 B DMA
         G.rb = G.cba / b.pitch;
         G.stg_wave = 2 * 2 * G.cba;
-        while (W > 4 && hist + (size_t)W * G.stg_wave > 160 * 1024) W -= 4;
-        if (hist + (size_t)W * G.stg_wave > 160 * 1024) { G.rb = 0; W = 16; }
+        while (W > 4 && hist + (size_t)W * G.stg_wave + 256 > 160 * 1024) W -= 4;
+        if (hist + (size_t)W * G.stg_wave + 256 > 160 * 1024) { G.rb = 0; W = 16; }
     }
-    const size_t shmem = hist + (G.rb ? (size_t)W * G.stg_wave : 0);
+    const size_t shmem = hist + (G.rb ? (size_t)W * G.stg_wave + 256 : 0);   // + slack for strip over-reads
     const long tiles = (b.n + 63) / 64;
     long wgs = (tiles + W - 1) / W;
     if (wgs > n_cu) wgs = n_cu;
@@ -774,7 +813,7 @@ int snk_launch_tiled(const DevParams *dp_dev, const DevParams &hp, const DevBatc
     G.nq = nq;
     G.Lh = (lcap + 1) / 2 < 64 ? 64 : ((lcap + 1) / 2 + 31) / 32 * 32;
     G.WB = G.Lh * 5;
-    G.WQ = G.Lh * nq;
+    G.WQ = G.Lh * (nq + 1);          // bin nq collects out-of-range qualities
     G.SET = G.WB + G.WQ;
     if (((size_t)2 * 2 * G.SET + 64) * sizeof(u32) > 160 * 1024) return 0;
     G.rb = G.nd = G.cba = G.stg_off = G.stg_wave = 0;
