@@ -30,6 +30,20 @@ struct DevAdapter {
     uint64_t nmask;         // bit c = adapter[c] == 'N' (matches a read 'N' exactly)
 };
 
+// Compact adapter descriptor for the wave-tiled kernel.  It travels BY VALUE in the kernel
+// argument segment so that every field sits in SGPRs: fetching DevAdapter fields from global
+// memory inside the screening loop cost a memory round trip per adapter character.
+#define SNK_TILE_MAX_ADA 4
+struct TileAdapter {
+    uint64_t cmask[4], nmask;   // as DevAdapter
+    uint64_t code4[4];          // 4 bits per adapter position (DevAdapter::code), 16 per word
+    int32_t len, S, mis, edge, negC;
+    int32_t budgetA[6];
+    int32_t rk[4];
+    int32_t pad_;
+};
+struct TileAdapters { TileAdapter a[2][SNK_TILE_MAX_ADA]; };
+
 struct DevParams {
     int32_t paired, phred, nq, low_qual;
     int32_t polyX_num;                 // -1 off
@@ -74,6 +88,6 @@ struct DevStats {
 void snk_launch_generic(const DevParams *dp, const DevBatch &b, const DevStats &st, int lcap,
                         int nq, void *stream);
 // returns 0 when the tiled kernel cannot run this configuration
-int snk_launch_tiled(const DevParams *dp_dev, const DevParams &dp_host, const DevBatch &b,
+int snk_launch_tiled(const DevParams &dp_host, const TileAdapters &ta, const DevBatch &b,
                      const DevStats &st, int lcap, int nq, int n_cu, void *stream);
 void snk_launch_finalize(const DevStats &st, int lcap, int nq, void *stream);

@@ -111,6 +111,7 @@ struct snk_ctx {
     int lcap = 0, nq = 0;
     int64_t sum_u64 = 0;
     DevParams hp;                 // host copy (device pointers inside)
+    TileAdapters ta;              // kernarg-resident adapter descriptors of the tiled kernel
     DevParams *d_params = nullptr;
     DevAdapter *d_ada = nullptr;
     int32_t *d_tables = nullptr;
@@ -219,11 +220,21 @@ static int build_ctx(snk_ctx *c) {
     D.n_ada[1] = P.n_adapters[1];
     D.tile_ok = 1;
     D.need_n = 0;
+    memset(&c->ta, 0, sizeof(c->ta));
     for (int m = 0; m < 2; ++m)
         for (int i = 0; i < P.n_adapters[m]; ++i) {
             const DevAdapter &A = ada[m * SNK_MAX_ADAPTERS + i];
-            if (!A.tile_ok) D.tile_ok = 0;
+            if (!A.tile_ok || i >= SNK_TILE_MAX_ADA) D.tile_ok = 0;
             if (A.nmask) D.need_n = 1;
+            if (i < SNK_TILE_MAX_ADA) {
+                TileAdapter &T = c->ta.a[m][i];
+                for (int k = 0; k < 4; ++k) T.cmask[k] = A.cmask[k];
+                T.nmask = A.nmask;
+                for (int ci = 0; ci < 64 && ci < A.len; ++ci) T.code4[ci >> 4] |= (uint64_t)(A.code[ci] & 15) << (4 * (ci & 15));
+                T.len = A.len; T.S = A.S; T.mis = A.mis; T.edge = A.edge; T.negC = A.negC;
+                for (int k = 0; k < 6; ++k) T.budgetA[k] = A.budgetA[k];
+                for (int k = 0; k < 4; ++k) T.rk[k] = A.rk[k];
+            }
         }
     D.thr_n = c->d_tables;
     D.thr_a = c->d_tables + L1;
@@ -383,7 +394,7 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
     if (c->timing) HIP_OK(hipEventRecord(c->ev0, s));
     int done = 0;
     if (kernel == 0 || kernel == 2) {
-        done = snk_launch_tiled(c->d_params, c->hp, D, st, c->lcap, c->nq, c->n_cu, stream);
+        done = snk_launch_tiled(c->hp, c->ta, D, st, c->lcap, c->nq, c->n_cu, stream);
         if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return SNK_E_UNSUPPORTED; }
     }
     if (!done) snk_launch_generic(c->d_params, D, st, c->lcap, c->nq, stream);

@@ -23,7 +23,7 @@
 //           clean = raw - removed needs no second pass over the surviving 80 %.
 //
 // LDS holds, per mate, raw and removed {base[pos][5], qual[pos][nq]} histograms as 16-bit
-// counters packed two per dword (positions p and p+Lh share a dword, so one strip never
+// counters packed two per dword (strips 2k and 2k+1 share dwords, so one strip never
 // hits a dword twice); the workgroup flushes them to the global uint64 block before a
 // counter can overflow.  Everything is integer/byte work: no MFMA, bound by HBM in theory
 // and by VALU issue in practice.
@@ -44,6 +44,14 @@ __device__ __forceinline__ u64 lowmask64(int n) { return n <= 0 ? 0ull : (n >= 6
 // (v_writelane_b32: uniform value -> one lane of a VGPR, the transpose primitive of phase 1).
 __device__ __forceinline__ int wl(int dst, int val, int lane) { return __snk_writelane(val, lane, dst); }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// Fire-and-forget LDS add.  Issued as inline asm on purpose: with a global_load_lds (LDS DMA)
+// in flight hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS store/atomic it knows about,
+// which would drain the prefetched chunk once per read.  The histogram words never overlap the
+// staging buffers; the flush waits lgkmcnt(0) explicitly before its barrier.
+__device__ __forceinline__ void lds_add_u32(u32 byte_addr, u32 val) {
+    asm volatile("ds_add_u32 %0, %1" ::"v"(byte_addr), "v"(val) : "memory");
+}
 
 __device__ __forceinline__ int wave_sum(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -176,13 +184,13 @@ struct Planes4 { };
 // Adapter search for the lanes with `todo`; returns the position or -1.
 // X[k] bit p = read[p] == "ACGT"[k] (exact), ones beyond the read; XN likewise for 'N'.
 template <int NW, bool FULL>
-__device__ int adapter_tile(const DevAdapter &A, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len,
-                            bool todo, const uint8_t *sptr) {
+__device__ int adapter_tile(const TileAdapter &A, const DevAdapter &AG, const u32 (&X)[4][NW], const u32 (&XN)[NW],
+                            int len, bool todo, const uint8_t *sptr) {
     const int al = A.len, S = max(A.S, 1), edge = A.edge, mis = A.mis;
     int result = -1;
     bool done = !todo;
     if (!done && len < al) {           // shorter than the adapter: negative offsets, rare -> sequential
-        result = adapter_pos_seq(sptr, len, A);
+        result = adapter_pos_seq(sptr, len, AG);
         done = true;
     }
     const u64 cm0 = A.cmask[0], cm1 = A.cmask[1], cm2 = A.cmask[2], cm3 = A.cmask[3];
@@ -210,8 +218,10 @@ __device__ int adapter_tile(const DevAdapter &A, const u32 (&X)[4][NW], const u3
 #pragma unroll
         for (int j = 0; j < NW; ++j) { C1[j] = C2[j] = C3[j] = C4[j] = 0; BY[j] = ~lowmask32(len - 32 * j); }
         const int steps = min(S - 1, al);
+        const u64 cw0 = A.code4[0], cw1 = A.code4[1], cw2 = A.code4[2], cw3 = A.code4[3];
         for (int c = 0; c < steps; ++c) {
-            const int code = A.code[c], cr = c & 31;
+            const u64 cw = c < 16 ? cw0 : (c < 32 ? cw1 : (c < 48 ? cw2 : cw3));
+            const int code = (int)((cw >> (4 * (c & 15))) & 15), cr = c & 31;
 #define SNK_STEP(PL)                                                         \
     if (c < 32) screen_step<NW, 0>(PL, cr, C1, C2, C3, C4);                  \
     else screen_step<NW, 1>(PL, cr, C1, C2, C3, C4);
@@ -269,7 +279,7 @@ __device__ int adapter_tile(const DevAdapter &A, const u32 (&X)[4][NW], const u3
                 n = len - p;                                         // compared length, edge <= n < al
                 res = p;
                 if (n < S) { skip_eval = true; skip_ok = !A.negC; }  // no run possible: survived <=> mis <= budget
-                else budget = A.budgetC[n - edge];
+                else budget = AG.budgetC[n - edge];
             } else {
                 have = false;
             }
@@ -300,10 +310,11 @@ typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
 // One tile = up to 64 pairs starting at t0, processed by one wave.
 template <int NW, bool FULL>
-__device__ void process_tile(const DevParams &P, const DevBatch &B, const DevStats &st, const TileGeom &G,
-                             u32 *lds, long t0, int cnt, const int (&pmv)[(NW + 1) / 2], const u32 (&inc)[(NW + 1) / 2]) {
+__device__ void process_tile(const DevParams &P, const TileAdapters &TA, const DevBatch &B, const DevStats &st, const TileGeom &G,
+                             u32 *lds, long t0, int cnt) {
     constexpr int NS = (NW + 1) / 2;
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));   // keep per-lane address math local to the tile (no hoisting out of the tile loop)
     const int mates = P.paired ? 2 : 1;
     const int phred = P.phred, nq = G.nq, lowQ = P.low_qual;
     const bool lanev = lane < cnt;
@@ -318,6 +329,7 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
 #pragma unroll
     for (int m = 0; m < 2; ++m) {       // static mate index: rs[]/estat[] must stay in registers
         if (m >= mates) continue;
+        asm volatile("" : "+v"(lane));
         const uint8_t *seq = B.seq[m], *qual = B.qual[m];
         u32 *rawB = lds + (m * 2 + 0) * G.SET, *rawQ = rawB + G.WB;
         int mylen = 0;
@@ -344,7 +356,7 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
         const bool fulllen = fixed && len0 == G.lcap;
         const u32 rawBw = (u32)((m * 2 + 0) * G.SET), rawQw = rawBw + (u32)G.WB;
         const u32 dumW = (u32)(4 * G.SET) + (u32)lane;   // per-lane scratch word (variable-length tiles)
-        const u32 Lh = (u32)G.Lh, nqu = (u32)nq;
+        const u32 Lh = (u32)G.Lh, nqu = (u32)nq, ulane = (u32)lane;
         auto do_read = [&](auto FL, const int r, const u32 (&cc)[NS], const u32 (&cq)[NS]) {
             constexpr bool FULLLEN = decltype(FL)::value;
             const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
@@ -384,14 +396,14 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
                 const u32 t2 = (c >> 1) & 3u;
                 const u32 cls = t2 ^ (t2 >> 1);
                 const u32 qi = min((u32)q, nqu);
-                u32 wB = rawBw + cls * Lh + (u32)pmv[s], wQ = rawQw + qi * Lh + (u32)pmv[s];
+                u32 wB = cls * Lh + ulane + (rawBw + 64u * (s >> 1)), wQ = qi * Lh + ulane + (rawQw + 64u * (s >> 1));
                 if (!FULLLEN) {
                     const bool valid = pos < len_r;
                     wB = valid ? wB : dumW;
                     wQ = valid ? wQ : dumW;
                 }
-                atomicAdd(&lds[wB], inc[s]);
-                atomicAdd(&lds[wQ], inc[s]);
+                atomicAdd(&lds[wB], (s & 1) ? 0x10000u : 1u);
+                atomicAdd(&lds[wQ], (s & 1) ? 0x10000u : 1u);
             }
             if (P.has_meanq) v_sumq = wl(v_sumq, wave_sum(qsum), r);
         };
@@ -404,10 +416,12 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
                 auto issue = [&](const int k) {
                     const long g0 = (t0 + (long)k * rb) * (long)B.pitch;
                     const int nbytes = min(rb, cnt - k * rb) * B.pitch;
-                    uint8_t *dst = stg + (k & 1) * 2048;
+                    uint8_t *dst = stg + (k & 1) * 2 * G.cba;
                     const int off = min(lane * 16, nbytes - 16);
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(seq + g0 + off), (lds_ptr_t)dst, 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(qual + g0 + off), (lds_ptr_t)(dst + 1024), 16, 0, 0);
+                    if (lane * 16 < G.cba) {          // same instruction count every chunk (counted vmcnt below)
+                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(seq + g0 + off), (lds_ptr_t)dst, 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(qual + g0 + off), (lds_ptr_t)(dst + G.cba), 16, 0, 0);
+                    }
                 };
                 issue(0);
                 for (int k = 0; k < nchunks; ++k) {
@@ -417,14 +431,14 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
-                    const uint8_t *cb = stg + (k & 1) * 2048 + lane;
+                    const uint8_t *cb = stg + (k & 1) * 2 * G.cba + lane;
                     for (int rr = 0; rr < rb; ++rr) {
                         const int r = k * rb + rr;
                         if (r >= cnt) break;
                         const uint8_t *sb = cb + rr * B.pitch;
                         u32 cc[NS], cq[NS];
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) { cc[s] = sb[64 * s]; cq[s] = sb[1024 + 64 * s]; }
+                        for (int s = 0; s < NS; ++s) { cc[s] = sb[64 * s]; cq[s] = sb[G.cba + 64 * s]; }
                         do_read(FL, r, cc, cq);
                     }
                 }
@@ -496,8 +510,8 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
                     if (__any(valid && !(cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T' || cu == 'N'))) bad = 1;
                     if (isn) {
                         const u32 t2 = (c >> 1) & 3u, clsw = t2 ^ (t2 >> 1);
-                        atomicSub(&lds[rawBw + clsw * Lh + (u32)pmv[s]], inc[s]);
-                        atomicAdd(&lds[rawBw + 4u * Lh + (u32)pmv[s]], inc[s]);
+                        atomicSub(&lds[rawBw + clsw * Lh + 64u * (s >> 1) + ulane], (s & 1) ? 0x10000u : 1u);
+                        atomicAdd(&lds[rawBw + 4u * Lh + 64u * (s >> 1) + ulane], (s & 1) ? 0x10000u : 1u);
                     }
                     if (FULL) {
                         SNK_PUT(XN, __ballot(valid && c == 'N'))
@@ -563,7 +577,7 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
         for (int i = 0; i < nada; ++i) {                           // src/read_filter.cpp:175-188
             const bool todo = good && ada_pos < 0;
             if (!__any(todo)) break;
-            const int pp = adapter_tile<NW, FULL>(P.ada[m * SNK_MAX_ADAPTERS + i], X, XN, R.len, todo,
+            const int pp = adapter_tile<NW, FULL>(TA.a[m][i], P.ada[m * SNK_MAX_ADAPTERS + i], X, XN, R.len, todo,
                                             seq + (t0 + lane) * (long)B.pitch);
             if (todo && pp >= 0) ada_pos = pp;
         }
@@ -572,6 +586,7 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
     }
 
     // ---------------------------------------------------------------- pair level
+    asm volatile("" : "+v"(lane));
     const int pe = mates - 1;
     int ecode = 0, emate = 0;
     if (estat[0]) { ecode = estat[0]; emate = 0; }
@@ -642,6 +657,7 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
         }
     }
     // ---------------------------------------------------------------- phase 3
+    asm volatile("" : "+v"(lane));
     // clean = raw - removed: only discarded / trimmed reads are walked again
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -652,29 +668,48 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
         u64 *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
         u64 *gbs = fcl + SNK_GS_N, *gqs = fcl + SNK_GS_N + (long)G.lcap * 5;
         u64 mod = __ballot(live && (reason != SNK_KEEP || R.clen != R.len));
-        while (mod) {
-            const int r = __ffsll((long long)mod) - 1;
-            mod &= mod - 1;
-            const int len_r = rl(R.len, r), clen_r = rl(R.clen, r), start_r = rl(R.start, r);
-            const bool disc = rl(reason, r) != SNK_KEEP;
-            const bool shifted = !disc && start_r > 0;
-            const int rm_lo = (disc || shifted) ? 0 : clen_r;       // removed raw positions [rm_lo, len)
-            const long base = (t0 + r) * (long)B.pitch;
+        u32 offp[NS];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int pos = 64 * s + lane;
-                if (pos < len_r) {
-                    const u32 c = seq[base + pos];
-                    const int q = (int)qual[base + pos] - phred;
-                    const u32 t2 = (c >> 1) & 3u;
-                    const u32 cls = (c & 0xDFu) == 'N' ? 4u : (t2 ^ (t2 >> 1));
-                    if (pos >= rm_lo && (u32)q < (u32)nq) {
-                        atomicAdd(&remB[cls * G.Lh + pmv[s]], inc[s]);
-                        atomicAdd(&remQ[q * G.Lh + pmv[s]], inc[s]);
-                    }
-                    if (shifted && pos >= start_r && pos < start_r + clen_r && (u32)q < (u32)nq) {
-                        atomicAdd(&gbs[(pos - start_r) * 5 + cls], 1ull);     // head-trimmed survivor: rare
-                        atomicAdd(&gqs[(long)(pos - start_r) * nq + q], 1ull);
+        for (int s = 0; s < NS; ++s) offp[s] = (u32)min(64 * s + lane, B.pitch - 1);
+        while (mod) {
+            // up to 4 reads per trip: their 8*NS byte loads are all in flight before the first use
+            int rr[4];
+            u32 cb[4][NS], qb[4][NS];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                rr[b] = -1;
+                if (mod) {
+                    rr[b] = __ffsll((long long)mod) - 1;
+                    mod &= mod - 1;
+                    const uint8_t *sp = seq + (t0 + rr[b]) * (long)B.pitch, *qp = qual + (t0 + rr[b]) * (long)B.pitch;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { cb[b][s] = sp[offp[s]]; qb[b][s] = qp[offp[s]]; }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (rr[b] < 0) continue;
+                const int r = rr[b];
+                const int len_r = rl(R.len, r), clen_r = rl(R.clen, r), start_r = rl(R.start, r);
+                const bool disc = rl(reason, r) != SNK_KEEP;
+                const bool shifted = !disc && start_r > 0;
+                const int rm_lo = (disc || shifted) ? 0 : clen_r;       // removed raw positions [rm_lo, len)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int pos = 64 * s + lane;
+                    if (pos < len_r) {
+                        const u32 c = cb[b][s];
+                        const int q = (int)qb[b][s] - phred;
+                        const u32 t2 = (c >> 1) & 3u;
+                        const u32 cls = (c & 0xDFu) == 'N' ? 4u : (t2 ^ (t2 >> 1));
+                        if (pos >= rm_lo && (u32)q < (u32)nq) {
+                            atomicAdd(&remB[cls * G.Lh + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
+                            atomicAdd(&remQ[q * G.Lh + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
+                        }
+                        if (shifted && pos >= start_r && pos < start_r + clen_r && (u32)q < (u32)nq) {
+                            atomicAdd(&gbs[(pos - start_r) * 5 + cls], 1ull);     // head-trimmed survivor: rare
+                            atomicAdd(&gqs[(long)(pos - start_r) * nq + q], 1ull);
+                        }
                     }
                 }
             }
@@ -684,7 +719,7 @@ __device__ void process_tile(const DevParams &P, const DevBatch &B, const DevSta
 
 template <int NW, bool FULL>
 __global__ void __launch_bounds__(1024)
-snk_tiled_kernel(const DevParams P, const DevBatch B, const DevStats st, const TileGeom G, const int iters,
+snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, const DevStats st, const TileGeom G, const int iters,
                  const int flush_every) {
     // parameters travel by value in the kernarg segment: the compiler keeps them in SGPRs instead
     // of re-loading them from global memory next to every atomic
@@ -695,16 +730,9 @@ snk_tiled_kernel(const DevParams P, const DevBatch B, const DevStats st, const T
     const int nwords = 4 * G.SET + 64;
     for (int i = threadIdx.x; i < nwords; i += blockDim.x) lds[i] = 0;
     __syncthreads();
-    // LDS histogram word of (position p, bin b) = b*Lh + (p mod Lh); high half-word when p >= Lh.
-    // Lh is a multiple of 32, so the 32 lanes of one ds_add group always hit 32 different banks.
-    int pmv[NS];
-    u32 inc[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int p = 64 * s + lane;
-        pmv[s] = p >= G.Lh ? p - G.Lh : p;
-        inc[s] = p >= G.Lh ? 0x10000u : 1u;
-    }
+    // LDS histogram word of (bin b, position p = 64*s + l) = b*Lh + 64*(s>>1) + l, half-word s&1:
+    // every address/increment of a strip is lane + compile-time constants (no per-lane tables), and
+    // the 64 lanes of one ds_add hit 64 consecutive dwords (conflict-free).
     const long GW = (long)gridDim.x * W;
     const long fb = file_block(G.lcap, G.nq);
     int flush_lo = 0;
@@ -713,8 +741,9 @@ snk_tiled_kernel(const DevParams P, const DevBatch B, const DevStats st, const T
         const long t0 = tile * 64;
         long rem = B.n - t0;
         const int cnt = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-        if (cnt > 0) process_tile<NW, FULL>(P, B, st, G, lds, t0, cnt, pmv, inc);
+        if (cnt > 0) process_tile<NW, FULL>(P, TA, B, st, G, lds, t0, cnt);
         if ((it + 1) % flush_every == 0 || it + 1 == iters) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm histogram adds
             __syncthreads();
             // flush: global raw += raw ; global clean += raw - removed
             int ovf = 0;
@@ -731,14 +760,15 @@ snk_tiled_kernel(const DevParams P, const DevBatch B, const DevStats st, const T
                         const long stride = w < G.WB ? 5 : G.nq;
                         const u32 alo = a & 0xFFFFu, blo = b & 0xFFFFu, ahi = a >> 16, bhi = b >> 16;
                         // slots of positions >= lcap hold the spill-over of lanes past the read end: dropped
-                        const bool lo_ok = pm < G.lcap, hi_ok = pm + G.Lh < G.lcap;
+                        const int plo = 128 * (pm >> 6) + (pm & 63), phi = plo + 64;
+                        const bool lo_ok = plo < G.lcap, hi_ok = phi < G.lcap;
                         if (w >= G.WB && bin == G.nq) {
                             if ((alo && lo_ok) || (ahi && hi_ok)) ovf = 1;       // quality outside [0,nq)
                         } else {
-                            if (alo && lo_ok) atomicAdd(&fraw[off + pm * stride], (u64)alo);
-                            if (alo != blo && lo_ok) atomicAdd(&fcl[off + pm * stride], (u64)alo - (u64)blo);
-                            if (ahi && hi_ok) atomicAdd(&fraw[off + (pm + G.Lh) * stride], (u64)ahi);
-                            if (ahi != bhi && hi_ok) atomicAdd(&fcl[off + (pm + G.Lh) * stride], (u64)ahi - (u64)bhi);
+                            if (alo && lo_ok) atomicAdd(&fraw[off + plo * stride], (u64)alo);
+                            if (alo != blo && lo_ok) atomicAdd(&fcl[off + plo * stride], (u64)alo - (u64)blo);
+                            if (ahi && hi_ok) atomicAdd(&fraw[off + phi * stride], (u64)ahi);
+                            if (ahi != bhi && hi_ok) atomicAdd(&fcl[off + phi * stride], (u64)ahi - (u64)bhi);
                         }
                         raw[w] = 0;
                         remv[w] = 0;
@@ -769,7 +799,8 @@ snk_tiled_kernel(const DevParams P, const DevBatch B, const DevStats st, const T
 }
 
 template <int NW, bool FULL>
-int launch(const DevParams &hp, const DevBatch &b, const DevStats &st, TileGeom G, int n_cu, void *stream) {
+int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, TileGeom G, int n_cu,
+           void *stream) {
     static bool attr_done = false;
     auto kern = snk_tiled_kernel<NW, FULL>;
     if (!attr_done) {
@@ -785,11 +816,19 @@ int launch(const DevParams &hp, const DevBatch &b, const DevStats &st, TileGeom 
     G.rb = 0; G.nd = 0; G.cba = 0; G.stg_off = (int)hist; G.stg_wave = 0;
     if (can_stage) {
         G.nd = 1;
-        G.cba = 1024;                      // bytes per array per buffer: one 64-lane x 16 B DMA
-        G.rb = G.cba / b.pitch;
-        G.stg_wave = 2 * 2 * G.cba;
-        while (W > 4 && hist + (size_t)W * G.stg_wave + 256 > 160 * 1024) W -= 4;
-        if (hist + (size_t)W * G.stg_wave + 256 > 160 * 1024) { G.rb = 0; W = 16; }
+        // bytes per array per buffer: one DMA of (cba/16) lanes x 16 B; the largest chunk that still
+        // lets 16 waves share the CU's LDS with the histograms
+        for (G.cba = 1024; G.cba >= 256; G.cba -= 256) {
+            G.rb = G.cba / b.pitch;
+            G.stg_wave = 2 * 2 * G.cba;
+            if (G.rb >= 1 && hist + (size_t)W * G.stg_wave + 256 <= 160 * 1024) break;
+            G.rb = 0;
+        }
+        if (G.rb == 0) {
+            G.cba = 1024; G.rb = G.cba / b.pitch; G.stg_wave = 2 * 2 * G.cba;
+            while (W > 4 && hist + (size_t)W * G.stg_wave + 256 > 160 * 1024) W -= 4;
+            if (hist + (size_t)W * G.stg_wave + 256 > 160 * 1024) { G.rb = 0; W = 16; }
+        }
     }
     const size_t shmem = hist + (G.rb ? (size_t)W * G.stg_wave + 256 : 0);   // + slack for strip over-reads
     const long tiles = (b.n + 63) / 64;
@@ -798,20 +837,20 @@ int launch(const DevParams &hp, const DevBatch &b, const DevStats &st, TileGeom 
     const long GW = wgs * W;
     const int iters = (int)((tiles + GW - 1) / GW);
     const int flush_every = 65535 / (W * 64);
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(W * 64), shmem, (hipStream_t)stream, hp, b, st, G, iters,
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(W * 64), shmem, (hipStream_t)stream, hp, ta, b, st, G, iters,
                        flush_every);
     return 1;
 }
 
 }  // namespace
 
-int snk_launch_tiled(const DevParams *dp_dev, const DevParams &hp, const DevBatch &b, const DevStats &st,
+int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st,
                      int lcap, int nq, int n_cu, void *stream) {
     if (!hp.tile_ok || lcap > 256 || b.n <= 0) return 0;
     TileGeom G;
     G.lcap = lcap;
     G.nq = nq;
-    G.Lh = (lcap + 1) / 2 < 64 ? 64 : ((lcap + 1) / 2 + 31) / 32 * 32;
+    G.Lh = 64 * (((lcap + 63) / 64 + 1) / 2);       // dwords per bin row: strips pair up in one dword
     G.WB = G.Lh * 5;
     G.WQ = G.Lh * (nq + 1);          // bin nq collects out-of-range qualities
     G.SET = G.WB + G.WQ;
@@ -820,8 +859,8 @@ int snk_launch_tiled(const DevParams *dp_dev, const DevParams &hp, const DevBatc
     const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq;
     const int nw = (lcap + 31) / 32;        // dwords per bit plane
 #define SNK_GO(NW_)                                                                    \
-    return full ? launch<NW_, true>(hp, b, st, G, n_cu, stream)                        \
-                : launch<NW_, false>(hp, b, st, G, n_cu, stream);
+    return full ? launch<NW_, true>(hp, ta, b, st, G, n_cu, stream)                    \
+                : launch<NW_, false>(hp, ta, b, st, G, n_cu, stream);
     if (nw <= 2) { SNK_GO(2) }
     else if (nw <= 4) { SNK_GO(4) }
     else if (nw <= 5) { SNK_GO(5) }
