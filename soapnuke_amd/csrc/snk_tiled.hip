@@ -602,13 +602,16 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         store_rec(B.out[0], t0 + lane, rs[0], reason, v);
         if (pe) store_rec(B.out[1], t0 + lane, rs[1], reason, v);
     }
-    // reason counters: one atomic per (family, tile)
+    // reason counters: one LDS add per (family, tile); the workgroup flushes them (chip-wide atomics on
+    // a handful of hot addresses once per tile cost a third of the kernel)
+    u32 *misc = lds + 4 * G.SET + 64;                 // [0,64) filter counters, [64,68) reads_number
+    u64 *maxk = reinterpret_cast<u64 *>(misc + 72);   // last-read keys of the 4 file stats
     {
-        u64 *fs = st.sum;
+        u32 *fs = misc;
         const u64 anyd = __ballot(live && reason != SNK_KEEP);
         if (anyd) {
             const int cd = __popcll(__ballot(live && reason == SNK_R_DUP));
-            if (cd && lane == 0) atomicAdd(&fs[SNK_FS_DUP], (u64)cd);
+            if (cd && lane == 0) atomicAdd(&fs[SNK_FS_DUP], (u32)cd);
             const int fam = reason_family(reason);
 #pragma unroll
             for (int f = SNK_FS_SHORT; f <= SNK_FS_ADAPTER; f += 4) {
@@ -618,10 +621,10 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                               c2 = __popcll(__ballot(live && fam == f && (v & 2))),
                               c3 = __popcll(__ballot(live && fam == f && v == 3));
                     if (lane == 0) {
-                        atomicAdd(&fs[f], (u64)c0);
-                        if (c1) atomicAdd(&fs[f + 1], (u64)c1);
-                        if (c2) atomicAdd(&fs[f + 2], (u64)c2);
-                        if (c3) atomicAdd(&fs[f + 3], (u64)c3);
+                        atomicAdd(&fs[f], (u32)c0);
+                        if (c1) atomicAdd(&fs[f + 1], (u32)c1);
+                        if (c2) atomicAdd(&fs[f + 2], (u32)c2);
+                        if (c3) atomicAdd(&fs[f + 3], (u32)c3);
                     }
                 }
             }
@@ -643,16 +646,16 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             const int last = 63 - __clzll((long long)liveM);
             const int ll = rl(R.len, last);
             if (lane == 0) {
-                atomicAdd(&fraw[SNK_GS_READS], (u64)__popcll(liveM));
-                atomicMax(&st.maxb[m], ((B.first_index + (u64)(t0 + last) + 1) << 16) | (u64)ll);
+                atomicAdd(&misc[64 + m], (u32)__popcll(liveM));
+                atomicMax(&maxk[m], ((B.first_index + (u64)(t0 + last) + 1) << 16) | (u64)ll);
             }
         }
         if (keptM) {
             const int last = 63 - __clzll((long long)keptM);
             const int ll = rl(R.clen, last);
             if (lane == 0) {
-                atomicAdd(&fcl[SNK_GS_READS], (u64)__popcll(keptM));
-                atomicMax(&st.maxb[2 + m], ((B.first_index + (u64)(t0 + last) + 1) << 16) | (u64)ll);
+                atomicAdd(&misc[66 + m], (u32)__popcll(keptM));
+                atomicMax(&maxk[2 + m], ((B.first_index + (u64)(t0 + last) + 1) << 16) | (u64)ll);
             }
         }
     }
@@ -727,7 +730,7 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
     constexpr int NS = (NW + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
     const int mates = P.paired ? 2 : 1;
-    const int nwords = 4 * G.SET + 64;
+    const int nwords = 4 * G.SET + 64 + 80;        // histograms, per-lane scratch words, misc counters
     for (int i = threadIdx.x; i < nwords; i += blockDim.x) lds[i] = 0;
     __syncthreads();
     // LDS histogram word of (bin b, position p = 64*s + l) = b*Lh + 64*(s>>1) + l, half-word s&1:
@@ -775,6 +778,22 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
                     }
                 }
             }
+            {   // per-workgroup scalar counters
+                u32 *misc = lds + 4 * G.SET + 64;
+                u64 *maxk = reinterpret_cast<u64 *>(misc + 72);
+                const int i = threadIdx.x;
+                if (i < 68) {
+                    const u32 v = misc[i];
+                    if (v) {
+                        if (i < 64) atomicAdd(&st.sum[i], (u64)v);
+                        else atomicAdd(&st.sum[SNK_FS_N + (i - 64) * fb + SNK_GS_READS], (u64)v);
+                        misc[i] = 0;
+                    }
+                } else if (i < 72) {
+                    const u64 v = maxk[i - 68];
+                    if (v) { atomicMax(&st.maxb[i - 68], v); maxk[i - 68] = 0; }
+                }
+            }
             if (__syncthreads_or(ovf)) {
                 // error path: some quality since the last flush was out of range -> find the reads
                 // (the reference corrupts its heap here, src/peprocess.cpp:1196; we report the first)
@@ -808,7 +827,7 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
             (void)hipGetLastError();
         attr_done = true;
     }
-    const size_t hist = ((size_t)2 * 2 * G.SET + 64) * sizeof(u32);
+    const size_t hist = ((size_t)2 * 2 * G.SET + 64 + 80) * sizeof(u32);
     // staging needs 16-byte rows; otherwise the register path is used
     const bool can_stage = (b.pitch % 16 == 0) && b.pitch <= 1024 &&
                            (((uintptr_t)b.seq[0] | (uintptr_t)b.qual[0] | (uintptr_t)b.seq[1] | (uintptr_t)b.qual[1]) % 16 == 0);
@@ -854,7 +873,7 @@ int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch
     G.WB = G.Lh * 5;
     G.WQ = G.Lh * (nq + 1);          // bin nq collects out-of-range qualities
     G.SET = G.WB + G.WQ;
-    if (((size_t)2 * 2 * G.SET + 64) * sizeof(u32) > 160 * 1024) return 0;
+    if (((size_t)2 * 2 * G.SET + 64 + 80) * sizeof(u32) > 160 * 1024) return 0;
     G.rb = G.nd = G.cba = G.stg_off = G.stg_wave = 0;
     const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq;
     const int nw = (lcap + 31) / 32;        // dwords per bit plane
