@@ -140,6 +140,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    ctx.last_kernel_ms()
     ctx.clear()
     kernel_ms = []
     t0 = time.perf_counter()
@@ -149,8 +150,8 @@ def main():
             pass
     barrier()
     elapsed = time.perf_counter() - t0
-    # per-launch kernel time: hipEvents recorded on the launch stream inside the C ABI
-    # (the last launch's pair; all launches are identical and back-to-back)
+    # average launch duration over the K timed steps: one hipEvent pair per launch, recorded on
+    # the launch stream inside the C ABI (warm-up pairs were drained before the timed region)
     kernel_ms.append(ctx.last_kernel_ms())
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

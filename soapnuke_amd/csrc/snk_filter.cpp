@@ -121,9 +121,8 @@ struct snk_ctx {
     uint8_t *st_buf = nullptr;
     size_t st_cap = 0;
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending, ev_free;   // one pair per timed launch
     float last_ms = 0.f;
-    bool last_timed = false;
 };
 
 extern "C" {
@@ -252,8 +251,6 @@ static int build_ctx(snk_ctx *c) {
     HIP_OK(hipMemset(c->d_sum, 0, c->sum_u64 * sizeof(uint64_t)));
     HIP_OK(hipMemset(c->d_max, 0, SNK_MAX_N * sizeof(uint64_t)));
     HIP_OK(hipMemset(c->d_err, 0xFF, sizeof(uint64_t)));
-    HIP_OK(hipEventCreate(&c->ev0));
-    HIP_OK(hipEventCreate(&c->ev1));
     return SNK_OK;
 }
 
@@ -313,8 +310,8 @@ void snk_destroy(snk_ctx *c) {
     }
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->st_buf) (void)hipFree(c->st_buf);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : c->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete c;
 }
 
@@ -355,10 +352,18 @@ int snk_set_timing(snk_ctx *c, int enabled) {
 
 int snk_last_kernel_ms(snk_ctx *c, float *ms) {
     if (!c || !ms) return SNK_E_PARAM;
-    if (c->last_timed) {
-        HIP_OK(hipEventSynchronize(c->ev1));
-        HIP_OK(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
-        c->last_timed = false;
+    // mean kernel time of all launches since the previous query (hipEvents on the launch stream)
+    if (!c->ev_pending.empty()) {
+        double tot = 0;
+        for (auto &e : c->ev_pending) {
+            float t = 0.f;
+            HIP_OK(hipEventSynchronize(e.second));
+            HIP_OK(hipEventElapsedTime(&t, e.first, e.second));
+            tot += t;
+            c->ev_free.push_back(e);
+        }
+        c->last_ms = (float)(tot / c->ev_pending.size());
+        c->ev_pending.clear();
     }
     *ms = c->last_ms;
     return SNK_OK;
@@ -391,14 +396,19 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
     D.out[1] = d_out2;
     DevStats st{c->d_sum, c->d_max, c->d_err};
     hipStream_t s = (hipStream_t)stream;
-    if (c->timing) HIP_OK(hipEventRecord(c->ev0, s));
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (c->timing) {
+        if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
+        else { HIP_OK(hipEventCreate(&ev.first)); HIP_OK(hipEventCreate(&ev.second)); }
+        HIP_OK(hipEventRecord(ev.first, s));
+    }
     int done = 0;
     if (kernel == 0 || kernel == 2) {
         done = snk_launch_tiled(c->hp, c->ta, D, st, c->lcap, c->nq, c->n_cu, stream);
         if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return SNK_E_UNSUPPORTED; }
     }
     if (!done) snk_launch_generic(c->d_params, D, st, c->lcap, c->nq, stream);
-    if (c->timing) { HIP_OK(hipEventRecord(c->ev1, s)); c->last_timed = true; }
+    if (c->timing) { HIP_OK(hipEventRecord(ev.second, s)); c->ev_pending.push_back(ev); }
     HIP_OK(hipGetLastError());
     return SNK_OK;
 }

@@ -1,0 +1,31 @@
+// snk_report.h -- stats merge + report writers of `SOAPnuke filter` (host side, plain C++).
+//
+// Counterpart of merge_stat/update_stat/print_stat of the reference
+// (src/peprocess.cpp:178-1075,1994-2005; src/seprocess.cpp:96-630; src/gc.cpp:68-119).
+// Input: one stats block (include/snk_filter.h layout) per *virtual reference thread*: the
+// reference's reports depend on how reads were dealt to its -T threads (SURVEY quirk Q3,
+// appendix C), so the host keeps one accumulator per virtual thread and replays the fold.
+#ifndef SNK_REPORT_H
+#define SNK_REPORT_H
+#include <stdint.h>
+#include "../../include/snk_filter.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// Writes the 10 (PE) / 6 (SE) report files into out_dir.  sums[t] / maxs[t]: the sum and max
+// blocks of virtual thread t (t = 0..n_threads-1), geometry (params->max_read_len,
+// params->max_base_quality+1).  Returns 0, or -1 with a message in err (cap bytes).
+int snk_write_reports(const snk_params *params, int n_threads, const uint64_t *const *sums,
+                      const uint64_t *const *maxs, const char *out_dir, char *err, int cap);
+
+// Virtual reference thread of input-order pair index r for -T threads and the given patchSize
+// (0 = default threads*2500): block = patchSize * (160/threads) pairs, owner = (r/block) % threads
+// (src/peprocess.cpp:81,2063,2092; src/process_argv.cpp:541-544).
+int64_t snk_vthread_block(int threads, int patch_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
