@@ -77,15 +77,28 @@ def write_reports(p, stats, out_dir):
     assert rc == 0, err.value
 
 
-def run_reference_cli(case, d, work):
-    """`SOAPnuke filter` of the compiled reference on the same reads (plain FASTQ, < 1 cycle of data: SURVEY Q10)."""
+def _gzip_copy(path):
+    import gzip
+    with open(path, "rb") as src, gzip.open(path + ".gz", "wb", compresslevel=1) as dst:
+        dst.write(src.read())
+
+
+def run_reference_cli(case, d, work, gz_input=False):
+    """`SOAPnuke filter` of the compiled reference on the same reads.  Its report files are right
+    either way; its *clean FASTQ* is only complete/in order for .gz input (or -T 1, or < 1 cycle of
+    reads): SURVEY quirk Q10 -- pass gz_input=True when the clean bytes are compared."""
     name, paired, L, n, threads, patch, skw, pkw, cli, cfg = case
     os.makedirs(work, exist_ok=True)
+    ext = ".fq.gz" if gz_input else ".fq"
     synth.write_fastq(os.path.join(work, "r1.fq"), d["seq"][0], d["qual"][0], L, 1)
-    cmd = [T.REF_BIN, "filter", "-1", os.path.join(work, "r1.fq"), "-C", "c1.fq", "-o", os.path.join(work, "ref"), "-T", str(threads)]
+    if gz_input:
+        _gzip_copy(os.path.join(work, "r1.fq"))
+    cmd = [T.REF_BIN, "filter", "-1", os.path.join(work, "r1" + ext), "-C", "c1.fq", "-o", os.path.join(work, "ref"), "-T", str(threads)]
     if paired:
         synth.write_fastq(os.path.join(work, "r2.fq"), d["seq"][1], d["qual"][1], L, 2)
-        cmd += ["-2", os.path.join(work, "r2.fq"), "-D", "c2.fq"]
+        if gz_input:
+            _gzip_copy(os.path.join(work, "r2.fq"))
+        cmd += ["-2", os.path.join(work, "r2" + ext), "-D", "c2.fq"]
     lines = list(cfg) + ([f"patch={patch}"] if patch else [])
     if lines:
         with open(os.path.join(work, "cfg"), "w") as f:

@@ -1,0 +1,71 @@
+"""End-to-end drop-in check on the GPU box: this repo's `SOAPnuke filter` (C++ host + HIP hot path)
+against the compiled reference binary on the same FASTQ files -- all report files byte-identical,
+decompressed clean FASTQ byte-identical.  The reference is fed < 1 cycle of reads (or .gz),
+SURVEY quirk Q10."""
+import filecmp
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import report_util as R
+import snk_testlib as T
+from soapnuke_amd import synth
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")]
+CLI = os.path.join(T.ROOT, "soapnuke_amd", "SOAPnuke")
+
+
+def _cat(path):
+    return gzip.open(path, "rb").read() if path.endswith(".gz") else open(path, "rb").read()
+
+
+def _run_ours(case, work, gz):
+    name, paired, L, n, threads, patch, skw, pkw, cli, cfg = case
+    ext = ".fq.gz" if gz else ".fq"
+    cmd = [CLI, "filter", "-1", os.path.join(work, "r1" + ext), "-C", "c1" + ext, "-o", os.path.join(work, "ours"), "-T", str(threads)]
+    if paired:
+        cmd += ["-2", os.path.join(work, "r2" + ext), "-D", "c2" + ext]
+    if os.path.exists(os.path.join(work, "cfg")):
+        cmd += ["-c", os.path.join(work, "cfg")]
+    r = subprocess.run(cmd + cli, capture_output=True)
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-500:])
+    return os.path.join(work, "ours")
+
+
+@pytest.mark.parametrize("case", R.REPORT_CASES, ids=[c[0] for c in R.REPORT_CASES])
+def test_cli_matches_reference_binary(case, tmp_path):
+    d, p = R.case_inputs(case)
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)   # writes r1.fq(.gz) / r2.fq(.gz) / cfg, runs the reference
+    ours = _run_ours(case, work, gz=False)
+    for f in (R.REPORT_FILES_PE if case[1] else R.REPORT_FILES_SE):
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in (["c1.fq", "c2.fq"] if case[1] else ["c1.fq"]):
+        assert _cat(os.path.join(ours, c)) == _cat(os.path.join(ref, c)), c
+
+
+def test_cli_gz_in_gz_out(tmp_path):
+    case = R.REPORT_CASES[0]
+    d, p = R.case_inputs(case)
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ours = _run_ours(case, work, gz=True)
+    for f in R.REPORT_FILES_PE:
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in ("c1.fq", "c2.fq"):
+        assert _cat(os.path.join(ours, c + ".gz")) == _cat(os.path.join(ref, c)), c
+
+
+def test_cli_error_surface(tmp_path):
+    r = subprocess.run([CLI, "filter", "-1", "/nonexistent.fq", "-C", "c.fq", "-o", str(tmp_path)], capture_output=True)
+    assert r.returncode == 1 and r.stderr.startswith(b"Error:")
+    r = subprocess.run([CLI, "filter", "-v"], capture_output=True)
+    assert r.returncode == 1 and b"2.1.9" in r.stderr
+    d = synth.make_batch(100, 50, paired=False, seed=1)
+    d["seq"][0][7, 3] = ord("#")
+    synth.write_fastq(str(tmp_path / "bad.fq"), d["seq"][0], d["qual"][0], 50, 1)
+    r = subprocess.run([CLI, "filter", "-1", str(tmp_path / "bad.fq"), "-C", "c.fq", "-o", str(tmp_path / "o")], capture_output=True)
+    assert r.returncode == 1 and b"Error:unrecognized sequence" in r.stderr

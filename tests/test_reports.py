@@ -69,7 +69,7 @@ def test_reports_from_hip_stats(case, tmp_path):
         ctx.filter_batch(ctx.make_batch(part, first_index=lo), rec)
         ctx.finalize()
         torch.cuda.synchronize()
-        stats[0] += s.cpu().numpy().view(np.uint64)
+        np.add(stats[0], s.cpu().numpy().view(np.uint64), out=stats[0])
         np.maximum(stats[1], mx.cpu().numpy().view(np.uint64), out=stats[1])
 
     stats = R.vthread_stats(case, d, p, run)
