@@ -299,7 +299,7 @@ __device__ int adapter_tile(const TileAdapter &A, const DevAdapter &AG, const u3
 }
 
 struct TileGeom {
-    int lcap, nq, Lh, WB, WQ, SET;
+    int lcap, nq, Lh, lg, WB, WQ, SET;   // Lh = 1 << lg dwords per histogram bin row
     // LDS staging of the read bytes (global_load_lds, 16 B/lane): per wave 2 buffers x
     // {bases, qualities} x cba bytes, a chunk = rb consecutive reads.  rb == 0: disabled.
     int rb, nd, cba, stg_off, stg_wave;
@@ -309,7 +309,9 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
 // One tile = up to 64 pairs starting at t0, processed by one wave.
-template <int NW, bool FULL>
+// The mate loops are deliberately NOT unrolled (one copy of phases 1-3 in the instruction cache);
+// per-mate results are handed over in the two ReadState values r0 / r1.
+template <int NW, bool FULL, bool STAGED>
 __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const DevBatch &B, const DevStats &st, const TileGeom &G,
                              u32 *lds, long t0, int cnt) {
     constexpr int NS = (NW + 1) / 2;
@@ -321,46 +323,49 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
     const long fb = file_block(G.lcap, nq);
     const long ts_off = SNK_GS_N + (long)G.lcap * 5 + (long)G.lcap * nq;
     const u64 gidx = B.first_index + (u64)(t0 + lane);
+    const int lgb = G.lg + 2;                         // log2(bytes per histogram bin row)
 
-    ReadState rs[2];
-    int estat[2] = {0, 0}, equal[2] = {0, 0};
+    ReadState r0, r1;
+    rs_init(r0, 0);
+    rs_init(r1, 0);
+    int e0 = 0, e1 = 0;
     const bool oobH = (0 - phred) < P.lq_head_q, oobT = (0 - phred) < P.lq_tail_q;
 
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {       // static mate index: rs[]/estat[] must stay in registers
-        if (m >= mates) continue;
+#pragma unroll 1
+    for (int m = 0; m < mates; ++m) {
         asm volatile("" : "+v"(lane));
         const uint8_t *seq = B.seq[m], *qual = B.qual[m];
-        u32 *rawB = lds + (m * 2 + 0) * G.SET, *rawQ = rawB + G.WB;
         int mylen = 0;
         if (lanev) mylen = B.len[m] ? (int)B.len[m][t0 + lane] : B.fixed_len[m];
         const int clen_v = min(mylen, G.lcap);
         // ------------------------------------------------------------ phase 1
-        // Straight-line per strip: 4 base ballots + 1 quality ballot written into the owning
-        // lane with v_writelane, two LDS histogram adds.  Nothing else: bits past a read's end
-        // are masked per lane in phase 2, base/low-quality counts are popcounts of the planes
-        // there, reads containing anything but ACGT (N, lower case, garbage) are detected there
-        // and repaired in a rare fix-up pass, and an out-of-range quality lands in an overflow
-        // bin that the flush checks.  Phase 1 is VALU/SALU-issue bound, not HBM bound.
-        u32 X[4][NW], LQ[NW], XN[NW], FG[NW], EQ[NW], LQH[NW], LQT[NW];
+        // Straight-line per strip: 4 base ballots written into the owning lane with v_writelane,
+        // one quality ballot counted on the scalar unit, two LDS histogram adds.  Nothing else: bits
+        // past a read's end are masked per lane in phase 2, base counts are popcounts of the planes
+        // there, reads containing anything but ACGT (N, lower case, garbage) are detected there and
+        // repaired in a rare fix-up pass, and an out-of-range quality lands in an overflow bin that
+        // the flush checks.  Phase 1 is VALU-issue bound, not HBM bound.
+        u32 X[4][NW], XN[NW], FG[NW], EQ[NW], LQH[NW], LQT[NW];
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             X[0][j] = X[1][j] = X[2][j] = X[3][j] = 0;
-            LQ[j] = XN[j] = FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
+            XN[j] = FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
         }
-        int v_sumq = 0;
+        int v_sumq = 0, v_lowq = 0;
         const int len0 = rl(clen_v, 0);
         const bool fixed = __all(!lanev || clen_v == len0);
         // every read of the tile fills the whole capacity: lanes past the end fall into histogram
         // slots of positions >= lcap, which are never flushed -> no validity masking at all
         const bool fulllen = fixed && len0 == G.lcap;
         const u32 rawBw = (u32)((m * 2 + 0) * G.SET), rawQw = rawBw + (u32)G.WB;
-        const u32 dumW = (u32)(4 * G.SET) + (u32)lane;   // per-lane scratch word (variable-length tiles)
-        const u32 Lh = (u32)G.Lh, nqu = (u32)nq, ulane = (u32)lane;
+        const u32 laneB = (rawBw + (u32)lane) * 4u, laneQ = (rawQw + (u32)lane) * 4u;   // byte addresses of bin row 0
+        const u32 dumB = ((u32)(4 * G.SET) + (u32)lane) * 4u;   // per-lane scratch word (variable-length tiles)
+        const u32 nqu = (u32)nq;
+        uint8_t *ldsb = reinterpret_cast<uint8_t *>(lds);
         auto do_read = [&](auto FL, const int r, const u32 (&cc)[NS], const u32 (&cq)[NS]) {
             constexpr bool FULLLEN = decltype(FL)::value;
             const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
-            int qsum = 0;
+            int qsum = 0, nlow = 0;
             u32 prev_last = 0xFFFFFFFFu;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -377,7 +382,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 SNK_PUT(X[2], __ballot(c == 'G'))
                 SNK_PUT(X[3], __ballot(c == 'T'))
                 const int q = (int)cq[s] - phred;
-                SNK_PUT(LQ, __ballot(q <= lowQ))
+                nlow += __popcll(__ballot(q <= lowQ) & lowmask64(len_r - 64 * s));
                 if (P.has_meanq) qsum += (pos < len_r) ? q : 0;
                 if (FULL) {
                     if (P.polyX_num != -1) {
@@ -393,25 +398,26 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 }
                 // raw per-position histograms (src/peprocess.cpp:1145-1201).  N / garbage land in a
                 // wrong base bin here and are moved by the fix-up pass; bin nq = quality overflow.
-                const u32 t2 = (c >> 1) & 3u;
-                const u32 cls = t2 ^ (t2 >> 1);
+                // class of ACGT from bits 1-2 of the character: A 00->0, C 01->1, T 10->3, G 11->2
+                const u32 cls = __builtin_amdgcn_ubfe(0xB4u, c & 6u, 2u);
                 const u32 qi = min((u32)q, nqu);
-                u32 wB = cls * Lh + ulane + (rawBw + 64u * (s >> 1)), wQ = qi * Lh + ulane + (rawQw + 64u * (s >> 1));
+                u32 aB = (cls << lgb) + laneB, aQ = (qi << lgb) + laneQ;
                 if (!FULLLEN) {
                     const bool valid = pos < len_r;
-                    wB = valid ? wB : dumW;
-                    wQ = valid ? wQ : dumW;
+                    aB = valid ? aB : dumB - 256u * (s >> 1);
+                    aQ = valid ? aQ : dumB - 256u * (s >> 1);
                 }
-                atomicAdd(&lds[wB], (s & 1) ? 0x10000u : 1u);
-                atomicAdd(&lds[wQ], (s & 1) ? 0x10000u : 1u);
+                atomicAdd(reinterpret_cast<u32 *>(ldsb + aB + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
+                atomicAdd(reinterpret_cast<u32 *>(ldsb + aQ + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
             }
+            v_lowq = wl(v_lowq, nlow, r);
             if (P.has_meanq) v_sumq = wl(v_sumq, wave_sum(qsum), r);
         };
         auto run_phase1 = [&](auto FL) {
-            if (G.rb > 0) {
+            if (STAGED) {
                 // bytes arrive in LDS by DMA (16 B/lane), the next chunk of rb reads in flight
                 // behind the ballots of the current one
-                uint8_t *stg = reinterpret_cast<uint8_t *>(lds) + G.stg_off + (threadIdx.x >> 6) * G.stg_wave;
+                uint8_t *stg = ldsb + G.stg_off + (threadIdx.x >> 6) * G.stg_wave;
                 const int rb = G.rb, nchunks = (cnt + rb - 1) / rb;
                 auto issue = [&](const int k) {
                     const long g0 = (t0 + (long)k * rb) * (long)B.pitch;
@@ -468,7 +474,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         if (fulllen) run_phase1(std::true_type{});
         else run_phase1(std::false_type{});
         // ------------------------------------------------------------ phase 2 (this mate)
-        ReadState &R = rs[m];
+        ReadState R;
         rs_init(R, clen_v);
         int v_adja = 0, v_nn = 0, v_bad = 0;
         bool needfix = false;
@@ -478,7 +484,6 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 const u32 in = lowmask32(R.len - 32 * j);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) X[k][j] &= in;
-                LQ[j] &= in;
                 needfix = needfix || (in & ~(X[0][j] | X[1][j] | X[2][j] | X[3][j])) != 0;
                 if (FULL) {
                     FG[j] = X[2][j];
@@ -509,9 +514,9 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     nN += __popcll(__ballot(isn));
                     if (__any(valid && !(cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T' || cu == 'N'))) bad = 1;
                     if (isn) {
-                        const u32 t2 = (c >> 1) & 3u, clsw = t2 ^ (t2 >> 1);
-                        atomicSub(&lds[rawBw + clsw * Lh + 64u * (s >> 1) + ulane], (s & 1) ? 0x10000u : 1u);
-                        atomicAdd(&lds[rawBw + 4u * Lh + 64u * (s >> 1) + ulane], (s & 1) ? 0x10000u : 1u);
+                        const u32 clsw = __builtin_amdgcn_ubfe(0xB4u, c & 6u, 2u);
+                        atomicSub(reinterpret_cast<u32 *>(ldsb + (clsw << lgb) + laneB + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
+                        atomicAdd(reinterpret_cast<u32 *>(ldsb + (4u << lgb) + laneB + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
                     }
                     if (FULL) {
                         SNK_PUT(XN, __ballot(valid && c == 'N'))
@@ -523,22 +528,20 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 v_bad = wl(v_bad, bad, r);
             }
         }
-        estat[m] = !lanev ? 0 : (mylen > G.lcap ? SNK_E_TOO_LONG : (mylen == 0 ? SNK_E_EMPTY_SEQ : (v_bad ? SNK_E_BAD_BASE : 0)));
-        equal[m] = 0;                     // quality-range errors are found by the flush (overflow bin)
+        const int estat = !lanev ? 0 : (mylen > G.lcap ? SNK_E_TOO_LONG : (mylen == 0 ? SNK_E_EMPTY_SEQ : (v_bad ? SNK_E_BAD_BASE : 0)));
         {   // counts from the planes, then "beyond the read = matches anything" for the adapter search
-            int na = 0, nl = 0;
+            int na = 0;
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const u32 in = lowmask32(R.len - 32 * j);
                 na += __popc(X[0][j]);
-                nl += __popc(LQ[j]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) X[k][j] |= ~in;
                 if (FULL) XN[j] |= ~in;
             }
             R.n_a = na + v_adja;
             R.n_n = v_nn;
-            R.lowq = nl;
+            R.lowq = v_lowq;
             R.sumq = v_sumq;
         }
         int hix = 0, tix = 0, polyg = 0;
@@ -571,7 +574,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             }
             if (P.has_polyG) polyg = run_down<NW>(FG, R.len);     // src/read_filter.cpp:472-482
         }
-        const bool good = lanev && !estat[m];
+        const bool good = lanev && !estat;
         int ada_pos = -1;
         const int nada = P.n_ada[m];
         for (int i = 0; i < nada; ++i) {                           // src/read_filter.cpp:175-188
@@ -583,24 +586,22 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         }
         if (ada_pos >= 0) { R.inc_ada = 1; R.adacut = R.len - ada_pos; }
         if (P.trim_on) trim_finish(P, m, R, hix, tix, polyg);
+        if (m == 0) { r0 = R; e0 = estat; }
+        else { r1 = R; e1 = estat; }
     }
 
     // ---------------------------------------------------------------- pair level
+    // (quality-range errors are found by the flush through the overflow bin)
     asm volatile("" : "+v"(lane));
     const int pe = mates - 1;
-    int ecode = 0, emate = 0;
-    if (estat[0]) { ecode = estat[0]; emate = 0; }
-    else if (pe && estat[1]) { ecode = estat[1]; emate = 1; }
-    else if (equal[0]) { ecode = equal[0]; emate = 0; }
-    else if (pe && equal[1]) { ecode = equal[1]; emate = 1; }
-    if (lanev && ecode) report_err(st, gidx, emate, ecode);
-    const bool live = lanev && !(estat[0] || (pe && estat[1]));
+    if (lanev && (e0 || (pe && e1))) report_err(st, gidx, e0 ? 0 : 1, e0 ? e0 : e1);
+    const bool live = lanev && !(e0 || (pe && e1));
     int v = 0, reason = SNK_KEEP;
     if (live) {
         const int dup = B.dup ? (int)B.dup[t0 + lane] : 0;
-        reason = pe ? discard_reason(P, rs[0], rs[1], dup, v) : discard_reason(P, rs[0], rs[0], dup, v);
-        store_rec(B.out[0], t0 + lane, rs[0], reason, v);
-        if (pe) store_rec(B.out[1], t0 + lane, rs[1], reason, v);
+        reason = pe ? discard_reason(P, r0, r1, dup, v) : discard_reason(P, r0, r0, dup, v);
+        store_rec(B.out[0], t0 + lane, r0, reason, v);
+        if (pe) store_rec(B.out[1], t0 + lane, r1, reason, v);
     }
     // reason counters: one LDS add per (family, tile); the workgroup flushes them (chip-wide atomics on
     // a handful of hot addresses once per tile cost a third of the kernel)
@@ -613,7 +614,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             const int cd = __popcll(__ballot(live && reason == SNK_R_DUP));
             if (cd && lane == 0) atomicAdd(&fs[SNK_FS_DUP], (u32)cd);
             const int fam = reason_family(reason);
-#pragma unroll
+#pragma unroll 1
             for (int f = SNK_FS_SHORT; f <= SNK_FS_ADAPTER; f += 4) {
                 const u64 bm = __ballot(live && fam == f);
                 if (bm) {
@@ -630,14 +631,16 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             }
         }
     }
-    // trimming-position counters (rare), reads_number, last-read key
     const bool kept = live && reason == SNK_KEEP;
     const u64 liveM = __ballot(live), keptM = __ballot(kept);
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        if (m >= mates) continue;
+    // ---------------------------------------------------------------- per mate: trimming-position
+    // counters (rare), reads_number, last-read key; then phase 3: clean = raw - removed, only
+    // discarded / trimmed reads are walked again
+#pragma unroll 1
+    for (int m = 0; m < mates; ++m) {
+        asm volatile("" : "+v"(lane));
+        const ReadState R = m ? r1 : r0;
         u64 *fraw = st.sum + SNK_FS_N + m * fb, *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
-        const ReadState &R = rs[m];
         if (live && P.copy_back)
             ts_update(fraw + ts_off, R.hd_h, R.lq_h, R.hd_t, R.lq_t, R.adacut, (pe && m == 1) ? R.len : 0, !pe);
         if (kept)
@@ -658,17 +661,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 atomicMax(&maxk[2 + m], ((B.first_index + (u64)(t0 + last) + 1) << 16) | (u64)ll);
             }
         }
-    }
-    // ---------------------------------------------------------------- phase 3
-    asm volatile("" : "+v"(lane));
-    // clean = raw - removed: only discarded / trimmed reads are walked again
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        if (m >= mates) continue;
-        const ReadState &R = rs[m];
         const uint8_t *seq = B.seq[m], *qual = B.qual[m];
         u32 *remB = lds + (m * 2 + 1) * G.SET, *remQ = remB + G.WB;
-        u64 *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
         u64 *gbs = fcl + SNK_GS_N, *gqs = fcl + SNK_GS_N + (long)G.lcap * 5;
         u64 mod = __ballot(live && (reason != SNK_KEEP || R.clen != R.len));
         u32 offp[NS];
@@ -703,11 +697,10 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     if (pos < len_r) {
                         const u32 c = cb[b][s];
                         const int q = (int)qb[b][s] - phred;
-                        const u32 t2 = (c >> 1) & 3u;
-                        const u32 cls = (c & 0xDFu) == 'N' ? 4u : (t2 ^ (t2 >> 1));
+                        const u32 cls = (c & 0xDFu) == 'N' ? 4u : __builtin_amdgcn_ubfe(0xB4u, c & 6u, 2u);
                         if (pos >= rm_lo && (u32)q < (u32)nq) {
-                            atomicAdd(&remB[cls * G.Lh + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
-                            atomicAdd(&remQ[q * G.Lh + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
+                            atomicAdd(&remB[(cls << G.lg) + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
+                            atomicAdd(&remQ[((u32)q << G.lg) + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
                         }
                         if (shifted && pos >= start_r && pos < start_r + clen_r && (u32)q < (u32)nq) {
                             atomicAdd(&gbs[(pos - start_r) * 5 + cls], 1ull);     // head-trimmed survivor: rare
@@ -720,7 +713,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
     }
 }
 
-template <int NW, bool FULL>
+template <int NW, bool FULL, bool STAGED>
 __global__ void __launch_bounds__(1024)
 snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, const DevStats st, const TileGeom G, const int iters,
                  const int flush_every) {
@@ -744,7 +737,7 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
         const long t0 = tile * 64;
         long rem = B.n - t0;
         const int cnt = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-        if (cnt > 0) process_tile<NW, FULL>(P, TA, B, st, G, lds, t0, cnt);
+        if (cnt > 0) process_tile<NW, FULL, STAGED>(P, TA, B, st, G, lds, t0, cnt);
         if ((it + 1) % flush_every == 0 || it + 1 == iters) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm histogram adds
             __syncthreads();
@@ -817,16 +810,22 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
     }
 }
 
-template <int NW, bool FULL>
-int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, TileGeom G, int n_cu,
-           void *stream) {
+template <int NW, bool FULL, bool STAGED>
+void go(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, const TileGeom &G, int iters,
+        int flush_every, unsigned wgs, int threads, size_t shmem, void *stream) {
     static bool attr_done = false;
-    auto kern = snk_tiled_kernel<NW, FULL>;
+    auto kern = snk_tiled_kernel<NW, FULL, STAGED>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_done = true;
     }
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), shmem, (hipStream_t)stream, hp, ta, b, st, G, iters, flush_every);
+}
+
+template <int NW, bool FULL>
+int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, TileGeom G, int n_cu,
+           void *stream) {
     const size_t hist = ((size_t)2 * 2 * G.SET + 64 + 80) * sizeof(u32);
     // staging needs 16-byte rows; otherwise the register path is used
     const bool can_stage = (b.pitch % 16 == 0) && b.pitch <= 1024 &&
@@ -856,8 +855,8 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
     const long GW = wgs * W;
     const int iters = (int)((tiles + GW - 1) / GW);
     const int flush_every = 65535 / (W * 64);
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(W * 64), shmem, (hipStream_t)stream, hp, ta, b, st, G, iters,
-                       flush_every);
+    if (G.rb) go<NW, FULL, true>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
+    else go<NW, FULL, false>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
     return 1;
 }
 
@@ -870,6 +869,7 @@ int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch
     G.lcap = lcap;
     G.nq = nq;
     G.Lh = 64 * (((lcap + 63) / 64 + 1) / 2);       // dwords per bin row: strips pair up in one dword
+    G.lg = G.Lh == 64 ? 6 : 7;
     G.WB = G.Lh * 5;
     G.WQ = G.Lh * (nq + 1);          // bin nq collects out-of-range qualities
     G.SET = G.WB + G.WQ;
