@@ -398,10 +398,10 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 }
                 // raw per-position histograms (src/peprocess.cpp:1145-1201).  N / garbage land in a
                 // wrong base bin here and are moved by the fix-up pass; bin nq = quality overflow.
-                // class of ACGT from bits 1-2 of the character: A 00->0, C 01->1, T 10->3, G 11->2
-                const u32 cls = __builtin_amdgcn_ubfe(0xB4u, c & 6u, 2u);
+                // LDS base rows are ordered by bits 1-2 of the character (A 00, C 01, T 10, G 11, then N):
+                // the row address is one shift-add of (c & 6); the flush swaps rows 2/3 back to ACGT order
                 const u32 qi = min((u32)q, nqu);
-                u32 aB = (cls << lgb) + laneB, aQ = (qi << lgb) + laneQ;
+                u32 aB = ((c & 6u) << (lgb - 1)) + laneB, aQ = (qi << lgb) + laneQ;
                 if (!FULLLEN) {
                     const bool valid = pos < len_r;
                     aB = valid ? aB : dumB - 256u * (s >> 1);
@@ -417,7 +417,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             if (STAGED) {
                 // bytes arrive in LDS by DMA (16 B/lane), the next chunk of rb reads in flight
                 // behind the ballots of the current one
-                uint8_t *stg = ldsb + G.stg_off + (threadIdx.x >> 6) * G.stg_wave;
+                uint8_t *stg = ldsb + G.stg_off + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * G.stg_wave;
                 const int rb = G.rb, nchunks = (cnt + rb - 1) / rb;
                 auto issue = [&](const int k) {
                     const long g0 = (t0 + (long)k * rb) * (long)B.pitch;
@@ -437,15 +437,28 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
-                    const uint8_t *cb = stg + (k & 1) * 2 * G.cba + lane;
-                    for (int rr = 0; rr < rb; ++rr) {
-                        const int r = k * rb + rr;
-                        if (r >= cnt) break;
-                        const uint8_t *sb = cb + rr * B.pitch;
-                        u32 cc[NS], cq[NS];
+                    // LDS -> register reads run one read ahead of the ballots, so that the wave never
+                    // sits in lgkmcnt(0) behind its own histogram adds
+                    const uint8_t *sb = stg + (k & 1) * 2 * G.cba + lane;
+                    const int nr = min(rb, cnt - k * rb);
+                    u32 ac[NS], aq[NS], bc[NS], bq[NS];     // two register sets alternate (no rotation moves)
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) { cc[s] = sb[64 * s]; cq[s] = sb[G.cba + 64 * s]; }
-                        do_read(FL, r, cc, cq);
+                    for (int s = 0; s < NS; ++s) { ac[s] = sb[64 * s]; aq[s] = sb[G.cba + 64 * s]; }
+                    for (int rr = 0; rr < nr; rr += 2) {
+                        const bool hb = rr + 1 < nr;
+                        if (hb) {
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) { bc[s] = sb[B.pitch + 64 * s]; bq[s] = sb[B.pitch + G.cba + 64 * s]; }
+                        }
+                        do_read(FL, k * rb + rr, ac, aq);
+                        sb += 2 * B.pitch;
+                        if (hb) {
+                            if (rr + 2 < nr) {
+#pragma unroll
+                                for (int s = 0; s < NS; ++s) { ac[s] = sb[64 * s]; aq[s] = sb[G.cba + 64 * s]; }
+                            }
+                            do_read(FL, k * rb + rr + 1, bc, bq);
+                        }
                     }
                 }
             } else {
@@ -514,8 +527,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     nN += __popcll(__ballot(isn));
                     if (__any(valid && !(cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T' || cu == 'N'))) bad = 1;
                     if (isn) {
-                        const u32 clsw = __builtin_amdgcn_ubfe(0xB4u, c & 6u, 2u);
-                        atomicSub(reinterpret_cast<u32 *>(ldsb + (clsw << lgb) + laneB + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
+                        atomicSub(reinterpret_cast<u32 *>(ldsb + ((c & 6u) << (lgb - 1)) + laneB + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
                         atomicAdd(reinterpret_cast<u32 *>(ldsb + (4u << lgb) + laneB + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
                     }
                     if (FULL) {
@@ -697,9 +709,11 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     if (pos < len_r) {
                         const u32 c = cb[b][s];
                         const int q = (int)qb[b][s] - phred;
-                        const u32 cls = (c & 0xDFu) == 'N' ? 4u : __builtin_amdgcn_ubfe(0xB4u, c & 6u, 2u);
+                        const bool isn = (c & 0xDFu) == 'N';
+                        const u32 row = isn ? 4u : (c & 6u) >> 1;                                  // LDS row order A C T G N
+                        const u32 cls = isn ? 4u : __builtin_amdgcn_ubfe(0xB4u, c & 6u, 2u);      // stats order A C G T N
                         if (pos >= rm_lo && (u32)q < (u32)nq) {
-                            atomicAdd(&remB[(cls << G.lg) + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
+                            atomicAdd(&remB[(row << G.lg) + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
                             atomicAdd(&remQ[((u32)q << G.lg) + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
                         }
                         if (shifted && pos >= start_r && pos < start_r + clen_r && (u32)q < (u32)nq) {
@@ -721,7 +735,8 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
     // of re-loading them from global memory next to every atomic
     extern __shared__ u32 lds[];
     constexpr int NS = (NW + 1) / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, W = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile index and addresses stay scalar
     const int mates = P.paired ? 2 : 1;
     const int nwords = 4 * G.SET + 64 + 80;        // histograms, per-lane scratch words, misc counters
     for (int i = threadIdx.x; i < nwords; i += blockDim.x) lds[i] = 0;
@@ -751,8 +766,8 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
                     if (a | b) {
                         long off;
                         int pm, bin;
-                        if (w < G.WB) { bin = w / G.Lh; pm = w - bin * G.Lh; off = SNK_GS_N + (long)bin; }
-                        else { const int ww = w - G.WB; bin = ww / G.Lh; pm = ww - bin * G.Lh; off = SNK_GS_N + (long)G.lcap * 5 + bin; }
+                        if (w < G.WB) { bin = w >> G.lg; pm = w - (bin << G.lg); off = SNK_GS_N + (long)(bin ^ ((bin >> 1) & (bin < 4))); }
+                        else { const int ww = w - G.WB; bin = ww >> G.lg; pm = ww - (bin << G.lg); off = SNK_GS_N + (long)G.lcap * 5 + bin; }
                         const long stride = w < G.WB ? 5 : G.nq;
                         const u32 alo = a & 0xFFFFu, blo = b & 0xFFFFu, ahi = a >> 16, bhi = b >> 16;
                         // slots of positions >= lcap hold the spill-over of lanes past the read end: dropped
