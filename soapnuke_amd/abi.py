@@ -164,7 +164,7 @@ EXPORTS = [
 
 def load_library(path=None):
     """dlopen the HIP extension.  Fails loudly: there is no CPU fallback."""
-    path = path or LIB_PATH
+    path = path or os.environ.get("SNK_LIB") or LIB_PATH      # SNK_LIB: profiling builds (tools/ablate.sh)
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

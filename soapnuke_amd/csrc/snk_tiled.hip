@@ -29,9 +29,16 @@
 // and by VALU issue in practice.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
 #include "snk_common.cuh"
 
 using namespace snk;
+
+// ablation builds for profiling only (tools/ablate.sh): 1 = phase 1 only, 2 = phases 1+2,
+// 3 = no phase 3, 4 = no adapter search.  The shipped library is built with 0.
+#ifndef SNK_ABL
+#define SNK_ABL 0
+#endif
 
 extern "C" __device__ int __snk_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
 
@@ -45,13 +52,38 @@ __device__ __forceinline__ u64 lowmask64(int n) { return n <= 0 ? 0ull : (n >= 6
 __device__ __forceinline__ int wl(int dst, int val, int lane) { return __snk_writelane(val, lane, dst); }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// Fire-and-forget LDS add.  Issued as inline asm on purpose: with a global_load_lds (LDS DMA)
-// in flight hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS store/atomic it knows about,
-// which would drain the prefetched chunk once per read.  The histogram words never overlap the
-// staging buffers; the flush waits lgkmcnt(0) explicitly before its barrier.
-__device__ __forceinline__ void lds_add_u32(u32 byte_addr, u32 val) {
-    asm volatile("ds_add_u32 %0, %1" ::"v"(byte_addr), "v"(val) : "memory");
+// Fire-and-forget LDS add with a compile-time offset.  Issued as inline asm on purpose: with a
+// global_load_lds (LDS DMA) in flight hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS
+// store/atomic it knows about, which would drain the prefetched chunk at the first histogram add
+// of every chunk.  The histogram words never overlap the staging buffers; the flush waits
+// lgkmcnt(0) explicitly before its barrier.  `addr` is an absolute LDS byte address.
+template <int OFF>
+__device__ __forceinline__ void lds_add_u32(u32 addr, u32 val) {
+    asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(OFF));
 }
+typedef __attribute__((address_space(3))) u32 *lds_u32_ptr;
+// asynchronous byte reads of one read's strips (bases at addr, qualities at addrq); pair with lds_wait
+template <int S, int NS>
+__device__ __forceinline__ void lds_read_strips(u32 (&c)[NS], u32 (&q)[NS], u32 addr, u32 addrq) {
+    if constexpr (S < NS) {
+        asm volatile("ds_read_u8 %0, %1 offset:%2" : "=&v"(c[S]) : "v"(addr), "n"(64 * S));
+        asm volatile("ds_read_u8 %0, %1 offset:%2" : "=&v"(q[S]) : "v"(addrq), "n"(64 * S));
+        lds_read_strips<S + 1>(c, q, addr, addrq);
+    }
+}
+// wait until at most N LDS ops are outstanding; the registers of the (asm) reads being waited for
+// are tied to the wait so that no use can be scheduled above it
+template <int N, int NS>
+__device__ __forceinline__ void lds_wait(u32 (&c)[NS], u32 (&q)[NS]) {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+#pragma unroll
+    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(c[s]), "+v"(q[s]));
+}
+
+// compile-time strip loop (the strip number feeds immediate offsets of the asm above)
+template <int V> struct IntC { static constexpr int v = V; };
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F &&f) { (f(IntC<I>{}), ...); }
 
 __device__ __forceinline__ int wave_sum(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -358,8 +390,9 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         // slots of positions >= lcap, which are never flushed -> no validity masking at all
         const bool fulllen = fixed && len0 == G.lcap;
         const u32 rawBw = (u32)((m * 2 + 0) * G.SET), rawQw = rawBw + (u32)G.WB;
-        const u32 laneB = (rawBw + (u32)lane) * 4u, laneQ = (rawQw + (u32)lane) * 4u;   // byte addresses of bin row 0
-        const u32 dumB = ((u32)(4 * G.SET) + (u32)lane) * 4u;   // per-lane scratch word (variable-length tiles)
+        const u32 lds0 = (u32)(uintptr_t)(lds_u32_ptr)lds;                   // absolute LDS address of the histograms
+        const u32 laneB = lds0 + (rawBw + (u32)lane) * 4u, laneQ = lds0 + (rawQw + (u32)lane) * 4u;   // bin row 0
+        const u32 dumB = lds0 + ((u32)(4 * G.SET) + (u32)lane) * 4u;   // per-lane scratch word (variable-length tiles)
         const u32 nqu = (u32)nq;
         uint8_t *ldsb = reinterpret_cast<uint8_t *>(lds);
         auto do_read = [&](auto FL, const int r, const u32 (&cc)[NS], const u32 (&cq)[NS]) {
@@ -367,8 +400,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
             int qsum = 0, nlow = 0;
             u32 prev_last = 0xFFFFFFFFu;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
+                constexpr int s = decltype(sc)::v;
                 const int pos = 64 * s + lane;
                 const u32 c = cc[s];
 #define SNK_PUT(PL, VAL)                                                                   \
@@ -407,17 +440,19 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     aB = valid ? aB : dumB - 256u * (s >> 1);
                     aQ = valid ? aQ : dumB - 256u * (s >> 1);
                 }
-                atomicAdd(reinterpret_cast<u32 *>(ldsb + aB + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
-                atomicAdd(reinterpret_cast<u32 *>(ldsb + aQ + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
-            }
+                lds_add_u32<256 * (s >> 1)>(aB, (s & 1) ? 0x10000u : 1u);
+                lds_add_u32<256 * (s >> 1)>(aQ, (s & 1) ? 0x10000u : 1u);
+            });
             v_lowq = wl(v_lowq, nlow, r);
             if (P.has_meanq) v_sumq = wl(v_sumq, wave_sum(qsum), r);
         };
+        auto lds_rd = [&](u32 (&c)[NS], u32 (&q)[NS], const u32 addr) { lds_read_strips<0>(c, q, addr, addr + (u32)G.cba); };
         auto run_phase1 = [&](auto FL) {
             if (STAGED) {
                 // bytes arrive in LDS by DMA (16 B/lane), the next chunk of rb reads in flight
                 // behind the ballots of the current one
-                uint8_t *stg = ldsb + G.stg_off + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * G.stg_wave;
+                const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                uint8_t *stg = ldsb + G.stg_off + wave * G.stg_wave;
                 const int rb = G.rb, nchunks = (cnt + rb - 1) / rb;
                 auto issue = [&](const int k) {
                     const long g0 = (t0 + (long)k * rb) * (long)B.pitch;
@@ -437,27 +472,28 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     } else {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
-                    // LDS -> register reads run one read ahead of the ballots, so that the wave never
-                    // sits in lgkmcnt(0) behind its own histogram adds
-                    const uint8_t *sb = stg + (k & 1) * 2 * G.cba + lane;
+                    // LDS -> register reads run one read ahead of the ballots.  Reads, histogram adds and
+                    // their waits are hand-placed asm: the compiler cannot see through the loop-carried LDS
+                    // queue and would drain it (lgkmcnt(0)) right after issuing the prefetch.  LDS ops return
+                    // in order, so "all but the newest K" is exact: K = 2*NS histogram adds follow the
+                    // prefetch.  Every read is waited for in the same straight-line block that issued it (no
+                    // register of an in-flight read crosses a branch).  The prefetch past the last read of
+                    // the chunk reads staging bytes that are never used.
+                    constexpr int K = 2 * NS;
                     const int nr = min(rb, cnt - k * rb);
+                    u32 sa = lds0 + (u32)(G.stg_off + wave * G.stg_wave + (k & 1) * 2 * G.cba + lane);
                     u32 ac[NS], aq[NS], bc[NS], bq[NS];     // two register sets alternate (no rotation moves)
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) { ac[s] = sb[64 * s]; aq[s] = sb[G.cba + 64 * s]; }
+                    lds_rd(ac, aq, sa);
+                    lds_wait<0>(ac, aq);
                     for (int rr = 0; rr < nr; rr += 2) {
-                        const bool hb = rr + 1 < nr;
-                        if (hb) {
-#pragma unroll
-                            for (int s = 0; s < NS; ++s) { bc[s] = sb[B.pitch + 64 * s]; bq[s] = sb[B.pitch + G.cba + 64 * s]; }
-                        }
+                        lds_rd(bc, bq, sa + (u32)B.pitch);
                         do_read(FL, k * rb + rr, ac, aq);
-                        sb += 2 * B.pitch;
-                        if (hb) {
-                            if (rr + 2 < nr) {
-#pragma unroll
-                                for (int s = 0; s < NS; ++s) { ac[s] = sb[64 * s]; aq[s] = sb[G.cba + 64 * s]; }
-                            }
+                        lds_wait<K>(bc, bq);
+                        sa += 2u * (u32)B.pitch;
+                        if (rr + 1 < nr) {
+                            lds_rd(ac, aq, sa);
                             do_read(FL, k * rb + rr + 1, bc, bq);
+                            lds_wait<K>(ac, aq);
                         }
                     }
                 }
@@ -486,6 +522,12 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         };
         if (fulllen) run_phase1(std::true_type{});
         else run_phase1(std::false_type{});
+        if (SNK_ABL == 1) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(X[0][j]), "v"(X[1][j]), "v"(X[2][j]), "v"(X[3][j]));
+            asm volatile("" ::"v"(v_lowq), "v"(v_sumq));
+            continue;
+        }
         // ------------------------------------------------------------ phase 2 (this mate)
         ReadState R;
         rs_init(R, clen_v);
@@ -527,8 +569,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     nN += __popcll(__ballot(isn));
                     if (__any(valid && !(cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T' || cu == 'N'))) bad = 1;
                     if (isn) {
-                        atomicSub(reinterpret_cast<u32 *>(ldsb + ((c & 6u) << (lgb - 1)) + laneB + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
-                        atomicAdd(reinterpret_cast<u32 *>(ldsb + (4u << lgb) + laneB + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
+                        atomicSub(reinterpret_cast<u32 *>(ldsb + ((c & 6u) << (lgb - 1)) + (laneB - lds0) + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
+                        atomicAdd(reinterpret_cast<u32 *>(ldsb + (4u << lgb) + (laneB - lds0) + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
                     }
                     if (FULL) {
                         SNK_PUT(XN, __ballot(valid && c == 'N'))
@@ -589,7 +631,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         const bool good = lanev && !estat;
         int ada_pos = -1;
         const int nada = P.n_ada[m];
-        for (int i = 0; i < nada; ++i) {                           // src/read_filter.cpp:175-188
+        for (int i = 0; i < (SNK_ABL == 4 ? 0 : nada); ++i) {      // src/read_filter.cpp:175-188
             const bool todo = good && ada_pos < 0;
             if (!__any(todo)) break;
             const int pp = adapter_tile<NW, FULL>(TA.a[m][i], P.ada[m * SNK_MAX_ADAPTERS + i], X, XN, R.len, todo,
@@ -602,6 +644,12 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         else { r1 = R; e1 = estat; }
     }
 
+    if (SNK_ABL == 1) return;
+    if (SNK_ABL == 2) {
+        asm volatile("" ::"v"(r0.clen), "v"(r0.start), "v"(r0.n_a), "v"(r0.n_n), "v"(r0.lowq), "v"(r0.adacut), "v"(r0.inc_ada));
+        asm volatile("" ::"v"(r1.clen), "v"(r1.start), "v"(r1.n_a), "v"(r1.n_n), "v"(r1.lowq), "v"(r1.adacut), "v"(r1.inc_ada));
+        return;
+    }
     // ---------------------------------------------------------------- pair level
     // (quality-range errors are found by the flush through the overflow bin)
     asm volatile("" : "+v"(lane));
@@ -680,7 +728,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         u32 offp[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) offp[s] = (u32)min(64 * s + lane, B.pitch - 1);
-        while (mod) {
+        while (SNK_ABL != 3 && mod) {
             // up to 4 reads per trip: their 8*NS byte loads are all in flight before the first use
             int rr[4];
             u32 cb[4][NS], qb[4][NS];
@@ -854,16 +902,16 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
         for (G.cba = 1024; G.cba >= 256; G.cba -= 256) {
             G.rb = G.cba / b.pitch;
             G.stg_wave = 2 * 2 * G.cba;
-            if (G.rb >= 1 && hist + (size_t)W * G.stg_wave + 256 <= 160 * 1024) break;
+            if (G.rb >= 1 && hist + (size_t)W * G.stg_wave + 2048 <= 160 * 1024) break;
             G.rb = 0;
         }
         if (G.rb == 0) {
             G.cba = 1024; G.rb = G.cba / b.pitch; G.stg_wave = 2 * 2 * G.cba;
-            while (W > 4 && hist + (size_t)W * G.stg_wave + 256 > 160 * 1024) W -= 4;
-            if (hist + (size_t)W * G.stg_wave + 256 > 160 * 1024) { G.rb = 0; W = 16; }
+            while (W > 4 && hist + (size_t)W * G.stg_wave + 2048 > 160 * 1024) W -= 4;
+            if (hist + (size_t)W * G.stg_wave + 2048 > 160 * 1024) { G.rb = 0; W = 16; }
         }
     }
-    const size_t shmem = hist + (G.rb ? (size_t)W * G.stg_wave + 256 : 0);   // + slack for strip over-reads
+    const size_t shmem = hist + (G.rb ? (size_t)W * G.stg_wave + 2048 : 0);   // + slack for strip / prefetch over-reads
     const long tiles = (b.n + 63) / 64;
     long wgs = (tiles + W - 1) / W;
     if (wgs > n_cu) wgs = n_cu;
