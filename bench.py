@@ -51,7 +51,10 @@ def cpu_baseline(data, n_sample):
     try:
         if os.path.exists(ref_bin):
             f1, f2 = os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")
-            copies = 2          # 2 x the unique pairs: keeps the reference's 5 s merge-poll quantum below ~1/2 of the wall
+            copies = 4          # 4 x the unique pairs (< one 6.4M-pair merge cycle): the reference's 5 s merge-poll quantum stays a small part of the wall
+            st = os.statvfs(tmp)
+            if st.f_bavail * st.f_frsize < 8 * (1 << 30):      # inputs + clean outputs of 4 copies need ~5 GB
+                copies = 2
             for k in range(copies):
                 for m, f in ((0, f1), (1, f2)):
                     part = f + f".{k}"
@@ -167,6 +170,18 @@ def main():
         value = 2.0 * n * world * args.steps / elapsed / 1e6
         k_ms = float(np.mean(kernel_ms))
         achieved = BYTES_PER_PAIR * n / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes of this same command (tools/profile.sh; bench.py
+        # cannot run rocprofv3 around itself): only quoted when the workload is the profiled one
+        traffic, extra = None, {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+                tj = json.load(fh)
+            if n == 10_000_000 and L == 150 and args.kernel in (0, 2):
+                traffic = int(tj["hbm_bytes_per_launch"])
+                extra = {"traffic_source": tj["source"], "valu_insts_per_read": tj["valu_insts_per_read"],
+                         "valu_issue_frac": tj["valu_issue_frac"]}
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "Mreads/s PE150 `filter` (adapter+qual), bit-exact vs ref",
             "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
@@ -179,8 +194,8 @@ def main():
                        "parallelism": f"shard{world}" if world > 1 else "single",
                        "clean_pairs_per_step_per_gpu": kept // args.steps},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel_ms": round(k_ms, 4), "bytes_per_launch": BYTES_PER_PAIR * n},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel_ms": round(k_ms, 4), "bytes_per_launch": BYTES_PER_PAIR * n, **extra},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, min(n_unique, 1_000_000))

@@ -407,8 +407,11 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
 #define SNK_PUT(PL, VAL)                                                                   \
     {                                                                                      \
         const u64 val_ = (VAL);                                                            \
-        PL[2 * s] = wl(PL[2 * s], (int)(u32)val_, r);                                      \
-        if (2 * s + 1 < NW) PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = wl(PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0], (int)(u32)(val_ >> 32), r); \
+        if (SNK_ABL == 13) { asm volatile("" ::"s"(val_)); }                               \
+        else {                                                                             \
+            PL[2 * s] = wl(PL[2 * s], (int)(u32)val_, r);                                  \
+            if (2 * s + 1 < NW) PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = wl(PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0], (int)(u32)(val_ >> 32), r); \
+        }                                                                                  \
     }
                 SNK_PUT(X[0], __ballot(c == 'A'))
                 SNK_PUT(X[1], __ballot(c == 'C'))
@@ -440,8 +443,11 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     aB = valid ? aB : dumB - 256u * (s >> 1);
                     aQ = valid ? aQ : dumB - 256u * (s >> 1);
                 }
+                if (SNK_ABL == 11) { asm volatile("" ::"v"(aB), "v"(aQ)); }
+                else {
                 lds_add_u32<256 * (s >> 1)>(aB, (s & 1) ? 0x10000u : 1u);
                 lds_add_u32<256 * (s >> 1)>(aQ, (s & 1) ? 0x10000u : 1u);
+                }
             });
             v_lowq = wl(v_lowq, nlow, r);
             if (P.has_meanq) v_sumq = wl(v_sumq, wave_sum(qsum), r);
@@ -459,7 +465,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     const int nbytes = min(rb, cnt - k * rb) * B.pitch;
                     uint8_t *dst = stg + (k & 1) * 2 * G.cba;
                     const int off = min(lane * 16, nbytes - 16);
-                    if (lane * 16 < G.cba) {          // same instruction count every chunk (counted vmcnt below)
+                    if (SNK_ABL != 12 && lane * 16 < G.cba) {          // same instruction count every chunk (counted vmcnt below)
                         __builtin_amdgcn_global_load_lds((glb_ptr_t)(seq + g0 + off), (lds_ptr_t)dst, 16, 0, 0);
                         __builtin_amdgcn_global_load_lds((glb_ptr_t)(qual + g0 + off), (lds_ptr_t)(dst + G.cba), 16, 0, 0);
                     }
@@ -479,7 +485,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     // prefetch.  Every read is waited for in the same straight-line block that issued it (no
                     // register of an in-flight read crosses a branch).  The prefetch past the last read of
                     // the chunk reads staging bytes that are never used.
-                    constexpr int K = 2 * NS;
+                    constexpr int K = SNK_ABL == 11 ? 0 : 2 * NS;
                     const int nr = min(rb, cnt - k * rb);
                     u32 sa = lds0 + (u32)(G.stg_off + wave * G.stg_wave + (k & 1) * 2 * G.cba + lane);
                     u32 ac[NS], aq[NS], bc[NS], bq[NS];     // two register sets alternate (no rotation moves)
@@ -522,7 +528,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         };
         if (fulllen) run_phase1(std::true_type{});
         else run_phase1(std::false_type{});
-        if (SNK_ABL == 1) {
+        if ((SNK_ABL == 1 || SNK_ABL >= 11)) {
 #pragma unroll
             for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(X[0][j]), "v"(X[1][j]), "v"(X[2][j]), "v"(X[3][j]));
             asm volatile("" ::"v"(v_lowq), "v"(v_sumq));
@@ -644,7 +650,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         else { r1 = R; e1 = estat; }
     }
 
-    if (SNK_ABL == 1) return;
+    if ((SNK_ABL == 1 || SNK_ABL >= 11)) return;
     if (SNK_ABL == 2) {
         asm volatile("" ::"v"(r0.clen), "v"(r0.start), "v"(r0.n_a), "v"(r0.n_n), "v"(r0.lowq), "v"(r0.adacut), "v"(r0.inc_ada));
         asm volatile("" ::"v"(r1.clen), "v"(r1.start), "v"(r1.n_a), "v"(r1.n_n), "v"(r1.lowq), "v"(r1.adacut), "v"(r1.inc_ada));
@@ -796,7 +802,8 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
     const long fb = file_block(G.lcap, G.nq);
     int flush_lo = 0;
     for (int it = 0; it < iters; ++it) {
-        const long tile = (long)it * GW + (long)blockIdx.x * W + wave;
+        // wave-major: the tiles of a partial last round spread over all CUs instead of filling a few
+        const long tile = (long)it * GW + (long)wave * gridDim.x + blockIdx.x;
         const long t0 = tile * 64;
         long rem = B.n - t0;
         const int cnt = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
@@ -854,7 +861,7 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
                 // error path: some quality since the last flush was out of range -> find the reads
                 // (the reference corrupts its heap here, src/peprocess.cpp:1196; we report the first)
                 for (int it2 = flush_lo; it2 <= it; ++it2) {
-                    const long t2 = ((long)it2 * GW + (long)blockIdx.x * W + wave) * 64;
+                    const long t2 = ((long)it2 * GW + (long)wave * gridDim.x + blockIdx.x) * 64;
                     const long rem2 = B.n - t2;
                     const int cnt2 = rem2 >= 64 ? 64 : (rem2 > 0 ? (int)rem2 : 0);
                     for (int m = 0; m < mates; ++m)
