@@ -384,6 +384,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             XN[j] = FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
         }
         int v_sumq = 0, v_lowq = 0;
+        const bool has_meanq = __builtin_amdgcn_readfirstlane(P.has_meanq) != 0;
         const int len0 = rl(clen_v, 0);
         const bool fixed = __all(!lanev || clen_v == len0);
         // every read of the tile fills the whole capacity: lanes past the end fall into histogram
@@ -398,7 +399,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         auto do_read = [&](auto FL, const int r, const u32 (&cc)[NS], const u32 (&cq)[NS]) {
             constexpr bool FULLLEN = decltype(FL)::value;
             const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
-            int qsum = 0, nlow = 0;
+            int nlow = 0;
             u32 prev_last = 0xFFFFFFFFu;
             static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                 constexpr int s = decltype(sc)::v;
@@ -413,13 +414,19 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             if (2 * s + 1 < NW) PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = wl(PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0], (int)(u32)(val_ >> 32), r); \
         }                                                                                  \
     }
-                SNK_PUT(X[0], __ballot(c == 'A'))
-                SNK_PUT(X[1], __ballot(c == 'C'))
-                SNK_PUT(X[2], __ballot(c == 'G'))
-                SNK_PUT(X[3], __ballot(c == 'T'))
+                {   // the four compares first, into four SGPR pairs: a v_writelane right behind the compare
+                    // that produced its operand stalls on the VALU -> SGPR write
+                    u64 b0 = __ballot(c == 'A'), b1 = __ballot(c == 'C'), b2 = __ballot(c == 'G'), b3 = __ballot(c == 'T');
+                    asm volatile("" : "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3));
+                    SNK_PUT(X[0], b0)
+                    SNK_PUT(X[1], b1)
+                    SNK_PUT(X[2], b2)
+                    SNK_PUT(X[3], b3)
+                }
                 const int q = (int)cq[s] - phred;
-                nlow += __popcll(__ballot(q <= lowQ) & lowmask64(len_r - 64 * s));
-                if (P.has_meanq) qsum += (pos < len_r) ? q : 0;
+                // (with FULLLEN every strip but the last lies inside the read: 64*(NS-1) <= 32*(NW-1) < lcap)
+                if (FULLLEN && s < NS - 1) nlow += __popcll(__ballot(q <= lowQ));
+                else nlow += __popcll(__ballot(q <= lowQ) & lowmask64(len_r - 64 * s));
                 if (FULL) {
                     if (P.polyX_num != -1) {
                         u32 pc = __shfl_up(c, 1);
@@ -450,7 +457,12 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 }
             });
             v_lowq = wl(v_lowq, nlow, r);
-            if (P.has_meanq) v_sumq = wl(v_sumq, wave_sum(qsum), r);
+            if (has_meanq) {                      // quality sum of the read (mean-quality filter only)
+                int qsum = 0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) qsum += (64 * s + lane < len_r) ? (int)cq[s] - phred : 0;
+                v_sumq = wl(v_sumq, wave_sum(qsum), r);
+            }
         };
         auto lds_rd = [&](u32 (&c)[NS], u32 (&q)[NS], const u32 addr) { lds_read_strips<0>(c, q, addr, addr + (u32)G.cba); };
         auto run_phase1 = [&](auto FL) {
@@ -730,11 +742,21 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         const uint8_t *seq = B.seq[m], *qual = B.qual[m];
         u32 *remB = lds + (m * 2 + 1) * G.SET, *remQ = remB + G.WB;
         u64 *gbs = fcl + SNK_GS_N, *gqs = fcl + SNK_GS_N + (long)G.lcap * 5;
-        u64 mod = __ballot(live && (reason != SNK_KEEP || R.clen != R.len));
+        const bool modl = live && (reason != SNK_KEEP || R.clen != R.len);
+        u64 mod = __ballot(modl);
+        if (SNK_ABL == 3 || !mod) continue;
+        // what the walk needs of a read, packed into one register (one v_readlane per read)
+        const u32 pk = (u32)R.len | ((u32)R.clen << 9) | ((u32)R.start << 18) | ((reason != SNK_KEEP ? 1u : 0u) << 27) |
+                       ((R.n_n > 0 ? 1u : 0u) << 28);
+        const uint8_t *seqt = seq + t0 * (long)B.pitch, *qualt = qual + t0 * (long)B.pitch;
+        const u32 lds0 = (u32)(uintptr_t)(lds_u32_ptr)lds;
+        const u32 remBa = lds0 + ((u32)((m * 2 + 1) * G.SET) + (u32)lane) * 4u, remQa = remBa + (u32)G.WB * 4u;
+        const u32 dumR = lds0 + ((u32)(4 * G.SET) + (u32)lane) * 4u;
+        const u32 nqu = (u32)nq;
         u32 offp[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) offp[s] = (u32)min(64 * s + lane, B.pitch - 1);
-        while (SNK_ABL != 3 && mod) {
+        while (mod) {
             // up to 4 reads per trip: their 8*NS byte loads are all in flight before the first use
             int rr[4];
             u32 cb[4][NS], qb[4][NS];
@@ -744,7 +766,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 if (mod) {
                     rr[b] = __ffsll((long long)mod) - 1;
                     mod &= mod - 1;
-                    const uint8_t *sp = seq + (t0 + rr[b]) * (long)B.pitch, *qp = qual + (t0 + rr[b]) * (long)B.pitch;
+                    const u32 ro = (u32)rr[b] * (u32)B.pitch;
+                    const uint8_t *sp = seqt + ro, *qp = qualt + ro;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) { cb[b][s] = sp[offp[s]]; qb[b][s] = qp[offp[s]]; }
                 }
@@ -753,25 +776,49 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             for (int b = 0; b < 4; ++b) {
                 if (rr[b] < 0) continue;
                 const int r = rr[b];
-                const int len_r = rl(R.len, r), clen_r = rl(R.clen, r), start_r = rl(R.start, r);
-                const bool disc = rl(reason, r) != SNK_KEEP;
+                const u32 w = (u32)rl((int)pk, r);
+                const int len_r = (int)(w & 511u), clen_r = (int)((w >> 9) & 511u), start_r = (int)((w >> 18) & 511u);
+                const bool disc = (w >> 27) & 1u, hasn = (w >> 28) & 1u;
                 const bool shifted = !disc && start_r > 0;
                 const int rm_lo = (disc || shifted) ? 0 : clen_r;       // removed raw positions [rm_lo, len)
+                // straight-line like phase 1: N / garbage go to the row of their bits 1-2 and are moved
+                // below, an out-of-range quality goes to the overflow bin (the flush reports it)
+                if (rm_lo == 0 && len_r == G.lcap) {
+                    // whole read, full capacity: lanes past the end hit slots of positions >= lcap (never flushed)
+                    static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
+                        constexpr int s = decltype(sc)::v;
+                        const u32 c = cb[b][s];
+                        const u32 qi = min((u32)((int)qb[b][s] - phred), nqu);
+                        lds_add_u32<256 * (s >> 1)>(((c & 6u) << (lgb - 1)) + remBa, (s & 1) ? 0x10000u : 1u);
+                        lds_add_u32<256 * (s >> 1)>((qi << lgb) + remQa, (s & 1) ? 0x10000u : 1u);
+                    });
+                } else {
+                    const u32 span = (u32)(len_r - rm_lo);
+                    static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
+                        constexpr int s = decltype(sc)::v;
+                        const u32 c = cb[b][s];
+                        const u32 qi = min((u32)((int)qb[b][s] - phred), nqu);
+                        const bool inr = (u32)(64 * s + lane - rm_lo) < span;
+                        const u32 aB = inr ? ((c & 6u) << (lgb - 1)) + remBa : dumR - 256u * (s >> 1);
+                        const u32 aQ = inr ? (qi << lgb) + remQa : dumR - 256u * (s >> 1);
+                        lds_add_u32<256 * (s >> 1)>(aB, (s & 1) ? 0x10000u : 1u);
+                        lds_add_u32<256 * (s >> 1)>(aQ, (s & 1) ? 0x10000u : 1u);
+                    });
+                }
+                if (hasn || shifted) {                                   // rare
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const int pos = 64 * s + lane;
-                    if (pos < len_r) {
+                    for (int s = 0; s < NS; ++s) {
+                        const int pos = 64 * s + lane;
                         const u32 c = cb[b][s];
                         const int q = (int)qb[b][s] - phred;
                         const bool isn = (c & 0xDFu) == 'N';
-                        const u32 row = isn ? 4u : (c & 6u) >> 1;                                  // LDS row order A C T G N
-                        const u32 cls = isn ? 4u : __builtin_amdgcn_ubfe(0xB4u, c & 6u, 2u);      // stats order A C G T N
-                        if (pos >= rm_lo && (u32)q < (u32)nq) {
-                            atomicAdd(&remB[(row << G.lg) + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
-                            atomicAdd(&remQ[((u32)q << G.lg) + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
+                        if (isn && pos >= rm_lo && pos < len_r) {          // bits 1-2 of 'N' / 'n': row 3
+                            atomicSub(&remB[(3u << G.lg) + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
+                            atomicAdd(&remB[(4u << G.lg) + 64 * (s >> 1) + lane], (s & 1) ? 0x10000u : 1u);
                         }
                         if (shifted && pos >= start_r && pos < start_r + clen_r && (u32)q < (u32)nq) {
-                            atomicAdd(&gbs[(pos - start_r) * 5 + cls], 1ull);     // head-trimmed survivor: rare
+                            const u32 cls = isn ? 4u : __builtin_amdgcn_ubfe(0xB4u, c & 6u, 2u);      // stats order A C G T N
+                            atomicAdd(&gbs[(pos - start_r) * 5 + cls], 1ull);     // head-trimmed survivor
                             atomicAdd(&gqs[(long)(pos - start_r) * nq + q], 1ull);
                         }
                     }
