@@ -195,19 +195,69 @@ __device__ __forceinline__ void shr_plane(u32 (&R)[NW], int st) {
     for (int j = 0; j < NW; ++j) R[j] = __builtin_amdgcn_alignbit(T[j + 1], T[j], r);
 }
 
-// one screening step: D = plane >> c (ones shifted in), C_k |= C_{k-1} & ~D
-template <int NW, int CQ>
-__device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C1)[NW], u32 (&C2)[NW],
-                                            u32 (&C3)[NW], u32 (&C4)[NW]) {
+// one screening step: D = plane >> c (ones shifted in), C_k |= C_{k-1} & ~D  (NC unary counter planes)
+template <int NW, int CQ, int NC>
+__device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C)[NC][NW]) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const u32 lo = (j + CQ < NW) ? Pl[(j + CQ < NW) ? j + CQ : 0] : 0xFFFFFFFFu;
         const u32 hi = (j + CQ + 1 < NW) ? Pl[(j + CQ + 1 < NW) ? j + CQ + 1 : 0] : 0xFFFFFFFFu;
         const u32 x = ~__builtin_amdgcn_alignbit(hi, lo, cr);
-        C4[j] |= C3[j] & x;
-        C3[j] |= C2[j] & x;
-        C2[j] |= C1[j] & x;
-        C1[j] |= x;
+#pragma unroll
+        for (int k = NC - 1; k >= 1; --k) C[k][j] |= C[k - 1][j] & x;
+        C[0][j] |= x;
+    }
+}
+
+// Bit-sliced screening of the candidates p = 0 .. len-edge of phases B and C over the first S-1 adapter
+// characters; NC = 2 when no mismatch budget exceeds 1 (the default parameters), else 4.
+template <int NW, bool FULL, int NC>
+__device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool done,
+                                              u32 (&aliveB)[NW], u32 (&aliveC)[NW]) {
+    const int al = A.len, S = max(A.S, 1), edge = A.edge, mis = A.mis;
+    u32 C[NC][NW], BY[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) C[k][j] = 0;
+        BY[j] = ~lowmask32(len - 32 * j);
+    }
+    const int steps = min(S - 1, al);
+    const u64 cw0 = A.code4[0], cw1 = A.code4[1], cw2 = A.code4[2], cw3 = A.code4[3];
+    for (int c = 0; c < steps; ++c) {
+        const u64 cw = c < 16 ? cw0 : (c < 32 ? cw1 : (c < 48 ? cw2 : cw3));
+        const int code = (int)((cw >> (4 * (c & 15))) & 15), cr = c & 31;
+#define SNK_STEP(PL)                                                 \
+    if (c < 32) screen_step<NW, 0, NC>(PL, cr, C);                   \
+    else screen_step<NW, 1, NC>(PL, cr, C);
+        switch (code) {
+        case 0: SNK_STEP(X[0]) break;
+        case 1: SNK_STEP(X[1]) break;
+        case 2: SNK_STEP(X[2]) break;
+        case 3: SNK_STEP(X[3]) break;
+        case 5: if (FULL) { SNK_STEP(XN) } else { SNK_STEP(BY) } break;
+        default: SNK_STEP(BY) break;       // matches nothing inside the read
+        }
+#undef SNK_STEP
+    }
+    // budgets as thermometer planes T_k = [budget >= k]; reject = mis count > budget
+    const int rk1 = A.rk[1], rk2 = A.rk[2], rk3 = A.rk[3];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const u32 valid = lowmask32(len - edge + 1 - 32 * j);
+        const u32 bm = lowmask32(len - al + 1 - 32 * j);                    // phase B region
+        const u32 t1 = lowmask32(len - edge - rk1 + 1 - 32 * j) & (mis >= 1 ? 0xFFFFFFFFu : ~bm);
+        u32 rej;
+        if (NC == 2) {
+            rej = (C[0][j] & ~t1) | C[1][j];
+        } else {
+            const u32 t2 = lowmask32(len - edge - rk2 + 1 - 32 * j) & (mis >= 2 ? 0xFFFFFFFFu : ~bm);
+            const u32 t3 = lowmask32(len - edge - rk3 + 1 - 32 * j) & (mis >= 3 ? 0xFFFFFFFFu : ~bm);
+            rej = (C[0][j] & ~t1) | (C[1][j] & ~t2) | (C[2 < NC ? 2 : 0][j] & ~t3) | C[3 < NC ? 3 : 0][j];
+        }
+        const u32 alive = done ? 0u : (valid & ~rej);
+        aliveB[j] = alive & bm;
+        aliveC[j] = alive & ~bm;
     }
 }
 
@@ -246,41 +296,8 @@ __device__ int adapter_tile(const TileAdapter &A, const DevAdapter &AG, const u3
     // ---------------- phases B+C screening: candidates p = 0 .. len-edge, bit-sliced
     u32 aliveB[NW], aliveC[NW];
     if (__any(!done)) {
-        u32 C1[NW], C2[NW], C3[NW], C4[NW], BY[NW];
-#pragma unroll
-        for (int j = 0; j < NW; ++j) { C1[j] = C2[j] = C3[j] = C4[j] = 0; BY[j] = ~lowmask32(len - 32 * j); }
-        const int steps = min(S - 1, al);
-        const u64 cw0 = A.code4[0], cw1 = A.code4[1], cw2 = A.code4[2], cw3 = A.code4[3];
-        for (int c = 0; c < steps; ++c) {
-            const u64 cw = c < 16 ? cw0 : (c < 32 ? cw1 : (c < 48 ? cw2 : cw3));
-            const int code = (int)((cw >> (4 * (c & 15))) & 15), cr = c & 31;
-#define SNK_STEP(PL)                                                         \
-    if (c < 32) screen_step<NW, 0>(PL, cr, C1, C2, C3, C4);                  \
-    else screen_step<NW, 1>(PL, cr, C1, C2, C3, C4);
-            switch (code) {
-            case 0: SNK_STEP(X[0]) break;
-            case 1: SNK_STEP(X[1]) break;
-            case 2: SNK_STEP(X[2]) break;
-            case 3: SNK_STEP(X[3]) break;
-            case 5: if (FULL) { SNK_STEP(XN) } else { SNK_STEP(BY) } break;
-            default: SNK_STEP(BY) break;       // matches nothing inside the read
-            }
-#undef SNK_STEP
-        }
-        // budgets as thermometer planes T_k = [budget >= k]; reject = mis count > budget
-        const int rk1 = A.rk[1], rk2 = A.rk[2], rk3 = A.rk[3];
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const u32 valid = lowmask32(len - edge + 1 - 32 * j);
-            const u32 bm = lowmask32(len - al + 1 - 32 * j);                    // phase B region
-            const u32 t1 = lowmask32(len - edge - rk1 + 1 - 32 * j) & (mis >= 1 ? 0xFFFFFFFFu : ~bm);
-            const u32 t2 = lowmask32(len - edge - rk2 + 1 - 32 * j) & (mis >= 2 ? 0xFFFFFFFFu : ~bm);
-            const u32 t3 = lowmask32(len - edge - rk3 + 1 - 32 * j) & (mis >= 3 ? 0xFFFFFFFFu : ~bm);
-            const u32 rej = (C1[j] & ~t1) | (C2[j] & ~t2) | (C3[j] & ~t3) | C4[j];
-            const u32 alive = done ? 0u : (valid & ~rej);
-            aliveB[j] = alive & bm;
-            aliveC[j] = alive & ~bm;
-        }
+        if (A.ncnt == 2) screen_planes<NW, FULL, 2>(A, X, XN, len, done, aliveB, aliveC);
+        else screen_planes<NW, FULL, 4>(A, X, XN, len, done, aliveB, aliveC);
     } else {
 #pragma unroll
         for (int j = 0; j < NW; ++j) aliveB[j] = aliveC[j] = 0;
@@ -687,25 +704,15 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
     u64 *maxk = reinterpret_cast<u64 *>(misc + 72);   // last-read keys of the 4 file stats
     {
         u32 *fs = misc;
-        const u64 anyd = __ballot(live && reason != SNK_KEEP);
-        if (anyd) {
-            const int cd = __popcll(__ballot(live && reason == SNK_R_DUP));
-            if (cd && lane == 0) atomicAdd(&fs[SNK_FS_DUP], (u32)cd);
+        if (__any(live && reason != SNK_KEEP)) {
+            // per-lane LDS adds (a dozen lanes, same-address conflicts are cheaper than walking the families)
+            if (live && reason == SNK_R_DUP) atomicAdd(&fs[SNK_FS_DUP], 1u);
             const int fam = reason_family(reason);
-#pragma unroll 1
-            for (int f = SNK_FS_SHORT; f <= SNK_FS_ADAPTER; f += 4) {
-                const u64 bm = __ballot(live && fam == f);
-                if (bm) {
-                    const int c0 = __popcll(bm), c1 = __popcll(__ballot(live && fam == f && (v & 1))),
-                              c2 = __popcll(__ballot(live && fam == f && (v & 2))),
-                              c3 = __popcll(__ballot(live && fam == f && v == 3));
-                    if (lane == 0) {
-                        atomicAdd(&fs[f], (u32)c0);
-                        if (c1) atomicAdd(&fs[f + 1], (u32)c1);
-                        if (c2) atomicAdd(&fs[f + 2], (u32)c2);
-                        if (c3) atomicAdd(&fs[f + 3], (u32)c3);
-                    }
-                }
+            if (live && fam >= 0) {
+                atomicAdd(&fs[fam], 1u);
+                if (v & 1) atomicAdd(&fs[fam + 1], 1u);
+                if (v & 2) atomicAdd(&fs[fam + 2], 1u);
+                if (v == 3) atomicAdd(&fs[fam + 3], 1u);
             }
         }
     }
