@@ -1,0 +1,58 @@
+/* snk_rmdup.h -- C ABI of the duplicate-marking pre-pass of `SOAPnuke filter` (config key
+ * `rmdup`, SURVEY 8(f) N1, BASELINE config 5), MI355X-native.
+ *
+ * What it replaces in the reference:
+ *   - peProcess::sub_thread_rmdup_step1 (src/peprocess.cpp:3609-3807; SE: seProcess,
+ *     src/seprocess.cpp:2480-2650): every raw pair is hashed with
+ *     std::hash<std::string>(seq1 + seq2)  (src/peprocess.cpp:3665,3680) -- libstdc++'s
+ *     _Hash_bytes, 64-bit, seed 0xc70f6907 -- into one uint64 per pair, in input order
+ *     (src/peprocess.cpp:3093-3124);
+ *   - rmdup::markDup (src/rmdup.cpp:14-149): dupFlag[i] = the hash of pair i occurred at an
+ *     earlier index (hash equality IS the duplicate criterion; collisions are duplicates),
+ *     plus its (uint64_t)-1 sentinel quirk (see snk_rmdup_mark_device);
+ *   - the flags then enter the discard cascade as `dup` (snk_batch.dup, src/sequence.cpp:207).
+ *
+ * Both entry points work on device memory and are asynchronous on `stream`.  The hash array of a
+ * whole run stays resident in HBM (8 B per pair: 1.6 GB for the 200 M pairs of config 5).
+ * Multi-GPU: ranks hash their own shard, exchange (hash, global index) by owner = hash % world
+ * (the one collective of this row, an all-to-all over RCCL, driven by soapnuke_amd/shard.py),
+ * mark locally with explicit global indices and send the flags back.
+ */
+#ifndef SNK_RMDUP_H
+#define SNK_RMDUP_H
+#include "snk_filter.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* d_hash[i] = std::hash<std::string>(mate1_i ++ mate2_i)  (SE contexts: mate1_i alone) for the
+ * batch->n pairs of a device-resident batch (same layout as snk_filter_batch_device; qualities
+ * are not read).  Returns SNK_OK or a negative error (snk_last_error).                        */
+int snk_rmdup_hash_device(snk_ctx *ctx, const snk_batch *batch, uint64_t *d_hash, void *stream);
+
+/* Number of elements whose hash lies in the bucket of (uint64_t)-1, i.e.
+ * hash % prime == (2^64-1) % prime with prime = rmdup::getPrime(total_n) (src/rmdup.cpp:150).
+ * Written to *d_count (device, uint64).  Only needed to reproduce the sentinel quirk across
+ * ranks; a single-GPU caller passes sentinel_bucket_total = -1 to snk_rmdup_mark_device.      */
+int snk_rmdup_bucket_count_device(snk_ctx *ctx, const uint64_t *d_hash, int64_t n, uint64_t total_n,
+                                  uint64_t *d_count, void *stream);
+
+/* d_dup[i] = 1 iff some j has d_hash[j] == d_hash[i] and index_j < index_i, where index_k =
+ * d_index[k] (global input-order indices, all distinct) or k when d_index is NULL.
+ * Sentinel quirk of the reference (src/rmdup.cpp:100,116): elements whose hash is 2^64-1 are
+ * flagged -- the first one included -- iff their bucket holds more than one element;
+ * sentinel_bucket_total is that bucket's population over all ranks, or -1 to count it here
+ * (single GPU).  total_n = pairs hashed in the whole run (all ranks); the reference refuses
+ * more than 2^32-1 (src/peprocess.cpp:3094) and so does this call (SNK_E_PARAM).
+ * The call allocates and frees its hash table (16 B x 2..4 n) on the device.                  */
+int snk_rmdup_mark_device(snk_ctx *ctx, const uint64_t *d_hash, const uint32_t *d_index, int64_t n,
+                          uint64_t total_n, int64_t sentinel_bucket_total, uint8_t *d_dup, void *stream);
+
+/* rmdup::getPrime(n) (host helper; 0 for n == 0 where the reference exits with "code error") */
+uint32_t snk_rmdup_prime(uint64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

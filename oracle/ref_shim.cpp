@@ -14,6 +14,7 @@
  * feed it valid reads.
  */
 #include "peprocess.h"
+#include "rmdup.h"
 #include "seprocess.h"
 #include "read_filter.h"
 #include "sequence.h"
@@ -247,4 +248,20 @@ int snkref_filter_batch(const snk_params *P, const snk_batch *B, snk_read_result
     return 0;
 }
 
+
+/* std::hash<std::string> exactly as src/peprocess.cpp:3680 calls it */
+uint64_t snkref_hash(const char *p, uint64_t len) { return (uint64_t)std::hash<std::string>()(std::string(p, len)); }
+
+/* rmdup::markDup of the reference (src/rmdup.cpp:14); the class frees `data` itself */
+void snkref_markdup(const uint64_t *hash, uint64_t n, uint8_t *dup) {
+    uint64_t *data = new uint64_t[n ? n : 1];
+    memcpy(data, hash, n * sizeof(uint64_t));
+    bool *flags = new bool[n ? n : 1];
+    memset(flags, 0, n ? n : 1);
+    rmdup *r = new rmdup(data, n);
+    r->markDup(flags);
+    delete r;
+    for (uint64_t i = 0; i < n; ++i) dup[i] = flags[i] ? 1 : 0;
+    delete[] flags;
+}
 } /* extern "C" */

@@ -12,6 +12,7 @@
 #include "snk_oracle.h"
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* float -> int the way the reference binary does it on x86-64 (cvttss2si):
@@ -444,4 +445,87 @@ int snk_oracle_filter_batch(const snk_params *P, const snk_batch *B,
         }
     }
     return SNK_OK;
+}
+
+/* ------------------------------------------------------------------ rmdup pre-pass */
+
+static uint64_t shift_mix(uint64_t v) { return v ^ (v >> 47); }
+
+/* libstdc++ _Hash_bytes, size_t == 8 (hash_bytes.cc), seed as std::hash<std::string> passes it */
+uint64_t snk_oracle_hash_bytes(const void *ptr, uint64_t len) {
+    const uint64_t mul = (((uint64_t)0xc6a4a793UL) << 32) + (uint64_t)0x5bd1e995UL;
+    const uint8_t *buf = (const uint8_t *)ptr;
+    const uint64_t len_aligned = len & ~(uint64_t)7;
+    uint64_t hash = (uint64_t)0xc70f6907UL ^ (len * mul);
+    for (uint64_t o = 0; o < len_aligned; o += 8) {
+        uint64_t w;
+        memcpy(&w, buf + o, 8);                               /* unaligned_load, little endian */
+        hash ^= shift_mix(w * mul) * mul;
+        hash *= mul;
+    }
+    if (len & 7) {
+        uint64_t w = 0;                                       /* load_bytes: little-endian partial word */
+        for (int i = (int)(len & 7) - 1; i >= 0; --i) w = (w << 8) + buf[len_aligned + i];
+        hash ^= w;
+        hash *= mul;
+    }
+    hash = shift_mix(hash) * mul;
+    hash = shift_mix(hash);
+    return hash;
+}
+
+void snk_oracle_hash_batch(const snk_batch *B, int paired, uint64_t *out) {
+    uint8_t *tmp = (uint8_t *)malloc(2 * (size_t)B->pitch + 8);
+    for (int64_t i = 0; i < B->n; ++i) {
+        const int l1 = B->len[0] ? B->len[0][i] : B->fixed_len[0];
+        int l2 = 0;
+        memcpy(tmp, B->seq[0] + i * (int64_t)B->pitch, l1);
+        if (paired) {
+            l2 = B->len[1] ? B->len[1][i] : B->fixed_len[1];
+            memcpy(tmp + l1, B->seq[1] + i * (int64_t)B->pitch, l2);      /* fq1seq + fq2seq, :3665 */
+        }
+        out[i] = snk_oracle_hash_bytes(tmp, (uint64_t)(l1 + l2));
+    }
+    free(tmp);
+}
+
+uint32_t snk_oracle_rmdup_prime(uint64_t n) {
+    const uint32_t real = n > 4294967295ull ? 4294967295u : (uint32_t)n;
+    if (n > 0 && n < 10) return (uint32_t)n;
+    uint32_t cur = real;
+    while (cur--) {                                           /* first candidate: real - 1 */
+        int is_prime = 1;
+        for (uint32_t j = 2; (uint64_t)j * j <= cur; ++j)
+            if (cur % j == 0) { is_prime = 0; break; }
+        if (is_prime) return cur;
+    }
+    return 0;                                                 /* n == 0: the reference exits "code error" */
+}
+
+void snk_oracle_markdup(const uint64_t *hash, uint64_t n, uint8_t *dup) {
+    memset(dup, 0, n);
+    if (n == 0) return;
+    /* earlier-occurrence test with an open-addressing set of the values seen so far */
+    uint64_t cap = 16;
+    while (cap < 2 * n) cap <<= 1;
+    uint64_t *keys = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    uint8_t *used = (uint8_t *)calloc(cap, 1);
+    const uint32_t prime = snk_oracle_rmdup_prime(n);
+    const uint64_t minus1 = ~(uint64_t)0;
+    uint64_t sentinel_bucket = 0;                             /* elements sharing the bucket of 2^64-1 */
+    for (uint64_t i = 0; i < n; ++i)
+        if (hash[i] % prime == minus1 % prime) sentinel_bucket++;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t h = hash[i];
+        uint64_t s = (h * 0x9E3779B97F4A7C15ull) >> 7 & (cap - 1);
+        int seen = 0;
+        while (used[s]) {
+            if (keys[s] == h) { seen = 1; break; }
+            s = (s + 1) & (cap - 1);
+        }
+        if (!seen) { used[s] = 1; keys[s] = h; }
+        dup[i] = (uint8_t)(seen || (h == minus1 && sentinel_bucket > 1));
+    }
+    free(keys);
+    free(used);
 }

@@ -34,6 +34,25 @@ int snk_oracle_filter_batch(const snk_params *P, const snk_batch *B,
                             snk_read_result *out1, snk_read_result *out2,
                             uint64_t *sum, uint64_t *maxb, snk_error *err);
 
+/* ---- rmdup pre-pass -------------------------------------------
+ * The reference hashes seq1+seq2 of every raw pair with std::hash<std::string>
+ * (src/peprocess.cpp:3665-3681; SE: the read alone, src/seprocess.cpp:2545), i.e.
+ * libstdc++'s _Hash_bytes (libstdc++-v3/libsupc++/hash_bytes.cc, 64-bit variant:
+ * seed 0xc70f6907, mul 0xc6a4a7935bd1e995, shift_mix(v) = v ^ (v >> 47); not under
+ * /root/reference -- pinned by GCC 11.4 here and by the known answers of SURVEY 8(c)),
+ * then marks every later occurrence of a hash value (rmdup::markDup,
+ * src/rmdup.cpp:14-149).                                                        */
+uint64_t snk_oracle_hash_bytes(const void *p, uint64_t len);
+/* hash of every pair (mate 1 ++ mate 2; SE: mate 1) of a host batch */
+void snk_oracle_hash_batch(const snk_batch *B, int paired, uint64_t *out);
+/* rmdup::getPrime (src/rmdup.cpp:150-185): n for n < 10, else the largest prime < n */
+uint32_t snk_oracle_rmdup_prime(uint64_t n);
+/* rmdup::markDup: dup[i] = 1 iff hash[i] occurred at an earlier index, plus the
+ * reference's sentinel quirk: it overwrites later occurrences with (uint64_t)-1 in
+ * its bucket copy, so a genuine hash of 2^64-1 is flagged -- first occurrence
+ * included -- whenever its bucket (hash % prime) holds more than one element.   */
+void snk_oracle_markdup(const uint64_t *hash, uint64_t n, uint8_t *dup);
+
 /* derive gs a/c/g/t/n/q20/q30/bases from the histograms exactly like the
  * product's finalize kernel does (used to cross-check that derivation).      */
 void snk_oracle_params_default(snk_params *p);

@@ -159,6 +159,8 @@ EXPORTS = [
     "snk_stats_geometry", "snk_bind_stats", "snk_stats_clear",
     "snk_filter_batch_device", "snk_filter_batch", "snk_stats_finalize",
     "snk_stats_fetch", "snk_stats_allreduce", "snk_set_timing", "snk_last_kernel_ms",
+    # include/snk_rmdup.h
+    "snk_rmdup_hash_device", "snk_rmdup_bucket_count_device", "snk_rmdup_mark_device", "snk_rmdup_prime",
 ]
 
 
@@ -188,4 +190,9 @@ def load_library(path=None):
     lib.snk_stats_allreduce.argtypes = [vp, vp, vp]
     lib.snk_set_timing.argtypes = [vp, i32]
     lib.snk_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.snk_rmdup_hash_device.argtypes = [vp, C.POINTER(Batch), vp, vp]
+    lib.snk_rmdup_bucket_count_device.argtypes = [vp, vp, C.c_int64, C.c_uint64, vp, vp]
+    lib.snk_rmdup_mark_device.argtypes = [vp, vp, vp, C.c_int64, C.c_uint64, C.c_int64, vp, vp]
+    lib.snk_rmdup_prime.argtypes = [C.c_uint64]
+    lib.snk_rmdup_prime.restype = C.c_uint32
     return lib

@@ -91,3 +91,11 @@ void snk_launch_generic(const DevParams *dp, const DevBatch &b, const DevStats &
 int snk_launch_tiled(const DevParams &dp_host, const TileAdapters &ta, const DevBatch &b,
                      const DevStats &st, int lcap, int nq, int n_cu, void *stream);
 void snk_launch_finalize(const DevStats &st, int lcap, int nq, void *stream);
+
+// rmdup pre-pass (snk_rmdup.hip); return 0 or a hipError_t
+int snk_launch_hash(const uint8_t *const seq[2], const uint16_t *const len[2], const int fixed_len[2], int pitch, long n,
+                    int paired, unsigned long long *out, int n_cu, void *stream);
+int snk_launch_bucket_count(const unsigned long long *hash, long n, unsigned prime, const unsigned *flag,
+                            unsigned long long *count, void *stream);
+int snk_launch_mark(const unsigned long long *hash, const unsigned *index, long n, unsigned prime, long bucket_total,
+                    unsigned char *dup, void *stream);

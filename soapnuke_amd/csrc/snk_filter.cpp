@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "snk_device.h"
+#include "../../include/snk_rmdup.h"
 
 namespace {
 
@@ -516,6 +517,58 @@ int snk_stats_allreduce(snk_ctx *c, void *comm, void *stream) {
         set_err("snk_stats_allreduce: ncclAllReduce failed");
         return SNK_E_HIP;
     }
+    return SNK_OK;
+}
+
+// ---------------------------------------------------------------- rmdup pre-pass (include/snk_rmdup.h)
+
+uint32_t snk_rmdup_prime(uint64_t n) {                  // rmdup::getPrime, src/rmdup.cpp:150-185
+    const uint32_t real = n > 4294967295ull ? 4294967295u : (uint32_t)n;
+    if (n > 0 && n < 10) return (uint32_t)n;
+    uint32_t cur = real;
+    while (cur--) {                                     // first candidate: real - 1
+        bool is_prime = true;
+        for (uint32_t j = 2; (uint64_t)j * j <= cur; ++j)
+            if (cur % j == 0) { is_prime = false; break; }
+        if (is_prime) return cur;
+    }
+    return 0;
+}
+
+int snk_rmdup_hash_device(snk_ctx *c, const snk_batch *b, uint64_t *d_hash, void *stream) {
+    if (!c || !b || !d_hash) { set_err("snk_rmdup_hash_device: null argument"); return SNK_E_PARAM; }
+    if (b->n < 0 || b->pitch <= 0) { set_err("snk_rmdup_hash_device: bad n/pitch"); return SNK_E_PARAM; }
+    const int mates = c->p.paired ? 2 : 1;
+    for (int m = 0; m < mates; ++m) {
+        if (!b->seq[m]) { set_err("snk_rmdup_hash_device: missing seq"); return SNK_E_PARAM; }
+        if (!b->len[m] && (b->fixed_len[m] < 0 || b->fixed_len[m] > b->pitch)) { set_err("snk_rmdup_hash_device: fixed_len exceeds pitch"); return SNK_E_PARAM; }
+    }
+    const int e = snk_launch_hash(b->seq, b->len, b->fixed_len, b->pitch, (long)b->n, c->p.paired ? 1 : 0,
+                                  (unsigned long long *)d_hash, c->n_cu, stream);
+    if (e) { set_err(std::string("snk_rmdup_hash_device: ") + hipGetErrorString((hipError_t)e)); return SNK_E_HIP; }
+    return SNK_OK;
+}
+
+int snk_rmdup_bucket_count_device(snk_ctx *c, const uint64_t *d_hash, int64_t n, uint64_t total_n, uint64_t *d_count,
+                                  void *stream) {
+    if (!c || !d_hash || !d_count || n < 0) { set_err("snk_rmdup_bucket_count_device: bad argument"); return SNK_E_PARAM; }
+    HIP_OK(hipMemsetAsync(d_count, 0, sizeof(uint64_t), (hipStream_t)stream));
+    const int e = snk_launch_bucket_count((const unsigned long long *)d_hash, (long)n, snk_rmdup_prime(total_n), nullptr,
+                                          (unsigned long long *)d_count, stream);
+    if (e) { set_err(std::string("snk_rmdup_bucket_count_device: ") + hipGetErrorString((hipError_t)e)); return SNK_E_HIP; }
+    return SNK_OK;
+}
+
+int snk_rmdup_mark_device(snk_ctx *c, const uint64_t *d_hash, const uint32_t *d_index, int64_t n, uint64_t total_n,
+                          int64_t sentinel_bucket_total, uint8_t *d_dup, void *stream) {
+    if (!c || !d_hash || !d_dup || n < 0) { set_err("snk_rmdup_mark_device: bad argument"); return SNK_E_PARAM; }
+    if (total_n > 4294967295ull || (uint64_t)n > total_n) {       // src/peprocess.cpp:3094
+        set_err("snk_rmdup_mark_device: reads number is too large to do remove duplication (limit 2^32-1) or n > total_n");
+        return SNK_E_PARAM;
+    }
+    const int e = snk_launch_mark((const unsigned long long *)d_hash, d_index, (long)n, snk_rmdup_prime(total_n),
+                                  (long)sentinel_bucket_total, d_dup, stream);
+    if (e) { set_err(std::string("snk_rmdup_mark_device: ") + hipGetErrorString((hipError_t)e)); return e == (int)hipErrorOutOfMemory ? SNK_E_NOMEM : SNK_E_HIP; }
     return SNK_OK;
 }
 

@@ -1,0 +1,256 @@
+// snk_rmdup.hip -- the duplicate-marking pre-pass of `SOAPnuke filter` (config key rmdup) on gfx950.
+//
+//  hash   one uint64 per raw pair: std::hash<std::string>(seq1 + seq2) as the reference computes
+//         it (src/peprocess.cpp:3665,3680), i.e. libstdc++ _Hash_bytes (64-bit: seed 0xc70f6907,
+//         mul 0xc6a4a7935bd1e995, shift_mix(v) = v ^ (v >> 47)).  The chain over the 8-byte words of
+//         a string is sequential, so one LANE owns one pair and walks its words; the wave first
+//         pulls its 64 rows in with coalesced 16-byte loads and parks them in LDS with a padded
+//         pitch (row-per-lane reads straight from HBM would touch 64 cache lines per instruction).
+//         The seam between mate 1 and mate 2 (len1 % 8 != 0) is a per-lane funnel shift.
+//         HBM-bound in theory: 2*L bytes in, 8 bytes out per pair.
+//  mark   rmdup::markDup (src/rmdup.cpp:14-149) = "this hash value occurred at an earlier index":
+//         an open-addressing table in HBM (uint64 key, uint32 smallest index), insert with
+//         atomicCAS + atomicMin, then one lookup per pair.  Random-access HBM work.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "snk_device.h"
+
+namespace {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr u64 HMUL = 0xc6a4a7935bd1e995ull, HSEED = 0xc70f6907ull, EMPTY = ~0ull;
+
+__device__ __forceinline__ u64 shift_mix(u64 v) { return v ^ (v >> 47); }
+
+// One lane = one pair.  LD(m, w) returns the w-th little-endian 8-byte word of the row of mate m.
+template <bool PAIRED, class LD>
+__device__ __forceinline__ u64 hash_chain(int l1, int l2, int wmax, bool valid, LD &&ld) {
+    const int total = l1 + l2, q = l1 >> 3, r8 = (l1 & 7) * 8;
+    const int nfull = valid ? (total >> 3) : 0, t8 = valid ? (total & 7) * 8 : 0;
+    u64 h = HSEED ^ ((u64)total * HMUL);
+    int steps = nfull + (t8 ? 1 : 0);
+    for (int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o));     // wave-uniform trip count
+    u64 bprev = 0;
+    for (int k = 0; k < steps; ++k) {
+        const int j = k - q;                                    // word of mate 2 that ends in this chunk
+        const u64 a = ld(0, min(k, wmax));
+        const u64 bcur = (PAIRED && j >= 0) ? ld(1, min(j, wmax)) : 0ull;
+        u64 d;
+        if (k < q) d = a;
+        else if (r8 == 0) d = bcur;
+        else d = ((j == 0) ? (a & ((1ull << r8) - 1ull)) : (bprev >> (64 - r8))) | (bcur << r8);
+        if (j >= 0) bprev = bcur;
+        if (k < nfull) {
+            h ^= shift_mix(d * HMUL) * HMUL;
+            h *= HMUL;
+        } else if (k == nfull && t8) {                          // load_bytes: the last len % 8 bytes
+            h ^= d & ((1ull << t8) - 1ull);
+            h *= HMUL;
+        }
+    }
+    h = shift_mix(h) * HMUL;
+    return shift_mix(h);
+}
+
+struct HashArgs {
+    const uint8_t *seq[2];
+    const uint16_t *len[2];
+    int fixed_len[2];
+    int pitch;
+    long n;
+    u64 *out;
+};
+
+// rows staged through LDS (pitch a multiple of 16, 16-byte aligned planes)
+template <bool PAIRED>
+__global__ void __launch_bounds__(256) snk_hash_lds_kernel(const HashArgs A, const int p2, const long tiles) {
+    extern __shared__ uint8_t smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;
+    uint8_t *rows = smem + (size_t)wave * 2 * 64 * p2;          // [mate][row][p2]
+    const int upr = A.pitch >> 4;                               // 16-byte units per row
+    const int rpp = 64 / upr;                                   // rows per pass of the wave
+    const int rowoff = lane / upr, col = lane - rowoff * upr;
+    const bool act = lane < rpp * upr;
+    const int wmax = (A.pitch >> 3) - 1;
+    for (long tile = (long)blockIdx.x * W + wave; tile < tiles; tile += (long)gridDim.x * W) {
+        const long t0 = tile * 64;
+        const long rem = A.n - t0;
+        const int cnt = rem >= 64 ? 64 : (int)rem;
+#pragma unroll
+        for (int m = 0; m < (PAIRED ? 2 : 1); ++m) {
+            const uint8_t *base = A.seq[m] + t0 * (long)A.pitch;
+            uint8_t *dst = rows + (size_t)m * 64 * p2;
+            for (int row0 = 0; row0 < cnt; row0 += rpp) {
+                const int row = row0 + rowoff;
+                if (act && row < cnt)
+                    *reinterpret_cast<uint4 *>(dst + (size_t)row * p2 + col * 16) =
+                        *reinterpret_cast<const uint4 *>(base + (long)row * A.pitch + col * 16);
+            }
+        }
+        // (one wave reads only what it wrote itself: no barrier, LDS ops of a wave are ordered)
+        const bool valid = lane < cnt;
+        int l1 = 0, l2 = 0;
+        if (valid) {
+            l1 = A.len[0] ? (int)A.len[0][t0 + lane] : A.fixed_len[0];
+            if (PAIRED) l2 = A.len[1] ? (int)A.len[1][t0 + lane] : A.fixed_len[1];
+            l1 = min(l1, A.pitch);
+            l2 = min(l2, A.pitch);
+        }
+        const uint8_t *r0 = rows + (size_t)lane * p2, *r1 = r0 + (size_t)64 * p2;
+        const u64 h = hash_chain<PAIRED>(l1, l2, wmax, valid, [&](int m, int w) {
+            return *reinterpret_cast<const u64 *>((m ? r1 : r0) + 8 * w);
+        });
+        if (valid) A.out[t0 + lane] = h;
+    }
+}
+
+// any pitch / alignment: each lane assembles its words from global bytes (slow path)
+template <bool PAIRED>
+__global__ void __launch_bounds__(256) snk_hash_direct_kernel(const HashArgs A) {
+    const int wmax = (A.pitch + 7) / 8 - 1;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long nround = (A.n + 63) / 64 * 64;                   // whole waves stay in the uniform loops
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
+        const bool valid = i < A.n;
+        int l1 = 0, l2 = 0;
+        if (valid) {
+            l1 = min(A.len[0] ? (int)A.len[0][i] : A.fixed_len[0], A.pitch);
+            if (PAIRED) l2 = min(A.len[1] ? (int)A.len[1][i] : A.fixed_len[1], A.pitch);
+        }
+        const long ii = valid ? i : 0;
+        const uint8_t *r0 = A.seq[0] + ii * (long)A.pitch, *r1 = PAIRED ? A.seq[1] + ii * (long)A.pitch : r0;
+        const int pitch = A.pitch;
+        const u64 h = hash_chain<PAIRED>(l1, l2, wmax, valid, [&](int m, int w) {
+            const uint8_t *p = (m ? r1 : r0);
+            u64 v = 0;
+            for (int b = 7; b >= 0; --b) v = (v << 8) | (u64)((8 * w + b < pitch) ? p[8 * w + b] : 0);
+            return v;
+        });
+        if (valid) A.out[i] = h;
+    }
+}
+
+__device__ __forceinline__ u64 slot_of(u64 h, int shift) { return (h * 0x9E3779B97F4A7C15ull) >> shift; }
+
+__global__ void __launch_bounds__(256) snk_mark_insert_kernel(const u64 *__restrict__ hash, const u32 *__restrict__ index, long n,
+                                                              u64 *keys, u32 *minidx, u64 mask, int shift, u32 *flag) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 h = hash[i];
+    const u32 my = index ? index[i] : (u32)i;
+    if (h == EMPTY) { atomicOr(flag, 1u); return; }             // the reference's sentinel value: decided apart
+    u64 s = slot_of(h, shift) & mask;
+    for (;;) {
+        const u64 k = atomicCAS(&keys[s], EMPTY, h);
+        if (k == EMPTY || k == h) { atomicMin(&minidx[s], my); return; }
+        s = (s + 1) & mask;
+    }
+}
+
+// population of the bucket of 2^64-1 (hash % prime); only runs when that value occurs at all
+__global__ void __launch_bounds__(256) snk_bucket_count_kernel(const u64 *__restrict__ hash, long n, u32 prime, const u32 *flag,
+                                                               u64 *count) {
+    if (flag && *flag == 0) return;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n && (hash[i] % prime) == (EMPTY % prime);
+    const u64 b = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (u64)__popcll(b));
+}
+
+__global__ void __launch_bounds__(256) snk_mark_lookup_kernel(const u64 *__restrict__ hash, const u32 *__restrict__ index, long n,
+                                                              const u64 *__restrict__ keys, const u32 *__restrict__ minidx, u64 mask,
+                                                              int shift, const u64 *bucket_count, long bucket_total, uint8_t *dup) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 h = hash[i];
+    const u32 my = index ? index[i] : (u32)i;
+    if (h == EMPTY) {                                           // src/rmdup.cpp:100,116
+        const u64 pop = bucket_total >= 0 ? (u64)bucket_total : *bucket_count;
+        dup[i] = pop > 1 ? 1 : 0;
+        return;
+    }
+    u64 s = slot_of(h, shift) & mask;
+    while (keys[s] != h) s = (s + 1) & mask;
+    dup[i] = minidx[s] != my ? 1 : 0;
+}
+
+}  // namespace
+
+#define RM_OK(call)                                      \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) return (int)e_;            \
+    } while (0)
+
+// returns 0 or a hipError_t
+int snk_launch_hash(const uint8_t *const seq[2], const uint16_t *const len[2], const int fixed_len[2], int pitch, long n,
+                    int paired, unsigned long long *out, int n_cu, void *stream) {
+    if (n <= 0) return 0;
+    HashArgs A;
+    for (int m = 0; m < 2; ++m) { A.seq[m] = seq[m]; A.len[m] = len[m]; A.fixed_len[m] = fixed_len[m]; }
+    A.pitch = pitch; A.n = n; A.out = out;
+    hipStream_t st = (hipStream_t)stream;
+    const bool aligned = pitch % 16 == 0 && pitch <= 1024 && ((uintptr_t)seq[0] % 16 == 0) && (!paired || (uintptr_t)seq[1] % 16 == 0);
+    const int p2 = pitch + 16;                                   // padded LDS pitch: consecutive rows start 4 banks apart
+    int W = 4;
+    while (W > 1 && (size_t)W * 2 * 64 * p2 > 150 * 1024) W >>= 1;
+    const size_t shmem = (size_t)W * 2 * 64 * p2;
+    if (aligned && shmem <= 150 * 1024) {
+        static bool attr[2] = {false, false};
+        const void *k = paired ? (const void *)snk_hash_lds_kernel<true> : (const void *)snk_hash_lds_kernel<false>;
+        if (!attr[paired ? 1 : 0]) {
+            RM_OK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr[paired ? 1 : 0] = true;
+        }
+        const long tiles = (n + 63) / 64;
+        long wgs = (tiles + W - 1) / W;
+        const long cap = (long)n_cu * (shmem > 80 * 1024 ? 1 : 2);
+        if (wgs > cap) wgs = cap;
+        if (paired) hipLaunchKernelGGL(snk_hash_lds_kernel<true>, dim3((unsigned)wgs), dim3(W * 64), shmem, st, A, p2, tiles);
+        else hipLaunchKernelGGL(snk_hash_lds_kernel<false>, dim3((unsigned)wgs), dim3(W * 64), shmem, st, A, p2, tiles);
+    } else {
+        long wgs = (n + 255) / 256;
+        if (wgs > (long)n_cu * 8) wgs = (long)n_cu * 8;
+        if (paired) hipLaunchKernelGGL(snk_hash_direct_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(snk_hash_direct_kernel<false>, dim3((unsigned)wgs), dim3(256), 0, st, A);
+    }
+    return (int)hipGetLastError();
+}
+
+int snk_launch_bucket_count(const unsigned long long *hash, long n, unsigned prime, const unsigned *flag,
+                            unsigned long long *count, void *stream) {
+    if (n <= 0 || prime == 0) return 0;
+    hipLaunchKernelGGL(snk_bucket_count_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, hash, n, prime,
+                       flag, count);
+    return (int)hipGetLastError();
+}
+
+int snk_launch_mark(const unsigned long long *hash, const unsigned *index, long n, unsigned prime, long bucket_total,
+                    unsigned char *dup, void *stream) {
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int lg = 4;
+    while ((1ull << lg) < 2ull * (u64)n) ++lg;
+    const u64 cap = 1ull << lg, mask = cap - 1;
+    u64 *keys = nullptr, *count = nullptr;
+    u32 *minidx = nullptr, *flag = nullptr;
+    RM_OK(hipMallocAsync((void **)&keys, cap * sizeof(u64) + 16, st));
+    RM_OK(hipMallocAsync((void **)&minidx, cap * sizeof(u32), st));
+    count = keys + cap;                                          // [count u64][flag u32] behind the keys
+    flag = reinterpret_cast<u32 *>(count + 1);
+    RM_OK(hipMemsetAsync(keys, 0xFF, cap * sizeof(u64), st));
+    RM_OK(hipMemsetAsync(count, 0, 16, st));
+    RM_OK(hipMemsetAsync(minidx, 0xFF, cap * sizeof(u32), st));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(snk_mark_insert_kernel, dim3(grid), dim3(256), 0, st, hash, index, n, keys, minidx, mask, 64 - lg, flag);
+    if (bucket_total < 0 && prime)
+        hipLaunchKernelGGL(snk_bucket_count_kernel, dim3(grid), dim3(256), 0, st, hash, n, prime, (const u32 *)flag, count);
+    hipLaunchKernelGGL(snk_mark_lookup_kernel, dim3(grid), dim3(256), 0, st, hash, index, n, (const u64 *)keys, (const u32 *)minidx, mask,
+                       64 - lg, (const u64 *)count, bucket_total, dup);
+    RM_OK(hipGetLastError());
+    RM_OK(hipFreeAsync(keys, st));
+    RM_OK(hipFreeAsync(minidx, st));
+    return 0;
+}

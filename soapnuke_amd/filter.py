@@ -113,6 +113,35 @@ class FilterContext:
         self._check(self.lib.snk_stats_fetch(self.ctx, s.ctypes.data, mx.ctypes.data, C.byref(err), self._stream()))
         return s, mx, (err.code, err.mate, err.index)
 
+    # ---- rmdup pre-pass (include/snk_rmdup.h) ----------------------------------------------
+    def hash_batch(self, batch, out=None):
+        """std::hash<std::string>(mate1 ++ mate2) of every pair of a device batch -> int64 cuda tensor
+        (the uint64 bit patterns; src/peprocess.cpp:3665,3680).  Asynchronous on the current stream."""
+        t, dev = self.torch, self.torch.device("cuda", self.device)
+        if out is None:
+            out = t.empty(int(batch.n), dtype=t.int64, device=dev)
+        self._check(self.lib.snk_rmdup_hash_device(self.ctx, C.byref(batch), out.data_ptr(), self._stream()))
+        return out
+
+    def bucket_count(self, hashes, total_n):
+        """Population of the bucket of 2**64-1 among `hashes` (sentinel quirk, multi-GPU only) -> int"""
+        t, dev = self.torch, self.torch.device("cuda", self.device)
+        cnt = t.zeros(1, dtype=t.int64, device=dev)
+        self._check(self.lib.snk_rmdup_bucket_count_device(self.ctx, hashes.data_ptr(), hashes.numel(), int(total_n),
+                                                           cnt.data_ptr(), self._stream()))
+        return cnt
+
+    def mark_dups(self, hashes, index=None, total_n=None, sentinel_bucket_total=-1):
+        """rmdup::markDup (src/rmdup.cpp:14): uint8 flag per hash, 1 = an equal hash has a smaller index.
+        index: optional int32/uint32 cuda tensor of global input-order indices (default: position)."""
+        t, dev = self.torch, self.torch.device("cuda", self.device)
+        n = hashes.numel()
+        dup = t.zeros(n, dtype=t.uint8, device=dev)
+        self._check(self.lib.snk_rmdup_mark_device(self.ctx, hashes.data_ptr(), 0 if index is None else index.data_ptr(), n,
+                                                   int(n if total_n is None else total_n), int(sentinel_bucket_total),
+                                                   dup.data_ptr(), self._stream()))
+        return dup
+
     def allreduce(self):
         """Sum/max all-reduce of the accumulators over torch.distributed (RCCL on GPUs):
         the only collective of this path."""

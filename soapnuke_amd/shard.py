@@ -18,3 +18,43 @@ def allreduce_stats(sum_t, max_t):
     import torch.distributed as dist
     dist.all_reduce(sum_t, op=dist.ReduceOp.SUM)
     dist.all_reduce(max_t, op=dist.ReduceOp.MAX)
+
+
+def rmdup_exchange_mark(hashes, first_index, total_n, mark_fn, bucket_count_fn):
+    """Global first-occurrence duplicate marking over all ranks (the one exchange step of
+    the rmdup row).  Every rank holds the hashes of its contiguous shard (int64 tensor, uint64 bit
+    patterns; global index of element k = first_index + k).  Elements travel to owner = hash % world
+    (all-to-all of (hash, global index) over RCCL), the owner marks "an equal hash with a smaller
+    global index exists" (rmdup::markDup semantics, src/rmdup.cpp:70-123, need the GLOBAL order), and
+    the flags travel back the same way.  mark_fn(hashes, index_int32, total_n, sentinel_bucket_total)
+    -> uint8 flags; bucket_count_fn(hashes, total_n) -> 1-element int64 tensor (both device side:
+    FilterContext.mark_dups / .bucket_count).  Returns the uint8 flags of this rank's shard."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    n = hashes.numel()
+    dev = hashes.device
+    # the sentinel quirk needs the population of one bucket over ALL ranks
+    cnt = bucket_count_fn(hashes, total_n).clone()
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    sentinel_total = int(cnt.item())
+    # owner = unsigned(hash) % world, computed on the int64 bit pattern
+    owner = (((((hashes >> 1) & 0x7FFFFFFFFFFFFFFF) % world) * 2 + (hashes & 1)) % world) if world > 1 else torch.zeros_like(hashes)
+    order = torch.argsort(owner, stable=True)
+    send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts)
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    gidx = (torch.arange(n, device=dev, dtype=torch.int64) + int(first_index))
+    send_h = hashes[order].contiguous()
+    send_i = gidx[order].contiguous()
+    recv_h = torch.empty(sum(rc), dtype=torch.int64, device=dev)
+    recv_i = torch.empty(sum(rc), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv_h, send_h, output_split_sizes=rc, input_split_sizes=sc)
+    dist.all_to_all_single(recv_i, send_i, output_split_sizes=rc, input_split_sizes=sc)
+    flags_owned = mark_fn(recv_h, recv_i.to(torch.int32), total_n, sentinel_total)   # indices < 2**32 (reference limit)
+    back = torch.empty(n, dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(back, flags_owned.contiguous(), output_split_sizes=sc, input_split_sizes=rc)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    out[order] = back
+    return out

@@ -38,6 +38,12 @@ def oracle_lib():
         lib.snk_oracle_adapter_pos.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_int]
         lib.snk_oracle_filter_batch.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Batch), C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.POINTER(abi.Error)]
+        lib.snk_oracle_hash_bytes.argtypes = [C.c_char_p, C.c_uint64]
+        lib.snk_oracle_hash_bytes.restype = C.c_uint64
+        lib.snk_oracle_hash_batch.argtypes = [C.POINTER(abi.Batch), C.c_int, C.c_void_p]
+        lib.snk_oracle_rmdup_prime.argtypes = [C.c_uint64]
+        lib.snk_oracle_rmdup_prime.restype = C.c_uint32
+        lib.snk_oracle_markdup.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         _oracle = lib
     return _oracle
 
@@ -53,6 +59,9 @@ def ref_lib():
         lib.snkref_adapter_pos.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_int]
         lib.snkref_filter_batch.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Batch), C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
+        lib.snkref_hash.argtypes = [C.c_char_p, C.c_uint64]
+        lib.snkref_hash.restype = C.c_uint64
+        lib.snkref_markdup.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         _ref = lib
     return _ref
 
@@ -139,3 +148,27 @@ def describe_stats_diff(params, a, b, limit=10):
             where = f"ts[{['hlq', 'ht', 'ta', 'tlq', 'tt'][t // 1000]}][{t % 1000}]"
         out.append(f"{names[k]}.{where}: {a[i]} vs {b[i]}")
     return f"{len(idx)} differing u64; " + "; ".join(out)
+
+
+# ---- rmdup pre-pass ---------------------------------------------------------------------
+
+def oracle_hash_batch(data, paired=True):
+    """uint64 hash per pair of a numpy batch through oracle/snk_oracle.c"""
+    b = host_batch(data)
+    out = np.zeros(data["n"], dtype=np.uint64)
+    oracle_lib().snk_oracle_hash_batch(C.byref(b), 1 if paired else 0, out.ctypes.data)
+    return out
+
+
+def oracle_markdup(h):
+    h = np.ascontiguousarray(h, dtype=np.uint64)
+    dup = np.zeros(len(h), dtype=np.uint8)
+    oracle_lib().snk_oracle_markdup(h.ctypes.data, len(h), dup.ctypes.data)
+    return dup
+
+
+def ref_markdup(h):
+    h = np.ascontiguousarray(h, dtype=np.uint64)
+    dup = np.zeros(len(h), dtype=np.uint8)
+    ref_lib().snkref_markdup(h.ctypes.data, len(h), dup.ctypes.data)
+    return dup

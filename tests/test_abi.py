@@ -14,7 +14,8 @@ def test_library_exports_every_declared_symbol():
     from soapnuke_amd import build
     build.build()
     lib = C.CDLL(abi.LIB_PATH)
-    hdr = open(os.path.join(T.ROOT, "include", "snk_filter.h")).read()
+    hdr = "".join(open(os.path.join(T.ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(T.ROOT, "include")))
+                  if h.endswith(".h"))                     # every public header: snk_filter.h, snk_rmdup.h
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)      # drop comments
     declared = set(re.findall(r"\b(snk_[a-z_]+)\s*\(", hdr)) - {"snk_file_block_u64", "snk_stats_u64",
                                                                "snk_file_off", "snk_bs_off", "snk_qs_off", "snk_ts_off"}

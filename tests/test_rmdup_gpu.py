@@ -1,0 +1,151 @@
+"""GPU parity of the rmdup pre-pass through the C ABI (include/snk_rmdup.h): the hash kernel against
+the oracle and the reference-made golden vectors, the marking kernels against the oracle's markDup --
+all bit-exact -- and the size-independent property at BASELINE scale (a replicated batch: every
+replica of a pair is a duplicate of the first)."""
+import os
+
+import numpy as np
+import pytest
+
+import snk_testlib as T
+from soapnuke_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rmdup.npz"))
+
+
+def _ctx(paired, L):
+    from soapnuke_amd.filter import FilterContext
+    return FilterContext(abi.default_params(paired=paired, max_read_len=L, rmdup=1), device=0)
+
+
+def _gpu_hash(d, paired, L):
+    ctx = _ctx(paired, L)
+    dev = ctx.upload(d)
+    h = ctx.hash_batch(ctx.make_batch(dev))
+    return h.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("name,paired,L,var", [("pe", True, 150, True), ("se", False, 100, True), ("pe_fixed", True, 150, False)])
+def test_hash_golden(name, paired, L, var):
+    d = synth.make_batch(1500, L, paired=paired, var_len=var, seed=424242)
+    assert np.array_equal(_gpu_hash(d, paired, L), GOLD[name + "_hash"])
+
+
+def _rand_batch(n, L, pitch, var, paired, seed):
+    """random ACGTN rows (garbage beyond the read end must not matter) with arbitrary lengths 0..L"""
+    rng = np.random.default_rng(seed)
+    d = {"n": n, "L": L, "pitch": pitch, "paired": paired, "seq": [], "qual": [], "len": []}
+    for m in range(2 if paired else 1):
+        d["seq"].append(np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=(n, pitch))])
+        d["qual"].append(np.full((n, pitch), 70, dtype=np.uint8))
+        if var:
+            ln = rng.integers(0, L + 1, size=n).astype(np.uint16)
+            ln[:min(n, 2 * L + 2)] = (np.arange(min(n, 2 * L + 2)) % (L + 1)).astype(np.uint16)   # every seam residue, empty reads
+            d["len"].append(ln)
+        else:
+            d["len"].append(None)
+    return d
+
+
+@pytest.mark.parametrize("paired", [True, False])
+@pytest.mark.parametrize("L,pitch,var", [(150, 160, False), (150, 160, True), (250, 256, True), (100, 100, True),
+                                          (36, 36, True), (64, 64, False), (8, 16, True), (1000, 1008, True), (151, 152, True)])
+def test_hash_vs_oracle(paired, L, pitch, var):
+    n = 5000 if L <= 250 else 2100
+    d = _rand_batch(n, L, pitch, var, paired, seed=1000 + L)
+    assert np.array_equal(_gpu_hash(d, paired, L), T.oracle_hash_batch(d, paired))
+
+
+def test_hash_odd_tile_counts():
+    for n in (1, 63, 64, 65, 127, 4097):
+        d = synth.make_batch(n, 150, paired=True, var_len=True, seed=n)
+        assert np.array_equal(_gpu_hash(d, True, 150), T.oracle_hash_batch(d, True))
+
+
+def _gpu_mark(h, index=None, total_n=None, sentinel_total=-1):
+    import torch
+    ctx = _ctx(True, 150)
+    ht = torch.from_numpy(np.ascontiguousarray(h).view(np.int64)).cuda()
+    it = None if index is None else torch.from_numpy(np.ascontiguousarray(index, dtype=np.uint32).view(np.int32)).cuda()
+    return ctx.mark_dups(ht, it, total_n, sentinel_total).cpu().numpy()
+
+
+@pytest.mark.parametrize("key", ["mark0", "mark1", "mark2", "mark3", "mark4", "mark_lone"])
+def test_mark_golden(key):
+    assert np.array_equal(_gpu_mark(GOLD[key + "_hash"]), GOLD[key + "_dup"])
+
+
+def test_mark_vs_oracle_random():
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 9, 10, 1000, 300000, 2_000_000):
+        for mode in range(3):
+            h = rng.integers(0, max(2, n // 2), n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+            if mode == 1:
+                h[rng.integers(0, n, max(1, n // 10))] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            if mode == 2:
+                h = rng.integers(0, 2**63, n, dtype=np.uint64) * np.uint64(3)
+                h[n // 2] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            assert np.array_equal(_gpu_mark(h), T.oracle_markdup(h)), (n, mode)
+
+
+def test_mark_with_explicit_indices():
+    # the multi-GPU owner side: elements arrive in arbitrary order with their global indices
+    rng = np.random.default_rng(8)
+    n = 100000
+    h = rng.integers(0, n // 4, n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    want = T.oracle_markdup(h)
+    perm = rng.permutation(n)
+    got = _gpu_mark(h[perm], index=perm.astype(np.uint32), total_n=n)
+    assert np.array_equal(got, want[perm])
+    # indices above 2^31 (uint32 compare)
+    big = (perm.astype(np.uint64) + np.uint64(4_000_000_000)).astype(np.uint32)
+    got = _gpu_mark(h[perm], index=big, total_n=4_294_000_000)
+    assert np.array_equal(got, want[perm])
+
+
+def test_too_many_reads_is_refused():
+    import torch
+    ctx = _ctx(True, 150)
+    h = torch.zeros(4, dtype=torch.int64, device="cuda")
+    with pytest.raises(Exception):
+        ctx.mark_dups(h, None, 1 << 32)
+
+
+def test_full_size_property_and_filter_integration():
+    """BASELINE-scale property: 1 M unique pairs replicated 4x -> exactly the replicas are duplicates;
+    and the flags, fed to the filter as snk_batch.dup, reproduce the oracle's records and counters."""
+    import torch
+    from soapnuke_amd.filter import FilterContext, records_to_numpy
+    n0, reps = 1_000_000, 4
+    d = synth.make_batch(n0, 150, paired=True, seed=5)
+    p = abi.default_params(paired=True, max_read_len=150, rmdup=1, adapters1=[synth.ADAPTER1], adapters2=[synth.ADAPTER2])
+    ctx = FilterContext(p, device=0)
+    dev = ctx.upload(d)
+    dev["seq"] = [x.repeat(reps, 1) for x in dev["seq"]]
+    dev["qual"] = [x.repeat(reps, 1) for x in dev["qual"]]
+    dev["n"] = n0 * reps
+    b = ctx.make_batch(dev)
+    h = ctx.hash_batch(b)
+    hn = h.cpu().numpy().view(np.uint64)
+    h0 = T.oracle_hash_batch(d, True)
+    assert np.array_equal(hn, np.tile(h0, reps))
+    dup = ctx.mark_dups(h)
+    first = T.oracle_markdup(h0)               # (synthetic pairs can collide among themselves: keep that exact)
+    want = np.concatenate([first] + [np.ones(n0, np.uint8)] * (reps - 1))
+    assert np.array_equal(dup.cpu().numpy(), want)
+    # the discard cascade consumes the flags (src/sequence.cpp:207): first 200k pairs of replica 2 vs oracle
+    m = 200_000
+    sub = {"n": m, "L": 150, "pitch": dev["pitch"], "seq": [x[n0:n0 + m] for x in dev["seq"]],
+           "qual": [x[n0:n0 + m] for x in dev["qual"]], "len": [None, None]}
+    rec = ctx.alloc_records(m)
+    ctx.filter_batch(ctx.make_batch(sub, first_index=n0, dup=dup[n0:n0 + m]), rec)
+    s, mx, err = ctx.fetch()
+    hd = {"n": m, "L": 150, "pitch": d["pitch"], "paired": True, "seq": [x[:m] for x in d["seq"]],
+          "qual": [x[:m] for x in d["qual"]], "len": [None, None]}
+    o = T.run_oracle(p, hd, first_index=n0, dup=np.ones(m, np.uint8))
+    assert err[0] == 0
+    for k in range(2):
+        assert np.array_equal(records_to_numpy(rec[k]), o["rec"][k])
+    assert np.array_equal(s, o["sum"]), T.describe_stats_diff(p, s, o["sum"])
