@@ -24,33 +24,60 @@ constexpr u64 HMUL = 0xc6a4a7935bd1e995ull, HSEED = 0xc70f6907ull, EMPTY = ~0ull
 
 __device__ __forceinline__ u64 shift_mix(u64 v) { return v ^ (v >> 47); }
 
-// One lane = one pair.  LD(m, w) returns the w-th little-endian 8-byte word of the row of mate m.
-template <bool PAIRED, class LD>
-__device__ __forceinline__ u64 hash_chain(int l1, int l2, int wmax, bool valid, LD &&ld) {
-    const int total = l1 + l2, q = l1 >> 3, r8 = (l1 & 7) * 8;
-    const int nfull = valid ? (total >> 3) : 0, t8 = valid ? (total & 7) * 8 : 0;
-    u64 h = HSEED ^ ((u64)total * HMUL);
-    int steps = nfull + (t8 ? 1 : 0);
-    for (int o = 32; o > 0; o >>= 1) steps = max(steps, __shfl_xor(steps, o));     // wave-uniform trip count
-    u64 bprev = 0;
-    for (int k = 0; k < steps; ++k) {
-        const int j = k - q;                                    // word of mate 2 that ends in this chunk
-        const u64 a = ld(0, min(k, wmax));
-        const u64 bcur = (PAIRED && j >= 0) ? ld(1, min(j, wmax)) : 0ull;
-        u64 d;
-        if (k < q) d = a;
-        else if (r8 == 0) d = bcur;
-        else d = ((j == 0) ? (a & ((1ull << r8) - 1ull)) : (bprev >> (64 - r8))) | (bcur << r8);
-        if (j >= 0) bprev = bcur;
-        if (k < nfull) {
-            h ^= shift_mix(d * HMUL) * HMUL;
-            h *= HMUL;
-        } else if (k == nfull && t8) {                          // load_bytes: the last len % 8 bytes
-            h ^= d & ((1ull << t8) - 1ull);
-            h *= HMUL;
-        }
+// One lane = one pair; the chain over the 8-byte words of mate 1 ++ mate 2 runs in two legs so that
+// only one mate's rows have to be staged at a time.  LD(w) returns the w-th little-endian word of the
+// lane's row of the mate currently staged.
+struct Chain {
+    u64 h, carry, bprev;
+    int q, r8, nfull, t8;
+};
+
+__device__ __forceinline__ int wave_max(int v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ void mix_word(Chain &c, int k, u64 d) {
+    if (k < c.nfull) {
+        c.h ^= shift_mix(d * HMUL) * HMUL;
+        c.h *= HMUL;
+    } else if (k == c.nfull && c.t8) {                          // load_bytes: the last len % 8 bytes
+        c.h ^= d & ((1ull << c.t8) - 1ull);
+        c.h *= HMUL;
     }
-    h = shift_mix(h) * HMUL;
+}
+__device__ __forceinline__ void chain_begin(Chain &c, int l1, int l2, bool valid) {
+    const int total = l1 + l2;
+    c.q = l1 >> 3;
+    c.r8 = (l1 & 7) * 8;
+    c.nfull = valid ? (total >> 3) : 0;
+    c.t8 = valid ? (total & 7) * 8 : 0;
+    c.h = HSEED ^ ((u64)total * HMUL);
+    c.carry = c.bprev = 0;
+}
+// leg 1: the whole words of mate 1, and the bytes of its last partial word (the seam)
+template <class LD>
+__device__ __forceinline__ void chain_mate1(Chain &c, int wmax, bool valid, LD &&ld) {
+    const int steps = wave_max(valid ? c.q : 0);
+    for (int k = 0; k < steps; ++k) {
+        const u64 a = ld(min(k, wmax));
+        if (k < c.q) mix_word(c, k, a);
+    }
+    const u64 last = ld(min(c.q, wmax));
+    c.carry = c.r8 ? (last & ((1ull << c.r8) - 1ull)) : 0ull;
+}
+// leg 2: mate 2 shifted behind the seam (PAIRED), or just the tail bytes of mate 1 (single end: ld unused)
+template <bool PAIRED, class LD>
+__device__ __forceinline__ u64 chain_mate2(Chain &c, int wmax, bool valid, LD &&ld) {
+    const int steps = wave_max(valid ? c.nfull - c.q + (c.t8 ? 1 : 0) : 0);
+    for (int j = 0; j < steps; ++j) {
+        const u64 bcur = PAIRED ? ld(min(j, wmax)) : 0ull;
+        u64 d;
+        if (c.r8 == 0) d = bcur;
+        else d = ((j == 0) ? c.carry : (c.bprev >> (64 - c.r8))) | (bcur << c.r8);
+        c.bprev = bcur;
+        mix_word(c, c.q + j, d);
+    }
+    const u64 h = shift_mix(c.h) * HMUL;
     return shift_mix(h);
 }
 
@@ -63,32 +90,32 @@ struct HashArgs {
     u64 *out;
 };
 
-// rows staged through LDS (pitch a multiple of 16, 16-byte aligned planes)
+// rows staged through LDS one mate at a time (pitch a multiple of 16, 16-byte aligned planes)
 template <bool PAIRED>
 __global__ void __launch_bounds__(256) snk_hash_lds_kernel(const HashArgs A, const int p2, const long tiles) {
     extern __shared__ uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;
-    uint8_t *rows = smem + (size_t)wave * 2 * 64 * p2;          // [mate][row][p2]
+    uint8_t *rows = smem + (size_t)wave * 64 * p2;              // [row][p2], mate 1 then mate 2
     const int upr = A.pitch >> 4;                               // 16-byte units per row
     const int rpp = 64 / upr;                                   // rows per pass of the wave
     const int rowoff = lane / upr, col = lane - rowoff * upr;
     const bool act = lane < rpp * upr;
     const int wmax = (A.pitch >> 3) - 1;
+    const uint8_t *myrow = rows + (size_t)lane * p2;
+    auto ld = [&](int w) { return *reinterpret_cast<const u64 *>(myrow + 8 * w); };
     for (long tile = (long)blockIdx.x * W + wave; tile < tiles; tile += (long)gridDim.x * W) {
         const long t0 = tile * 64;
         const long rem = A.n - t0;
         const int cnt = rem >= 64 ? 64 : (int)rem;
-#pragma unroll
-        for (int m = 0; m < (PAIRED ? 2 : 1); ++m) {
+        auto stage = [&](int m) {                               // coalesced 16-byte loads -> padded LDS rows
             const uint8_t *base = A.seq[m] + t0 * (long)A.pitch;
-            uint8_t *dst = rows + (size_t)m * 64 * p2;
             for (int row0 = 0; row0 < cnt; row0 += rpp) {
                 const int row = row0 + rowoff;
                 if (act && row < cnt)
-                    *reinterpret_cast<uint4 *>(dst + (size_t)row * p2 + col * 16) =
+                    *reinterpret_cast<uint4 *>(rows + (size_t)row * p2 + col * 16) =
                         *reinterpret_cast<const uint4 *>(base + (long)row * A.pitch + col * 16);
             }
-        }
+        };
         // (one wave reads only what it wrote itself: no barrier, LDS ops of a wave are ordered)
         const bool valid = lane < cnt;
         int l1 = 0, l2 = 0;
@@ -98,10 +125,12 @@ __global__ void __launch_bounds__(256) snk_hash_lds_kernel(const HashArgs A, con
             l1 = min(l1, A.pitch);
             l2 = min(l2, A.pitch);
         }
-        const uint8_t *r0 = rows + (size_t)lane * p2, *r1 = r0 + (size_t)64 * p2;
-        const u64 h = hash_chain<PAIRED>(l1, l2, wmax, valid, [&](int m, int w) {
-            return *reinterpret_cast<const u64 *>((m ? r1 : r0) + 8 * w);
-        });
+        Chain c;
+        chain_begin(c, l1, l2, valid);
+        stage(0);
+        chain_mate1(c, wmax, valid, ld);
+        if (PAIRED) stage(1);
+        const u64 h = chain_mate2<PAIRED>(c, wmax, valid, ld);
         if (valid) A.out[t0 + lane] = h;
     }
 }
@@ -120,14 +149,18 @@ __global__ void __launch_bounds__(256) snk_hash_direct_kernel(const HashArgs A) 
             if (PAIRED) l2 = min(A.len[1] ? (int)A.len[1][i] : A.fixed_len[1], A.pitch);
         }
         const long ii = valid ? i : 0;
-        const uint8_t *r0 = A.seq[0] + ii * (long)A.pitch, *r1 = PAIRED ? A.seq[1] + ii * (long)A.pitch : r0;
         const int pitch = A.pitch;
-        const u64 h = hash_chain<PAIRED>(l1, l2, wmax, valid, [&](int m, int w) {
-            const uint8_t *p = (m ? r1 : r0);
-            u64 v = 0;
-            for (int b = 7; b >= 0; --b) v = (v << 8) | (u64)((8 * w + b < pitch) ? p[8 * w + b] : 0);
-            return v;
-        });
+        auto words_of = [&](const uint8_t *p) {
+            return [=](int w) {
+                u64 v = 0;
+                for (int b = 7; b >= 0; --b) v = (v << 8) | (u64)((8 * w + b < pitch) ? p[8 * w + b] : 0);
+                return v;
+            };
+        };
+        Chain c;
+        chain_begin(c, l1, l2, valid);
+        chain_mate1(c, wmax, valid, words_of(A.seq[0] + ii * (long)pitch));
+        const u64 h = chain_mate2<PAIRED>(c, wmax, valid, words_of((PAIRED ? A.seq[1] : A.seq[0]) + ii * (long)pitch));
         if (valid) A.out[i] = h;
     }
 }
@@ -194,9 +227,8 @@ int snk_launch_hash(const uint8_t *const seq[2], const uint16_t *const len[2], c
     hipStream_t st = (hipStream_t)stream;
     const bool aligned = pitch % 16 == 0 && pitch <= 1024 && ((uintptr_t)seq[0] % 16 == 0) && (!paired || (uintptr_t)seq[1] % 16 == 0);
     const int p2 = pitch + 16;                                   // padded LDS pitch: consecutive rows start 4 banks apart
-    int W = 4;
-    while (W > 1 && (size_t)W * 2 * 64 * p2 > 150 * 1024) W >>= 1;
-    const size_t shmem = (size_t)W * 2 * 64 * p2;
+    const int W = 4;
+    const size_t shmem = (size_t)W * 64 * p2;                    // one mate's rows at a time
     if (aligned && shmem <= 150 * 1024) {
         static bool attr[2] = {false, false};
         const void *k = paired ? (const void *)snk_hash_lds_kernel<true> : (const void *)snk_hash_lds_kernel<false>;
@@ -206,7 +238,7 @@ int snk_launch_hash(const uint8_t *const seq[2], const uint16_t *const len[2], c
         }
         const long tiles = (n + 63) / 64;
         long wgs = (tiles + W - 1) / W;
-        const long cap = (long)n_cu * (shmem > 80 * 1024 ? 1 : 2);
+        const long cap = (long)n_cu * (long)max((size_t)1, (size_t)(150 * 1024) / shmem);   // all resident at once
         if (wgs > cap) wgs = cap;
         if (paired) hipLaunchKernelGGL(snk_hash_lds_kernel<true>, dim3((unsigned)wgs), dim3(W * 64), shmem, st, A, p2, tiles);
         else hipLaunchKernelGGL(snk_hash_lds_kernel<false>, dim3((unsigned)wgs), dim3(W * 64), shmem, st, A, p2, tiles);
