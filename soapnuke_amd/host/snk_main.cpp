@@ -25,6 +25,7 @@
 
 #include "../../include/snk_filter.h"
 #include "snk_report.h"
+#include "../../include/snk_rmdup.h"
 
 using std::cerr;
 using std::cout;
@@ -129,6 +130,7 @@ void read_config(Options &o, const char *path) {             // src/process_argv
         else if (key == "trimBadTail") o.trim_bad_tail = val;
         else if (key == "outFileType") o.out_file_type = val;
         else if (key == "seqType") { /* only affects tile/index parsing, not on this path */ }
+        else if (key == "rmdup") p.rmdup = 1;
         else die("parameter " + key + " is not supported by the GPU filter path yet");
     }
 }
@@ -379,6 +381,94 @@ int main(int argc, char **argv) {
         HIPCHK(hipMalloc(&d_len[m], (size_t)B * 2)); HIPCHK(hipMalloc(&d_rec[m], (size_t)B * sizeof(snk_read_result)));
         memset(h_seq[m], 0, plane); memset(h_qual[m], 0, plane);
     }
+    // ---- rmdup pre-pass (src/peprocess.cpp:3071-3152): hash every raw pair on the GPU, keep the hashes
+    // resident, mark every later occurrence; the flags enter the cascade as snk_batch.dup below.
+    uint8_t *d_dup_all = nullptr;
+    Writer dupw[2][64];
+    if (o.p.rmdup) {
+        if (T > 64) die("rmdup: more than 64 threads");
+        Reader pr[2];
+        pr[0].open(o.fq1);
+        if (mates == 2) pr[1].open(o.fq2);
+        std::vector<uint64_t *> chunks;
+        std::vector<int> chunk_n;
+        uint64_t nall = 0;
+        for (;;) {
+            int n = 0;
+            for (; n < B; ++n) {
+                bool ok[2] = {true, true};
+                for (int m = 0; m < mates; ++m) {
+                    const char *sq; int ln;
+                    if (!pr[m].line(sq, ln)) { ok[m] = false; continue; }          // id
+                    if (!pr[m].line(sq, ln)) die("truncated fastq record");
+                    if (ln > lcap) die("read longer than the first batch's longest read (" + std::to_string(lcap) + ")");
+                    memcpy(h_seq[m] + (size_t)n * pitch, sq, ln);
+                    h_len[m][n] = (uint16_t)ln;
+                    const char *t; int tn;
+                    if (!pr[m].line(t, tn) || !pr[m].line(t, tn)) die("truncated fastq record");
+                }
+                if (mates == 2 && ok[0] != ok[1]) die("reads number in fq1 and fq2 are different");
+                if (!ok[0]) break;
+            }
+            if (n == 0) break;
+            uint64_t *dh;
+            HIPCHK(hipMalloc(&dh, (size_t)n * sizeof(uint64_t)));
+            snk_batch b;
+            memset(&b, 0, sizeof b);
+            b.n = n;
+            b.pitch = pitch;
+            for (int m = 0; m < mates; ++m) {
+                HIPCHK(hipMemcpyAsync(d_seq[m], h_seq[m], (size_t)n * pitch, hipMemcpyHostToDevice, 0));
+                HIPCHK(hipMemcpyAsync(d_len[m], h_len[m], (size_t)n * 2, hipMemcpyHostToDevice, 0));
+                b.seq[m] = d_seq[m];
+                b.qual[m] = d_qual[m];
+                b.len[m] = d_len[m];
+            }
+            if (snk_rmdup_hash_device(ctx, &b, dh, nullptr) != SNK_OK) die(snk_last_error());
+            HIPCHK(hipStreamSynchronize(0));                 // the pinned planes are refilled next
+            chunks.push_back(dh);
+            chunk_n.push_back(n);
+            nall += (uint64_t)n;
+            if (n < B) break;
+        }
+        if (nall > 4294967295ull) die("reads number is too large to do remove duplication," + std::to_string(nall));
+        uint64_t *d_hash_all;
+        HIPCHK(hipMalloc(&d_hash_all, (size_t)nall * sizeof(uint64_t)));
+        HIPCHK(hipMalloc(&d_dup_all, (size_t)nall));
+        uint64_t off = 0;
+        for (size_t k = 0; k < chunks.size(); ++k) {
+            HIPCHK(hipMemcpyAsync(d_hash_all + off, chunks[k], (size_t)chunk_n[k] * sizeof(uint64_t), hipMemcpyDeviceToDevice, 0));
+            off += (uint64_t)chunk_n[k];
+        }
+        HIPCHK(hipStreamSynchronize(0));
+        for (uint64_t *c : chunks) HIPCHK(hipFree(c));
+        cout << "totalReadsNum:\t" << nall << endl;
+        if (snk_rmdup_mark_device(ctx, d_hash_all, nullptr, (int64_t)nall, nall, -1, d_dup_all, nullptr) != SNK_OK) die(snk_last_error());
+        HIPCHK(hipStreamSynchronize(0));
+        HIPCHK(hipFree(d_hash_all));
+        std::vector<uint8_t> flags((size_t)nall);
+        HIPCHK(hipMemcpy(flags.data(), d_dup_all, (size_t)nall, hipMemcpyDeviceToHost));
+        uint64_t ndup = 0;
+        for (uint8_t f : flags) ndup += f;
+        log << "duplicate reads number:\t" << ndup << endl;
+        if (mates == 1) {
+            // Reference quirk (SE only): seProcess records "reads so far" BEFORE counting the quality line of
+            // the patch's last read (src/seprocess.cpp:1086,1159 vs src/peprocess.cpp:2147), so inside every
+            // full patch read i is filtered with the flag of read i-1 (read 0: the byte in front of the
+            // array, 0 in practice); only the partial patch at the end of the file (:1112) is aligned.
+            // Reproduced here, on the host, so that outputs stay identical; the C ABI flags are the true ones.
+            const uint64_t ps = o.patch_size > 0 ? (uint64_t)o.patch_size : (uint64_t)T * 20000 / 8;
+            const uint64_t full_end = nall / ps * ps;
+            std::vector<uint8_t> eff(flags);
+            for (uint64_t i = 0; i < full_end; ++i) eff[i] = i ? flags[i - 1] : 0;
+            HIPCHK(hipMemcpy(d_dup_all, eff.data(), (size_t)nall, hipMemcpyHostToDevice));
+        }
+        for (int t = 0; t < T; ++t)                            // dupReads.<thread>.<mate>.gz, src/peprocess.cpp:167-174
+            for (int m = 0; m < mates; ++m)                    // SE: only .1.gz (src/seprocess.cpp:89)
+                dupw[m][t].open(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz", true);
+        for (int m = 0; m < mates; ++m) { memset(h_seq[m], 0, plane); }
+    }
+    uint64_t ndup_written = 0;
     std::vector<string> ids[2], raw_seq[2], raw_qual[2];
     uint64_t total = 0;
     const int dq = o.p.output_quality_phred - o.p.quality_phred;
@@ -417,6 +507,7 @@ int main(int argc, char **argv) {
                 b.len[m] = d_len[m] + lo;
             }
             b.first_index = g;
+            if (d_dup_all) b.dup = d_dup_all + g;
             if (snk_bind_stats(ctx, d_sum[vt], d_max[vt]) != SNK_OK) die(snk_last_error());
             if (snk_filter_batch_device(ctx, &b, d_rec[0] + lo, mates == 2 ? d_rec[1] + lo : nullptr, nullptr, 0) != SNK_OK)
                 die(snk_last_error());
@@ -427,6 +518,16 @@ int main(int argc, char **argv) {
         HIPCHK(hipStreamSynchronize(0));
         // clean output, input order (src/peprocess.cpp:3383-3484)
         for (int i = 0; i < n; ++i) {
+            if (d_dup_all && h_rec[0][i].reason == SNK_R_DUP) {          // C_fastq::toString of the raw records, :1541
+                const int vt = (int)(((total + (uint64_t)i) / (uint64_t)vblock) % (uint64_t)T);
+                for (int m = 0; m < mates; ++m) {
+                    const Rec &r = cur[m][i];
+                    string &out = dupw[m][vt].acc;
+                    out += r.id; out += '\n'; out += r.seq; out += "\n+\n"; out += r.qual; out += '\n';
+                    if (out.size() > (1u << 22)) dupw[m][vt].flush();
+                }
+                ++ndup_written;
+            }
             if (h_rec[0][i].reason != SNK_KEEP) continue;
             for (int m = 0; m < mates; ++m) {
                 const Rec &r = cur[m][i];
@@ -466,6 +567,10 @@ int main(int argc, char **argv) {
         }
     }
     for (int m = 0; m < mates; ++m) wr[m].close();
+    if (d_dup_all) {
+        for (int t = 0; t < T; ++t) for (int m = 0; m < mates; ++m) dupw[m][t].close();
+        log << "dup number:\t" << ndup_written << endl;
+    }
 
     // ---- stats: finalize each virtual thread's block, fetch, check errors, write the reports
     std::vector<std::vector<uint64_t>> sums(T, std::vector<uint64_t>(nsum)), maxs(T, std::vector<uint64_t>(SNK_MAX_N));

@@ -59,6 +59,36 @@ def test_cli_gz_in_gz_out(tmp_path):
         assert _cat(os.path.join(ours, c + ".gz")) == _cat(os.path.join(ref, c)), c
 
 
+@pytest.mark.parametrize("paired,n", [(True, 20000), (False, 20000), (False, 20100), (True, 19999)])
+def test_cli_rmdup_matches_reference_binary(paired, n, tmp_path):
+    """config key `rmdup`: GPU hash + marking pre-pass, flags into the cascade, the
+    dupReads.<thread>.<mate>.gz side files -- all against the reference binary."""
+    L, threads, patch = 150, 3, 250       # n = 20100: a partial last patch (SE: the only one whose flags are aligned)
+    d = synth.make_batch(n, L, paired=paired, seed=61)
+    for m in range(2 if paired else 1):
+        d["seq"][m][10000:12000] = d["seq"][m][0:2000]           # duplicates by sequence, qualities differ
+        d["seq"][m][15000:15500] = d["seq"][m][0:500]            # third copies, in another virtual thread's block
+        d["seq"][m][n - 40:n - 20] = d["seq"][m][700:720]        # duplicates inside the last patch
+    cli = ["-f", synth.ADAPTER1, "-J"] + (["-r", synth.ADAPTER2] if paired else [])
+    case = ("rmdup", paired, L, n, threads, patch, {}, {}, cli, ["rmdup"])
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ours = _run_ours(case, work, gz=False)
+    for f in (R.REPORT_FILES_PE if paired else R.REPORT_FILES_SE):
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in (["c1.fq", "c2.fq"] if paired else ["c1.fq"]):
+        assert _cat(os.path.join(ours, c)) == _cat(os.path.join(ref, c)), c
+    ndup = 0
+    for t in range(threads):
+        for m in range(2 if paired else 1):
+            f = f"dupReads.{t}.{m + 1}.gz"
+            a, b = _cat(os.path.join(ours, f)), _cat(os.path.join(ref, f))
+            assert a == b, f
+            ndup += a.count(b"\n") // 4
+    assert ndup == 2520 * (2 if paired else 1)
+    assert b"dup number:\t2520" in open(os.path.join(ours, "log"), "rb").read()
+
+
 def test_cli_error_surface(tmp_path):
     r = subprocess.run([CLI, "filter", "-1", "/nonexistent.fq", "-C", "c.fq", "-o", str(tmp_path)], capture_output=True)
     assert r.returncode == 1 and r.stderr.startswith(b"Error:")
