@@ -179,7 +179,7 @@ def main():
             if n == 10_000_000 and L == 150 and args.kernel in (0, 2):
                 traffic = int(tj["hbm_bytes_per_launch"])
                 extra = {"traffic_source": tj["source"], "valu_insts_per_read": tj["valu_insts_per_read"],
-                         "valu_issue_frac": tj["valu_issue_frac"]}
+                         "valu_issue_frac": tj["valu_issue_frac"], "salu_insts_per_read": tj.get("salu_insts_per_read")}
         except (OSError, KeyError, ValueError):
             pass
         out = {
