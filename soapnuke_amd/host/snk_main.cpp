@@ -6,21 +6,34 @@
 // the input, FASTQ parsed once into pinned structure-of-arrays batches, the per-read hot path on
 // the GPU, clean reads written in input order by the host.  No temp files, no `cat`.
 //
-// Round-1 scope: correctness of the drop-in surface; the host pipeline is
-// single-threaded and synchronous (its overlap/parallel inflate is row N2).
+// Host pipeline: one reader thread per input file (inflate / read + line index), a
+// pack stage (records -> pinned SoA planes, parallel over records), the GPU stage (async copies and
+// kernels on a stream per slot), and a write stage (parallel formatting; for .gz output every worker
+// deflates its slice into its own gzip member, level 2, members concatenated in input order -- the
+// same legal-gzip trick the reference uses for its per-thread part files, src/peprocess.cpp:2386).
+// Three batch slots are in flight, so reading, packing, the GPU and writing overlap.
 #include <getopt.h>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <time.h>
 #include <zlib.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <fstream>
+#include <functional>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/snk_filter.h"
@@ -40,7 +53,8 @@ struct Options {
     snk_params p;
     string trim, trim_bad_head, trim_bad_tail, out_file_type = "fastq";
     int threads = 6, patch_size = 0, batch_pairs = 1 << 18, device = 0;
-    bool in_gz = true, out_gz = true;
+    bool in_gz = true, out_gz = true, pe_info = false;
+    string base_convert;
 };
 
 [[noreturn]] void die(const string &msg) {          // the reference's convention: message, exit(1)
@@ -131,6 +145,8 @@ void read_config(Options &o, const char *path) {             // src/process_argv
         else if (key == "outFileType") o.out_file_type = val;
         else if (key == "seqType") { /* only affects tile/index parsing, not on this path */ }
         else if (key == "rmdup") p.rmdup = 1;
+        else if (key == "pe_info") o.pe_info = true;
+        else if (key == "baseConvert") o.base_convert = val;
         else die("parameter " + key + " is not supported by the GPU filter path yet");
     }
 }
@@ -226,81 +242,269 @@ string local_time() {                                   // get_local_time(), src
     return s.str();
 }
 
-// ------------------------------------------------------------------ FASTQ in
-struct Reader {
-    gzFile f = nullptr;
-    std::vector<char> buf;
-    size_t pos = 0, end = 0;
-    bool eof = false;
-    void open(const string &path) {
-        struct stat st;
-        if (stat(path.c_str(), &st) != 0 || st.st_size == 0) die("cannot open file or empty file," + path);
-        f = gzopen(path.c_str(), "rb");                // reads plain files transparently
-        if (!f) die("cannot open file," + path);
-        gzbuffer(f, 1 << 22);
-        buf.resize(1 << 24);
+// ------------------------------------------------------------------ host pipeline pieces
+template <class T>
+class Channel {                                        // bounded FIFO between pipeline stages
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+public:
+    explicit Channel(size_t cap) : cap_(cap) {}
+    void push(T v) {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(v));
+        cv_.notify_all();
     }
-    bool line(const char *&s, int &n) {                // next line without its '\n' / '\r'
-        for (;;) {
-            char *nl = pos < end ? (char *)memchr(&buf[pos], '\n', end - pos) : nullptr;
-            if (nl) {
-                s = &buf[pos];
-                n = (int)(nl - s);
-                pos = (size_t)(nl - buf.data()) + 1;
-                if (n > 0 && s[n - 1] == '\r') --n;
-                return true;
-            }
-            if (eof) {
-                if (pos >= end) return false;
-                s = &buf[pos];
-                n = (int)(end - pos);
-                pos = end;
-                return true;
-            }
-            memmove(buf.data(), &buf[pos], end - pos);
-            end -= pos;
-            pos = 0;
-            if (end == buf.size()) buf.resize(buf.size() * 2);
-            int got = gzread(f, &buf[end], (unsigned)(buf.size() - end));
-            if (got < 0) die("read error in input fastq");
-            if (got == 0) eof = true;
-            end += (size_t)got;
-        }
+    bool pop(T &v) {                                   // false: closed and drained
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        v = std::move(q_.front());
+        q_.pop_front();
+        cv_.notify_all();
+        return true;
+    }
+    void close() {
+        std::unique_lock<std::mutex> l(m_);
+        closed_ = true;
+        cv_.notify_all();
     }
 };
 
-struct Writer {
-    gzFile gz = nullptr;
-    FILE *fp = nullptr;
-    string acc;
-    void open(const string &path, bool gzip) {
-        if (gzip) {
-            gz = gzopen(path.c_str(), "wb");
-            if (!gz) die("cannot write to the file," + path);
-            gzsetparams(gz, 2, Z_DEFAULT_STRATEGY);    // level 2 as src/peprocess.cpp:1809
-            gzbuffer(gz, 1 << 23);
-        } else {
-            fp = fopen(path.c_str(), "w");
-            if (!fp) die("cannot write to the file," + path);
-        }
+void parallel_for(int workers, int n, const std::function<void(int, int, int)> &f) {   // f(worker, lo, hi)
+    workers = std::max(1, std::min(workers, n));
+    if (workers == 1) { f(0, 0, n); return; }
+    std::vector<std::thread> th;
+    for (int w = 0; w < workers; ++w) {
+        const int lo = (int)((long)n * w / workers), hi = (int)((long)n * (w + 1) / workers);
+        th.emplace_back([&f, w, lo, hi] { f(w, lo, hi); });
     }
-    void flush() {
-        if (acc.empty()) return;
-        if (gz) gzwrite(gz, acc.data(), (unsigned)acc.size());
-        else fwrite(acc.data(), 1, acc.size(), fp);
-        acc.clear();
-    }
-    void close() { flush(); if (gz) gzclose(gz); if (fp) fclose(fp); }
+    for (auto &t : th) t.join();
+}
+
+// n whole FASTQ records of one file as they were read, plus the index of their 4n lines
+struct RawChunk {
+    const char *base = nullptr;                        // into `own` (inflated data) or into the mmap of a plain file
+    std::vector<char> own;
+    std::vector<uint32_t> ls, le;                      // line start / end (end excludes the line terminator)
+    int n = 0;
+    const char *line(int k, int &len) const { len = (int)(le[k] - ls[k]); return base + ls[k]; }
 };
+
+// gz input (multi-member ok: zlib's gzread): inflate + line index on one thread per file (inflate-bound).
+// Every line loses its last `space_num` characters, the number of trailing white-space characters of the
+// FIRST line of fq1 (src/peprocess.cpp:2066-2077: 1 for "\n", 2 for "\r\n", more with trailing blanks).
+void reader_gz(const string path, int batch, int space_num, Channel<RawChunk *> *out) {
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) die("cannot open file," + path);
+    gzbuffer(f, 1 << 22);
+    const size_t block = (size_t)1 << 26;
+    RawChunk *cur = new RawChunk;
+    cur->own.resize(block * 2);
+    size_t fill = 0, scan = 0, line_start = 0;
+    bool eof = false;
+    const size_t want = (size_t)batch * 4;
+    auto add_line = [&](size_t s, size_t e_incl_nl) {
+        size_t e = e_incl_nl > s + (size_t)space_num ? e_incl_nl - (size_t)space_num : s;
+        cur->ls.push_back((uint32_t)s);
+        cur->le.push_back((uint32_t)e);
+    };
+    for (;;) {
+        while (scan < fill && cur->ls.size() < want) {
+            const char *p = (const char *)memchr(cur->own.data() + scan, '\n', fill - scan);
+            if (!p) { scan = fill; break; }
+            const size_t nl = (size_t)(p - cur->own.data());
+            add_line(line_start, nl + 1);
+            line_start = scan = nl + 1;
+        }
+        if (cur->ls.size() == want) {                  // a full batch: hand it over, keep the unread tail
+            RawChunk *next = new RawChunk;
+            next->own.resize(std::max(cur->own.size(), block * 2));
+            const size_t left = fill - line_start;
+            memcpy(next->own.data(), cur->own.data() + line_start, left);
+            cur->n = batch;
+            cur->base = cur->own.data();
+            out->push(cur);
+            cur = next;
+            fill = left;
+            scan = 0;
+            line_start = 0;
+            continue;
+        }
+        if (eof) {
+            if (line_start < fill) add_line(line_start, fill + (size_t)space_num);       // last line without '\n'
+            if (cur->ls.size() % 4) die("truncated fastq record");
+            cur->n = (int)(cur->ls.size() / 4);
+            cur->base = cur->own.data();
+            if (cur->n) out->push(cur); else delete cur;
+            break;
+        }
+        if (fill + block > cur->own.size()) cur->own.resize(cur->own.size() * 2);
+        const int got = gzread(f, cur->own.data() + fill, (unsigned)block);
+        if (got < 0) die("read error in input fastq");
+        if (got == 0) eof = true;
+        fill += (size_t)got;
+        if (fill > 0xF0000000ull) die("batch larger than 4 GB: lower the batch size");
+    }
+    gzclose(f);
+    out->close();
+}
+
+// plain input: the file is mapped, chunks point into the mapping (no copy), and the newline index of a
+// window is built by `workers` threads in parallel
+void reader_plain(const string path, int batch, int space_num, int workers, Channel<RawChunk *> *out) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) die("cannot open file," + path);
+    struct stat st;
+    fstat(fd, &st);
+    const size_t size = (size_t)st.st_size;
+    const char *base = (const char *)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (base == MAP_FAILED) die("cannot map file," + path);
+    madvise((void *)base, size, MADV_SEQUENTIAL);
+    const size_t want = (size_t)batch * 4;
+    size_t pos = 0;
+    double per_line = 100.0;
+    while (pos < size) {
+        std::vector<std::vector<uint32_t>> found;
+        size_t win_end = pos, total = 0;
+        // grow the window until it holds `want` line ends (or the file ends); only the extension is scanned
+        while (total < want && win_end < size) {
+            const size_t need = want - total;
+            size_t ext_end = std::min(size, win_end + (size_t)(per_line * 1.03 * (double)need) + 65536);
+            if (ext_end - pos > 0xF0000000ull) die("batch larger than 4 GB: lower the batch size");
+            const size_t a = win_end, len = ext_end - win_end;
+            const int k = (int)std::max<size_t>(1, std::min<size_t>((size_t)workers, len / (1 << 20)));
+            const size_t at = found.size();
+            found.resize(at + (size_t)k);
+            parallel_for(k, k, [&](int, int lo, int hi) {
+                for (int w = lo; w < hi; ++w) {
+                    const size_t s0 = a + len * (size_t)w / (size_t)k, s1 = a + len * (size_t)(w + 1) / (size_t)k;
+                    std::vector<uint32_t> &v = found[at + (size_t)w];
+                    v.reserve((size_t)((double)(s1 - s0) / per_line * 1.2) + 16);
+                    const char *p = base + s0, *e = base + s1;
+                    while (p < e && (p = (const char *)memchr(p, '\n', (size_t)(e - p)))) { v.push_back((uint32_t)(p - (base + pos))); ++p; }
+                }
+            });
+            for (size_t w = at; w < found.size(); ++w) total += found[w].size();
+            win_end = ext_end;
+            if (total) per_line = (double)(win_end - pos) / (double)total;
+        }
+        RawChunk *c = new RawChunk;
+        c->base = base + pos;
+        const size_t take = std::min(total, want);
+        c->ls.reserve(take + 1);
+        c->le.reserve(take + 1);
+        uint32_t start = 0;
+        size_t got = 0;
+        for (const auto &v : found) {
+            for (uint32_t nl : v) {
+                if (got == take) break;
+                const uint32_t e_incl = nl + 1;
+                c->ls.push_back(start);
+                c->le.push_back(e_incl > start + (uint32_t)space_num ? e_incl - (uint32_t)space_num : start);
+                start = e_incl;
+                ++got;
+            }
+            if (got == take) break;
+        }
+        size_t consumed = start;
+        if (total < want && pos + start < size) {        // end of file, last line without '\n'
+            c->ls.push_back(start);
+            c->le.push_back((uint32_t)(size - pos));
+            consumed = size - pos;
+        }
+        if (c->ls.size() % 4) die("truncated fastq record");
+        c->n = (int)(c->ls.size() / 4);
+        pos += consumed;
+        if (c->n) out->push(c); else { delete c; break; }
+    }
+    out->close();                                        // the mapping stays until exit: chunks point into it
+    close(fd);
+}
+
+bool is_gzip_file(const string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) die("cannot open file," + path);
+    unsigned char m[2] = {0, 0};
+    const size_t n = fread(m, 1, 2, f);
+    fclose(f);
+    return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
+}
+
+void reader_main(const string path, int batch, int space_num, int workers, Channel<RawChunk *> *out) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || st.st_size == 0) die("cannot open file or empty file," + path);
+    if (is_gzip_file(path)) reader_gz(path, batch, space_num, out);
+    else reader_plain(path, batch, space_num, workers, out);
+}
+
+int first_line_space_num(const string &path) {          // src/peprocess.cpp:2066-2077
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) die("cannot open file," + path);
+    char buf[1000];                                      // READBUF
+    int sp = 0;
+    if (gzgets(f, buf, sizeof buf) != NULL) {
+        int n = (int)strlen(buf);
+        while (n > 0 && isspace((unsigned char)buf[n - 1])) { ++sp; --n; }
+    }
+    gzclose(f);
+    return sp > 0 ? sp : 1;
+}
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) die(string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
-struct HostBatch {
-    int mates, pitch, cap;
-    uint8_t *seq[2] = {nullptr, nullptr}, *qual[2] = {nullptr, nullptr};
-    uint16_t *len[2] = {nullptr, nullptr};
-    std::vector<string> ids[2];
+// one gzip member (level 2 as src/peprocess.cpp:1809) of `in`, appended to `out`
+void gzip_member(const string &in, string &out) {
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, 2, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("deflateInit2 failed");
+    const size_t bound = deflateBound(&z, (uLong)in.size()) + 64;
+    const size_t at = out.size();
+    out.resize(at + bound);
+    z.next_in = (Bytef *)in.data();
+    z.avail_in = (uInt)in.size();
+    z.next_out = (Bytef *)&out[at];
+    z.avail_out = (uInt)bound;
+    if (deflate(&z, Z_FINISH) != Z_STREAM_END) die("deflate failed");
+    out.resize(at + (bound - z.avail_out));
+    deflateEnd(&z);
+}
+
+struct OutFile {                                        // clean / dup output: bytes are produced by the workers
+    FILE *fp = nullptr;
+    bool gz = false;
+    void open(const string &path, bool gzip) {
+        fp = fopen(path.c_str(), "wb");
+        if (!fp) die("cannot write to the file," + path);
+        gz = gzip;
+    }
+    void write_text(const string &text) {               // serial path (dup side files): compress here if needed
+        if (text.empty()) return;
+        if (!gz) { fwrite(text.data(), 1, text.size(), fp); return; }
+        string z;
+        gzip_member(text, z);
+        fwrite(z.data(), 1, z.size(), fp);
+    }
+    void close() {
+        if (!fp) return;
+        if (gz && ftell(fp) == 0) { string z; gzip_member(string(), z); fwrite(z.data(), 1, z.size(), fp); }   // valid empty .gz
+        fclose(fp);
+        fp = nullptr;
+    }
+};
+
+struct Slot {                                           // one batch in flight
+    uint8_t *h_seq[2] = {nullptr, nullptr}, *h_qual[2] = {nullptr, nullptr}, *d_seq[2] = {nullptr, nullptr}, *d_qual[2] = {nullptr, nullptr};
+    uint16_t *h_len[2] = {nullptr, nullptr}, *d_len[2] = {nullptr, nullptr};
+    snk_read_result *h_rec[2] = {nullptr, nullptr}, *d_rec[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    RawChunk *raw[2] = {nullptr, nullptr};
     int n = 0;
+    uint64_t first = 0;
 };
 
 }  // namespace
@@ -314,42 +518,40 @@ int main(int argc, char **argv) {
     std::ofstream log(o.log.c_str());
     if (!log) die("cannot open such file," + o.log);
     log << local_time() << "\tAnalysis start!" << endl;
-
-    Reader rd[2];
-    rd[0].open(o.fq1);
-    if (mates == 2) rd[1].open(o.fq2);
-    Writer wr[2];
-    wr[0].open(o.out_dir + "/" + o.clean1, o.out_gz);
-    if (mates == 2) wr[1].open(o.out_dir + "/" + o.clean2, o.out_gz);
-
-    // ---- first batch decides the capacity (longest read) and the pitch
-    const int B = o.batch_pairs;
-    struct Rec { string id, seq, qual; };
-    std::vector<Rec> first[2];
-    auto read_record = [&](int m, Rec &r) -> bool {
-        const char *s; int n;
-        if (!rd[m].line(s, n)) return false;
-        r.id.assign(s, n);
-        if (!rd[m].line(s, n)) die("truncated fastq record");
-        r.seq.assign(s, n);
-        if (!rd[m].line(s, n)) die("truncated fastq record");
-        if (!rd[m].line(s, n)) die("truncated fastq record");
-        r.qual.assign(s, n);
-        if (r.qual.size() != r.seq.size()) die("sequence and quality lengths differ," + r.id);
-        return true;
-    };
-    int maxlen = 1;
-    for (int i = 0; i < B; ++i) {
-        Rec a, b;
-        const bool ok1 = read_record(0, a);
-        const bool ok2 = mates == 2 ? read_record(1, b) : ok1;
-        if (ok1 != ok2) die("reads number in fq1 and fq2 are different");
-        if (!ok1) break;
-        maxlen = std::max<int>(maxlen, (int)a.seq.size());
-        first[0].push_back(std::move(a));
-        if (mates == 2) { maxlen = std::max<int>(maxlen, (int)b.seq.size()); first[1].push_back(std::move(b)); }
+    const int B = o.batch_pairs, T = o.threads, WK = std::max(1, o.threads);
+    const string inputs[2] = {o.fq1, o.fq2};
+    { struct stat st; for (int m = 0; m < mates; ++m) if (stat(inputs[m].c_str(), &st) != 0 || st.st_size == 0) die("cannot open file or empty file," + inputs[m]); }
+    const int space_num = first_line_space_num(o.fq1);
+    char bc_from = 0, bc_to = 0;                          // baseConvert "TtoU" / "T2U" / "TU" (src/peprocess.cpp:1629-1646)
+    if (!o.base_convert.empty()) {
+        string b = o.base_convert;
+        if (b.find("TO") != string::npos) b.replace(b.find("TO"), 2, "");
+        if (b.find("2") != string::npos) b.replace(b.find("2"), 1, "");
+        if (b.size() != 2) die("base_conver value format error");
+        bc_from = (char)toupper(b[0]);
+        bc_to = b[1];
     }
-    if (first[0].empty()) die("no data");
+
+    // ---- readers
+    Channel<RawChunk *> chan[2] = {Channel<RawChunk *>(2), Channel<RawChunk *>(2)};
+    std::vector<std::thread> readers;
+    auto start_readers = [&] { for (int m = 0; m < mates; ++m) readers.emplace_back(reader_main, inputs[m], B, space_num, std::max(1, WK / mates), &chan[m]); };
+    auto join_readers = [&] { for (auto &t : readers) t.join(); readers.clear(); };
+    auto next_chunks = [&](RawChunk *c[2]) -> bool {
+        bool ok[2] = {true, true};
+        c[0] = c[1] = nullptr;
+        for (int m = 0; m < mates; ++m) ok[m] = chan[m].pop(c[m]);
+        if (mates == 2 && (ok[0] != ok[1] || (ok[0] && c[0]->n != c[1]->n))) die("reads number in fq1 and fq2 are different");
+        return ok[0];
+    };
+
+    // ---- the first batch decides the capacity (longest read) and the pitch
+    start_readers();
+    RawChunk *first[2];
+    if (!next_chunks(first)) die("no data");
+    int maxlen = 1;
+    for (int m = 0; m < mates; ++m)
+        for (int i = 0; i < first[m]->n; ++i) { int l; first[m]->line(4 * i + 1, l); maxlen = std::max(maxlen, l); }
     if (maxlen > SNK_READ_MAX_LEN) die("read longer than 1000 bases");
     o.p.max_read_len = maxlen;
     const int pitch = (maxlen + 15) / 16 * 16;
@@ -360,7 +562,6 @@ int main(int argc, char **argv) {
     int32_t lcap, nq; int64_t nsum;
     snk_stats_geometry(ctx, &lcap, &nq, &nsum);
     // one accumulator per virtual reference thread
-    const int T = o.threads;
     const int64_t vblock = snk_vthread_block(T, o.patch_size);
     std::vector<uint64_t *> d_sum(T), d_max(T);
     for (int t = 0; t < T; ++t) {
@@ -369,68 +570,75 @@ int main(int argc, char **argv) {
         HIPCHK(hipMemset(d_sum[t], 0, nsum * sizeof(uint64_t)));
         HIPCHK(hipMemset(d_max[t], 0, SNK_MAX_N * sizeof(uint64_t)));
     }
-    // pinned SoA planes + device mirrors
-    uint8_t *h_seq[2], *h_qual[2], *d_seq[2], *d_qual[2];
-    uint16_t *h_len[2], *d_len[2];
-    snk_read_result *h_rec[2], *d_rec[2];
+    const int NSLOT = 3;
     const size_t plane = (size_t)B * pitch;
-    for (int m = 0; m < mates; ++m) {
-        HIPCHK(hipHostMalloc(&h_seq[m], plane)); HIPCHK(hipHostMalloc(&h_qual[m], plane));
-        HIPCHK(hipHostMalloc(&h_len[m], (size_t)B * 2)); HIPCHK(hipHostMalloc(&h_rec[m], (size_t)B * sizeof(snk_read_result)));
-        HIPCHK(hipMalloc(&d_seq[m], plane)); HIPCHK(hipMalloc(&d_qual[m], plane));
-        HIPCHK(hipMalloc(&d_len[m], (size_t)B * 2)); HIPCHK(hipMalloc(&d_rec[m], (size_t)B * sizeof(snk_read_result)));
-        memset(h_seq[m], 0, plane); memset(h_qual[m], 0, plane);
+    std::vector<Slot> slots(NSLOT);
+    for (Slot &s : slots) {
+        for (int m = 0; m < mates; ++m) {
+            HIPCHK(hipHostMalloc(&s.h_seq[m], plane)); HIPCHK(hipHostMalloc(&s.h_qual[m], plane));
+            HIPCHK(hipHostMalloc(&s.h_len[m], (size_t)B * 2)); HIPCHK(hipHostMalloc(&s.h_rec[m], (size_t)B * sizeof(snk_read_result)));
+            HIPCHK(hipMalloc(&s.d_seq[m], plane)); HIPCHK(hipMalloc(&s.d_qual[m], plane));
+            HIPCHK(hipMalloc(&s.d_len[m], (size_t)B * 2)); HIPCHK(hipMalloc(&s.d_rec[m], (size_t)B * sizeof(snk_read_result)));
+            memset(s.h_seq[m], 0, plane); memset(s.h_qual[m], 0, plane);
+        }
+        HIPCHK(hipStreamCreate(&s.stream));
+        HIPCHK(hipEventCreate(&s.done));
     }
+    // records -> pinned planes (parallel over records)
+    auto pack = [&](Slot &s, bool with_qual) {
+        const int n = s.n;
+        std::atomic<int> bad(0);
+        parallel_for(WK, n, [&](int, int lo, int hi) {
+            for (int m = 0; m < mates; ++m)
+                for (int i = lo; i < hi; ++i) {
+                    int ls, lq;
+                    const char *sq = s.raw[m]->line(4 * i + 1, ls), *ql = s.raw[m]->line(4 * i + 3, lq);
+                    if (ls > lcap) { bad = 1; continue; }
+                    if (lq != ls) { bad = 2; continue; }
+                    memcpy(s.h_seq[m] + (size_t)i * pitch, sq, ls);
+                    if (with_qual) memcpy(s.h_qual[m] + (size_t)i * pitch, ql, lq);
+                    s.h_len[m][i] = (uint16_t)ls;
+                }
+        });
+        if (bad == 1) die("read longer than the first batch's longest read (" + std::to_string(lcap) + ")");
+        if (bad == 2) die("sequence and quality lengths differ");
+    };
+
     // ---- rmdup pre-pass (src/peprocess.cpp:3071-3152): hash every raw pair on the GPU, keep the hashes
     // resident, mark every later occurrence; the flags enter the cascade as snk_batch.dup below.
     uint8_t *d_dup_all = nullptr;
-    Writer dupw[2][64];
+    std::vector<OutFile> dupw[2];
     if (o.p.rmdup) {
-        if (T > 64) die("rmdup: more than 64 threads");
-        Reader pr[2];
-        pr[0].open(o.fq1);
-        if (mates == 2) pr[1].open(o.fq2);
         std::vector<uint64_t *> chunks;
         std::vector<int> chunk_n;
         uint64_t nall = 0;
-        for (;;) {
-            int n = 0;
-            for (; n < B; ++n) {
-                bool ok[2] = {true, true};
-                for (int m = 0; m < mates; ++m) {
-                    const char *sq; int ln;
-                    if (!pr[m].line(sq, ln)) { ok[m] = false; continue; }          // id
-                    if (!pr[m].line(sq, ln)) die("truncated fastq record");
-                    if (ln > lcap) die("read longer than the first batch's longest read (" + std::to_string(lcap) + ")");
-                    memcpy(h_seq[m] + (size_t)n * pitch, sq, ln);
-                    h_len[m][n] = (uint16_t)ln;
-                    const char *t; int tn;
-                    if (!pr[m].line(t, tn) || !pr[m].line(t, tn)) die("truncated fastq record");
-                }
-                if (mates == 2 && ok[0] != ok[1]) die("reads number in fq1 and fq2 are different");
-                if (!ok[0]) break;
-            }
-            if (n == 0) break;
+        RawChunk *c[2] = {first[0], first[1]};
+        bool have = true;
+        Slot &s = slots[0];
+        while (have) {
+            s.n = c[0]->n;
+            s.raw[0] = c[0]; s.raw[1] = c[1];
+            pack(s, false);
             uint64_t *dh;
-            HIPCHK(hipMalloc(&dh, (size_t)n * sizeof(uint64_t)));
+            HIPCHK(hipMalloc(&dh, (size_t)s.n * sizeof(uint64_t)));
             snk_batch b;
             memset(&b, 0, sizeof b);
-            b.n = n;
+            b.n = s.n;
             b.pitch = pitch;
             for (int m = 0; m < mates; ++m) {
-                HIPCHK(hipMemcpyAsync(d_seq[m], h_seq[m], (size_t)n * pitch, hipMemcpyHostToDevice, 0));
-                HIPCHK(hipMemcpyAsync(d_len[m], h_len[m], (size_t)n * 2, hipMemcpyHostToDevice, 0));
-                b.seq[m] = d_seq[m];
-                b.qual[m] = d_qual[m];
-                b.len[m] = d_len[m];
+                HIPCHK(hipMemcpyAsync(s.d_seq[m], s.h_seq[m], (size_t)s.n * pitch, hipMemcpyHostToDevice, s.stream));
+                HIPCHK(hipMemcpyAsync(s.d_len[m], s.h_len[m], (size_t)s.n * 2, hipMemcpyHostToDevice, s.stream));
+                b.seq[m] = s.d_seq[m]; b.qual[m] = s.d_qual[m]; b.len[m] = s.d_len[m];
             }
-            if (snk_rmdup_hash_device(ctx, &b, dh, nullptr) != SNK_OK) die(snk_last_error());
-            HIPCHK(hipStreamSynchronize(0));                 // the pinned planes are refilled next
+            if (snk_rmdup_hash_device(ctx, &b, dh, s.stream) != SNK_OK) die(snk_last_error());
+            HIPCHK(hipStreamSynchronize(s.stream));        // the pinned planes are refilled next
             chunks.push_back(dh);
-            chunk_n.push_back(n);
-            nall += (uint64_t)n;
-            if (n < B) break;
+            chunk_n.push_back(s.n);
+            nall += (uint64_t)s.n;
+            for (int m = 0; m < mates; ++m) delete c[m];
+            have = next_chunks(c);
         }
+        join_readers();
         if (nall > 4294967295ull) die("reads number is too large to do remove duplication," + std::to_string(nall));
         uint64_t *d_hash_all;
         HIPCHK(hipMalloc(&d_hash_all, (size_t)nall * sizeof(uint64_t)));
@@ -441,7 +649,7 @@ int main(int argc, char **argv) {
             off += (uint64_t)chunk_n[k];
         }
         HIPCHK(hipStreamSynchronize(0));
-        for (uint64_t *c : chunks) HIPCHK(hipFree(c));
+        for (uint64_t *ch : chunks) HIPCHK(hipFree(ch));
         cout << "totalReadsNum:\t" << nall << endl;
         if (snk_rmdup_mark_device(ctx, d_hash_all, nullptr, (int64_t)nall, nall, -1, d_dup_all, nullptr) != SNK_OK) die(snk_last_error());
         HIPCHK(hipStreamSynchronize(0));
@@ -463,33 +671,110 @@ int main(int argc, char **argv) {
             for (uint64_t i = 0; i < full_end; ++i) eff[i] = i ? flags[i - 1] : 0;
             HIPCHK(hipMemcpy(d_dup_all, eff.data(), (size_t)nall, hipMemcpyHostToDevice));
         }
-        for (int t = 0; t < T; ++t)                            // dupReads.<thread>.<mate>.gz, src/peprocess.cpp:167-174
-            for (int m = 0; m < mates; ++m)                    // SE: only .1.gz (src/seprocess.cpp:89)
-                dupw[m][t].open(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz", true);
-        for (int m = 0; m < mates; ++m) { memset(h_seq[m], 0, plane); }
+        for (int m = 0; m < mates; ++m) {                   // dupReads.<thread>.<mate>.gz, src/peprocess.cpp:167-174 (SE: .1.gz only)
+            dupw[m].resize(T);
+            for (int t = 0; t < T; ++t) dupw[m][t].open(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz", true);
+        }
+        for (Slot &sl : slots) for (int m = 0; m < mates; ++m) memset(sl.h_seq[m], 0, plane);
+        // second pass over the input
+        chan[0].~Channel(); new (&chan[0]) Channel<RawChunk *>(2);
+        chan[1].~Channel(); new (&chan[1]) Channel<RawChunk *>(2);
+        start_readers();
+        if (!next_chunks(first)) die("no data");
     }
-    uint64_t ndup_written = 0;
-    std::vector<string> ids[2], raw_seq[2], raw_qual[2];
-    uint64_t total = 0;
+
+    // ---- main pass: pack+GPU stage (this thread) and write stage (its own thread), NSLOT batches in flight
+    OutFile wr[2];
+    wr[0].open(o.out_dir + "/" + o.clean1, o.out_gz);
+    if (mates == 2) wr[1].open(o.out_dir + "/" + o.clean2, o.out_gz);
+    Channel<Slot *> free_slots(NSLOT + 1), to_write(NSLOT + 1);
+    for (Slot &s : slots) free_slots.push(&s);
     const int dq = o.p.output_quality_phred - o.p.quality_phred;
-    bool more = true;
-    std::vector<Rec> cur[2];
-    cur[0].swap(first[0]);
-    cur[1].swap(first[1]);
-    while (!cur[0].empty()) {
-        const int n = (int)cur[0].size();
-        for (int m = 0; m < mates; ++m)
-            for (int i = 0; i < n; ++i) {
-                const Rec &r = cur[m][i];
-                if ((int)r.seq.size() > lcap) die("read longer than the first batch's longest read (" + std::to_string(lcap) + "): " + r.id);
-                memcpy(h_seq[m] + (size_t)i * pitch, r.seq.data(), r.seq.size());
-                memcpy(h_qual[m] + (size_t)i * pitch, r.qual.data(), r.qual.size());
-                h_len[m][i] = (uint16_t)r.seq.size();
+    const bool fasta = o.out_file_type == "fasta";
+    uint64_t ndup_written = 0;
+    std::thread writer([&] {
+        Slot *sp;
+        std::vector<string> text[2], zbuf[2];
+        while (to_write.pop(sp)) {
+            Slot &s = *sp;
+            HIPCHK(hipEventSynchronize(s.done));
+            const int n = s.n;
+            for (int m = 0; m < mates; ++m) { text[m].assign(WK, string()); zbuf[m].assign(WK, string()); }
+            // clean output, input order (src/peprocess.cpp:3383-3484): every worker formats (and deflates) a slice
+            parallel_for(WK, n, [&](int w, int lo, int hi) {
+                for (int m = 0; m < mates; ++m) {
+                    string &out = text[m][w];
+                    out.reserve((size_t)(hi - lo) * (size_t)(2 * lcap + 64));
+                    for (int i = lo; i < hi; ++i) {
+                        if (s.h_rec[0][i].reason != SNK_KEEP) continue;
+                        const snk_read_result &x = s.h_rec[m][i];
+                        int li, lsq, lql;
+                        const char *id = s.raw[m]->line(4 * i, li), *sq = s.raw[m]->line(4 * i + 1, lsq), *ql = s.raw[m]->line(4 * i + 3, lql);
+                        const size_t id_at = out.size();
+                        out.append(id, li);
+                        if (o.pe_info) out += (m == 0 ? "/1" : "/2");            // preOutput, src/peprocess.cpp:1617-1628
+                        if (fasta) {
+                            const size_t at = out.find('@', id_at);
+                            if (at != string::npos) out[at] = '>';
+                        }
+                        out += '\n';
+                        const size_t sq_at = out.size();
+                        out.append(sq + x.clean_start, x.clean_len);
+                        if (bc_from)
+                            for (size_t k = sq_at; k < out.size(); ++k) if (toupper((unsigned char)out[k]) == bc_from) out[k] = bc_to;
+                        if (fasta) { out += '\n'; continue; }
+                        out += "\n+\n";
+                        const size_t q_at = out.size();
+                        out.append(ql + x.clean_start, x.clean_len);
+                        if (dq) for (size_t k = q_at; k < out.size(); ++k) out[k] = (char)(out[k] + dq);
+                        out += '\n';
+                    }
+                    if (wr[m].gz && !out.empty()) gzip_member(out, zbuf[m][w]);
+                }
+            });
+            for (int m = 0; m < mates; ++m)
+                for (int w = 0; w < WK; ++w) {
+                    const string &bytes = wr[m].gz ? zbuf[m][w] : text[m][w];
+                    if (!bytes.empty()) fwrite(bytes.data(), 1, bytes.size(), wr[m].fp);
+                }
+            if (d_dup_all) {                                   // C_fastq::toString of the raw records, src/peprocess.cpp:1541
+                std::vector<string> acc[2];
+                for (int m = 0; m < mates; ++m) acc[m].assign(T, string());
+                for (int i = 0; i < n; ++i) {
+                    if (s.h_rec[0][i].reason != SNK_R_DUP) continue;
+                    const int vt = (int)(((s.first + (uint64_t)i) / (uint64_t)vblock) % (uint64_t)T);
+                    for (int m = 0; m < mates; ++m) {
+                        int li, lsq, lql;
+                        const char *id = s.raw[m]->line(4 * i, li), *sq = s.raw[m]->line(4 * i + 1, lsq), *ql = s.raw[m]->line(4 * i + 3, lql);
+                        string &out = acc[m][vt];
+                        out.append(id, li); out += '\n'; out.append(sq, lsq); out += "\n+\n"; out.append(ql, lql); out += '\n';
+                    }
+                    ++ndup_written;
+                }
+                for (int m = 0; m < mates; ++m) for (int t = 0; t < T; ++t) dupw[m][t].write_text(acc[m][t]);
             }
+            log << local_time() << " processed_reads:\t" << s.first + (uint64_t)n << endl;
+            for (int m = 0; m < mates; ++m) { delete s.raw[m]; s.raw[m] = nullptr; }
+            free_slots.push(sp);
+        }
+    });
+
+    uint64_t total = 0;
+    RawChunk *c[2] = {first[0], first[1]};
+    bool have = true;
+    while (have) {
+        Slot *sp;
+        free_slots.pop(sp);
+        Slot &s = *sp;
+        s.n = c[0]->n;
+        s.first = total;
+        s.raw[0] = c[0]; s.raw[1] = c[1];
+        pack(s, true);
+        const int n = s.n;
         for (int m = 0; m < mates; ++m) {
-            HIPCHK(hipMemcpyAsync(d_seq[m], h_seq[m], (size_t)n * pitch, hipMemcpyHostToDevice, 0));
-            HIPCHK(hipMemcpyAsync(d_qual[m], h_qual[m], (size_t)n * pitch, hipMemcpyHostToDevice, 0));
-            HIPCHK(hipMemcpyAsync(d_len[m], h_len[m], (size_t)n * 2, hipMemcpyHostToDevice, 0));
+            HIPCHK(hipMemcpyAsync(s.d_seq[m], s.h_seq[m], (size_t)n * pitch, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(hipMemcpyAsync(s.d_qual[m], s.h_qual[m], (size_t)n * pitch, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(hipMemcpyAsync(s.d_len[m], s.h_len[m], (size_t)n * 2, hipMemcpyHostToDevice, s.stream));
         }
         // split at virtual-thread block boundaries so every segment lands in its thread's accumulator
         for (int lo = 0; lo < n;) {
@@ -502,75 +787,33 @@ int main(int argc, char **argv) {
             b.n = hi - lo;
             b.pitch = pitch;
             for (int m = 0; m < mates; ++m) {
-                b.seq[m] = d_seq[m] + (size_t)lo * pitch;
-                b.qual[m] = d_qual[m] + (size_t)lo * pitch;
-                b.len[m] = d_len[m] + lo;
+                b.seq[m] = s.d_seq[m] + (size_t)lo * pitch;
+                b.qual[m] = s.d_qual[m] + (size_t)lo * pitch;
+                b.len[m] = s.d_len[m] + lo;
             }
             b.first_index = g;
             if (d_dup_all) b.dup = d_dup_all + g;
             if (snk_bind_stats(ctx, d_sum[vt], d_max[vt]) != SNK_OK) die(snk_last_error());
-            if (snk_filter_batch_device(ctx, &b, d_rec[0] + lo, mates == 2 ? d_rec[1] + lo : nullptr, nullptr, 0) != SNK_OK)
+            if (snk_filter_batch_device(ctx, &b, s.d_rec[0] + lo, mates == 2 ? s.d_rec[1] + lo : nullptr, s.stream, 0) != SNK_OK)
                 die(snk_last_error());
             lo = hi;
         }
         for (int m = 0; m < mates; ++m)
-            HIPCHK(hipMemcpyAsync(h_rec[m], d_rec[m], (size_t)n * sizeof(snk_read_result), hipMemcpyDeviceToHost, 0));
-        HIPCHK(hipStreamSynchronize(0));
-        // clean output, input order (src/peprocess.cpp:3383-3484)
-        for (int i = 0; i < n; ++i) {
-            if (d_dup_all && h_rec[0][i].reason == SNK_R_DUP) {          // C_fastq::toString of the raw records, :1541
-                const int vt = (int)(((total + (uint64_t)i) / (uint64_t)vblock) % (uint64_t)T);
-                for (int m = 0; m < mates; ++m) {
-                    const Rec &r = cur[m][i];
-                    string &out = dupw[m][vt].acc;
-                    out += r.id; out += '\n'; out += r.seq; out += "\n+\n"; out += r.qual; out += '\n';
-                    if (out.size() > (1u << 22)) dupw[m][vt].flush();
-                }
-                ++ndup_written;
-            }
-            if (h_rec[0][i].reason != SNK_KEEP) continue;
-            for (int m = 0; m < mates; ++m) {
-                const Rec &r = cur[m][i];
-                const snk_read_result &x = h_rec[m][i];
-                string &out = wr[m].acc;
-                if (o.out_file_type == "fasta") {
-                    string id = r.id;
-                    const size_t at = id.find("@");
-                    if (at != string::npos) id.replace(at, 1, ">");
-                    out += id; out += '\n';
-                    out.append(r.seq, x.clean_start, x.clean_len); out += '\n';
-                } else {
-                    out += r.id; out += '\n';
-                    out.append(r.seq, x.clean_start, x.clean_len);
-                    out += "\n+\n";
-                    if (dq == 0) out.append(r.qual, x.clean_start, x.clean_len);
-                    else for (int k = 0; k < x.clean_len; ++k) out += (char)(r.qual[x.clean_start + k] + dq);
-                    out += '\n';
-                }
-                if (out.size() > (1u << 24)) wr[m].flush();
-            }
-        }
+            HIPCHK(hipMemcpyAsync(s.h_rec[m], s.d_rec[m], (size_t)n * sizeof(snk_read_result), hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(hipEventRecord(s.done, s.stream));
+        to_write.push(sp);
         total += (uint64_t)n;
-        log << local_time() << " processed_reads:\t" << total << endl;
-        // next batch
-        for (int m = 0; m < 2; ++m) cur[m].clear();
-        if (more) {
-            for (int i = 0; i < B; ++i) {
-                Rec a, b;
-                const bool ok1 = read_record(0, a);
-                const bool ok2 = mates == 2 ? read_record(1, b) : ok1;
-                if (ok1 != ok2) die("reads number in fq1 and fq2 are different");
-                if (!ok1) { more = false; break; }
-                cur[0].push_back(std::move(a));
-                if (mates == 2) cur[1].push_back(std::move(b));
-            }
-        }
+        have = next_chunks(c);
     }
+    to_write.close();
+    writer.join();
+    join_readers();
     for (int m = 0; m < mates; ++m) wr[m].close();
     if (d_dup_all) {
-        for (int t = 0; t < T; ++t) for (int m = 0; m < mates; ++m) dupw[m][t].close();
+        for (int m = 0; m < mates; ++m) for (int t = 0; t < T; ++t) dupw[m][t].close();
         log << "dup number:\t" << ndup_written << endl;
     }
+    HIPCHK(hipDeviceSynchronize());
 
     // ---- stats: finalize each virtual thread's block, fetch, check errors, write the reports
     std::vector<std::vector<uint64_t>> sums(T, std::vector<uint64_t>(nsum)), maxs(T, std::vector<uint64_t>(SNK_MAX_N));
