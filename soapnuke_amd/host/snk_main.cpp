@@ -146,7 +146,7 @@ void read_config(Options &o, const char *path) {             // src/process_argv
         else if (key == "seqType") { /* only affects tile/index parsing, not on this path */ }
         else if (key == "rmdup") p.rmdup = 1;
         else if (key == "pe_info") o.pe_info = true;
-        else if (key == "baseConvert") o.base_convert = val;
+        else if (key == "baseConvert") die("parameter baseConvert is not supported by the GPU filter path yet (the reference converts before its clean statistics)");
         else die("parameter " + key + " is not supported by the GPU filter path yet");
     }
 }

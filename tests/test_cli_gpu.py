@@ -7,6 +7,7 @@ import gzip
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import report_util as R
@@ -87,6 +88,38 @@ def test_cli_rmdup_matches_reference_binary(paired, n, tmp_path):
             ndup += a.count(b"\n") // 4
     assert ndup == 2520 * (2 if paired else 1)
     assert b"dup number:\t2520" in open(os.path.join(ours, "log"), "rb").read()
+
+
+def test_cli_pe_info_outqual_and_crlf(tmp_path):
+    """config keys pe_info + outQualSys (output-side transforms) and CRLF input (the first-line white-space rule)."""
+    n, L = 3000, 100
+    d = synth.make_batch(n, L, paired=True, seed=71)
+    d["qual"][0][:] = np.minimum(d["qual"][0], 33 + 30)            # stay printable after +31
+    d["qual"][1][:] = np.minimum(d["qual"][1], 33 + 30)
+    case = ("peinfo", True, L, n, 2, 300, {}, {}, ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J"], ["pe_info", "outQualSys=1"])
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ours = _run_ours(case, work, gz=False)
+    for f in R.REPORT_FILES_PE:
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in ("c1.fq", "c2.fq"):
+        a = _cat(os.path.join(ours, c))
+        assert a == _cat(os.path.join(ref, c)), c
+        assert b"/1/1" in a or b"/2/2" in a                        # ids already end in /1 /2: pe_info appends again
+    # the same reads with CRLF line ends: both tools strip 2 characters per line
+    for m in (1, 2):
+        txt = open(os.path.join(work, f"r{m}.fq"), "rb").read().replace(b"\n", b"\r\n")
+        open(os.path.join(work, f"r{m}.fq"), "wb").write(txt)
+        subprocess.check_call(["gzip", "-1", "-f", "-k", os.path.join(work, f"r{m}.fq")])
+    cmd_tail = ["-C", "c1.fq", "-D", "c2.fq", "-T", "2", "-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-c", os.path.join(work, "cfg")]
+    r = subprocess.run([T.REF_BIN, "filter", "-1", os.path.join(work, "r1.fq.gz"), "-2", os.path.join(work, "r2.fq.gz"), "-o", os.path.join(work, "ref2")] + cmd_tail, capture_output=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    r = subprocess.run([CLI, "filter", "-1", os.path.join(work, "r1.fq"), "-2", os.path.join(work, "r2.fq"), "-o", os.path.join(work, "ours2")] + cmd_tail, capture_output=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    for c in ("c1.fq", "c2.fq"):
+        assert _cat(os.path.join(work, "ours2", c)) == _cat(os.path.join(work, "ref2", c)), c
+    for f in R.REPORT_FILES_PE:
+        assert filecmp.cmp(os.path.join(work, "ours2", f), os.path.join(work, "ref2", f), shallow=False), f
 
 
 def test_cli_error_surface(tmp_path):
