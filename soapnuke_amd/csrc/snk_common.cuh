@@ -140,12 +140,15 @@ __device__ __forceinline__ int reason_family(int reason) {
     }
 }
 
-__device__ __forceinline__ void ts_inc(u64 *ts, long idx) {
-    if (idx >= 0 && idx < SNK_TS_N) atomicAdd(&ts[idx], 1ull);   // outside the struct the reference is UB
+// CT = u64 (the stats block itself) or u32 (the tiled kernel's per-workgroup copy)
+template <class CT>
+__device__ __forceinline__ void ts_inc(CT *ts, long idx) {
+    if (idx >= 0 && idx < SNK_TS_N) atomicAdd(&ts[idx], (CT)1);   // outside the struct the reference is UB
 }
 
 // src/peprocess.cpp:1107-1143 (fq1) / :1325-1360 (fq2) / src/seprocess.cpp:647-682
-__device__ inline void ts_update(u64 *ts, int hd_h, int lq_h, int hd_t, int lq_t, int ada, long base_len,
+template <class CT>
+__device__ inline void ts_update(CT *ts, int hd_h, int lq_h, int hd_t, int lq_t, int ada, long base_len,
                                  bool se) {
     if (hd_h > 0 || lq_h > 0) {
         if (hd_h >= lq_h) ts_inc(ts, SNK_TS_HT + hd_h); else ts_inc(ts, SNK_TS_HLQ + lq_h);

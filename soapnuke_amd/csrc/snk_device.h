@@ -81,6 +81,8 @@ struct DevStats {
     unsigned long long *sum;   // snk_stats_u64(lcap,nq)
     unsigned long long *maxb;  // SNK_MAX_N
     unsigned long long *err;   // 1 word: min over offending reads of (index<<8 | mate<<4 | code)
+    unsigned *tsw;             // tiled kernel: one private uint32 copy of the 4 x SNK_TS_N trimming-position
+                               // counters per workgroup (n_cu of them), drained into `sum` at the end of a launch
 };
 
 #define SNK_ERR_NONE 0xFFFFFFFFFFFFFFFFull

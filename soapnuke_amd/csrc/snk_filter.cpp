@@ -117,6 +117,13 @@ struct snk_ctx {
     DevAdapter *d_ada = nullptr;
     int32_t *d_tables = nullptr;
     unsigned long long *d_sum = nullptr, *d_max = nullptr, *d_err = nullptr;
+    // per-workgroup trimming-position counters of the tiled kernel (DevStats::tsw): 8 copies, one per
+    // stream that launches through this context (launches of one stream are ordered, so they can share a
+    // copy; concurrent launches of different streams may be bound to different stats blocks and must not)
+    unsigned *d_tsw = nullptr;
+    void *ts_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ts_used[8] = {false, false, false, false, false, false, false, false};
+    unsigned ts_next = 0;
     bool own_stats = false;
     // staging for the host-pointer entry point
     uint8_t *st_buf = nullptr;
@@ -255,6 +262,9 @@ static int build_ctx(snk_ctx *c) {
     HIP_OK(hipMemset(c->d_sum, 0, c->sum_u64 * sizeof(uint64_t)));
     HIP_OK(hipMemset(c->d_max, 0, SNK_MAX_N * sizeof(uint64_t)));
     HIP_OK(hipMemset(c->d_err, 0xFF, sizeof(uint64_t)));
+    HIP_OK(hipMalloc(&c->d_tsw, (size_t)8 * c->n_cu * 4 * SNK_TS_N * sizeof(unsigned)));
+    HIP_OK(hipMemset(c->d_tsw, 0, (size_t)8 * c->n_cu * 4 * SNK_TS_N * sizeof(unsigned)));
+
     return SNK_OK;
 }
 
@@ -313,6 +323,8 @@ void snk_destroy(snk_ctx *c) {
         if (c->d_max) (void)hipFree(c->d_max);
     }
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_tsw) (void)hipFree(c->d_tsw);
+
     if (c->st_buf) (void)hipFree(c->st_buf);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : c->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -398,7 +410,7 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
     D.first_index = b->first_index;
     D.out[0] = d_out1;
     D.out[1] = d_out2;
-    DevStats st{c->d_sum, c->d_max, c->d_err};
+    DevStats st{c->d_sum, c->d_max, c->d_err, c->d_tsw};
     hipStream_t s = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (c->timing) {
@@ -408,6 +420,16 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
     }
     int done = 0;
     if (kernel == 0 || kernel == 2) {
+        int slot = -1;
+        for (int k = 0; k < 8 && slot < 0; ++k) if (c->ts_used[k] && c->ts_stream[k] == stream) slot = k;
+        for (int k = 0; k < 8 && slot < 0; ++k) if (!c->ts_used[k]) slot = k;
+        if (slot < 0) {                                   // a ninth stream: take over a copy once its owner is idle
+            slot = (int)(c->ts_next++ & 7u);
+            HIP_OK(hipStreamSynchronize((hipStream_t)c->ts_stream[slot]));
+        }
+        c->ts_used[slot] = true;
+        c->ts_stream[slot] = stream;
+        st.tsw = c->d_tsw + (size_t)slot * c->n_cu * 4 * SNK_TS_N;
         done = snk_launch_tiled(c->hp, c->ta, D, st, c->lcap, c->nq, c->n_cu, stream);
         if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return SNK_E_UNSUPPORTED; }
     }
@@ -471,7 +493,7 @@ int snk_filter_batch(snk_ctx *c, const snk_batch *b, snk_read_result *out1, snk_
 
 int snk_stats_finalize(snk_ctx *c, void *stream) {
     if (!c) return SNK_E_PARAM;
-    DevStats st{c->d_sum, c->d_max, c->d_err};
+    DevStats st{c->d_sum, c->d_max, c->d_err, c->d_tsw};
     snk_launch_finalize(st, c->lcap, c->nq, stream);
     HIP_OK(hipGetLastError());
     return SNK_OK;

@@ -85,9 +85,15 @@ template <int V> struct IntC { static constexpr int v = V; };
 template <int... I, class F>
 __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F &&f) { (f(IntC<I>{}), ...); }
 
+// sum over the 64 lanes, uniform result: DPP row scan + two row broadcasts (6 VALU, no LDS round trips)
 __device__ __forceinline__ int wave_sum(int v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);    // row_shr:8  -> lane 15 of a row = row total
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);    // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);    // row_bcast:31 into rows 2 and 3
+    return rl(v, 63);
 }
 
 // Exact outcome of one alignment of the reference's scan (src/read_filter.cpp:726-741 and
@@ -446,8 +452,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 else nlow += __popcll(__ballot(q <= lowQ) & lowmask64(len_r - 64 * s));
                 if (FULL) {
                     if (P.polyX_num != -1) {
-                        u32 pc = __shfl_up(c, 1);
-                        if (lane == 0) pc = prev_last;
+                        // character of the previous position: wave_shr:1, lane 0 keeps `old` = last of the previous strip
+                        const u32 pc = (u32)__builtin_amdgcn_update_dpp((int)prev_last, (int)c, 0x138, 0xF, 0xF, false);
                         prev_last = (u32)rl((int)c, 63);
                         SNK_PUT(EQ, __ballot(c == pc))
                     }
@@ -726,10 +732,14 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         asm volatile("" : "+v"(lane));
         const ReadState R = m ? r1 : r0;
         u64 *fraw = st.sum + SNK_FS_N + m * fb, *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
-        if (live && P.copy_back)
-            ts_update(fraw + ts_off, R.hd_h, R.lq_h, R.hd_t, R.lq_t, R.adacut, (pe && m == 1) ? R.len : 0, !pe);
-        if (kept)
-            ts_update(fcl + ts_off, R.hd_h, R.lq_h, R.hd_t, R.lq_t, R.adacut, (pe && m == 1) ? R.clen : R.len, !pe);
+        // trimming-position counters: a few dozen hot addresses -> the workgroup's private uint32 copy
+        // (chip-wide atomics on them cost 4 ms per 10 M pairs with trimBadTail on); drained at the end
+        u32 *wts = st.tsw + (size_t)blockIdx.x * (4 * SNK_TS_N);
+        if (__any(live && (max(max(R.hd_h, R.lq_h), max(R.hd_t, R.lq_t)) > 0 || R.adacut >= 0)) && lane == 0) misc[68] = 1u;   // something to drain (the fields default to -1)
+        if (SNK_ABL != 5 && live && P.copy_back)
+            ts_update(wts + m * SNK_TS_N, R.hd_h, R.lq_h, R.hd_t, R.lq_t, R.adacut, (pe && m == 1) ? R.len : 0, !pe);
+        if (SNK_ABL != 5 && kept)
+            ts_update(wts + (2 + m) * SNK_TS_N, R.hd_h, R.lq_h, R.hd_t, R.lq_t, R.adacut, (pe && m == 1) ? R.clen : R.len, !pe);
         if (liveM) {
             const int last = 63 - __clzll((long long)liveM);
             const int ll = rl(R.len, last);
@@ -930,6 +940,29 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
                 }
             }
             flush_lo = it + 1;
+        }
+    }
+    // drain this workgroup's trimming-position counters into the bound stats block (only if a tile
+    // touched them; indices live within lcap+1 of the five array boundaries, src/peprocess.cpp:1124-1140).
+    // Its own global atomics above must have landed: L2 is the point of coherence for both, the barrier
+    // orders the workgroup.
+    __threadfence();
+    __syncthreads();
+    if (lds[4 * G.SET + 64 + 68]) {
+        u32 *wts = st.tsw + (size_t)blockIdx.x * (4 * SNK_TS_N);
+        const long ts_off = SNK_GS_N + (long)G.lcap * 5 + (long)G.lcap * G.nq;
+        // every index is (array boundary c*1000) + v with |v| <= the longest read / trim setting + 1
+        int hw = max(max(max(P.hard[0], P.hard[1]), max(P.hard[2], P.hard[3])), max(P.lq_head_len, P.lq_tail_len));
+        hw = min(500, max(hw, G.lcap) + 2);                   // 500: the windows tile the whole block
+        const int win = 2 * hw;
+        for (int j = threadIdx.x; j < 4 * 6 * win; j += blockDim.x) {
+            const int f = j / (6 * win), r = j - f * 6 * win, c = r / win, k = c * 1000 + (r - c * win) - hw;
+            if (k < 0 || k >= SNK_TS_N) continue;
+            const int i = f * SNK_TS_N + k;
+            if (__hip_atomic_load(&wts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                const u32 v = atomicExch(&wts[i], 0u);
+                if (v) atomicAdd(&st.sum[SNK_FS_N + f * fb + ts_off + k], (u64)v);
+            }
         }
     }
 }
