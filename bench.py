@@ -132,6 +132,11 @@ def main():
 
     def step():
         ctx.filter_batch(batch, rec, kernel=args.kernel)
+
+    def merge():
+        # the path's one collective: the reference merges its per-thread statistics once per
+        # run (merge_stat, src/peprocess.cpp:1994); here one sum + one max all-reduce over RCCL, inside the
+        # timed region
         if world > 1:
             ctx.allreduce()
 
@@ -142,6 +147,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    merge()
     barrier()
     ctx.last_kernel_ms()
     ctx.clear()
@@ -149,8 +155,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if world == 1:
-            pass
+    merge()
     barrier()
     elapsed = time.perf_counter() - t0
     # average launch duration over the K timed steps: one hipEvent pair per launch, recorded on
