@@ -197,7 +197,7 @@ def main():
                        "pairs_per_gpu_per_step": n, "read_len": L, "Mpairs_per_s": round(value / 2, 3),
                        "kernel": {0: "auto", 1: "generic", 2: "tiled"}[args.kernel],
                        "parallelism": f"shard{world}" if world > 1 else "single",
-                       "clean_pairs_per_step_per_gpu": kept // args.steps},
+                       "clean_pairs_per_step_per_gpu": kept // (args.steps * world)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel_ms": round(k_ms, 4), "bytes_per_launch": BYTES_PER_PAIR * n, **extra},
