@@ -1,5 +1,5 @@
 // snk_device.h -- structures shared by the host side of the C ABI (snk_filter.cpp)
-// and the gfx950 kernels (snk_kernels.hip).  Internal; the public surface is
+// and the gfx950 kernels (snk_generic.hip, snk_tiled.hip, snk_rmdup.hip).  Internal; the public surface is
 // include/snk_filter.h.
 #pragma once
 #include <stdint.h>

@@ -2,12 +2,13 @@
 //
 // One wavefront owns a tile of 64 read pairs and walks it in three phases:
 //
-//  phase 1  lane = read POSITION.  For each of the tile's reads the wave loads the
-//           base and quality bytes with coalesced 64-byte strips, turns the per-base
-//           predicates (==A/C/G/T/N, Q<=lowQual, ...) into 64-bit ballots on the scalar
-//           unit, adds the raw per-position histograms into LDS (lane l owns positions
-//           l, l+64, ... so the adds of one instruction never collide), and *transposes*
-//           the ballots into the lane that owns the read with v_writelane.
+//  phase 1  lane = read POSITION.  The tile's read bytes arrive in LDS by DMA
+//           (global_load_lds, 16 B/lane, next chunk in flight); per read the wave reads
+//           its 64-position strips one read ahead, turns the per-base predicates
+//           (==A/C/G/T, Q<=lowQual, ...) into 64-bit ballots, adds the raw per-position
+//           histograms into LDS (lane l owns positions l, l+64, ... so the adds of one
+//           instruction never collide), and *transposes* the ballots into the lane that
+//           owns the read with v_writelane.  LDS reads / adds / waits are hand-placed asm.
 //  phase 2  lane = READ.  Each lane now holds its read as bit planes (one bit per
 //           position).  Adapter search (src/read_filter.cpp:707-790) runs bit-sliced over
 //           all candidate offsets at once: for the first S-1 adapter characters (S =
@@ -25,8 +26,9 @@
 // LDS holds, per mate, raw and removed {base[pos][5], qual[pos][nq]} histograms as 16-bit
 // counters packed two per dword (strips 2k and 2k+1 share dwords, so one strip never
 // hits a dword twice); the workgroup flushes them to the global uint64 block before a
-// counter can overflow.  Everything is integer/byte work: no MFMA, bound by HBM in theory
-// and by VALU issue in practice.
+// counter can overflow; the few hot trimming-position counters live in a per-workgroup
+// uint32 copy in HBM.  Everything is integer/byte work: no MFMA, bound by HBM in theory
+// and by instruction issue in practice.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <utility>
@@ -267,8 +269,6 @@ __device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&
     }
 }
 
-struct Planes4 { };
-
 // Adapter search for the lanes with `todo`; returns the position or -1.
 // X[k] bit p = read[p] == "ACGT"[k] (exact), ones beyond the read; XN likewise for 'N'.
 template <int NW, bool FULL>
@@ -357,7 +357,7 @@ struct TileGeom {
     int lcap, nq, Lh, lg, WB, WQ, SET;   // Lh = 1 << lg dwords per histogram bin row
     // LDS staging of the read bytes (global_load_lds, 16 B/lane): per wave 2 buffers x
     // {bases, qualities} x cba bytes, a chunk = rb consecutive reads.  rb == 0: disabled.
-    int rb, nd, cba, stg_off, stg_wave;
+    int rb, cba, stg_off, stg_wave;
 };
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -988,9 +988,8 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
     const bool can_stage = (b.pitch % 16 == 0) && b.pitch <= 1024 &&
                            (((uintptr_t)b.seq[0] | (uintptr_t)b.qual[0] | (uintptr_t)b.seq[1] | (uintptr_t)b.qual[1]) % 16 == 0);
     int W = 16;
-    G.rb = 0; G.nd = 0; G.cba = 0; G.stg_off = (int)hist; G.stg_wave = 0;
+    G.rb = 0; G.cba = 0; G.stg_off = (int)hist; G.stg_wave = 0;
     if (can_stage) {
-        G.nd = 1;
         // bytes per array per buffer: one DMA of (cba/16) lanes x 16 B; the largest chunk that still
         // lets 16 waves share the CU's LDS with the histograms
         for (G.cba = 1024; G.cba >= 256; G.cba -= 256) {
@@ -1031,7 +1030,7 @@ int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch
     G.WQ = G.Lh * (nq + 1);          // bin nq collects out-of-range qualities
     G.SET = G.WB + G.WQ;
     if (((size_t)2 * 2 * G.SET + 64 + 80) * sizeof(u32) > 160 * 1024) return 0;
-    G.rb = G.nd = G.cba = G.stg_off = G.stg_wave = 0;
+    G.rb = G.cba = G.stg_off = G.stg_wave = 0;
     const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq;
     const int nw = (lcap + 31) / 32;        // dwords per bit plane
 #define SNK_GO(NW_)                                                                    \

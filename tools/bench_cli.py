@@ -23,6 +23,10 @@ for k in range((n + u - 1) // u):
         with open(f[m], "ab") as out, open(f[m] + ".part", "rb") as src:
             out.write(src.read())
         os.unlink(f[m] + ".part")
+gzin = len(sys.argv) > 4 and sys.argv[4] == "gz"     # python tools/bench_cli.py 4000000 16 "" gz
+if gzin:
+    for m in range(2):
+        subprocess.check_call(["gzip", "-1", "-k", f[m]])
 args = ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-l", "10", "-q", "0.1", "-T", str(T)]
 res = {}
 for name, exe in (("ours", os.path.join(ROOT, "soapnuke_amd", "SOAPnuke")), ("reference", os.path.join(ROOT, "oracle", "_ref", "SOAPnuke"))):
@@ -31,9 +35,10 @@ for name, exe in (("ours", os.path.join(ROOT, "soapnuke_amd", "SOAPnuke")), ("re
     for out_ext in (".fq", ".fq.gz"):
         o = os.path.join(tmp, name + out_ext.replace(".", "_"))
         t0 = time.time()
-        r = subprocess.run([exe, "filter", "-1", f[0], "-2", f[1], "-C", "c1" + out_ext, "-D", "c2" + out_ext, "-o", o] + args,
+        inp = [x + ".gz" for x in f] if gzin else f
+        r = subprocess.run([exe, "filter", "-1", inp[0], "-2", inp[1], "-C", "c1" + out_ext, "-D", "c2" + out_ext, "-o", o] + args,
                            capture_output=True)
         w = time.time() - t0
-        print(f"{name:10s} plain -> {out_ext:7s} {n} pairs  wall {w:6.2f} s  {2 * n / w / 1e6:7.3f} Mreads/s  rc {r.returncode}", flush=True)
+        print(f"{name:10s} {'gz   ' if gzin else 'plain'} -> {out_ext:7s} {n} pairs  wall {w:6.2f} s  {2 * n / w / 1e6:7.3f} Mreads/s  rc {r.returncode}", flush=True)
         subprocess.call(["rm", "-rf", o])
 subprocess.call(["rm", "-rf", tmp])
