@@ -38,6 +38,12 @@ class FilterContext:
         self._check(self.lib.snk_bind_stats(self.ctx, self.sum.data_ptr(), self.max.data_ptr()))
         self.clear()
 
+    def bind(self, sum_t, max_t):
+        """Accumulate the following launches into other (zeroed, same-shape int64 cuda) tensors -- e.g. one
+        block per virtual reference thread (snk_bind_stats)."""
+        self.sum, self.max = sum_t, max_t
+        self._check(self.lib.snk_bind_stats(self.ctx, sum_t.data_ptr(), max_t.data_ptr()))
+
     def _check(self, rc):
         if rc != 0:
             raise FilterError(f"snk error {rc}: {self.lib.snk_last_error().decode()}")

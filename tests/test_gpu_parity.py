@@ -202,3 +202,37 @@ def test_full_size_properties():
     o = T.run_oracle(p, sub)
     for m in range(2):
         assert np.array_equal(a["rec"][m][:20000], o["rec"][m])
+
+
+def test_many_streams_many_stats_blocks():
+    """Launches from 12 streams (more than the context's 8 per-stream copies of the trimming-position
+    counters) into 4 alternating stats blocks: every block must equal the oracle's for its own chunks."""
+    import torch
+    from soapnuke_amd.filter import FilterContext, records_to_numpy
+    n, chunks, nblk = 60000, 24, 4
+    d = synth.make_batch(n, 150, paired=True, var_len=True, seed=31)
+    p = abi.default_params(paired=True, max_read_len=150, **PE_CASES["C3_full"])
+    ctx = FilterContext(p, device=0)
+    dev = ctx.upload(d)
+    rec = ctx.alloc_records(n)
+    blocks = [(torch.zeros_like(ctx.sum), torch.zeros_like(ctx.max)) for _ in range(nblk)]
+    streams = [torch.cuda.Stream() for _ in range(12)]
+    torch.cuda.synchronize()
+    edges = np.linspace(0, n, chunks + 1).astype(int)
+    want = [T.new_stats(p) for _ in range(nblk)]
+    for k, (a, z) in enumerate(zip(edges[:-1], edges[1:])):
+        sub = {"n": int(z - a), "L": 150, "pitch": dev["pitch"], "seq": [x[a:z] for x in dev["seq"]],
+               "qual": [x[a:z] for x in dev["qual"]], "len": [x[a:z] for x in dev["len"]]}
+        ctx.bind(*blocks[k % nblk])
+        with torch.cuda.stream(streams[k % len(streams)]):
+            ctx.filter_batch(ctx.make_batch(sub, first_index=int(a)), [r[a:z] for r in rec])
+        hs = {"n": int(z - a), "L": 150, "pitch": d["pitch"], "paired": True, "seq": [x[a:z] for x in d["seq"]],
+              "qual": [x[a:z] for x in d["qual"]], "len": [x[a:z] for x in d["len"]]}
+        T.run_oracle(p, hs, first_index=int(a), stats=want[k % nblk])
+    torch.cuda.synchronize()
+    for k in range(nblk):
+        ctx.bind(*blocks[k])
+        s, mx, err = ctx.fetch()
+        assert err[0] == 0
+        assert np.array_equal(s, want[k][0]), (k, T.describe_stats_diff(p, s, want[k][0]))
+        assert np.array_equal(mx, want[k][1])
