@@ -695,11 +695,16 @@ int main(int argc, char **argv) {
     std::thread writer([&] {
         Slot *sp;
         std::vector<string> text[2], zbuf[2];
+        struct DupPiece { int vt; string z[2]; };            // one gzip member per (worker slice, virtual thread, mate)
+        std::vector<std::vector<DupPiece>> dpieces;
+        std::vector<uint64_t> dcount;
         while (to_write.pop(sp)) {
             Slot &s = *sp;
             HIPCHK(hipEventSynchronize(s.done));
             const int n = s.n;
             for (int m = 0; m < mates; ++m) { text[m].assign(WK, string()); zbuf[m].assign(WK, string()); }
+            dpieces.assign(WK, std::vector<DupPiece>());
+            dcount.assign(WK, 0);
             // clean output, input order (src/peprocess.cpp:3383-3484): every worker formats (and deflates) a slice
             parallel_for(WK, n, [&](int w, int lo, int hi) {
                 for (int m = 0; m < mates; ++m) {
@@ -731,28 +736,42 @@ int main(int argc, char **argv) {
                     }
                     if (wr[m].gz && !out.empty()) gzip_member(out, zbuf[m][w]);
                 }
+                if (d_dup_all) {                               // C_fastq::toString of the raw records, src/peprocess.cpp:1541
+                    string acc[2];
+                    int cur_vt = -1;
+                    auto flush_piece = [&] {
+                        if (cur_vt < 0 || acc[0].empty()) return;
+                        dpieces[w].emplace_back();
+                        DupPiece &pc = dpieces[w].back();
+                        pc.vt = cur_vt;
+                        for (int m = 0; m < mates; ++m) { gzip_member(acc[m], pc.z[m]); acc[m].clear(); }
+                    };
+                    for (int i = lo; i < hi; ++i) {
+                        if (s.h_rec[0][i].reason != SNK_R_DUP) continue;
+                        const int vt = (int)(((s.first + (uint64_t)i) / (uint64_t)vblock) % (uint64_t)T);
+                        if (vt != cur_vt) { flush_piece(); cur_vt = vt; }
+                        for (int m = 0; m < mates; ++m) {
+                            int li, lsq, lql;
+                            const char *id = s.raw[m]->line(4 * i, li), *sq = s.raw[m]->line(4 * i + 1, lsq), *ql = s.raw[m]->line(4 * i + 3, lql);
+                            string &out = acc[m];
+                            out.append(id, li); out += '\n'; out.append(sq, lsq); out += "\n+\n"; out.append(ql, lql); out += '\n';
+                        }
+                        ++dcount[w];
+                    }
+                    flush_piece();
+                }
             });
             for (int m = 0; m < mates; ++m)
                 for (int w = 0; w < WK; ++w) {
                     const string &bytes = wr[m].gz ? zbuf[m][w] : text[m][w];
                     if (!bytes.empty()) fwrite(bytes.data(), 1, bytes.size(), wr[m].fp);
                 }
-            if (d_dup_all) {                                   // C_fastq::toString of the raw records, src/peprocess.cpp:1541
-                std::vector<string> acc[2];
-                for (int m = 0; m < mates; ++m) acc[m].assign(T, string());
-                for (int i = 0; i < n; ++i) {
-                    if (s.h_rec[0][i].reason != SNK_R_DUP) continue;
-                    const int vt = (int)(((s.first + (uint64_t)i) / (uint64_t)vblock) % (uint64_t)T);
-                    for (int m = 0; m < mates; ++m) {
-                        int li, lsq, lql;
-                        const char *id = s.raw[m]->line(4 * i, li), *sq = s.raw[m]->line(4 * i + 1, lsq), *ql = s.raw[m]->line(4 * i + 3, lql);
-                        string &out = acc[m][vt];
-                        out.append(id, li); out += '\n'; out.append(sq, lsq); out += "\n+\n"; out.append(ql, lql); out += '\n';
-                    }
-                    ++ndup_written;
+            if (d_dup_all)
+                for (int w = 0; w < WK; ++w) {                 // worker order = input order within every side file
+                    for (const DupPiece &pc : dpieces[w])
+                        for (int m = 0; m < mates; ++m) fwrite(pc.z[m].data(), 1, pc.z[m].size(), dupw[m][pc.vt].fp);
+                    ndup_written += dcount[w];
                 }
-                for (int m = 0; m < mates; ++m) for (int t = 0; t < T; ++t) dupw[m][t].write_text(acc[m][t]);
-            }
             log << local_time() << " processed_reads:\t" << s.first + (uint64_t)n << endl;
             for (int m = 0; m < mates; ++m) { delete s.raw[m]; s.raw[m] = nullptr; }
             free_slots.push(sp);
