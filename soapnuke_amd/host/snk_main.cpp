@@ -53,7 +53,8 @@ struct Options {
     snk_params p;
     string trim, trim_bad_head, trim_bad_tail, out_file_type = "fastq";
     int threads = 6, patch_size = 0, batch_pairs = 1 << 18, device = 0;
-    bool in_gz = true, out_gz = true, pe_info = false;
+    bool in_gz = true, out_gz = true, pe_info = false, index_remove = false;
+    string seq_type = "0";
     string base_convert;
 };
 
@@ -143,7 +144,8 @@ void read_config(Options &o, const char *path) {             // src/process_argv
         else if (key == "trimBadHead") o.trim_bad_head = val;
         else if (key == "trimBadTail") o.trim_bad_tail = val;
         else if (key == "outFileType") o.out_file_type = val;
-        else if (key == "seqType") { /* only affects tile/index parsing, not on this path */ }
+        else if (key == "seqType") { o.seq_type = val; if (val != "0" && val != "1") die("seq_type value should be 0 or 1"); }
+        else if (key == "index") o.index_remove = true;
         else if (key == "rmdup") p.rmdup = 1;
         else if (key == "pe_info") o.pe_info = true;
         else if (key == "baseConvert") die("parameter baseConvert is not supported by the GPU filter path yet (the reference converts before its clean statistics)");
@@ -716,7 +718,19 @@ int main(int argc, char **argv) {
                         int li, lsq, lql;
                         const char *id = s.raw[m]->line(4 * i, li), *sq = s.raw[m]->line(4 * i + 1, lsq), *ql = s.raw[m]->line(4 * i + 3, lql);
                         const size_t id_at = out.size();
-                        out.append(id, li);
+                        if (!o.index_remove) out.append(id, li);
+                        else if (o.seq_type == "0") {                 // "@FC:4:1101:1799:2201#GAAGCACG/2": drop '#'..before '/' (src/read_filter.cpp:357-378)
+                            bool cp = true;
+                            for (int k = 0; k < li; ++k) {
+                                if (id[k] == '#') cp = false;
+                                if (cp) out += id[k];
+                                else if (id[k] == '/') { cp = true; out += id[k]; }
+                            }
+                        } else {                                       // new style: cut at the last ':' (:379-381)
+                            int cut = li;                                  // no ':' at all: substr(0, npos) keeps the whole id
+                            for (int k = li - 1; k >= 0; --k) if (id[k] == ':') { cut = k; break; }
+                            out.append(id, cut);
+                        }
                         if (o.pe_info) out += (m == 0 ? "/1" : "/2");            // preOutput, src/peprocess.cpp:1617-1628
                         if (fasta) {
                             const size_t at = out.find('@', id_at);

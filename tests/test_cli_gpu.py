@@ -122,6 +122,32 @@ def test_cli_pe_info_outqual_and_crlf(tmp_path):
         assert filecmp.cmp(os.path.join(work, "ours2", f), os.path.join(work, "ref2", f), shallow=False), f
 
 
+@pytest.mark.parametrize("seq_type", ["0", "1"])
+def test_cli_index_removal(seq_type, tmp_path):
+    """config keys index + seqType: the index is cut out of the read names of the clean output (src/read_filter.cpp:357-382)."""
+    n, L = 2000, 100
+    d = synth.make_batch(n, L, paired=True, seed=72)
+    work = str(tmp_path)
+    for m in (1, 2):
+        with open(os.path.join(work, f"r{m}.fq"), "wb") as f:
+            for i in range(n):
+                rid = (b"@FCD1PB1ACXX:4:1101:%d:2201#GAAGCACG/%d" % (i, m)) if seq_type == "0" else (b"@HISEQ:310:C5MH9ANXX:1:1101:%d:2043 %d:N:0:TCGGTCAC" % (i, m))
+                f.write(rid + b"\n" + d["seq"][m - 1][i, :L].tobytes() + b"\n+\n" + d["qual"][m - 1][i, :L].tobytes() + b"\n")
+        subprocess.check_call(["gzip", "-1", "-f", "-k", os.path.join(work, f"r{m}.fq")])
+    open(os.path.join(work, "cfg"), "w").write(f"index\nseqType={seq_type}\npatch=300\n")
+    tail = ["-C", "c1.fq", "-D", "c2.fq", "-T", "2", "-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-c", os.path.join(work, "cfg")]
+    r = subprocess.run([T.REF_BIN, "filter", "-1", os.path.join(work, "r1.fq.gz"), "-2", os.path.join(work, "r2.fq.gz"), "-o", os.path.join(work, "ref")] + tail, capture_output=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    r = subprocess.run([CLI, "filter", "-1", os.path.join(work, "r1.fq"), "-2", os.path.join(work, "r2.fq"), "-o", os.path.join(work, "ours")] + tail, capture_output=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    for c in ("c1.fq", "c2.fq"):
+        a = _cat(os.path.join(work, "ours", c))
+        assert a == _cat(os.path.join(work, "ref", c)), c
+        assert b"#GAAGCACG" not in a and b"N:0:TCGGTCAC" not in a
+    for f in R.REPORT_FILES_PE:
+        assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
+
+
 def test_cli_error_surface(tmp_path):
     r = subprocess.run([CLI, "filter", "-1", "/nonexistent.fq", "-C", "c.fq", "-o", str(tmp_path)], capture_output=True)
     assert r.returncode == 1 and r.stderr.startswith(b"Error:")
