@@ -236,3 +236,36 @@ def test_many_streams_many_stats_blocks():
         assert err[0] == 0
         assert np.array_equal(s, want[k][0]), (k, T.describe_stats_diff(p, s, want[k][0]))
         assert np.array_equal(mx, want[k][1])
+
+
+@pytest.mark.parametrize("name", ["C2_adatrim_lowq", "C3_full"])
+@pytest.mark.parametrize("pitch,var_len", [(152, False), (156, True), (152, True)])
+def test_pitch_not_multiple_of_16(name, pitch, var_len):
+    """pitch % 16 != 0 (and, through a row offset, planes that are not 16-byte aligned): the tiled kernel
+    takes its register path instead of the LDS-DMA staging."""
+    import torch
+    from soapnuke_amd.filter import FilterContext, records_to_numpy
+    d = synth.make_batch(30000, 150, paired=True, var_len=var_len, seed=41, pitch=pitch)
+    p = abi.default_params(paired=True, max_read_len=150, **PE_CASES[name])
+    for first in (0, 1):                                   # row offset 1: plane pointers are 8 (mod 16)
+        sub_h = {"n": d["n"] - first, "L": 150, "pitch": pitch, "paired": True, "seq": [x[first:] for x in d["seq"]],
+                 "qual": [x[first:] for x in d["qual"]], "len": [None if x is None else x[first:] for x in d["len"]]}
+        ctx = FilterContext(p, device=0)
+        dev = ctx.upload(d)
+        sub = {"n": d["n"] - first, "L": 150, "pitch": pitch, "seq": [x[first:] for x in dev["seq"]],
+               "qual": [x[first:] for x in dev["qual"]], "len": [None if x is None else x[first:] for x in dev["len"]]}
+        rec = ctx.alloc_records(sub["n"])
+        ctx.filter_batch(ctx.make_batch(sub), rec, kernel=2)
+        s, mx, err = ctx.fetch()
+        o = T.run_oracle(p, sub_h)
+        got = dict(rec=[records_to_numpy(r) for r in rec], sum=s, max=mx, err=err)
+        assert_same(p, got, o, True)
+
+
+@pytest.mark.parametrize("L", [51, 64, 65, 96, 97, 128, 129, 255, 256, 257, 1000])
+def test_capacity_boundaries(L):
+    """read-length capacities around the plane-word / strip / tiled-kernel limits (tiled up to 256, generic beyond)"""
+    n = 6000 if L <= 257 else 1500
+    d = synth.make_batch(n, L, paired=True, var_len=True, seed=50 + L)
+    p = abi.default_params(paired=True, max_read_len=L, **PE_CASES["C3_full"])
+    assert_same(p, run_hip_device(p, d, 0), T.run_oracle(p, d), True)
