@@ -149,3 +149,26 @@ def test_full_size_property_and_filter_integration():
     for k in range(2):
         assert np.array_equal(records_to_numpy(rec[k]), o["rec"][k])
     assert np.array_equal(s, o["sum"]), T.describe_stats_diff(p, s, o["sum"])
+
+
+def test_exchange_path_single_rank_nccl():
+    """The multi-GPU exchange (shard.rmdup_exchange_mark) with the real device kernels, world_size 1 over
+    RCCL: all-to-all to self, explicit global indices, flags back."""
+    import torch
+    import torch.distributed as dist
+    from soapnuke_amd.shard import rmdup_exchange_mark
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(12)
+        n = 200000
+        h = rng.integers(0, n // 3, n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        h[[5, 77777]] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        ctx = _ctx(True, 150)
+        ht = torch.from_numpy(h.view(np.int64)).cuda()
+        flags = rmdup_exchange_mark(ht, 0, n, lambda hh, ii, tot, sen: ctx.mark_dups(hh, ii, tot, sen),
+                                    lambda hh, tot: ctx.bucket_count(hh, tot))
+        assert np.array_equal(flags.cpu().numpy(), T.oracle_markdup(h))
+    finally:
+        dist.destroy_process_group()
