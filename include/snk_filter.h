@@ -68,6 +68,16 @@ typedef struct snk_params {
     const char *adapters[2][SNK_MAX_ADAPTERS]; /* NUL-terminated, compared as-is */
     int32_t rmdup;                /* gp.rmdup: honour snk_batch.dup */
     int32_t max_read_len;         /* capacity: longest read this context will see (<=1000) */
+    /* contaminant screening (config keys contam1/contam2, ctMatchR, global_contams,
+     * glob_cotm_mR, glob_cotm_mM).  Strings exactly as the reference holds them -- comma-separated
+     * lists -- NULL or "" = off.  Only the verdicts matter downstream: with contam_trim == 0 a hit
+     * discards the read/pair (src/sequence.cpp:116-127,264-290); the contam trimming itself is
+     * commented out in the reference (src/read_filter.cpp:443-452).  Matchers use gp.adaMis/adaEdge
+     * of mate 1 for both mates (src/read_filter.cpp:513,611). */
+    const char *contam[2];        /* gp.contam1_seq, gp.contam2_seq */
+    const char *ct_match_r;       /* gp.ctMatchR ("0.2"; a list when contam is a list) */
+    const char *global_contams;   /* gp.global_contams */
+    const char *g_mrs, *g_mms;    /* gp.g_mrs, gp.g_mms (one value per global contaminant) */
 } snk_params;
 
 /* fill with the reference defaults (src/global_parameter.h:20-83) */

@@ -60,6 +60,12 @@ static C_global_parameter make_gp(const snk_params *P) {
     gp.adaMis2 = P->ada_mis[1]; gp.adaMR2 = P->ada_mr[1]; gp.adaEdge2 = P->ada_edge[1];
     for (int i = 0; i < P->n_adapters[0]; i++) gp.ada1s.push_back(P->adapters[0][i]);
     for (int i = 0; i < P->n_adapters[1]; i++) gp.ada2s.push_back(P->adapters[1][i]);
+    if (P->contam[0]) gp.contam1_seq = P->contam[0];
+    if (P->contam[1]) gp.contam2_seq = P->contam[1];
+    if (P->ct_match_r && *P->ct_match_r) gp.ctMatchR = P->ct_match_r;
+    if (P->global_contams) gp.global_contams = P->global_contams;
+    if (P->g_mrs) gp.g_mrs = P->g_mrs;
+    if (P->g_mms) gp.g_mms = P->g_mms;
     gp.trim_fq1 = "t1"; gp.trim_fq2 = "t2";     /* keep every trimmed copy (trim_result) */
     gp.clean_fq1 = "c1"; gp.clean_fq2 = "c2";
     gp.rmdup = false;
@@ -263,5 +269,17 @@ void snkref_markdup(const uint64_t *hash, uint64_t n, uint8_t *dup) {
     delete r;
     for (uint64_t i = 0; i < n; ++i) dup[i] = flags[i] ? 1 : 0;
     delete[] flags;
+}
+
+/* hasContam(ref, contam, gp, mr) / global_contam_pos() of the reference, src/read_filter.cpp:507,961 */
+int snkref_has_contam(const char *read, int read_len, const char *contam, int contam_len, float mr, int ada_mis, int ada_edge) {
+    C_global_parameter gp;
+    gp.adaMis = ada_mis; gp.adaEdge = ada_edge;
+    std::string r(read, read_len), c(contam, contam_len);
+    return hasContam(r, c, gp, mr);
+}
+int snkref_global_contam_pos(const char *read, int read_len, const char *contam, int contam_len, float mr, int mm) {
+    std::string r(read, read_len), c(contam, contam_len);
+    return global_contam_pos(r, c, mr, mm);
 }
 } /* extern "C" */

@@ -10,6 +10,7 @@
  * tests/test_oracle_vs_ref.py and the golden vectors in tests/golden/.
  */
 #include "snk_oracle.h"
+#include <ctype.h>
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
@@ -124,6 +125,234 @@ int snk_oracle_polyG_number(const uint8_t *s, int len) {
     return n;
 }
 
+/* hasContam(), src/read_filter.cpp:507-603 / :604-700.  N in the READ never counts as a mismatch
+ * (it does not count as a match either: the run is not reset, :536-542).                       */
+int snk_oracle_has_contam(const uint8_t *ref, int readLen, const char *contam, int contamLen,
+                          int segMatchThr, int adaMis, int adaEdge) {
+    if (contamLen == 0) return -1;
+    const float misGrad = (float)((contamLen - adaEdge) / (adaMis + 1));      /* :513 int division */
+    float segGrad;
+    if (segMatchThr - 7 + 1 == 0) segGrad = 0;                                /* :517-521 */
+    else segGrad = (float)((contamLen - adaEdge) / (segMatchThr - 7 + 1));
+    int r1, mis, maxSegMatch, misMatchTemp, segMatchTemp;
+    for (r1 = 0; r1 < contamLen - adaEdge; ++r1) {                            /* :523-547 */
+        mis = 0;
+        maxSegMatch = 0;
+        misMatchTemp = f2i_x86((float)r1 / misGrad);
+        segMatchTemp = segGrad != 0 ? f2i_x86(7 + (float)r1 / segGrad) : 7;
+        for (int c = 0; c < r1 + adaEdge; ++c) {
+            const int rc = rd(ref, readLen, c);
+            if ((uint8_t)contam[contamLen - r1 - adaEdge + c] == rc) {
+                maxSegMatch++;
+                if (maxSegMatch >= segMatchTemp) return 0;
+            } else if (rc != 'N') {
+                mis++;
+                maxSegMatch = 0;
+                if (mis > misMatchTemp) break;
+            }
+        }
+        if (mis <= misMatchTemp) return 0;
+    }
+    for (r1 = 0; r1 <= readLen - contamLen; ++r1) {                           /* :549-573 */
+        maxSegMatch = 0;
+        mis = 0;
+        for (int c = 0; c < contamLen; ++c) {
+            const int rc = rd(ref, readLen, r1 + c);
+            if ((uint8_t)contam[c] == rc) {
+                maxSegMatch++;
+                if (maxSegMatch >= segMatchThr) return r1;
+            } else if (rc != 'N') {
+                mis++;
+                maxSegMatch = 0;
+                if (mis > adaMis) break;
+            }
+        }
+        if (mis <= adaMis) return r1;
+    }
+    for (r1 = 0; r1 < contamLen - adaEdge; ++r1) {                            /* :575-601: no segGrad guard here */
+        mis = 0;
+        maxSegMatch = 0;
+        misMatchTemp = f2i_x86((float)r1 / misGrad);
+        segMatchTemp = f2i_x86(7 + (float)r1 / segGrad);
+        for (int c = 0; c < r1 + adaEdge; ++c) {
+            const int rc = rd(ref, readLen, readLen - r1 - adaEdge + c);
+            if ((uint8_t)contam[c] == rc) {
+                maxSegMatch++;
+                if (maxSegMatch >= segMatchTemp) return readLen - r1 - adaEdge;
+            } else if (rc != 'N') {
+                mis++;
+                maxSegMatch = 0;
+                if (mis > misMatchTemp) break;
+            }
+        }
+        if (mis <= misMatchTemp) return readLen - r1 - adaEdge;
+    }
+    return -1;
+}
+
+/* global_contam_pos(), src/read_filter.cpp:961-1062.  total_score / overlap are carried from one
+ * alignment to the next inside each of the three sections, exactly as there.                    */
+int snk_oracle_global_contam_pos(const uint8_t *ref, int rl, const char *gc, int cl,
+                                 float min_matchRatio, int mismatch_number) {
+    const int mismatch_score = -200, match_score = 1;
+    const int total_mismatch_score = mismatch_number * mismatch_score;
+    const int min_match_len = (int)((float)cl * min_matchRatio);
+    const int lower_score = (min_match_len - mismatch_number) + total_mismatch_score;
+    int total_score = -1000, overlap = 0;
+    for (int i = cl - min_match_len; i >= 0; i--) {                           /* front, :973-999 */
+        const int j_max = cl - i > rl ? rl : cl - i;
+        for (int j = 0; j != j_max; j++) {
+            if (ref[j] == (uint8_t)gc[i + j]) {
+                if (total_score > total_mismatch_score) { total_score += match_score; overlap++; }
+                else {
+                    if (j_max - j < min_match_len) break;
+                    total_score = match_score;
+                    overlap = 1;
+                }
+            } else {
+                if (total_score > total_mismatch_score) { total_score += mismatch_score; overlap++; }
+                else if (j_max - j < min_match_len) break;
+            }
+            if (total_score >= lower_score && overlap >= min_match_len) return 0;
+        }
+    }
+    total_score = -1000;                                                      /* middle, :1001-1029 */
+    overlap = 0;
+    for (int i = 0; i <= rl - cl; i++) {
+        for (int j = 0; j != cl; j++) {
+            if (ref[i + j] == (uint8_t)gc[j]) {
+                if (total_score > total_mismatch_score) { total_score += match_score; overlap++; }
+                else {
+                    if (cl - j < min_match_len) break;
+                    total_score = match_score;
+                    overlap = 1;
+                }
+            } else {
+                if (total_score > total_mismatch_score) { total_score += mismatch_score; overlap++; }
+                else if (cl - j < min_match_len) break;
+            }
+            if (total_score >= lower_score && overlap >= min_match_len) return i + j - overlap + 1;
+        }
+    }
+    total_score = -1000;                                                      /* tail, :1031-1060 */
+    overlap = 0;
+    const int i_min = cl > rl ? cl - rl : 0;
+    for (int i = i_min; i <= cl - min_match_len; i++) {
+        for (int j = 0; j != cl - i; j++) {
+            if (ref[rl - (cl - i) + j] == (uint8_t)gc[j]) {
+                if (total_score > total_mismatch_score) { total_score += match_score; overlap++; }
+                else {
+                    total_score = match_score;
+                    overlap = 1;
+                    if (cl - i - j < min_match_len) break;
+                }
+            } else {
+                if (total_score > total_mismatch_score) { total_score += mismatch_score; overlap++; }
+                else if (cl - i - j < min_match_len) break;
+            }
+            if (total_score >= lower_score && overlap >= min_match_len) return rl - cl + i + j - overlap + 1;
+        }
+    }
+    return -1;
+}
+
+/* the contaminant lists of one context, parsed once per batch */
+#define ORC_MAX_CT 16
+typedef struct {
+    int n[2];                                   /* contam1 / contam2 entries */
+    char seq[2][ORC_MAX_CT][260];
+    int len[2][ORC_MAX_CT], thr[2][ORC_MAX_CT];
+    int ng;                                     /* global contaminants */
+    char gseq[ORC_MAX_CT][2][260];              /* forward, reverse complement */
+    int glen[ORC_MAX_CT], gmm[ORC_MAX_CT];
+    float gmr[ORC_MAX_CT];
+    int bad;                                    /* list-size mismatch: the reference exits */
+} contam_cfg;
+
+static int split_commas(const char *s, char out[][260], int maxn) {
+    int n = 0;
+    if (!s) return 0;
+    const char *p = s;
+    for (;;) {
+        const char *e = strchr(p, ',');
+        size_t l = e ? (size_t)(e - p) : strlen(p);
+        if (n < maxn) {
+            if (l > 259) l = 259;
+            memcpy(out[n], p, l);
+            out[n][l] = 0;
+            n++;
+        }
+        if (!e) break;
+        p = e + 1;
+    }
+    return n;
+}
+
+static void parse_contams(const snk_params *P, contam_cfg *C) {
+    memset(C, 0, sizeof(*C));
+    static char mrs[ORC_MAX_CT][260], gm[ORC_MAX_CT][260], gfw[ORC_MAX_CT][260];
+    for (int m = 0; m < 2; m++) {
+        const char *cs = P->contam[m];
+        if (!cs || !*cs) continue;
+        const char *mr = P->ct_match_r ? P->ct_match_r : "0.2";
+        if (!strchr(cs, ',')) {                                   /* src/read_filter.cpp:190-193 + :616 (double) */
+            C->n[m] = 1;
+            strncpy(C->seq[m][0], cs, 259);
+            C->len[m][0] = (int)strlen(C->seq[m][0]);
+            C->thr[m][0] = (int)ceil((double)C->len[m][0] * atof(mr));
+        } else {                                                  /* hasContams, :483-506 (float) */
+            C->n[m] = split_commas(cs, C->seq[m], ORC_MAX_CT);
+            const int nm = strchr(mr, ',') ? split_commas(mr, mrs, ORC_MAX_CT) : -1;
+            if (nm != C->n[m]) { C->bad = 1; return; }
+            for (int i = 0; i < C->n[m]; i++) {
+                C->len[m][i] = (int)strlen(C->seq[m][i]);
+                const float tmp_mr = (float)atof(mrs[i]);
+                C->thr[m][i] = (int)ceilf((float)C->len[m][i] * tmp_mr);
+            }
+        }
+    }
+    if (P->global_contams && *P->global_contams) {                /* hasGlobalContams, :927-960 */
+        C->ng = split_commas(P->global_contams, gfw, ORC_MAX_CT);
+        const int a = split_commas(P->g_mrs ? P->g_mrs : "", mrs, ORC_MAX_CT), b = split_commas(P->g_mms ? P->g_mms : "", gm, ORC_MAX_CT);
+        if (a != C->ng || b != C->ng) { C->bad = 1; return; }
+        for (int i = 0; i < C->ng; i++) {
+            const int l = (int)strlen(gfw[i]);
+            C->glen[i] = l;
+            C->gmr[i] = (float)atof(mrs[i]);
+            C->gmm[i] = atoi(gm[i]);
+            memcpy(C->gseq[i][0], gfw[i], (size_t)l + 1);
+            for (int k = 0; k < l; k++) {                         /* reversecomplementary(), :1064-1090 */
+                const int ch = toupper((unsigned char)gfw[i][l - 1 - k]);
+                char o;
+                switch (ch) {
+                case 'A': o = 'T'; break;
+                case 'T': o = 'A'; break;
+                case 'C': o = 'G'; break;
+                case 'G': o = 'C'; break;
+                case 'N': o = 'N'; break;
+                default: C->bad = 1; return;                       /* "Error:unrecognized base" */
+                }
+                C->gseq[i][1][k] = o;
+            }
+            C->gseq[i][1][l] = 0;
+        }
+    }
+}
+
+/* include_contam / include_global_contam of one read, src/read_filter.cpp:189-248 */
+static void contam_flags(const snk_params *P, const contam_cfg *C, int mate, const uint8_t *seq, int len,
+                         int *inc_contam, int *inc_global) {
+    *inc_contam = *inc_global = 0;
+    for (int i = 0; i < C->n[mate]; i++) {
+        const int pos = snk_oracle_has_contam(seq, len, C->seq[mate][i], C->len[mate][i], C->thr[mate][i],
+                                              P->ada_mis[0], P->ada_edge[0]);
+        if (pos >= 0) { *inc_contam = 1; break; }                 /* later entries cannot change the verdict */
+    }
+    for (int i = 0; i < C->ng && !*inc_global; i++)
+        for (int d = 0; d < 2 && !*inc_global; d++)
+            if (snk_oracle_global_contam_pos(seq, len, C->gseq[i][d], C->glen[i], C->gmr[i], C->gmm[i]) >= 0) *inc_global = 1;
+}
+
 /* C_fastq_stat_result + the C_fastq cut fields of the filter's private copy */
 typedef struct {
     int len;
@@ -132,12 +361,14 @@ typedef struct {
     int lowq, sumq;
     float n_ratio, a_ratio, lowq_ratio, mean_q;
     int include_adapter;                 /* include_adapter_seq: 1 / -1 */
+    int inc_contam, inc_gcontam;         /* include_contam, include_global_contam */
     int hd_h, lq_h, hd_t, lq_t, adacut;  /* -1 == unset */
     int start, clen;                     /* trimmed view */
 } rd_t;
 
-/* stat_read(), src/read_filter.cpp:80-313 (tile/fov/contam parts are out of
- * scope: empty parameters make them no-ops, :86,:125,:189-248)               */
+/* stat_read(), src/read_filter.cpp:80-313 (tile/fov parts are out of scope: empty
+ * parameters make them no-ops, :86,:125)                                       */
+static const contam_cfg *g_ct = NULL;          /* contaminant lists of the batch being processed */
 static int stat_read(const snk_params *P, int mate, const uint8_t *seq,
                      const uint8_t *qual, int len, rd_t *r) {
     memset(r, 0, sizeof(*r));
@@ -156,6 +387,7 @@ static int stat_read(const snk_params *P, int mate, const uint8_t *seq,
         r->include_adapter = 1;
         r->adacut = len - ada_pos;
     }
+    if (g_ct) contam_flags(P, g_ct, mate, seq, len, &r->inc_contam, &r->inc_gcontam);   /* :189-248 */
     if (len == 0) return SNK_E_EMPTY_SEQ;                          /* :250-253 */
     int last_char = 'Q', contig_base = 0, max_contig = 1;          /* :255-257 */
     for (int ix = 0; ix < len; ix++) {                             /* :258-287 */
@@ -274,6 +506,12 @@ static int pe_discard(const snk_params *P, const rd_t *r1, const rd_t *r2, int d
                    (uint64_t)r2->clen > (uint64_t)(int64_t)P->max_read_length);
         if (v > 0) { fam(fs, SNK_FS_LONG, v); *vout = v; return SNK_R_LONG; }
     }
+    if (!P->contam_trim) {                                         /* :264-290 (global first in PE) */
+        v = pe_dis(r1->inc_gcontam == 1, r2->inc_gcontam == 1);
+        if (v > 0) { fam(fs, SNK_FS_GCONTAM, v); *vout = v; return SNK_R_GCONTAM; }
+        v = pe_dis(r1->inc_contam == 1, r2->inc_contam == 1);
+        if (v > 0) { fam(fs, SNK_FS_CONTAM, v); *vout = v; return SNK_R_CONTAM; }
+    }
     if (P->n_ratio != -1) {                                        /* :291-303 */
         v = pe_dis(r1->n_ratio >= P->n_ratio, r2->n_ratio >= P->n_ratio);
         if (v > 0) { fam(fs, SNK_FS_NRATE, v); *vout = v; return SNK_R_NRATE; }
@@ -309,6 +547,10 @@ static int se_discard(const snk_params *P, const rd_t *r, int dup, uint64_t *fs)
         (uint64_t)r->clen < (uint64_t)(int64_t)P->min_read_length) { fs[SNK_FS_SHORT]++; return SNK_R_SHORT; }
     if (P->max_read_length != -1 &&
         (uint64_t)r->clen > (uint64_t)(int64_t)P->max_read_length) { fs[SNK_FS_LONG]++; return SNK_R_LONG; }
+    if (!P->contam_trim) {                                         /* :116-128 (contam first in SE) */
+        if (r->inc_contam == 1) { fs[SNK_FS_CONTAM]++; return SNK_R_CONTAM; }
+        if (r->inc_gcontam == 1) { fs[SNK_FS_GCONTAM]++; return SNK_R_GCONTAM; }
+    }
     if (P->n_ratio != -1 && r->n_ratio >= P->n_ratio) { fs[SNK_FS_NRATE]++; return SNK_R_NRATE; }
     if (P->highA_ratio != -1 && r->a_ratio >= P->highA_ratio) { fs[SNK_FS_HIGHA]++; return SNK_R_HIGHA; }
     if (P->polyX_num != -1 && r->contig >= P->polyX_num) { fs[SNK_FS_POLYX]++; return SNK_R_POLYX; }
@@ -392,6 +634,10 @@ int snk_oracle_filter_batch(const snk_params *P, const snk_batch *B,
     /* src/peprocess.cpp:1441 / src/seprocess.cpp:881 */
     const int copy_back = P->ada_trim || P->contam_trim || P->has_hard_trim || P->has_lq_trim;
     if (err) { err->code = SNK_OK; err->mate = 0; err->index = 0; }
+    static contam_cfg ct;                                         /* (the oracle is single-threaded test code) */
+    parse_contams(P, &ct);
+    if (ct.bad) { if (err) err->code = SNK_E_PARAM; return SNK_E_PARAM; }
+    g_ct = (ct.n[0] || ct.n[1] || ct.ng) ? &ct : NULL;
 
     for (int64_t i = 0; i < B->n; i++) {
         rd_t r[2];

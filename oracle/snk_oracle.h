@@ -23,6 +23,15 @@ int snk_oracle_adapter_pos(const uint8_t *read, int read_len,
                            const char *adapter, int adapter_len,
                            int ada_mis, float ada_mr, int ada_edge);
 
+/* hasContam(), src/read_filter.cpp:507-603 (and its 3-argument twin :604-700): position or -1.
+ * seg_match_thr = (int)ceil(contamLen * ratio) is computed by the caller (float for list entries,
+ * double for a single contaminant, as the two overloads do).                                    */
+int snk_oracle_has_contam(const uint8_t *read, int read_len, const char *contam, int contam_len,
+                          int seg_match_thr, int ada_mis, int ada_edge);
+/* global_contam_pos(), src/read_filter.cpp:961-1062 */
+int snk_oracle_global_contam_pos(const uint8_t *read, int read_len, const char *contam, int contam_len,
+                                 float min_match_ratio, int mismatch_number);
+
 /* polyG_number(), src/read_filter.cpp:472-482 */
 int snk_oracle_polyG_number(const uint8_t *read, int read_len);
 

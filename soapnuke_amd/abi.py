@@ -9,6 +9,9 @@ import os
 SNK_READ_MAX_LEN = 1000
 SNK_MAX_ADAPTERS = 16
 SNK_FS_N, SNK_GS_N, SNK_TS_N, SNK_MAX_N = 64, 16, 5000, 8
+# enum snk_fs_index (families of 4: total, fq1 only, fq2 only, both)
+SNK_FS_DUP, SNK_FS_SHORT, SNK_FS_LONG, SNK_FS_GCONTAM, SNK_FS_CONTAM = 0, 4, 8, 12, 16
+SNK_FS_NRATE, SNK_FS_HIGHA, SNK_FS_POLYX, SNK_FS_LOWQUAL, SNK_FS_MEANQ, SNK_FS_ADAPTER = 20, 24, 28, 32, 36, 40
 
 # enum snk_reason
 KEEP, R_DUP, R_TILE, R_FOV, R_SHORT, R_LONG, R_GCONTAM, R_CONTAM, R_NRATE, R_HIGHA, \
@@ -41,6 +44,8 @@ class Params(C.Structure):
         ("n_adapters", C.c_int32 * 2),
         ("adapters", (C.c_char_p * SNK_MAX_ADAPTERS) * 2),
         ("rmdup", C.c_int32), ("max_read_len", C.c_int32),
+        ("contam", C.c_char_p * 2), ("ct_match_r", C.c_char_p),
+        ("global_contams", C.c_char_p), ("g_mrs", C.c_char_p), ("g_mms", C.c_char_p),
     ]
 
 
@@ -100,7 +105,8 @@ def default_params(paired=True, max_read_len=150, **kw):
     """Reference defaults (src/global_parameter.h:20-83) + keyword overrides.
 
     adapters1/adapters2: lists of str; hard_trim: 4 (PE) / 2 (SE) ints;
-    trim_bad_head / trim_bad_tail: (qual, maxlen) tuples.
+    trim_bad_head / trim_bad_tail: (qual, maxlen) tuples; contam1/contam2/ct_match_r/
+    global_contams/g_mrs/g_mms: the config file's comma-separated strings.
     """
     p = Params()
     p.struct_size = C.sizeof(Params)
@@ -139,6 +145,15 @@ def default_params(paired=True, max_read_len=150, **kw):
         elif k == "trim_bad_tail":
             p.has_lq_trim = 1
             p.lq_tail_qual, p.lq_tail_len = v
+        elif k in ("contam1", "contam2", "ct_match_r", "global_contams", "g_mrs", "g_mms"):
+            b = v.encode() if isinstance(v, str) else bytes(v)      # comma-separated lists, as in the config file
+            keep.append(b)
+            if k == "contam1":
+                p.contam[0] = b
+            elif k == "contam2":
+                p.contam[1] = b
+            else:
+                setattr(p, k, b)
         elif k in ("ada_mis", "ada_mr", "ada_edge"):
             arr = getattr(p, k)
             arr[0], arr[1] = (v if isinstance(v, (tuple, list)) else (v, v))

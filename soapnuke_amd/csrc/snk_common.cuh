@@ -68,6 +68,97 @@ __device__ inline int adapter_pos_seq(const uint8_t *s, int len, const DevAdapte
     return -1;
 }
 
+// hasContam(), src/read_filter.cpp:507-603: sequential; an 'N' in the read is neither match nor mismatch.
+__device__ inline int has_contam_seq(const uint8_t *s, int len, const DevContam &C) {
+    if (C.len == 0) return -1;
+    for (int r1 = 0; r1 < C.nC; ++r1) {                              // head, :523-547
+        int mis = 0, run = 0;
+        const int budget = C.mm[r1], seg = C.sm1[r1];
+        for (int c = 0; c < r1 + C.edge; ++c) {
+            const int rc = rdc(s, len, c);
+            if ((int)C.seq[C.len - r1 - C.edge + c] == rc) { if (++run >= seg) return 0; }
+            else if (rc != 'N') { ++mis; run = 0; if (mis > budget) break; }
+        }
+        if (mis <= budget) return 0;
+    }
+    for (int r1 = 0; r1 <= len - C.len; ++r1) {                      // middle, :549-573
+        int mis = 0, run = 0;
+        for (int c = 0; c < C.len; ++c) {
+            const int rc = rdc(s, len, r1 + c);
+            if ((int)C.seq[c] == rc) { if (++run >= C.S) return r1; }
+            else if (rc != 'N') { ++mis; run = 0; if (mis > C.mis) break; }
+        }
+        if (mis <= C.mis) return r1;
+    }
+    for (int r1 = 0; r1 < C.nC; ++r1) {                              // tail, :575-601
+        int mis = 0, run = 0;
+        const int budget = C.mm[r1], seg = C.sm3[r1], st = len - r1 - C.edge;
+        for (int c = 0; c < r1 + C.edge; ++c) {
+            const int rc = rdc(s, len, st + c);
+            if ((int)C.seq[c] == rc) { if (++run >= seg) return st; }
+            else if (rc != 'N') { ++mis; run = 0; if (mis > budget) break; }
+        }
+        if (mis <= budget) return st;
+    }
+    return -1;
+}
+
+// global_contam_pos(), src/read_filter.cpp:961-1062 (score / overlap carried across alignments of a section)
+__device__ inline int global_contam_pos_seq(const uint8_t *ref, int rl, const uint8_t *gc, int cl, int min_match_len, int mmn) {
+    const int mismatch_score = -200, tms = mmn * mismatch_score, lower = (min_match_len - mmn) + tms;
+    int total = -1000, overlap = 0;
+    for (int i = cl - min_match_len; i >= 0; --i) {
+        const int j_max = cl - i > rl ? rl : cl - i;
+        for (int j = 0; j != j_max; ++j) {
+            if (ref[j] == gc[i + j]) {
+                if (total > tms) { total += 1; ++overlap; }
+                else { if (j_max - j < min_match_len) break; total = 1; overlap = 1; }
+            } else {
+                if (total > tms) { total += mismatch_score; ++overlap; }
+                else if (j_max - j < min_match_len) break;
+            }
+            if (total >= lower && overlap >= min_match_len) return 0;
+        }
+    }
+    total = -1000; overlap = 0;
+    for (int i = 0; i <= rl - cl; ++i)
+        for (int j = 0; j != cl; ++j) {
+            if (ref[i + j] == gc[j]) {
+                if (total > tms) { total += 1; ++overlap; }
+                else { if (cl - j < min_match_len) break; total = 1; overlap = 1; }
+            } else {
+                if (total > tms) { total += mismatch_score; ++overlap; }
+                else if (cl - j < min_match_len) break;
+            }
+            if (total >= lower && overlap >= min_match_len) return i + j - overlap + 1;
+        }
+    total = -1000; overlap = 0;
+    const int i_min = cl > rl ? cl - rl : 0;
+    for (int i = i_min; i <= cl - min_match_len; ++i)
+        for (int j = 0; j != cl - i; ++j) {
+            if (ref[rl - (cl - i) + j] == gc[j]) {
+                if (total > tms) { total += 1; ++overlap; }
+                else { total = 1; overlap = 1; if (cl - i - j < min_match_len) break; }
+            } else {
+                if (total > tms) { total += mismatch_score; ++overlap; }
+                else if (cl - i - j < min_match_len) break;
+            }
+            if (total >= lower && overlap >= min_match_len) return rl - cl + i + j - overlap + 1;
+        }
+    return -1;
+}
+
+// include_contam (bit 0) / include_global_contam (bit 1) of one read, src/read_filter.cpp:189-248
+__device__ inline int contam_flags(const DevParams &P, int mate, const uint8_t *s, int len) {
+    int f = 0;
+    for (int i = 0; i < P.n_ct[mate] && !(f & 1); ++i)
+        if (has_contam_seq(s, len, P.ct[mate * SNK_MAX_CONTAMS + i]) >= 0) f |= 1;
+    for (int i = 0; i < P.n_gct && !(f & 2); ++i)
+        for (int d = 0; d < 2 && !(f & 2); ++d)
+            if (global_contam_pos_seq(s, len, P.gct[i].seq[d], P.gct[i].len, P.gct[i].min_match_len, P.gct[i].mm) >= 0) f |= 2;
+    return f;
+}
+
 // A3 fastq_trim() arithmetic once the per-read scan results are known
 // (src/read_filter.cpp:383-468).  lq_hix/lq_tix/polyg: the three run lengths.
 __device__ __forceinline__ void trim_finish(const DevParams &P, int mate, ReadState &r, int lq_hix,
@@ -101,8 +192,9 @@ __device__ __forceinline__ int pe_dis(bool a, bool b) { return (a ? 1 : 0) + (b 
 
 // A6: the cascade (src/sequence.cpp:198-387 PE, :76-178 SE); returns the reason and
 // the pe_dis() code, counters are the caller's business.
+// cfa / cfb: contaminant verdicts of the mates, bit 0 = include_contam, bit 1 = include_global_contam
 __device__ inline int discard_reason(const DevParams &P, const ReadState &a, const ReadState &b, int dup,
-                                     int &vout) {
+                                     int &vout, int cfa = 0, int cfb = 0) {
     const bool pe = P.paired;
     int v;
     vout = 0;
@@ -116,6 +208,15 @@ __device__ inline int discard_reason(const DevParams &P, const ReadState &a, con
         return SNK_R_EMPTY;
     }
     if (P.has_max) { SNK_TEST((u32)a.clen > P.max_len_u, (u32)b.clen > P.max_len_u, SNK_R_LONG) }
+    if (P.contam_discard && (cfa | cfb)) {                          // src/sequence.cpp:264-290 (PE), :116-127 (SE)
+        if (pe) {
+            SNK_TEST(cfa & 2, cfb & 2, SNK_R_GCONTAM)
+            SNK_TEST(cfa & 1, cfb & 1, SNK_R_CONTAM)
+        } else {
+            if (cfa & 1) return SNK_R_CONTAM;
+            if (cfa & 2) return SNK_R_GCONTAM;
+        }
+    }
     if (P.has_n) { SNK_TEST(a.n_n >= P.thr_n[a.len], b.n_n >= P.thr_n[b.len], SNK_R_NRATE) }
     if (P.has_highA) { SNK_TEST(a.n_a >= P.thr_a[a.len], b.n_a >= P.thr_a[b.len], SNK_R_HIGHA) }
     if (P.polyX_num != -1) { SNK_TEST(a.polyx, b.polyx, SNK_R_POLYX) }
@@ -130,6 +231,8 @@ __device__ __forceinline__ int reason_family(int reason) {
     switch (reason) {
     case SNK_R_SHORT: return SNK_FS_SHORT;
     case SNK_R_LONG: return SNK_FS_LONG;
+    case SNK_R_GCONTAM: return SNK_FS_GCONTAM;
+    case SNK_R_CONTAM: return SNK_FS_CONTAM;
     case SNK_R_NRATE: return SNK_FS_NRATE;
     case SNK_R_HIGHA: return SNK_FS_HIGHA;
     case SNK_R_POLYX: return SNK_FS_POLYX;

@@ -30,6 +30,26 @@ struct DevAdapter {
     uint64_t nmask;         // bit c = adapter[c] == 'N' (matches a read 'N' exactly)
 };
 
+// One hasContam() contaminant (src/read_filter.cpp:507-603): the per-r1 thresholds of its head and
+// tail loops precomputed on the host with the reference's int->float->int arithmetic.
+#define SNK_MAX_CONTAMS 8
+struct DevContam {
+    int32_t len;            // contamLen
+    int32_t S;              // segMatchThr of the middle loop (:549-573)
+    int32_t mis;            // gp.adaMis
+    int32_t edge;           // gp.adaEdge
+    int32_t nC;             // contamLen - adaEdge: trip count of the head (:523) and tail (:575) loops
+    int32_t mm[SNK_DEV_MAX_ADA_LEN];   // misMatchTemp(r1) = (int)(r1/misGrad)
+    int32_t sm1[SNK_DEV_MAX_ADA_LEN];  // segMatchTemp(r1) of the head loop (7 when segGrad == 0)
+    int32_t sm3[SNK_DEV_MAX_ADA_LEN];  // segMatchTemp(r1) of the tail loop (no such guard there)
+    uint8_t seq[SNK_DEV_MAX_ADA_LEN];
+};
+// One global contaminant (src/read_filter.cpp:927-1062): forward and reverse-complement strand.
+struct DevGContam {
+    int32_t len, min_match_len, mm;
+    uint8_t seq[2][SNK_DEV_MAX_ADA_LEN];
+};
+
 // Compact adapter descriptor for the wave-tiled kernel.  It travels BY VALUE in the kernel
 // argument segment so that every field sits in SGPRs: fetching DevAdapter fields from global
 // memory inside the screening loop cost a memory round trip per adapter character.
@@ -62,6 +82,10 @@ struct DevParams {
     //   discard iff sumq  <  thr_meanq[len]        (mean quality)
     const int32_t *thr_n, *thr_a, *thr_lowq, *thr_meanq;
     const DevAdapter *ada;             // [2][SNK_MAX_ADAPTERS]
+    // contaminant screening (generic kernel only; tile_ok is 0 when any is configured)
+    int32_t n_ct[2], n_gct, contam_discard;
+    const DevContam *ct;               // [2][SNK_MAX_CONTAMS]
+    const DevGContam *gct;             // [SNK_MAX_CONTAMS]
 };
 
 // device view of one patch (see snk_batch)

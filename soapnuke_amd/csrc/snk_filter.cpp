@@ -6,6 +6,7 @@
 //  and launches the gfx950 kernels.  No CPU fallback exists: every
 // entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <ctype.h>
 #include <dlfcn.h>
 #include <limits.h>
 #include <math.h>
@@ -59,6 +60,104 @@ int32_t thr_meanq(int len, int mq) {
         if (below(mid)) lo = mid; else hi = mid;
     }
     return (int32_t)hi;
+}
+
+// ---- contaminant lists: the reference's own parsing and int->float->int arithmetic
+std::vector<std::string> split_commas(const char *s) {
+    std::vector<std::string> out;
+    if (!s) return out;
+    std::string cur;
+    for (const char *p = s; *p; ++p) {
+        if (*p == ',') { out.push_back(cur); cur.clear(); }
+        else cur.push_back(*p);
+    }
+    out.push_back(cur);
+    return out;
+}
+
+// hasContam(), src/read_filter.cpp:507-603: everything that depends only on (contam, segMatchThr, adaMis, adaEdge)
+bool build_contam(DevContam &C, const std::string &seq, int S, int adaMis, int adaEdge) {
+    memset(&C, 0, sizeof(C));
+    const int cl = (int)seq.size();
+    if (cl >= SNK_DEV_MAX_ADA_LEN) return false;
+    C.len = cl;
+    C.S = S;
+    C.mis = adaMis;
+    C.edge = adaEdge;
+    C.nC = cl - adaEdge;
+    memcpy(C.seq, seq.data(), cl);
+    if (cl == 0) return true;
+    const float misGrad = (float)((cl - adaEdge) / (adaMis + 1));                      // :513
+    float segGrad;
+    if (S - 7 + 1 == 0) segGrad = 0;                                                   // :517-521
+    else segGrad = (float)((cl - adaEdge) / (S - 7 + 1));
+    for (int r1 = 0; r1 < C.nC && r1 < SNK_DEV_MAX_ADA_LEN; ++r1) {
+        C.mm[r1] = f2i_x86((float)r1 / misGrad);
+        C.sm1[r1] = segGrad != 0 ? f2i_x86(7 + (float)r1 / segGrad) : 7;               // :529-533
+        C.sm3[r1] = f2i_x86(7 + (float)r1 / segGrad);                                  // :580 (no guard)
+    }
+    return true;
+}
+
+// returns "" or an error message; fills ct[2][SNK_MAX_CONTAMS], gct[SNK_MAX_CONTAMS]
+std::string build_contams(const snk_params &P, std::vector<DevContam> &ct, int n_ct[2], std::vector<DevGContam> &gct, int &n_gct) {
+    ct.assign(2 * SNK_MAX_CONTAMS, DevContam());
+    gct.assign(SNK_MAX_CONTAMS, DevGContam());
+    for (auto &x : ct) memset(&x, 0, sizeof(x));
+    for (auto &x : gct) memset(&x, 0, sizeof(x));
+    n_ct[0] = n_ct[1] = n_gct = 0;
+    const char *mr = (P.ct_match_r && *P.ct_match_r) ? P.ct_match_r : "0.2";
+    for (int m = 0; m < 2; ++m) {
+        const char *cs = P.contam[m];
+        if (!cs || !*cs) continue;
+        if (!strchr(cs, ',')) {                                    // single: hasContam(ref, contam, gp), double ratio (:616)
+            const int cl = (int)strlen(cs);
+            if (!build_contam(ct[m * SNK_MAX_CONTAMS], cs, (int)ceil((double)cl * atof(mr)), P.ada_mis[0], P.ada_edge[0]))
+                return "contaminant longer than 255";
+            n_ct[m] = 1;
+        } else {                                                   // hasContams (:483-506), float ratios
+            const std::vector<std::string> seqs = split_commas(cs), mrs = split_commas(mr);
+            if (!strchr(mr, ',') || seqs.size() != mrs.size()) return "the number of ctMatchR value should equal to that of contam sequences";
+            if (seqs.size() > SNK_MAX_CONTAMS) return "too many contaminants";
+            for (size_t i = 0; i < seqs.size(); ++i) {
+                const float tmp_mr = (float)atof(mrs[i].c_str());
+                if (!build_contam(ct[m * SNK_MAX_CONTAMS + i], seqs[i], (int)ceilf((float)seqs[i].size() * tmp_mr), P.ada_mis[0], P.ada_edge[0]))
+                    return "contaminant longer than 255";
+            }
+            n_ct[m] = (int)seqs.size();
+        }
+    }
+    if (P.global_contams && *P.global_contams) {                    // hasGlobalContams, :927-960
+        const std::vector<std::string> seqs = split_commas(P.global_contams), mrs = split_commas(P.g_mrs ? P.g_mrs : ""),
+                                       mms = split_commas(P.g_mms ? P.g_mms : "");
+        if (!P.g_mrs || !P.g_mms || seqs.size() != mrs.size() || seqs.size() != mms.size())
+            return "the number of global contamination sequences should equal to that of related parameters";
+        if (seqs.size() > SNK_MAX_CONTAMS) return "too many global contaminants";
+        for (size_t i = 0; i < seqs.size(); ++i) {
+            DevGContam &G = gct[i];
+            const int cl = (int)seqs[i].size();
+            if (cl >= SNK_DEV_MAX_ADA_LEN) return "global contaminant longer than 255";
+            G.len = cl;
+            G.min_match_len = (int)((float)cl * (float)atof(mrs[i].c_str()));           // :969
+            G.mm = atoi(mms[i].c_str());
+            memcpy(G.seq[0], seqs[i].data(), cl);
+            for (int k = 0; k < cl; ++k) {                           // reversecomplementary(), :1068-1090
+                const int ch = toupper((unsigned char)seqs[i][cl - 1 - k]);
+                uint8_t o;
+                switch (ch) {
+                case 'A': o = 'T'; break;
+                case 'T': o = 'A'; break;
+                case 'C': o = 'G'; break;
+                case 'G': o = 'C'; break;
+                case 'N': o = 'N'; break;
+                default: return "unrecognized base," + seqs[i];
+                }
+                G.seq[1][k] = o;
+            }
+        }
+        n_gct = (int)seqs.size();
+    }
+    return "";
 }
 
 void build_adapter(DevAdapter &A, const char *seq, int mis, float mr, int edge) {
@@ -115,6 +214,8 @@ struct snk_ctx {
     TileAdapters ta;              // kernarg-resident adapter descriptors of the tiled kernel
     DevParams *d_params = nullptr;
     DevAdapter *d_ada = nullptr;
+    DevContam *d_ct = nullptr;
+    DevGContam *d_gct = nullptr;
     int32_t *d_tables = nullptr;
     unsigned long long *d_sum = nullptr, *d_max = nullptr, *d_err = nullptr;
     // per-workgroup trimming-position counters of the tiled kernel (DevStats::tsw): 8 copies, one per
@@ -180,6 +281,23 @@ static int build_ctx(snk_ctx *c) {
     HIP_OK(hipMalloc(&c->d_ada, ada.size() * sizeof(DevAdapter)));
     HIP_OK(hipMemcpy(c->d_ada, ada.data(), ada.size() * sizeof(DevAdapter), hipMemcpyHostToDevice));
 
+    // ---- contaminants
+    std::vector<DevContam> ct;
+    std::vector<DevGContam> gct;
+    int n_ct[2], n_gct;
+    {
+        const std::string e = build_contams(P, ct, n_ct, gct, n_gct);
+        if (!e.empty()) { set_err("snk_create: " + e); return SNK_E_PARAM; }
+    }
+    if (n_ct[0] | n_ct[1]) {
+        HIP_OK(hipMalloc(&c->d_ct, ct.size() * sizeof(DevContam)));
+        HIP_OK(hipMemcpy(c->d_ct, ct.data(), ct.size() * sizeof(DevContam), hipMemcpyHostToDevice));
+    }
+    if (n_gct) {
+        HIP_OK(hipMalloc(&c->d_gct, gct.size() * sizeof(DevGContam)));
+        HIP_OK(hipMemcpy(c->d_gct, gct.data(), gct.size() * sizeof(DevGContam), hipMemcpyHostToDevice));
+    }
+
     // ---- per-length thresholds
     const int L1 = c->lcap + 1;
     std::vector<int32_t> tab(4 * (size_t)L1);
@@ -225,8 +343,12 @@ static int build_ctx(snk_ctx *c) {
     D.lcap = c->lcap;
     D.n_ada[0] = P.n_adapters[0];
     D.n_ada[1] = P.n_adapters[1];
-    D.tile_ok = 1;
+    D.tile_ok = (n_ct[0] | n_ct[1] | n_gct) ? 0 : 1;   // contaminant screening: generic kernel
     D.need_n = 0;
+    D.n_ct[0] = n_ct[0]; D.n_ct[1] = n_ct[1]; D.n_gct = n_gct;
+    D.contam_discard = P.contam_trim ? 0 : 1;        // gp.contam_discard_or_trim == "discard"
+    D.ct = c->d_ct;
+    D.gct = c->d_gct;
     memset(&c->ta, 0, sizeof(c->ta));
     for (int m = 0; m < 2; ++m)
         for (int i = 0; i < P.n_adapters[m]; ++i) {
@@ -323,6 +445,8 @@ void snk_destroy(snk_ctx *c) {
         if (c->d_max) (void)hipFree(c->d_max);
     }
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_ct) (void)hipFree(c->d_ct);
+    if (c->d_gct) (void)hipFree(c->d_gct);
     if (c->d_tsw) (void)hipFree(c->d_tsw);
 
     if (c->st_buf) (void)hipFree(c->st_buf);

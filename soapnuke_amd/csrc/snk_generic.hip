@@ -100,6 +100,7 @@ snk_generic_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int n
     const int pe = P.paired ? 1 : 0;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < B.n; i += (long)gridDim.x * blockDim.x) {
         ReadState r[2];
+        int cf[2] = {0, 0};
         const uint8_t *s[2], *q[2];
         const unsigned long long gidx = B.first_index + (unsigned long long)i;
         bool bad = false;
@@ -109,13 +110,14 @@ snk_generic_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int n
             q[m] = B.qual[m] + i * (long)B.pitch;
             if (len > lcap) { report_err(st, gidx, m, SNK_E_TOO_LONG); bad = true; break; }
             int e;
+            if (P.n_ct[m] | P.n_gct) cf[m] = contam_flags(P, m, s[m], len);        // src/read_filter.cpp:189-248
             stat_read_dev(P, m, s[m], q[m], len, r[m], e);
             if (e) { report_err(st, gidx, m, e); bad = true; break; }
         }
         if (bad) continue;
         for (int m = 0; m <= pe; ++m) fastq_trim_dev(P, m, s[m], q[m], r[m]);
         int v = 0;
-        const int reason = discard_reason(P, r[0], r[pe], B.dup ? B.dup[i] : 0, v);
+        const int reason = discard_reason(P, r[0], r[pe], B.dup ? B.dup[i] : 0, v, cf[0], cf[pe]);
         count_reason(st.sum, pe, reason, v);
         store_rec(B.out[0], i, r[0], reason, v);
         if (pe) store_rec(B.out[1], i, r[1], reason, v);

@@ -55,6 +55,7 @@ struct Options {
     int threads = 6, patch_size = 0, batch_pairs = 1 << 18, device = 0;
     bool in_gz = true, out_gz = true, pe_info = false, index_remove = false;
     string seq_type = "0";
+    string contam[2], ct_match_r, global_contams, g_mrs, g_mms;     // kept here: snk_params points into them
     string base_convert;
 };
 
@@ -146,6 +147,13 @@ void read_config(Options &o, const char *path) {             // src/process_argv
         else if (key == "outFileType") o.out_file_type = val;
         else if (key == "seqType") { o.seq_type = val; if (val != "0" && val != "1") die("seq_type value should be 0 or 1"); }
         else if (key == "index") o.index_remove = true;
+        else if (key == "contam_trim") p.contam_trim = 1;
+        else if (key == "contam1") o.contam[0] = val;
+        else if (key == "contam2") o.contam[1] = val;
+        else if (key == "ctMatchR") o.ct_match_r = val;
+        else if (key == "global_contams") o.global_contams = val;
+        else if (key == "glob_cotm_mR") o.g_mrs = val;
+        else if (key == "glob_cotm_mM") o.g_mms = val;
         else if (key == "rmdup") p.rmdup = 1;
         else if (key == "pe_info") o.pe_info = true;
         else if (key == "baseConvert") die("parameter baseConvert is not supported by the GPU filter path yet (the reference converts before its clean statistics)");
@@ -232,6 +240,12 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
     o.p.n_adapters[1] = (int)o.ada2.size();
     for (size_t i = 0; i < o.ada1.size(); ++i) o.p.adapters[0][i] = o.ada1[i].c_str();
     for (size_t i = 0; i < o.ada2.size(); ++i) o.p.adapters[1][i] = o.ada2[i].c_str();
+    o.p.contam[0] = o.contam[0].empty() ? nullptr : o.contam[0].c_str();
+    o.p.contam[1] = o.contam[1].empty() ? nullptr : o.contam[1].c_str();
+    o.p.ct_match_r = o.ct_match_r.empty() ? nullptr : o.ct_match_r.c_str();
+    o.p.global_contams = o.global_contams.empty() ? nullptr : o.global_contams.c_str();
+    o.p.g_mrs = o.g_mrs.empty() ? nullptr : o.g_mrs.c_str();
+    o.p.g_mms = o.g_mms.empty() ? nullptr : o.g_mms.c_str();
     if (o.log.find("/") == string::npos) o.log = o.out_dir + "/" + o.log;
     if (o.out_file_type != "fastq" && o.out_file_type != "fasta") die("output_file_type value error");
 }

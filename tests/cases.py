@@ -32,3 +32,45 @@ def se_kwargs(kw):
     if "hard_trim" in kw:
         kw["hard_trim"] = kw["hard_trim"][:2]
     return kw
+
+
+# contaminant screening: config strings exactly as the reference takes them
+CT1, CT2 = "ACGTTGCAAGGCTTAACCGGTTAGCATGCAAT", "TTGGCCAAGGTTCCAAGGTTAACCGGTT"
+GC1 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+CONTAM_CASES = {
+    "single": dict(contam1=CT1, contam2=CT2, ct_match_r="0.5"),
+    "single_default_mr": dict(contam1=CT1 + CT1[:25], ct_match_r="0.2"),
+    "list": dict(contam1=CT1 + ",GGGGGGGGGGGGGGGGGGGGGGGG", contam2=CT2 + ",CCCCCCCCCCCCCCCCCCCCCC", ct_match_r="0.6,0.7"),
+    "global": dict(global_contams=CT1 + "," + GC1, g_mrs="0.5,0.4", g_mms="1,2"),
+    "both_trim": dict(contam1=CT1, ct_match_r="0.4", global_contams=GC1, g_mrs="0.4", g_mms="1", contam_trim=1),
+    "both_discard": dict(contam1=CT1, contam2=CT1, ct_match_r="0.4", global_contams=GC1, g_mrs="0.4", g_mms="1",
+                         adapters1=[A1], adapters2=[A2], ada_trim=1),
+}
+
+
+def plant_contams(d, kw, seed=4):
+    """writes whole / head-truncated / tail-truncated copies of the configured contaminants into 5 % of the reads each"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    seqs = []
+    for k in ("contam1", "contam2", "global_contams"):
+        if k in kw:
+            seqs += kw[k].split(",")
+    n = d["n"]
+    for m in range(len(d["seq"])):
+        for s in seqs:
+            b = np.frombuffer(s.encode(), dtype=np.uint8)
+            for r in rng.choice(n, n // 20, replace=False):
+                L = int(d["len"][m][r]) if d["len"][m] is not None else d["L"]
+                k, mode = int(rng.integers(8, len(b) + 1)), int(rng.integers(0, 3))
+                if mode == 0 and L >= len(b):
+                    p = int(rng.integers(0, L - len(b) + 1))
+                    d["seq"][m][r, p:p + len(b)] = b
+                elif mode == 1:
+                    d["seq"][m][r, :k] = b[len(b) - k:]
+                else:
+                    d["seq"][m][r, L - k:L] = b[:k]
+
+
+def contam_kwargs(kw, paired):
+    return {k: v for k, v in kw.items() if paired or k not in ("contam2", "adapters2")}

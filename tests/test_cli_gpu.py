@@ -148,6 +148,30 @@ def test_cli_index_removal(seq_type, tmp_path):
         assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
 
 
+@pytest.mark.parametrize("paired", [True, False])
+def test_cli_contaminants_match_reference_binary(paired, tmp_path):
+    """config keys contam1/contam2/ctMatchR + global_contams/glob_cotm_mR/glob_cotm_mM"""
+    from cases import CT1, CT2, GC1, plant_contams
+    n, L = 12000, 150
+    kw = dict(contam1=CT1 + ",GGGGGGGGGGGGGGGGGGGGGGGG", contam2=CT2 + ",CCCCCCCCCCCCCCCCCCCCCC", global_contams=GC1)
+    d = synth.make_batch(n, L, paired=paired, seed=93)
+    plant_contams(d, kw)
+    cfg = ["contam1=" + kw["contam1"], "ctMatchR=0.6,0.7", "global_contams=" + GC1, "glob_cotm_mR=0.4", "glob_cotm_mM=1"]
+    if paired:
+        cfg.append("contam2=" + kw["contam2"])
+    cli = ["-f", synth.ADAPTER1, "-J"] + (["-r", synth.ADAPTER2] if paired else [])
+    case = ("contam", paired, L, n, 3, 250, {}, {}, cli, cfg)
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ours = _run_ours(case, work, gz=False)
+    for f in (R.REPORT_FILES_PE if paired else R.REPORT_FILES_SE):
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in (["c1.fq", "c2.fq"] if paired else ["c1.fq"]):
+        assert _cat(os.path.join(ours, c)) == _cat(os.path.join(ref, c)), c
+    txt = open(os.path.join(ours, "Statistics_of_Filtered_Reads.txt")).read()
+    assert "Reads with contam sequence" in txt and "Reads with global contam sequence" in txt
+
+
 def test_cli_error_surface(tmp_path):
     r = subprocess.run([CLI, "filter", "-1", "/nonexistent.fq", "-C", "c.fq", "-o", str(tmp_path)], capture_output=True)
     assert r.returncode == 1 and r.stderr.startswith(b"Error:")

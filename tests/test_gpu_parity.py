@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import snk_testlib as T
-from cases import PE_CASES, se_kwargs
+from cases import CONTAM_CASES, PE_CASES, contam_kwargs, plant_contams, se_kwargs
 from soapnuke_amd import abi, synth
 
 pytestmark = pytest.mark.gpu
@@ -269,3 +269,21 @@ def test_capacity_boundaries(L):
     d = synth.make_batch(n, L, paired=True, var_len=True, seed=50 + L)
     p = abi.default_params(paired=True, max_read_len=L, **PE_CASES["C3_full"])
     assert_same(p, run_hip_device(p, d, 0), T.run_oracle(p, d), True)
+
+
+@pytest.mark.parametrize("name", sorted(CONTAM_CASES))
+@pytest.mark.parametrize("paired", [True, False])
+def test_contaminant_screening(name, paired):
+    """contam1/contam2 (+ctMatchR) and global_contams: verdicts computed on the device (generic kernel), SURVEY 8f N3"""
+    kw = CONTAM_CASES[name]
+    d = synth.make_batch(12000, 150, paired=paired, var_len=(name != "single"), seed=91)
+    plant_contams(d, kw)
+    p = abi.default_params(paired=paired, max_read_len=150, **contam_kwargs(kw, paired))
+    assert_same(p, run_hip_device(p, d, 0), T.run_oracle(p, d), paired)
+
+
+def test_contaminant_list_size_mismatch_is_refused():
+    from soapnuke_amd.filter import FilterContext, FilterError
+    p = abi.default_params(paired=True, max_read_len=150, contam1="ACGTACGTACGT,GGGGGGGGGGGG", ct_match_r="0.5")
+    with pytest.raises(FilterError):
+        FilterContext(p, device=0)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import snk_testlib as T
-from cases import PE_CASES, se_kwargs
+from cases import CONTAM_CASES, PE_CASES, contam_kwargs, plant_contams, se_kwargs
 from soapnuke_amd import abi, synth
 
 pytestmark = pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref/libsnkref.so not built (make -C oracle ref)")
@@ -88,3 +88,59 @@ def test_lowercase_reads():
 def test_capacity_larger_than_reads():
     d = synth.make_batch(2000, 100, paired=True, var_len=True, seed=15)
     _compare(abi.default_params(paired=True, max_read_len=300, **PE_CASES["hard_lq_trim"]), d, True)
+
+
+# ---- contaminant screening
+
+@pytest.mark.parametrize("name", sorted(CONTAM_CASES))
+@pytest.mark.parametrize("paired", [True, False])
+def test_contam_batch(name, paired):
+    kw = CONTAM_CASES[name]
+    d = synth.make_batch(3000, 150, paired=paired, var_len=(name != "single"), seed=91)
+    plant_contams(d, kw)
+    p = abi.default_params(paired=paired, max_read_len=150, **contam_kwargs(kw, paired))
+    _compare(p, d, paired)
+    o = T.run_oracle(p, d)
+    if not kw.get("contam_trim"):
+        assert o["sum"][abi.SNK_FS_GCONTAM] + o["sum"][abi.SNK_FS_CONTAM] > 50      # the planted copies are found
+
+
+def test_contam_matchers_fuzz():
+    """hasContam / global_contam_pos of the reference vs the oracle on planted and random reads"""
+    o, r = T.oracle_lib(), T.ref_lib()
+    o.snk_oracle_has_contam.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    r.snkref_has_contam.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_float, C.c_int, C.c_int]
+    o.snk_oracle_global_contam_pos.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_float, C.c_int]
+    r.snkref_global_contam_pos.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_float, C.c_int]
+    rng = np.random.default_rng(2)
+    B = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    hits = 0
+    for it in range(8000):
+        cl = int(rng.integers(7, 45))
+        rl = int(rng.integers(cl, 160))
+        contam = bytes(B[rng.integers(0, 4, cl)])
+        read = bytearray(B[rng.choice(5, rl, p=[.24, .24, .24, .24, .04])])
+        mode = it % 4
+        if mode == 1:
+            p = int(rng.integers(0, rl - cl + 1))
+            read[p:p + cl] = contam
+            for k in rng.integers(0, cl, int(rng.integers(0, 4))):
+                read[p + int(k)] = B[rng.integers(0, 4)]
+        elif mode == 2:
+            k = int(rng.integers(3, cl))
+            read[:k] = contam[cl - k:]
+        elif mode == 3:
+            k = int(rng.integers(3, cl))
+            read[rl - k:] = contam[:k]
+        mr = float(np.float32(rng.choice([0.2, 0.3, 0.5, 0.15, 0.9, 0.1])))
+        mis, edge = int(rng.integers(0, 4)), int(rng.integers(1, 8))
+        thr = int(np.ceil(np.float32(cl) * np.float32(mr)))
+        a = o.snk_oracle_has_contam(bytes(read), rl, contam, cl, thr, mis, edge)
+        b = r.snkref_has_contam(bytes(read), rl, contam, cl, mr, mis, edge)
+        assert a == b, ("hasContam", cl, rl, mr, mis, edge, mode)
+        gmr, mm = float(np.float32(rng.choice([0.3, 0.5, 0.7, 0.2]))), int(rng.integers(0, 3))
+        a = o.snk_oracle_global_contam_pos(bytes(read), rl, contam, cl, gmr, mm)
+        b = r.snkref_global_contam_pos(bytes(read), rl, contam, cl, gmr, mm)
+        assert a == b, ("global_contam_pos", cl, rl, gmr, mm, mode)
+        hits += b >= 0
+    assert hits > 1000
