@@ -56,6 +56,7 @@ struct Options {
     bool in_gz = true, out_gz = true, pe_info = false, index_remove = false;
     string seq_type = "0";
     string contam[2], ct_match_r, global_contams, g_mrs, g_mms;     // kept here: snk_params points into them
+    string trim_fq[2];                                               // trimFq1 / trimFq2 (gz): trimmed, not filtered
     string base_convert;
 };
 
@@ -147,6 +148,8 @@ void read_config(Options &o, const char *path) {             // src/process_argv
         else if (key == "outFileType") o.out_file_type = val;
         else if (key == "seqType") { o.seq_type = val; if (val != "0" && val != "1") die("seq_type value should be 0 or 1"); }
         else if (key == "index") o.index_remove = true;
+        else if (key == "trimFq1") o.trim_fq[0] = val;
+        else if (key == "trimFq2") o.trim_fq[1] = val;
         else if (key == "contam_trim") p.contam_trim = 1;
         else if (key == "contam1") o.contam[0] = val;
         else if (key == "contam2") o.contam[1] = val;
@@ -703,6 +706,13 @@ int main(int argc, char **argv) {
     OutFile wr[2];
     wr[0].open(o.out_dir + "/" + o.clean1, o.out_gz);
     if (mates == 2) wr[1].open(o.out_dir + "/" + o.clean2, o.out_gz);
+    // trimFq1/trimFq2: every read after trimming, before the discard cascade (src/peprocess.cpp:1460-1466,1938-1944)
+    const bool trim_out = !o.trim_fq[0].empty();
+    OutFile trimw[2];
+    if (trim_out) {
+        if (mates == 2 && o.trim_fq[1].empty()) die("trimFq2 is required with trimFq1");
+        for (int m = 0; m < mates; ++m) trimw[m].open(o.out_dir + "/" + o.trim_fq[m], ends_with_gz(o.trim_fq[m]));
+    }
     Channel<Slot *> free_slots(NSLOT + 1), to_write(NSLOT + 1);
     for (Slot &s : slots) free_slots.push(&s);
     const int dq = o.p.output_quality_phred - o.p.quality_phred;
@@ -710,7 +720,7 @@ int main(int argc, char **argv) {
     uint64_t ndup_written = 0;
     std::thread writer([&] {
         Slot *sp;
-        std::vector<string> text[2], zbuf[2];
+        std::vector<string> text[2], zbuf[2], ttext[2], tzbuf[2];
         struct DupPiece { int vt; string z[2]; };            // one gzip member per (worker slice, virtual thread, mate)
         std::vector<std::vector<DupPiece>> dpieces;
         std::vector<uint64_t> dcount;
@@ -718,49 +728,62 @@ int main(int argc, char **argv) {
             Slot &s = *sp;
             HIPCHK(hipEventSynchronize(s.done));
             const int n = s.n;
-            for (int m = 0; m < mates; ++m) { text[m].assign(WK, string()); zbuf[m].assign(WK, string()); }
+            for (int m = 0; m < mates; ++m) {
+                text[m].assign(WK, string()); zbuf[m].assign(WK, string());
+                ttext[m].assign(WK, string()); tzbuf[m].assign(WK, string());
+            }
             dpieces.assign(WK, std::vector<DupPiece>());
             dcount.assign(WK, 0);
             // clean output, input order (src/peprocess.cpp:3383-3484): every worker formats (and deflates) a slice
             parallel_for(WK, n, [&](int w, int lo, int hi) {
+                // one record of mate m in output form; pe_times: how often preOutput ran on the object
+                // (twice for clean reads when the trim files are on)
+                auto put = [&](string &out, int m, int i, int pe_times) {
+                    const snk_read_result &x = s.h_rec[m][i];
+                    int li, lsq, lql;
+                    const char *id = s.raw[m]->line(4 * i, li), *sq = s.raw[m]->line(4 * i + 1, lsq), *ql = s.raw[m]->line(4 * i + 3, lql);
+                    const size_t id_at = out.size();
+                    if (!o.index_remove) out.append(id, li);
+                    else if (o.seq_type == "0") {                 // "@FC:4:1101:1799:2201#GAAGCACG/2": drop '#'..before '/' (src/read_filter.cpp:357-378)
+                        bool cp = true;
+                        for (int k = 0; k < li; ++k) {
+                            if (id[k] == '#') cp = false;
+                            if (cp) out += id[k];
+                            else if (id[k] == '/') { cp = true; out += id[k]; }
+                        }
+                    } else {                                       // new style: cut at the last ':' (:379-381)
+                        int cut = li;                                  // no ':' at all: substr(0, npos) keeps the whole id
+                        for (int k = li - 1; k >= 0; --k) if (id[k] == ':') { cut = k; break; }
+                        out.append(id, cut);
+                    }
+                    if (o.pe_info && mates == 2)                  // preOutput, src/peprocess.cpp:1617-1628 (seProcess::preOutput has no such step)
+                        for (int t = 0; t < pe_times; ++t) out += (m == 0 ? "/1" : "/2");
+                    if (fasta) {
+                        const size_t at = out.find('@', id_at);
+                        if (at != string::npos) out[at] = '>';
+                    }
+                    out += '\n';
+                    const size_t sq_at = out.size();
+                    out.append(sq + x.clean_start, x.clean_len);
+                    if (bc_from)
+                        for (size_t k = sq_at; k < out.size(); ++k) if (toupper((unsigned char)out[k]) == bc_from) out[k] = bc_to;
+                    if (fasta) { out += '\n'; return; }
+                    out += "\n+\n";
+                    const size_t q_at = out.size();
+                    out.append(ql + x.clean_start, x.clean_len);
+                    if (dq) for (size_t k = q_at; k < out.size(); ++k) out[k] = (char)(out[k] + dq);
+                    out += '\n';
+                };
                 for (int m = 0; m < mates; ++m) {
                     string &out = text[m][w];
                     out.reserve((size_t)(hi - lo) * (size_t)(2 * lcap + 64));
-                    for (int i = lo; i < hi; ++i) {
-                        if (s.h_rec[0][i].reason != SNK_KEEP) continue;
-                        const snk_read_result &x = s.h_rec[m][i];
-                        int li, lsq, lql;
-                        const char *id = s.raw[m]->line(4 * i, li), *sq = s.raw[m]->line(4 * i + 1, lsq), *ql = s.raw[m]->line(4 * i + 3, lql);
-                        const size_t id_at = out.size();
-                        if (!o.index_remove) out.append(id, li);
-                        else if (o.seq_type == "0") {                 // "@FC:4:1101:1799:2201#GAAGCACG/2": drop '#'..before '/' (src/read_filter.cpp:357-378)
-                            bool cp = true;
-                            for (int k = 0; k < li; ++k) {
-                                if (id[k] == '#') cp = false;
-                                if (cp) out += id[k];
-                                else if (id[k] == '/') { cp = true; out += id[k]; }
-                            }
-                        } else {                                       // new style: cut at the last ':' (:379-381)
-                            int cut = li;                                  // no ':' at all: substr(0, npos) keeps the whole id
-                            for (int k = li - 1; k >= 0; --k) if (id[k] == ':') { cut = k; break; }
-                            out.append(id, cut);
-                        }
-                        if (o.pe_info) out += (m == 0 ? "/1" : "/2");            // preOutput, src/peprocess.cpp:1617-1628
-                        if (fasta) {
-                            const size_t at = out.find('@', id_at);
-                            if (at != string::npos) out[at] = '>';
-                        }
-                        out += '\n';
-                        const size_t sq_at = out.size();
-                        out.append(sq + x.clean_start, x.clean_len);
-                        if (bc_from)
-                            for (size_t k = sq_at; k < out.size(); ++k) if (toupper((unsigned char)out[k]) == bc_from) out[k] = bc_to;
-                        if (fasta) { out += '\n'; continue; }
-                        out += "\n+\n";
-                        const size_t q_at = out.size();
-                        out.append(ql + x.clean_start, x.clean_len);
-                        if (dq) for (size_t k = q_at; k < out.size(); ++k) out[k] = (char)(out[k] + dq);
-                        out += '\n';
+                    for (int i = lo; i < hi; ++i)
+                        if (s.h_rec[0][i].reason == SNK_KEEP) put(out, m, i, trim_out ? 2 : 1);
+                    if (trim_out) {
+                        string &tout = ttext[m][w];
+                        tout.reserve((size_t)(hi - lo) * (size_t)(2 * lcap + 64));
+                        for (int i = lo; i < hi; ++i) put(tout, m, i, 1);
+                        if (trimw[m].gz && !tout.empty()) gzip_member(tout, tzbuf[m][w]);
                     }
                     if (wr[m].gz && !out.empty()) gzip_member(out, zbuf[m][w]);
                 }
@@ -794,6 +817,12 @@ int main(int argc, char **argv) {
                     const string &bytes = wr[m].gz ? zbuf[m][w] : text[m][w];
                     if (!bytes.empty()) fwrite(bytes.data(), 1, bytes.size(), wr[m].fp);
                 }
+            if (trim_out)
+                for (int m = 0; m < mates; ++m)
+                    for (int w = 0; w < WK; ++w) {
+                        const string &bytes = trimw[m].gz ? tzbuf[m][w] : ttext[m][w];
+                        if (!bytes.empty()) fwrite(bytes.data(), 1, bytes.size(), trimw[m].fp);
+                    }
             if (d_dup_all)
                 for (int w = 0; w < WK; ++w) {                 // worker order = input order within every side file
                     for (const DupPiece &pc : dpieces[w])
@@ -856,6 +885,7 @@ int main(int argc, char **argv) {
     writer.join();
     join_readers();
     for (int m = 0; m < mates; ++m) wr[m].close();
+    if (trim_out) for (int m = 0; m < mates; ++m) trimw[m].close();
     if (d_dup_all) {
         for (int m = 0; m < mates; ++m) for (int t = 0; t < T; ++t) dupw[m][t].close();
         log << "dup number:\t" << ndup_written << endl;

@@ -172,6 +172,27 @@ def test_cli_contaminants_match_reference_binary(paired, tmp_path):
     assert "Reads with contam sequence" in txt and "Reads with global contam sequence" in txt
 
 
+@pytest.mark.parametrize("paired", [True, False])
+def test_cli_trim_outputs(paired, tmp_path):
+    """config keys trimFq1/trimFq2: every read after trimming, before the cascade; with pe_info the clean ids
+    carry the suffix twice (preOutput ran twice on the object)."""
+    n, L = 8000, 150
+    d = synth.make_batch(n, L, paired=paired, seed=94)
+    cfg = ["trimFq1=t1.fq.gz", "pe_info"] + (["trimFq2=t2.fq.gz", "trimBadTail=20,30"] if paired else [])
+    cli = ["-f", synth.ADAPTER1, "-J", "-t", "2,1,0,3" if paired else "2,1"] + (["-r", synth.ADAPTER2] if paired else [])
+    case = ("trimout", paired, L, n, 2, 300, {}, {}, cli, cfg)
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ours = _run_ours(case, work, gz=False)
+    for f in (R.REPORT_FILES_PE if paired else R.REPORT_FILES_SE):
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in (["c1.fq", "c2.fq", "t1.fq.gz", "t2.fq.gz"] if paired else ["c1.fq", "t1.fq.gz"]):
+        a = _cat(os.path.join(ours, c))
+        assert a == _cat(os.path.join(ref, c)), c
+        if c.startswith("t"):
+            assert a.count(b"\n") == 4 * n
+
+
 def test_cli_error_surface(tmp_path):
     r = subprocess.run([CLI, "filter", "-1", "/nonexistent.fq", "-C", "c.fq", "-o", str(tmp_path)], capture_output=True)
     assert r.returncode == 1 and r.stderr.startswith(b"Error:")
