@@ -148,14 +148,15 @@ __device__ inline int global_contam_pos_seq(const uint8_t *ref, int rl, const ui
     return -1;
 }
 
-// include_contam (bit 0) / include_global_contam (bit 1) of one read, src/read_filter.cpp:189-248
-__device__ inline int contam_flags(const DevParams &P, int mate, const uint8_t *s, int len) {
+// include_contam (bit 0) / include_global_contam (bit 1) of one read, src/read_filter.cpp:189-248.
+// ct: the n_ct hasContam() contaminants of this mate, gct: the n_gct global ones (global memory or LDS copies)
+__device__ inline int contam_flags(const DevContam *ct, int n_ct, const DevGContam *gct, int n_gct, const uint8_t *s, int len) {
     int f = 0;
-    for (int i = 0; i < P.n_ct[mate] && !(f & 1); ++i)
-        if (has_contam_seq(s, len, P.ct[mate * SNK_MAX_CONTAMS + i]) >= 0) f |= 1;
-    for (int i = 0; i < P.n_gct && !(f & 2); ++i)
+    for (int i = 0; i < n_ct && !(f & 1); ++i)
+        if (has_contam_seq(s, len, ct[i]) >= 0) f |= 1;
+    for (int i = 0; i < n_gct && !(f & 2); ++i)
         for (int d = 0; d < 2 && !(f & 2); ++d)
-            if (global_contam_pos_seq(s, len, P.gct[i].seq[d], P.gct[i].len, P.gct[i].min_match_len, P.gct[i].mm) >= 0) f |= 2;
+            if (global_contam_pos_seq(s, len, gct[i].seq[d], gct[i].len, gct[i].min_match_len, gct[i].mm) >= 0) f |= 2;
     return f;
 }
 

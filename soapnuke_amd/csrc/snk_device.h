@@ -97,6 +97,7 @@ struct DevBatch {
     const uint8_t *qual[2];
     const uint16_t *len[2];
     const uint8_t *dup;
+    const uint8_t *cf;          // tiled kernel: contaminant verdicts from snk_contam_kernel (bits 0-1 mate 1, bits 2-3 mate 2) or null
     uint64_t first_index;
     snk_read_result *out[2];
 };
@@ -117,6 +118,8 @@ void snk_launch_generic(const DevParams *dp, const DevBatch &b, const DevStats &
 int snk_launch_tiled(const DevParams &dp_host, const TileAdapters &ta, const DevBatch &b,
                      const DevStats &st, int lcap, int nq, int n_cu, void *stream);
 void snk_launch_finalize(const DevStats &st, int lcap, int nq, void *stream);
+// contaminant verdicts of a batch (one work-item per pair) into cf[n], for the tiled kernel
+void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, void *stream);
 
 // rmdup pre-pass (snk_rmdup.hip); return 0 or a hipError_t
 int snk_launch_hash(const uint8_t *const seq[2], const uint16_t *const len[2], const int fixed_len[2], int pitch, long n,

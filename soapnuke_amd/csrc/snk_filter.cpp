@@ -343,7 +343,7 @@ static int build_ctx(snk_ctx *c) {
     D.lcap = c->lcap;
     D.n_ada[0] = P.n_adapters[0];
     D.n_ada[1] = P.n_adapters[1];
-    D.tile_ok = (n_ct[0] | n_ct[1] | n_gct) ? 0 : 1;   // contaminant screening: generic kernel
+    D.tile_ok = 1;
     D.need_n = 0;
     D.n_ct[0] = n_ct[0]; D.n_ct[1] = n_ct[1]; D.n_gct = n_gct;
     D.contam_discard = P.contam_trim ? 0 : 1;        // gp.contam_discard_or_trim == "discard"
@@ -554,7 +554,17 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         c->ts_used[slot] = true;
         c->ts_stream[slot] = stream;
         st.tsw = c->d_tsw + (size_t)slot * c->n_cu * 4 * SNK_TS_N;
+        unsigned char *d_cf = nullptr;
+        if ((c->hp.n_ct[0] | c->hp.n_ct[1] | c->hp.n_gct) && c->hp.tile_ok && c->lcap <= 256) {
+            // contaminant screening: the sequential matchers run as their own pass, the tiled kernel
+            // consumes the verdicts (stream-ordered scratch)
+            HIP_OK(hipMallocAsync((void **)&d_cf, (size_t)b->n, s));
+            snk_launch_contam(c->d_params, D, d_cf, stream);
+            D.cf = d_cf;
+        }
         done = snk_launch_tiled(c->hp, c->ta, D, st, c->lcap, c->nq, c->n_cu, stream);
+        if (d_cf) HIP_OK(hipFreeAsync(d_cf, s));
+        D.cf = nullptr;
         if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return SNK_E_UNSUPPORTED; }
     }
     if (!done) snk_launch_generic(c->d_params, D, st, c->lcap, c->nq, stream);

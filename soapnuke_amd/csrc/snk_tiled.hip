@@ -700,7 +700,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
     int v = 0, reason = SNK_KEEP;
     if (live) {
         const int dup = B.dup ? (int)B.dup[t0 + lane] : 0;
-        reason = pe ? discard_reason(P, r0, r1, dup, v) : discard_reason(P, r0, r0, dup, v);
+        const int cfv = B.cf ? (int)B.cf[t0 + lane] : 0;      // contaminant verdicts (snk_contam_kernel), rare configuration
+        reason = pe ? discard_reason(P, r0, r1, dup, v, cfv & 3, (cfv >> 2) & 3) : discard_reason(P, r0, r0, dup, v, cfv & 3, cfv & 3);
         store_rec(B.out[0], t0 + lane, r0, reason, v);
         if (pe) store_rec(B.out[1], t0 + lane, r1, reason, v);
     }

@@ -271,15 +271,17 @@ def test_capacity_boundaries(L):
     assert_same(p, run_hip_device(p, d, 0), T.run_oracle(p, d), True)
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("name", sorted(CONTAM_CASES))
 @pytest.mark.parametrize("paired", [True, False])
-def test_contaminant_screening(name, paired):
-    """contam1/contam2 (+ctMatchR) and global_contams: verdicts computed on the device (generic kernel), SURVEY 8f N3"""
+def test_contaminant_screening(name, paired, kernel):
+    """contam1/contam2 (+ctMatchR) and global_contams, SURVEY 8f N3: verdicts from the sequential matchers on the
+    device -- inline in the generic kernel, or as their own pass in front of the tiled kernel"""
     kw = CONTAM_CASES[name]
     d = synth.make_batch(12000, 150, paired=paired, var_len=(name != "single"), seed=91)
     plant_contams(d, kw)
     p = abi.default_params(paired=paired, max_read_len=150, **contam_kwargs(kw, paired))
-    assert_same(p, run_hip_device(p, d, 0), T.run_oracle(p, d), paired)
+    assert_same(p, run_hip_device(p, d, kernel, chunks=3), T.run_oracle(p, d), paired)
 
 
 def test_contaminant_list_size_mismatch_is_refused():
