@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "../../include/snk_filter.h"
+#include "snk_inflate.h"
 #include "snk_report.h"
 #include "../../include/snk_rmdup.h"
 
@@ -307,45 +308,109 @@ void parallel_for(int workers, int n, const std::function<void(int, int, int)> &
 // n whole FASTQ records of one file as they were read, plus the index of their 4n lines
 struct RawChunk {
     const char *base = nullptr;                        // into `own` (inflated data) or into the mmap of a plain file
-    std::vector<char> own;
+    char *own = nullptr;                               // uninitialised storage (no zero fill of 100+ MB per chunk)
+    size_t own_cap = 0;
+    ~RawChunk() { free(own); }
+    void reserve(size_t n) {
+        if (n <= own_cap) return;
+        own = (char *)realloc(own, n);
+        if (!own) { fprintf(stderr, "Error:out of memory\n"); exit(1); }
+        own_cap = n;
+    }
     std::vector<uint32_t> ls, le;                      // line start / end (end excludes the line terminator)
     int n = 0;
     const char *line(int k, int &len) const { len = (int)(le[k] - ls[k]); return base + ls[k]; }
 };
 
-// gz input (multi-member ok: zlib's gzread): inflate + line index on one thread per file (inflate-bound).
-// Every line loses its last `space_num` characters, the number of trailing white-space characters of the
-// FIRST line of fq1 (src/peprocess.cpp:2066-2077: 1 for "\n", 2 for "\r\n", more with trailing blanks).
-void reader_gz(const string path, int batch, int space_num, Channel<RawChunk *> *out) {
-    gzFile f = gzopen(path.c_str(), "rb");
-    if (!f) die("cannot open file," + path);
-    gzbuffer(f, 1 << 22);
-    const size_t block = (size_t)1 << 26;
+// gz input (multi-member ok): inflate (snk_inflate.h, from the mapped file) + line index on one thread per
+// file.  Every line loses its last `space_num` characters, the number of trailing white-space characters of
+// the FIRST line of fq1 (src/peprocess.cpp:2066-2077: 1 for "\n", 2 for "\r\n", more with trailing blanks).
+// Chunk buffers carry the last 32 KiB of the stream in front of their data (the inflate window).
+// offsets (relative to p) of every '\n' in p[0, n), found by `workers` threads
+void parallel_newlines(const char *p, size_t n, int workers, std::vector<uint32_t> &pos) {
+    pos.clear();
+    const int k = (int)std::max<size_t>(1, std::min<size_t>((size_t)workers, n / (1 << 20)));
+    std::vector<std::vector<uint32_t>> part((size_t)k);
+    parallel_for(k, k, [&](int, int lo, int hi) {
+        for (int w = lo; w < hi; ++w) {
+            const char *a = p + n * (size_t)w / (size_t)k, *e = p + n * (size_t)(w + 1) / (size_t)k;
+            std::vector<uint32_t> &v = part[(size_t)w];
+            v.reserve((size_t)(e - a) / 64 + 16);
+            while (a < e && (a = (const char *)memchr(a, '\n', (size_t)(e - a)))) { v.push_back((uint32_t)(a - p)); ++a; }
+        }
+    });
+    size_t tot = 0;
+    for (auto &v : part) tot += v.size();
+    pos.reserve(tot);
+    for (auto &v : part) pos.insert(pos.end(), v.begin(), v.end());
+}
+
+void reader_gz(const string path, int batch, int space_num, int workers, Channel<RawChunk *> *out) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) die("cannot open file," + path);
+    struct stat st;
+    fstat(fd, &st);
+    const uint8_t *zin = (const uint8_t *)mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (zin == MAP_FAILED) die("cannot map file," + path);
+    madvise((void *)zin, (size_t)st.st_size, MADV_SEQUENTIAL);
+    snk::GzipInflate z;
+    z.init(zin, (size_t)st.st_size);
+    z.set_verify_crc(false);
+    // the CRC-32 of the members is checked by a helper thread, one decoded block behind the decoder
+    struct CrcJob { const uint8_t *p; size_t n; std::vector<snk::GzipInflate::MemberEnd> ends; };
+    Channel<CrcJob> crc_q(64);
+    std::atomic<int> crc_pending(0);
+    std::thread crc_thread([&] {
+        CrcJob j;
+        uint32_t crc = 0;
+        while (crc_q.pop(j)) {
+            size_t pos = 0;
+            for (const auto &e : j.ends) {
+                crc = (uint32_t)crc32_z(crc, j.p + pos, e.out_off - pos);
+                if (crc != e.crc) die("read error in input fastq (gzip CRC mismatch)," + path);
+                crc = 0;
+                pos = e.out_off;
+            }
+            crc = (uint32_t)crc32_z(crc, j.p + pos, j.n - pos);
+            --crc_pending;
+        }
+    });
+    auto crc_drain = [&] { while (crc_pending.load() > 0) std::this_thread::yield(); };   // before a buffer changes hands
+    const size_t H = snk::GzipInflate::HIST, block = (size_t)1 << 24;
     RawChunk *cur = new RawChunk;
-    cur->own.resize(block * 2);
-    size_t fill = 0, scan = 0, line_start = 0;
+    const size_t cap0 = H + (size_t)batch * 400 + 2 * block;      // a whole batch of ~150 bp records without regrowth
+    cur->reserve(cap0);
+    memset(cur->own, 0, H);
+    size_t fill = 0, scan = 0, line_start = 0;          // relative to the data area (own.data() + H)
     bool eof = false;
     const size_t want = (size_t)batch * 4;
+    std::vector<uint32_t> nlpos;
     auto add_line = [&](size_t s, size_t e_incl_nl) {
         size_t e = e_incl_nl > s + (size_t)space_num ? e_incl_nl - (size_t)space_num : s;
         cur->ls.push_back((uint32_t)s);
         cur->le.push_back((uint32_t)e);
     };
     for (;;) {
-        while (scan < fill && cur->ls.size() < want) {
-            const char *p = (const char *)memchr(cur->own.data() + scan, '\n', fill - scan);
-            if (!p) { scan = fill; break; }
-            const size_t nl = (size_t)(p - cur->own.data());
-            add_line(line_start, nl + 1);
-            line_start = scan = nl + 1;
+        char *data = cur->own + H;
+        if (scan < fill && cur->ls.size() < want) {     // index the new text (the inflate thread only waits for the scan)
+            parallel_newlines(data + scan, fill - scan, workers, nlpos);
+            const size_t base_off = scan;
+            scan = fill;
+            for (uint32_t rel : nlpos) {
+                const size_t nl = base_off + rel;
+                add_line(line_start, nl + 1);
+                line_start = nl + 1;
+                if (cur->ls.size() == want) break;      // the rest is indexed again as part of the next chunk
+            }
         }
-        if (cur->ls.size() == want) {                  // a full batch: hand it over, keep the unread tail
+        if (cur->ls.size() == want) {                  // a full batch: hand it over, keep the unread tail + window
             RawChunk *next = new RawChunk;
-            next->own.resize(std::max(cur->own.size(), block * 2));
+            next->reserve(std::max(cur->own_cap, cap0));
             const size_t left = fill - line_start;
-            memcpy(next->own.data(), cur->own.data() + line_start, left);
+            memcpy(next->own, data + line_start - H, H + left);   // (reaches into cur's own window area: valid)
             cur->n = batch;
-            cur->base = cur->own.data();
+            cur->base = data;
+            crc_drain();
             out->push(cur);
             cur = next;
             fill = left;
@@ -357,18 +422,23 @@ void reader_gz(const string path, int batch, int space_num, Channel<RawChunk *> 
             if (line_start < fill) add_line(line_start, fill + (size_t)space_num);       // last line without '\n'
             if (cur->ls.size() % 4) die("truncated fastq record");
             cur->n = (int)(cur->ls.size() / 4);
-            cur->base = cur->own.data();
+            cur->base = data;
+            crc_drain();
             if (cur->n) out->push(cur); else delete cur;
             break;
         }
-        if (fill + block > cur->own.size()) cur->own.resize(cur->own.size() * 2);
-        const int got = gzread(f, cur->own.data() + fill, (unsigned)block);
-        if (got < 0) die("read error in input fastq");
-        if (got == 0) eof = true;
-        fill += (size_t)got;
+        if (H + fill + block > cur->own_cap) { crc_drain(); cur->reserve(cur->own_cap * 2); data = cur->own + H; }
+        const size_t got = z.run((uint8_t *)data + fill, block);
+        if (z.error()) die(string("read error in input fastq (") + z.error() + ")," + path);
+        if (got) { ++crc_pending; crc_q.push(CrcJob{(const uint8_t *)data + fill, got, z.member_ends()}); }
+        if (got == 0 && z.done()) eof = true;
+        fill += got;
         if (fill > 0xF0000000ull) die("batch larger than 4 GB: lower the batch size");
     }
-    gzclose(f);
+    crc_q.close();
+    crc_thread.join();
+    munmap((void *)zin, (size_t)st.st_size);
+    close(fd);
     out->close();
 }
 
@@ -456,7 +526,7 @@ bool is_gzip_file(const string &path) {
 void reader_main(const string path, int batch, int space_num, int workers, Channel<RawChunk *> *out) {
     struct stat st;
     if (stat(path.c_str(), &st) != 0 || st.st_size == 0) die("cannot open file or empty file," + path);
-    if (is_gzip_file(path)) reader_gz(path, batch, space_num, out);
+    if (is_gzip_file(path)) reader_gz(path, batch, space_num, workers, out);
     else reader_plain(path, batch, space_num, workers, out);
 }
 
