@@ -361,42 +361,65 @@ private:
         }
         const uint32_t lmask = (1u << LIT_BITS) - 1, dmask = (1u << DIST_BITS) - 1;
         for (;;) {
-            // fast path: room for the longest match plus the copy overrun, input for a whole symbol pair
+            // fast path: room for the longest match plus the copy overrun, input for a whole symbol pair.
+            // The bit buffer lives in locals: the byte stores to `out` may alias the members and would
+            // force them through memory on every literal.
             if (out_end - out >= 258 + 8 && in_end_ - in_ >= 16) {
-                refill();
-                uint32_t e = lit_[bitbuf_ & lmask];
-                if (((e >> 8) & 15) == T_SUB) e = lit_[(e >> 16) + ((bitbuf_ >> LIT_BITS) & ((1u << ((e >> 12) & 15)) - 1))];
-                const uint32_t t = (e >> 8) & 15;
-                bitbuf_ >>= (e & 0xFF); bitcnt_ -= (int)(e & 0xFF);
-                if (t == T_LIT) {
-                    *out++ = (uint8_t)(e >> 16);
-                    // a second literal from the same refill (48 bits are still there)
-                    uint32_t e2 = lit_[bitbuf_ & lmask];
-                    if (((e2 >> 8) & 15) == T_LIT) {
-                        bitbuf_ >>= (e2 & 0xFF); bitcnt_ -= (int)(e2 & 0xFF);
-                        *out++ = (uint8_t)(e2 >> 16);
+                uint64_t bb = bitbuf_;
+                int bc = bitcnt_;
+                const uint8_t *in = in_;
+                const uint8_t *const in_lim = in_end_ - 16;
+                uint8_t *const out_lim = out_end - (258 + 8);
+                const uint64_t member_base = member_out_ - (uint64_t)(acc_from_ - out);   // bytes of the member before `out`
+                uint8_t *const out_base = out;
+                const char *bad = nullptr;
+                bool eob = false;
+                while (out <= out_lim && in <= in_lim) {
+                    uint64_t w;
+                    memcpy(&w, in, 8);
+                    bb |= w << bc;
+                    in += (63 - bc) >> 3;
+                    bc |= 56;
+                    uint32_t e = lit_[bb & lmask];
+                    if (__builtin_expect(((e >> 8) & 15) == T_SUB, 0)) e = lit_[(e >> 16) + ((bb >> LIT_BITS) & ((1u << ((e >> 12) & 15)) - 1))];
+                    uint32_t t = (e >> 8) & 15;
+                    bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
+                    if (t == T_LIT) {                       // up to three literals per refill (3 x 15 bits <= 56)
+                        *out++ = (uint8_t)(e >> 16);
+                        e = lit_[bb & lmask];
+                        if (((e >> 8) & 15) != T_LIT) continue;
+                        bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
+                        *out++ = (uint8_t)(e >> 16);
+                        e = lit_[bb & lmask];
+                        if (((e >> 8) & 15) != T_LIT) continue;
+                        bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
+                        *out++ = (uint8_t)(e >> 16);
+                        continue;
                     }
-                    continue;
+                    if (__builtin_expect(t == T_LEN, 1)) {
+                        const int xb = (int)((e >> 12) & 15);
+                        const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << xb) - 1));
+                        bb >>= xb; bc -= xb;
+                        uint32_t d = dist_[bb & dmask];
+                        if (__builtin_expect(((d >> 8) & 15) == T_SUB, 0)) d = dist_[(d >> 16) + ((bb >> DIST_BITS) & ((1u << ((d >> 12) & 15)) - 1))];
+                        if (__builtin_expect(((d >> 8) & 15) != T_LEN, 0)) { bad = "invalid distance code"; break; }
+                        bb >>= (d & 0xFF); bc -= (int)(d & 0xFF);
+                        const int dxb = (int)((d >> 12) & 15);
+                        const uint32_t dist = (d >> 16) + (uint32_t)(bb & ((1u << dxb) - 1));
+                        bb >>= dxb; bc -= dxb;
+                        if (__builtin_expect((uint64_t)dist > member_base + (uint64_t)(out - out_base), 0)) { bad = "invalid distance too far back"; break; }
+                        copy_match(out, dist, len);
+                        out += len;
+                        continue;
+                    }
+                    if (t == T_EOB) { eob = true; break; }
+                    bad = "invalid literal/length code";
+                    break;
                 }
-                if (t == T_LEN) {
-                    const int xb = (int)((e >> 12) & 15);
-                    const uint32_t len = (e >> 16) + (uint32_t)(bitbuf_ & ((1u << xb) - 1));
-                    bitbuf_ >>= xb; bitcnt_ -= xb;
-                    uint32_t d = dist_[bitbuf_ & dmask];
-                    if (((d >> 8) & 15) == T_SUB) d = dist_[(d >> 16) + ((bitbuf_ >> DIST_BITS) & ((1u << ((d >> 12) & 15)) - 1))];
-                    if (((d >> 8) & 15) != T_LEN) { err_ = "invalid distance code"; return out; }
-                    bitbuf_ >>= (d & 0xFF); bitcnt_ -= (int)(d & 0xFF);
-                    const int dxb = (int)((d >> 12) & 15);
-                    const uint32_t dist = (d >> 16) + (uint32_t)(bitbuf_ & ((1u << dxb) - 1));
-                    bitbuf_ >>= dxb; bitcnt_ -= dxb;
-                    if ((uint64_t)dist > in_member(out)) { err_ = "invalid distance too far back"; return out; }
-                    copy_match(out, dist, len);
-                    out += len;
-                    continue;
-                }
-                if (t == T_EOB) { state_ = final_ ? MEMBER_TRAILER : BLOCK_HEADER; return out; }
-                err_ = "invalid literal/length code";
-                return out;
+                bitbuf_ = bb; bitcnt_ = bc; in_ = in;
+                if (bad) { err_ = bad; return out; }
+                if (eob) { state_ = final_ ? MEMBER_TRAILER : BLOCK_HEADER; return out; }
+                if (out_end - out >= 258 + 8 && in_end_ - in_ >= 16) continue;      // (cannot happen; keeps the invariant obvious)
             }
             // careful path (ends of the buffers): one symbol at a time, everything checked
             if (out == out_end) return out;

@@ -1,0 +1,67 @@
+"""The CLI's own gzip/DEFLATE decoder (soapnuke_amd/host/snk_inflate.h) against zlib: byte-identical output on
+every kind of stream the reader can meet, errors on damaged ones.  Pure host code (g++ + zlib), no GPU."""
+import gzip
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import snk_testlib as T
+from soapnuke_amd import synth
+
+SRC = os.path.join(T.ROOT, "tools", "micro", "inflate_test.cpp")
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("inf") / "inflate_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", out, SRC, "-lz"])
+    return out
+
+
+def _fastq_bytes(n=20000):
+    d = synth.make_batch(n, 150, paired=False, seed=3)
+    rows = []
+    for i in range(n):
+        rows.append(b"@SNK:1:1101:%09d/1\n" % i + d["seq"][0][i, :150].tobytes() + b"\n+\n" + d["qual"][0][i, :150].tobytes() + b"\n")
+    return b"".join(rows)
+
+
+def test_identical_to_zlib(exe, tmp_path):
+    raw = _fastq_bytes()
+    files = {}
+    for lvl in (1, 2, 6, 9):
+        files[f"l{lvl}"] = gzip.compress(raw, compresslevel=lvl)
+    co = zlib.compressobj(0, zlib.DEFLATED, 31)
+    files["stored"] = co.compress(raw[:1500000]) + co.flush()
+    files["multi"] = gzip.compress(raw[:1000], 1) + gzip.compress(b"", 6) + gzip.compress(raw[1000:2_000_000], 2) + gzip.compress(raw[2_000_000:], 9)
+    files["empty"] = gzip.compress(b"")
+    files["tiny"] = gzip.compress(b"@r\nACGT\n+\nIIII\n")
+    files["runs"] = gzip.compress(b"A" * 1_000_000 + b"ACGT" * 100000, 9)
+    files["random"] = gzip.compress(np.random.default_rng(1).integers(0, 256, 1_000_000, dtype=np.uint8).tobytes(), 6)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)                  # fixed Huffman blocks
+    files["fixed"] = co.compress(raw[:300000]) + co.flush()
+    files["named_header"] = b"\x1f\x8b\x08\x08\x00\x00\x00\x00\x00\x03name.fq\x00" + gzip.compress(raw[:50000])[10:]
+    for name, blob in files.items():
+        p = str(tmp_path / (name + ".gz"))
+        open(p, "wb").write(blob)
+        for chunk in ("4194304", "777"):                                          # big blocks; tiny blocks = careful path + cut matches
+            r = subprocess.run([exe, p, chunk], capture_output=True)
+            assert r.returncode == 0 and b"IDENTICAL" in r.stdout, (name, chunk, r.stdout[-200:])
+
+
+def test_damaged_streams_are_errors(exe, tmp_path):
+    raw = _fastq_bytes(3000)
+    good = gzip.compress(raw, 6)
+    bad_crc = bytearray(good)
+    bad_crc[-6] ^= 0x55
+    truncated = good[: len(good) // 2]
+    flipped = bytearray(good)
+    flipped[len(good) // 2] ^= 0xFF
+    for name, blob in (("crc", bytes(bad_crc)), ("trunc", truncated), ("flip", bytes(flipped)), ("notgz", b"@r\nACGT\n+\nIIII\n" * 10)):
+        p = str(tmp_path / (name + ".gz"))
+        open(p, "wb").write(blob)
+        r = subprocess.run([exe, p, "65536"], capture_output=True)
+        assert r.returncode == 2 and b"ERROR" in r.stdout, (name, r.stdout[-200:])
