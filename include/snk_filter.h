@@ -96,7 +96,9 @@ typedef struct snk_batch {
     const uint8_t  *seq[2];   /* seq[1]/qual[1] ignored for SE */
     const uint8_t  *qual[2];
     const uint16_t *len[2];   /* per-read lengths or NULL */
-    const uint8_t  *dup;      /* per-pair duplicate flag (rmdup) or NULL */
+    const uint8_t  *dup;      /* per-pair host verdicts or NULL: bit 0 duplicate (honoured when params.rmdup;
+                                 from snk_rmdup_mark_device), bit 1 "in a filtered tile", bit 2 "in a filtered
+                                 fov" (decided by the host from the read name, src/read_filter.cpp:14-150) */
     uint64_t first_index;     /* input-order index of pair 0 (for the "last read seen"
                                  semantics of gs.read_length, src/peprocess.cpp:1202) */
 } snk_batch;

@@ -493,7 +493,9 @@ static int pe_discard(const snk_params *P, const rd_t *r1, const rd_t *r2, int d
                       uint64_t *fs, int *vout) {
     int v;
     *vout = 0;
-    if (P->rmdup && dup) { fs[SNK_FS_DUP]++; return SNK_R_DUP; }
+    if (P->rmdup && (dup & 1)) { fs[SNK_FS_DUP]++; return SNK_R_DUP; }
+    if (dup & 2) { fs[SNK_FS_TILE]++; return SNK_R_TILE; }         /* :213-231, verdict of fq1's read name */
+    if (dup & 4) { fs[SNK_FS_FOV]++; return SNK_R_FOV; }
     if (P->min_read_length != -1) {                                /* :232-249 */
         v = pe_dis((uint64_t)r1->clen < (uint64_t)(int64_t)P->min_read_length,
                    (uint64_t)r2->clen < (uint64_t)(int64_t)P->min_read_length);
@@ -542,7 +544,9 @@ static int pe_discard(const snk_params *P, const rd_t *r1, const rd_t *r2, int d
 
 /* se_discard(), src/sequence.cpp:76-178 */
 static int se_discard(const snk_params *P, const rd_t *r, int dup, uint64_t *fs) {
-    if (P->rmdup && dup) { fs[SNK_FS_DUP]++; return SNK_R_DUP; }
+    if (P->rmdup && (dup & 1)) { fs[SNK_FS_DUP]++; return SNK_R_DUP; }
+    if (dup & 2) { fs[SNK_FS_TILE]++; return SNK_R_TILE; }         /* :84-99 */
+    if (dup & 4) { fs[SNK_FS_FOV]++; return SNK_R_FOV; }
     if (P->min_read_length != -1 &&
         (uint64_t)r->clen < (uint64_t)(int64_t)P->min_read_length) { fs[SNK_FS_SHORT]++; return SNK_R_SHORT; }
     if (P->max_read_length != -1 &&

@@ -202,7 +202,9 @@ __device__ inline int discard_reason(const DevParams &P, const ReadState &a, con
 #define SNK_TEST(COND_A, COND_B, REASON)                 \
     v = pe_dis((COND_A), pe && (COND_B));                \
     if (v > 0) { vout = pe ? v : 0; return REASON; }
-    if (P.rmdup && dup) return SNK_R_DUP;
+    if (P.rmdup && (dup & 1)) return SNK_R_DUP;
+    if (dup & 2) return SNK_R_TILE;                                  // src/sequence.cpp:213-231 (fq1's read name decides)
+    if (dup & 4) return SNK_R_FOV;
     if (P.has_min) {
         SNK_TEST((u32)a.clen < P.min_len_u, (u32)b.clen < P.min_len_u, SNK_R_SHORT)
     } else if (pe && (a.clen == 0 || b.clen == 0)) {

@@ -530,7 +530,7 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         D.qual[m] = m < mates ? b->qual[m] : nullptr;
         D.len[m] = m < mates ? b->len[m] : nullptr;
     }
-    D.dup = c->p.rmdup ? b->dup : nullptr;
+    D.dup = b->dup;                                   // bit 0 needs params.rmdup (checked in the cascade), bits 1-2 do not
     D.first_index = b->first_index;
     D.out[0] = d_out1;
     D.out[1] = d_out2;
@@ -612,7 +612,7 @@ int snk_filter_batch(snk_ctx *c, const snk_batch *b, snk_read_result *out1, snk_
             d.len[m] = (const uint16_t *)(c->st_buf + o_len[m]);
         }
     }
-    if (b->dup && c->p.rmdup) {
+    if (b->dup) {
         HIP_OK(hipMemcpyAsync(c->st_buf + o_dup, b->dup, n, hipMemcpyHostToDevice, 0));
         d.dup = c->st_buf + o_dup;
     }

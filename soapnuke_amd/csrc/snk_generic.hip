@@ -66,6 +66,8 @@ __device__ void fastq_trim_dev(const DevParams &P, int mate, const uint8_t *s, c
 
 __device__ void count_reason(unsigned long long *fs, bool pe, int reason, int v) {
     if (reason == SNK_R_DUP) { atomicAdd(&fs[SNK_FS_DUP], 1ull); return; }
+    if (reason == SNK_R_TILE) { atomicAdd(&fs[SNK_FS_TILE], 1ull); return; }
+    if (reason == SNK_R_FOV) { atomicAdd(&fs[SNK_FS_FOV], 1ull); return; }
     const int f = reason_family(reason);
     if (f < 0) return;
     atomicAdd(&fs[f], 1ull);

@@ -714,6 +714,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         if (__any(live && reason != SNK_KEEP)) {
             // per-lane LDS adds (a dozen lanes, same-address conflicts are cheaper than walking the families)
             if (live && reason == SNK_R_DUP) atomicAdd(&fs[SNK_FS_DUP], 1u);
+            if (live && reason == SNK_R_TILE) atomicAdd(&fs[SNK_FS_TILE], 1u);
+            if (live && reason == SNK_R_FOV) atomicAdd(&fs[SNK_FS_FOV], 1u);
             const int fam = reason_family(reason);
             if (live && fam >= 0) {
                 atomicAdd(&fs[fam], 1u);

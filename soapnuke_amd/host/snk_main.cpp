@@ -30,6 +30,7 @@
 #include <fstream>
 #include <functional>
 #include <iostream>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -58,6 +59,7 @@ struct Options {
     string seq_type = "0";
     string contam[2], ct_match_r, global_contams, g_mrs, g_mms;     // kept here: snk_params points into them
     string trim_fq[2];                                               // trimFq1 / trimFq2 (gz): trimmed, not filtered
+    string tile, fov;                                                // reads of these tiles / fovs are dropped (by name)
     string base_convert;
 };
 
@@ -149,6 +151,8 @@ void read_config(Options &o, const char *path) {             // src/process_argv
         else if (key == "outFileType") o.out_file_type = val;
         else if (key == "seqType") { o.seq_type = val; if (val != "0" && val != "1") die("seq_type value should be 0 or 1"); }
         else if (key == "index") o.index_remove = true;
+        else if (key == "tile") o.tile = val;
+        else if (key == "fov") o.fov = val;
         else if (key == "trimFq1") o.trim_fq[0] = val;
         else if (key == "trimFq2") o.trim_fq[1] = val;
         else if (key == "contam_trim") p.contam_trim = 1;
@@ -244,6 +248,7 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
     o.p.n_adapters[1] = (int)o.ada2.size();
     for (size_t i = 0; i < o.ada1.size(); ++i) o.p.adapters[0][i] = o.ada1[i].c_str();
     for (size_t i = 0; i < o.ada2.size(); ++i) o.p.adapters[1][i] = o.ada2[i].c_str();
+    if (!o.fov.empty() && o.seq_type != "0") { cerr << "Warning:Zebra-500 data(--fov), --seqType is 0" << endl; exit(1); }   // src/read_filter.cpp:137-140
     o.p.contam[0] = o.contam[0].empty() ? nullptr : o.contam[0].c_str();
     o.p.contam[1] = o.contam[1].empty() ? nullptr : o.contam[1].c_str();
     o.p.ct_match_r = o.ct_match_r.empty() ? nullptr : o.ct_match_r.c_str();
@@ -260,6 +265,53 @@ string local_time() {                                   // get_local_time(), src
     std::ostringstream s;
     s << l->tm_year + 1900 << "-" << l->tm_mon + 1 << "-" << l->tm_mday << "  " << l->tm_hour << ":" << l->tm_min << ":" << l->tm_sec;
     return s.str();
+}
+
+// ------------------------------------------------------------------ tile / fov verdicts from the read name
+// check_tile_or_fov(), src/read_filter.cpp:14-79: only whole list elements ever match; a range element
+// "a-b" is parsed (and its format checked) but compared as a string, so it never matches a 4-digit tile.
+bool check_tile_or_fov(const string &tile, const string &param) {
+    auto check_range = [](const string &e) {
+        if (split(e, '-').size() != 2) die("input tile parameter format error," + e);
+    };
+    if (param.find(",") == string::npos) {
+        if (param.find("C") == string::npos && param.find("-") != string::npos) {
+            check_range(param);
+            const auto e = split(param, '-');
+            return atoi(e[0].c_str()) <= atoi(e[1].c_str()) && tile == param;
+        }
+        return tile == param;
+    }
+    const bool fov_style = param.find("C") != string::npos;
+    for (const string &e : split(param, ',')) {
+        if (!fov_style && e.find("-") != string::npos) {
+            check_range(e);
+            const auto r = split(e, '-');
+            if (atoi(r[0].c_str()) <= atoi(r[1].c_str()) && tile == e) return true;
+        } else if (e == tile) return true;
+    }
+    return false;
+}
+// read_tile / read_fov of stat_read(), src/read_filter.cpp:86-150 (its stderr warnings are not reproduced)
+string read_tile(const char *id, int n, const string &seq_type) {
+    const int want = seq_type == "0" ? 2 : 4;
+    int i = 0, num = 0;
+    for (; i < n; ++i) {
+        if (id[i] == ':') ++num;
+        if (num >= want) break;
+    }
+    string t;
+    for (int j = 0; j != 4; ++j) {
+        const int k = i + j + 1;
+        if (k < n && id[k] >= '0' && id[k] <= '9') t += id[k];
+    }
+    return t;
+}
+string read_fov(const char *id, int n) {
+    int i = 0;
+    for (; i < n; ++i)
+        if (id[i] == 'C' && i + 8 < n && id[i + 4] == 'R') break;
+    return i < n ? string(id + i, (size_t)std::min(8, n - i)) : string();
 }
 
 // ------------------------------------------------------------------ host pipeline pieces
@@ -589,6 +641,7 @@ struct Slot {                                           // one batch in flight
     uint8_t *h_seq[2] = {nullptr, nullptr}, *h_qual[2] = {nullptr, nullptr}, *d_seq[2] = {nullptr, nullptr}, *d_qual[2] = {nullptr, nullptr};
     uint16_t *h_len[2] = {nullptr, nullptr}, *d_len[2] = {nullptr, nullptr};
     snk_read_result *h_rec[2] = {nullptr, nullptr}, *d_rec[2] = {nullptr, nullptr};
+    uint8_t *h_flags = nullptr, *d_flags = nullptr;      // per-pair host verdicts (tile / fov bits, + the duplicate bit)
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     RawChunk *raw[2] = {nullptr, nullptr};
@@ -622,14 +675,19 @@ int main(int argc, char **argv) {
     }
 
     // ---- readers
-    Channel<RawChunk *> chan[2] = {Channel<RawChunk *>(2), Channel<RawChunk *>(2)};
+    std::unique_ptr<Channel<RawChunk *>> chan[2];          // one per input file, re-made for every pass over the input
     std::vector<std::thread> readers;
-    auto start_readers = [&] { for (int m = 0; m < mates; ++m) readers.emplace_back(reader_main, inputs[m], B, space_num, std::max(1, WK / mates), &chan[m]); };
+    auto start_readers = [&] {
+        for (int m = 0; m < mates; ++m) {
+            chan[m].reset(new Channel<RawChunk *>(2));
+            readers.emplace_back(reader_main, inputs[m], B, space_num, std::max(1, WK / mates), chan[m].get());
+        }
+    };
     auto join_readers = [&] { for (auto &t : readers) t.join(); readers.clear(); };
     auto next_chunks = [&](RawChunk *c[2]) -> bool {
         bool ok[2] = {true, true};
         c[0] = c[1] = nullptr;
-        for (int m = 0; m < mates; ++m) ok[m] = chan[m].pop(c[m]);
+        for (int m = 0; m < mates; ++m) ok[m] = chan[m]->pop(c[m]);
         if (mates == 2 && (ok[0] != ok[1] || (ok[0] && c[0]->n != c[1]->n))) die("reads number in fq1 and fq2 are different");
         return ok[0];
     };
@@ -670,6 +728,7 @@ int main(int argc, char **argv) {
             HIPCHK(hipMalloc(&s.d_len[m], (size_t)B * 2)); HIPCHK(hipMalloc(&s.d_rec[m], (size_t)B * sizeof(snk_read_result)));
             memset(s.h_seq[m], 0, plane); memset(s.h_qual[m], 0, plane);
         }
+        HIPCHK(hipHostMalloc(&s.h_flags, (size_t)B)); HIPCHK(hipMalloc(&s.d_flags, (size_t)B));
         HIPCHK(hipStreamCreate(&s.stream));
         HIPCHK(hipEventCreate(&s.done));
     }
@@ -696,6 +755,7 @@ int main(int argc, char **argv) {
     // ---- rmdup pre-pass (src/peprocess.cpp:3071-3152): hash every raw pair on the GPU, keep the hashes
     // resident, mark every later occurrence; the flags enter the cascade as snk_batch.dup below.
     uint8_t *d_dup_all = nullptr;
+    std::vector<uint8_t> dup_host;                        // the same flags on the host (combined with tile/fov bits per batch)
     std::vector<OutFile> dupw[2];
     if (o.p.rmdup) {
         std::vector<uint64_t *> chunks;
@@ -759,15 +819,15 @@ int main(int argc, char **argv) {
             std::vector<uint8_t> eff(flags);
             for (uint64_t i = 0; i < full_end; ++i) eff[i] = i ? flags[i - 1] : 0;
             HIPCHK(hipMemcpy(d_dup_all, eff.data(), (size_t)nall, hipMemcpyHostToDevice));
+            flags.swap(eff);
         }
+        dup_host.swap(flags);
         for (int m = 0; m < mates; ++m) {                   // dupReads.<thread>.<mate>.gz, src/peprocess.cpp:167-174 (SE: .1.gz only)
             dupw[m].resize(T);
             for (int t = 0; t < T; ++t) dupw[m][t].open(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz", true);
         }
         for (Slot &sl : slots) for (int m = 0; m < mates; ++m) memset(sl.h_seq[m], 0, plane);
         // second pass over the input
-        chan[0].~Channel(); new (&chan[0]) Channel<RawChunk *>(2);
-        chan[1].~Channel(); new (&chan[1]) Channel<RawChunk *>(2);
         start_readers();
         if (!next_chunks(first)) die("no data");
     }
@@ -917,6 +977,20 @@ int main(int argc, char **argv) {
         s.raw[0] = c[0]; s.raw[1] = c[1];
         pack(s, true);
         const int n = s.n;
+        const bool name_verdicts = !o.tile.empty() || !o.fov.empty();
+        if (name_verdicts) {                                // tile / fov of fq1's read name (src/read_filter.cpp:86-150, src/sequence.cpp:213-231)
+            parallel_for(WK, n, [&](int, int lo, int hi) {
+                for (int i = lo; i < hi; ++i) {
+                    int li;
+                    const char *id = s.raw[0]->line(4 * i, li);
+                    uint8_t f = dup_host.empty() ? 0 : (uint8_t)(dup_host[total + (uint64_t)i] & 1);
+                    if (!o.tile.empty() && check_tile_or_fov(read_tile(id, li, o.seq_type), o.tile)) f |= 2;
+                    if (!o.fov.empty() && check_tile_or_fov(read_fov(id, li), o.fov)) f |= 4;
+                    s.h_flags[i] = f;
+                }
+            });
+            HIPCHK(hipMemcpyAsync(s.d_flags, s.h_flags, (size_t)n, hipMemcpyHostToDevice, s.stream));
+        }
         for (int m = 0; m < mates; ++m) {
             HIPCHK(hipMemcpyAsync(s.d_seq[m], s.h_seq[m], (size_t)n * pitch, hipMemcpyHostToDevice, s.stream));
             HIPCHK(hipMemcpyAsync(s.d_qual[m], s.h_qual[m], (size_t)n * pitch, hipMemcpyHostToDevice, s.stream));
@@ -938,7 +1012,8 @@ int main(int argc, char **argv) {
                 b.len[m] = s.d_len[m] + lo;
             }
             b.first_index = g;
-            if (d_dup_all) b.dup = d_dup_all + g;
+            if (name_verdicts) b.dup = s.d_flags + lo;
+            else if (d_dup_all) b.dup = d_dup_all + g;
             if (snk_bind_stats(ctx, d_sum[vt], d_max[vt]) != SNK_OK) die(snk_last_error());
             if (snk_filter_batch_device(ctx, &b, s.d_rec[0] + lo, mates == 2 ? s.d_rec[1] + lo : nullptr, s.stream, 0) != SNK_OK)
                 die(snk_last_error());

@@ -193,6 +193,38 @@ def test_cli_trim_outputs(paired, tmp_path):
             assert a.count(b"\n") == 4 * n
 
 
+@pytest.mark.parametrize("kind,cfgline", [("tile_old", "tile=1102"), ("tile_old", "tile=1101,1104"),
+                                          ("tile_new", "tile=1103,1101"), ("fov", "fov=C002R003"), ("fov", "fov=C001R002,C004R001")])
+def test_cli_tile_and_fov_filters(kind, cfgline, tmp_path):
+    """config keys tile / fov: reads are dropped by name (src/read_filter.cpp:14-150, src/sequence.cpp:213-231),
+    (range elements "a-b" make the reference binary crash: not compared)."""
+    n, L = 4000, 100
+    d = synth.make_batch(n, L, paired=True, seed=73)
+    work = str(tmp_path)
+    for m in (1, 2):
+        with open(os.path.join(work, f"r{m}.fq"), "wb") as f:
+            for i in range(n):
+                t = 1101 + i % 5
+                if kind == "tile_old":
+                    rid = b"@FCD1PB1ACXX:4:%d:%d:2201#GAAGCACG/%d" % (t, i, m)
+                elif kind == "tile_new":
+                    rid = b"@HISEQ:310:C5MH9ANXX:1:%d:%d:2043 %d:N:0:TCGGTCAC" % (t, i, m)
+                else:
+                    rid = b"@CL100012345L1C%03dR%03d_%d/%d" % (1 + i % 4, 1 + i % 3, i, m)
+                f.write(rid + b"\n" + d["seq"][m - 1][i, :L].tobytes() + b"\n+\n" + d["qual"][m - 1][i, :L].tobytes() + b"\n")
+        subprocess.check_call(["gzip", "-1", "-f", "-k", os.path.join(work, f"r{m}.fq")])
+    open(os.path.join(work, "cfg"), "w").write(cfgline + ("\nseqType=1" if kind == "tile_new" else "") + "\npatch=300\n")
+    tail = ["-C", "c1.fq", "-D", "c2.fq", "-T", "2", "-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-c", os.path.join(work, "cfg")]
+    r = subprocess.run([T.REF_BIN, "filter", "-1", os.path.join(work, "r1.fq.gz"), "-2", os.path.join(work, "r2.fq.gz"), "-o", os.path.join(work, "ref")] + tail, capture_output=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    r = subprocess.run([CLI, "filter", "-1", os.path.join(work, "r1.fq"), "-2", os.path.join(work, "r2.fq"), "-o", os.path.join(work, "ours")] + tail, capture_output=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    for c in ("c1.fq", "c2.fq"):
+        assert _cat(os.path.join(work, "ours", c)) == _cat(os.path.join(work, "ref", c)), c
+    for f in R.REPORT_FILES_PE:
+        assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
+
+
 def test_cli_error_surface(tmp_path):
     r = subprocess.run([CLI, "filter", "-1", "/nonexistent.fq", "-C", "c.fq", "-o", str(tmp_path)], capture_output=True)
     assert r.returncode == 1 and r.stderr.startswith(b"Error:")

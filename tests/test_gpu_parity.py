@@ -136,6 +136,21 @@ def test_rmdup_flags(kernel):
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("paired,rmdup", [(True, 1), (True, 0), (False, 1)])
+def test_host_verdict_bits(kernel, paired, rmdup):
+    """snk_batch.dup as a flag byte: bit 0 duplicate (only with params.rmdup), bit 1 tile, bit 2 fov -- the
+    first three steps of the cascade (src/sequence.cpp:200-231)."""
+    n = 6000
+    d = synth.make_batch(n, 150, paired=paired, seed=28)
+    flags = np.random.default_rng(2).choice(np.arange(8, dtype=np.uint8), n, p=[.72, .04, .04, .04, .04, .04, .04, .04])
+    kw = PE_CASES["C2_adatrim_lowq"] if paired else se_kwargs(PE_CASES["C2_adatrim_lowq"])
+    p = abi.default_params(paired=paired, max_read_len=150, rmdup=rmdup, **kw)
+    o = T.run_oracle(p, d, dup=flags)
+    assert_same(p, run_hip_device(p, d, kernel, dup=flags), o, paired)
+    assert o["sum"][1] > 0 and o["sum"][2] > 0 and (o["sum"][0] > 0) == bool(rmdup)      # SNK_FS_TILE, SNK_FS_FOV, SNK_FS_DUP
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
 def test_error_reporting(kernel):
     """unrecognized base / quality out of range: same first-offender as the oracle
     (the reference exit(1)s: src/read_filter.cpp:283)."""
