@@ -60,7 +60,7 @@ struct TileAdapter {
     int32_t len, S, mis, edge, negC;
     int32_t budgetA[6];
     int32_t rk[4];
-    int32_t ncnt;               // unary mismatch-counter planes the screening needs: 2 (all budgets <= 1) or 4
+    int32_t pad_;
 };
 struct TileAdapters { TileAdapter a[2][SNK_TILE_MAX_ADA]; };
 

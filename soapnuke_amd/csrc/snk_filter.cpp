@@ -363,9 +363,6 @@ static int build_ctx(snk_ctx *c) {
                 T.len = A.len; T.S = A.S; T.mis = A.mis; T.edge = A.edge; T.negC = A.negC;
                 for (int k = 0; k < 6; ++k) T.budgetA[k] = A.budgetA[k];
                 for (int k = 0; k < 4; ++k) T.rk[k] = A.rk[k];
-                int maxbc = A.mis;                     // budgets of the screened phases (B: mis, C: budgetC[])
-                for (int r1 = 0; r1 < A.nC && r1 < SNK_DEV_MAX_ADA_LEN; ++r1) if (A.budgetC[r1] > maxbc) maxbc = A.budgetC[r1];
-                T.ncnt = maxbc <= 1 ? 2 : 4;
             }
         }
     D.thr_n = c->d_tables;

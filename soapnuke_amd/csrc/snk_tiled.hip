@@ -218,7 +218,7 @@ __device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C
 }
 
 // Bit-sliced screening of the candidates p = 0 .. len-edge of phases B and C over the first S-1 adapter
-// characters; NC = 2 when no mismatch budget exceeds 1 (the default parameters), else 4.
+// characters with NC unary mismatch-counter planes (4: budgets up to 3, the tiled kernel's limit).
 template <int NW, bool FULL, int NC>
 __device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool done,
                                               u32 (&aliveB)[NW], u32 (&aliveC)[NW]) {
@@ -302,8 +302,7 @@ __device__ int adapter_tile(const TileAdapter &A, const DevAdapter &AG, const u3
     // ---------------- phases B+C screening: candidates p = 0 .. len-edge, bit-sliced
     u32 aliveB[NW], aliveC[NW];
     if (__any(!done)) {
-        if (A.ncnt == 2) screen_planes<NW, FULL, 2>(A, X, XN, len, done, aliveB, aliveC);
-        else screen_planes<NW, FULL, 4>(A, X, XN, len, done, aliveB, aliveC);
+        screen_planes<NW, FULL, 4>(A, X, XN, len, done, aliveB, aliveC);
     } else {
 #pragma unroll
         for (int j = 0; j < NW; ++j) aliveB[j] = aliveC[j] = 0;
