@@ -54,8 +54,9 @@ typedef struct snk_params {
     int32_t min_read_length;      /* gp.min_read_length     (30)  -4 */
     int32_t max_read_length;      /* gp.max_read_length     (-1)     */
     int32_t ada_trim;             /* gp.adapter_discard_or_trim=="trim" (-J) */
-    int32_t contam_trim;          /* gp.contam_discard_or_trim=="trim"; only feeds the
-                                     "copy cut fields back" test, src/peprocess.cpp:1441 */
+    int32_t contam_trim;          /* gp.contam_discard_or_trim=="trim": contaminant hits do not discard (the trimming
+                                     itself is commented out in the reference); also feeds the "copy cut fields
+                                     back" test, src/peprocess.cpp:1441 */
     int32_t has_hard_trim;        /* !gp.trim.empty() (-t) */
     int32_t hard_trim[4];         /* head1,tail1,head2,tail2 (SE: head,tail) */
     int32_t has_lq_trim;          /* trimBadHead or trimBadTail given (-x/-y) */

@@ -366,8 +366,8 @@ typedef struct {
     int start, clen;                     /* trimmed view */
 } rd_t;
 
-/* stat_read(), src/read_filter.cpp:80-313 (tile/fov parts are out of scope: empty
- * parameters make them no-ops, :86,:125)                                       */
+/* stat_read(), src/read_filter.cpp:80-313 (the tile/fov strings of :86-150 depend on the read name only:
+ * the host decides them and passes the verdict as bits 1-2 of snk_batch.dup)   */
 static const contam_cfg *g_ct = NULL;          /* contaminant lists of the batch being processed */
 static int stat_read(const snk_params *P, int mate, const uint8_t *seq,
                      const uint8_t *qual, int len, rd_t *r) {
