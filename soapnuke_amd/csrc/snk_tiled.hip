@@ -33,6 +33,7 @@
 #include <type_traits>
 #include <utility>
 #include "snk_common.cuh"
+#include "snk_bittr.cuh"
 
 using namespace snk;
 
@@ -40,6 +41,12 @@ using namespace snk;
 // 3 = no phase 3, 4 = no adapter search.  The shipped library is built with 0.
 #ifndef SNK_ABL
 #define SNK_ABL 0
+#endif
+// 1: the base planes travel from lane = position to lane = read as 2-bit codes collected with
+// v_alignbit and one 64x64 bit-matrix transpose per strip (snk_bittr.cuh); 0: four ballots + eight
+// v_writelane per strip and read (the first design, kept for A/B timing)
+#ifndef SNK_TR
+#define SNK_TR 1
 #endif
 
 extern "C" __device__ int __snk_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
@@ -406,6 +413,13 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             XN[j] = FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
         }
         int v_sumq = 0, v_lowq = 0;
+        // SNK_TR: lane = position collects bit 1 (cL) and bit 2 (cH) of the characters of the reads it has seen,
+        // newest read on top (A 00, C 01, T 10, G 11); reads 0..31 are parked in pL/pH when read 32 arrives.
+        // nf: scalar mask of the reads holding anything but ACGT (they go through the fix-up pass).
+        u32 cL[NS], cH[NS], pL[NS], pH[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) cL[s] = cH[s] = pL[s] = pH[s] = 0;
+        u64 nf = 0;
         const bool has_meanq = __builtin_amdgcn_readfirstlane(P.has_meanq) != 0;
         const int len0 = rl(clen_v, 0);
         const bool fixed = __all(!lanev || clen_v == len0);
@@ -423,10 +437,17 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
             int nlow = 0;
             u32 prev_last = 0xFFFFFFFFu;
+            u64 inv = 0;
+            if (SNK_TR && r == 32) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { pL[s] = cL[s]; pH[s] = cH[s]; }
+            }
             static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                 constexpr int s = decltype(sc)::v;
                 const int pos = 64 * s + lane;
                 const u32 c = cc[s];
+                u32 code = __builtin_amdgcn_ubfe(c, 1u, 2u);
+                if (SNK_TR) asm("" : "+v"(code));     // one v_bfe feeds the row address, the bit collector and the ACGT test
 #define SNK_PUT(PL, VAL)                                                                   \
     {                                                                                      \
         const u64 val_ = (VAL);                                                            \
@@ -436,7 +457,15 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             if (2 * s + 1 < NW) PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = wl(PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0], (int)(u32)(val_ >> 32), r); \
         }                                                                                  \
     }
-                {   // the four compares first, into four SGPR pairs: a v_writelane right behind the compare
+                if (SNK_TR) {
+                    cL[s] = __builtin_amdgcn_alignbit(code, cL[s], 1u);
+                    cH[s] = __builtin_amdgcn_alignbit(c >> 2, cH[s], 1u);
+                    // exact ACGT test: the character its own bits 1-2 stand for (byte `code` of "ACTG") vs the character
+                    const u32 ex = __builtin_amdgcn_perm(0u, 0x47544341u, code);
+                    u64 bal;
+                    asm("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_0 src1_sel:BYTE_0" : "=s"(bal) : "v"(ex), "v"(c));
+                    inv |= (FULLLEN && s < NS - 1) ? bal : (bal & lowmask64(len_r - 64 * s));
+                } else {   // the four compares first, into four SGPR pairs: a v_writelane right behind the compare
                     // that produced its operand stalls on the VALU -> SGPR write
                     u64 b0 = __ballot(c == 'A'), b1 = __ballot(c == 'C'), b2 = __ballot(c == 'G'), b3 = __ballot(c == 'T');
                     asm volatile("" : "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3));
@@ -466,7 +495,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 // LDS base rows are ordered by bits 1-2 of the character (A 00, C 01, T 10, G 11, then N):
                 // the row address is one shift-add of (c & 6); the flush swaps rows 2/3 back to ACGT order
                 const u32 qi = min((u32)q, nqu);
-                u32 aB = ((c & 6u) << (lgb - 1)) + laneB, aQ = (qi << lgb) + laneQ;
+                u32 aB = (code << lgb) + laneB, aQ = (qi << lgb) + laneQ;
                 if (!FULLLEN) {
                     const bool valid = pos < len_r;
                     aB = valid ? aB : dumB - 256u * (s >> 1);
@@ -479,6 +508,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 }
             });
             v_lowq = wl(v_lowq, nlow, r);
+            if (SNK_TR && inv) nf |= 1ull << r;
             if (has_meanq) {                      // quality sum of the read (mean-quality filter only)
                 int qsum = 0;
 #pragma unroll
@@ -573,13 +603,51 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         rs_init(R, clen_v);
         int v_adja = 0, v_nn = 0, v_bad = 0;
         bool needfix = false;
+        u32 VAL[NW];                      // SNK_TR: exact-ACGT positions of the reads that went through the fix-up pass
+        if (SNK_TR) {
+            // hand-over lane = position -> lane = read: one 64 x 64 bit transpose per strip and code bit
+            if (cnt < 64) {               // last tile of a batch: the newest read sits on top, move read 0 (32) to bit 0
+                if (cnt <= 32) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { pL[s] = cL[s] >> (32 - cnt); pH[s] = cH[s] >> (32 - cnt); cL[s] = cH[s] = 0; }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { cL[s] >>= (64 - cnt); cH[s] >>= (64 - cnt); }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                u32 l0 = pL[s], l1 = cL[s], h0 = pH[s], h1 = cH[s];
+                if (2 * s + 1 < NW) {
+                    bit_transpose64(l0, l1, lane);
+                    bit_transpose64(h0, h1, lane);
+                } else {
+                    l0 = bit_transpose64_lo(l0, l1, lane);
+                    h0 = bit_transpose64_lo(h0, h1, lane);
+                }
+                X[0][2 * s] = ~(h0 | l0);
+                X[1][2 * s] = l0 & ~h0;
+                X[2][2 * s] = h0 & l0;
+                X[3][2 * s] = h0 & ~l0;
+                if (2 * s + 1 < NW) {
+                    const int j1 = (2 * s + 1 < NW) ? 2 * s + 1 : 0;
+                    X[0][j1] = ~(h1 | l1);
+                    X[1][j1] = l1 & ~h1;
+                    X[2][j1] = h1 & l1;
+                    X[3][j1] = h1 & ~l1;
+                }
+            }
+            needfix = (nf >> lane) & 1ull;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) VAL[j] = 0xFFFFFFFFu;
+        }
         {   // mask the garbage past each read and look for anything that is not ACGT
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const u32 in = lowmask32(R.len - 32 * j);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) X[k][j] &= in;
-                needfix = needfix || (in & ~(X[0][j] | X[1][j] | X[2][j] | X[3][j])) != 0;
+                if (!SNK_TR) needfix = needfix || (in & ~(X[0][j] | X[1][j] | X[2][j] | X[3][j])) != 0;
                 if (FULL) {
                     FG[j] = X[2][j];
                     EQ[j] &= in;
@@ -616,10 +684,18 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                         SNK_PUT(XN, __ballot(valid && c == 'N'))
                         SNK_PUT(FG, __ballot(valid && cu == 'G'))
                     }
+                    if (SNK_TR) SNK_PUT(VAL, __ballot(valid && (c == 'A' || c == 'C' || c == 'G' || c == 'T')))
                 }
                 v_adja = wl(v_adja, adjA, r);
                 v_nn = wl(v_nn, nN, r);
                 v_bad = wl(v_bad, bad, r);
+            }
+            if (SNK_TR && __any(needfix)) {       // the planes are exact: no bit where the character is not that letter
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) X[k][j] &= VAL[j];
+                }
             }
         }
         const int estat = !lanev ? 0 : (mylen > G.lcap ? SNK_E_TOO_LONG : (mylen == 0 ? SNK_E_EMPTY_SEQ : (v_bad ? SNK_E_BAD_BASE : 0)));
