@@ -42,13 +42,6 @@ using namespace snk;
 #ifndef SNK_ABL
 #define SNK_ABL 0
 #endif
-// 1: the base planes travel from lane = position to lane = read as 2-bit codes collected with
-// v_alignbit and one 64x64 bit-matrix transpose per strip (snk_bittr.cuh); 0: four ballots + eight
-// v_writelane per strip and read (the first design, kept for A/B timing)
-#ifndef SNK_TR
-#define SNK_TR 1
-#endif
-
 extern "C" __device__ int __snk_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
 
 namespace {
@@ -408,19 +401,24 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         // the flush checks.  Phase 1 is VALU-issue bound, not HBM bound.
         u32 X[4][NW], XN[NW], FG[NW], EQ[NW], LQH[NW], LQT[NW];
 #pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            X[0][j] = X[1][j] = X[2][j] = X[3][j] = 0;
-            XN[j] = FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
-        }
-        int v_sumq = 0, v_lowq = 0;
-        // SNK_TR: lane = position collects bit 1 (cL) and bit 2 (cH) of the characters of the reads it has seen,
-        // newest read on top (A 00, C 01, T 10, G 11); reads 0..31 are parked in pL/pH when read 32 arrives.
-        // nf: scalar mask of the reads holding anything but ACGT (they go through the fix-up pass).
-        u32 cL[NS], cH[NS], pL[NS], pH[NS];
+        for (int j = 0; j < NW; ++j) XN[j] = FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
+        int v_sumq = 0;
+        // Four bit planes per strip are collected by the lane that owns the POSITION, one bit per read, and
+        // cross over to lane = read in the hand-over below (64 x 64 bit transposes):
+        //   cL / cH  bits 1 / 2 of the character (A 00, C 01, T 10, G 11)
+        //   cV       the character is exactly A, C, G or T
+        //   cQ       quality <= lowQual
+        // cL takes bit 0 of its source (v_alignbit ..., 1: newest read on top); the others take the SIGN of a
+        // difference (v_alignbit acc, x, 31 = acc << 1 | x >> 31: newest read at the bottom, reversed at the
+        // hand-over).  Reads 0..31 are parked in p* when read 32 arrives.
+        u32 cL[NS], cH[NS], cV[NS], cQ[NS], pL[NS], pH[NS], pV[NS], pQ[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) cL[s] = cH[s] = pL[s] = pH[s] = 0;
-        u64 nf = 0;
-        const bool has_meanq = __builtin_amdgcn_readfirstlane(P.has_meanq) != 0;
+        for (int s = 0; s < NS; ++s) cL[s] = cH[s] = cV[s] = cQ[s] = pL[s] = pH[s] = pV[s] = pQ[s] = 0;
+        auto park = [&]() {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { pL[s] = cL[s]; pH[s] = cH[s]; pV[s] = cV[s]; pQ[s] = cQ[s]; }
+        };
+        const int has_meanq = __builtin_amdgcn_readfirstlane(P.has_meanq);
         const int len0 = rl(clen_v, 0);
         const bool fixed = __all(!lanev || clen_v == len0);
         // every read of the tile fills the whole capacity: lanes past the end fall into histogram
@@ -428,57 +426,44 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         const bool fulllen = fixed && len0 == G.lcap;
         const u32 rawBw = (u32)((m * 2 + 0) * G.SET), rawQw = rawBw + (u32)G.WB;
         const u32 lds0 = (u32)(uintptr_t)(lds_u32_ptr)lds;                   // absolute LDS address of the histograms
-        const u32 laneB = lds0 + (rawBw + (u32)lane) * 4u, laneQ = lds0 + (rawQw + (u32)lane) * 4u;   // bin row 0
+        const u32 laneB = lds0 + (rawBw + (u32)lane) * 4u;                   // base bin row 0
+        // quality rows: the character itself is clamped to [phred-1, phred+nq] -> rows -1 (underflow, the spare
+        // sixth base row) .. nq (overflow); the flush reports both
+        const u32 laneQc = lds0 + (rawQw + (u32)lane) * 4u - ((u32)phred << lgb);
+        u32 qlo_v = (u32)(phred - 1);
+        asm volatile("" : "+v"(qlo_v));                                     // v_med3 takes one scalar operand only
+        const u32 qhi = (u32)(phred + nq);
+        const u32 klow = (u32)(phred + lowQ + 1);
         const u32 dumB = lds0 + ((u32)(4 * G.SET) + (u32)lane) * 4u;   // per-lane scratch word (variable-length tiles)
-        const u32 nqu = (u32)nq;
         uint8_t *ldsb = reinterpret_cast<uint8_t *>(lds);
         auto do_read = [&](auto FL, const int r, const u32 (&cc)[NS], const u32 (&cq)[NS]) {
             constexpr bool FULLLEN = decltype(FL)::value;
             const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
-            int nlow = 0;
             u32 prev_last = 0xFFFFFFFFu;
-            u64 inv = 0;
-            if (SNK_TR && r == 32) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { pL[s] = cL[s]; pH[s] = cH[s]; }
-            }
             static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                 constexpr int s = decltype(sc)::v;
                 const int pos = 64 * s + lane;
-                const u32 c = cc[s];
+                const u32 c = cc[s], qb = cq[s];
                 u32 code = __builtin_amdgcn_ubfe(c, 1u, 2u);
-                if (SNK_TR) asm("" : "+v"(code));     // one v_bfe feeds the row address, the bit collector and the ACGT test
+                asm("" : "+v"(code));     // one v_bfe feeds the row address, the bit collector and the ACGT test
 #define SNK_PUT(PL, VAL)                                                                   \
     {                                                                                      \
         const u64 val_ = (VAL);                                                            \
-        if (SNK_ABL == 13) { asm volatile("" ::"s"(val_)); }                               \
-        else {                                                                             \
-            PL[2 * s] = wl(PL[2 * s], (int)(u32)val_, r);                                  \
-            if (2 * s + 1 < NW) PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = wl(PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0], (int)(u32)(val_ >> 32), r); \
-        }                                                                                  \
+        PL[2 * s] = wl(PL[2 * s], (int)(u32)val_, r);                                      \
+        if (2 * s + 1 < NW) PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = wl(PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0], (int)(u32)(val_ >> 32), r); \
     }
-                if (SNK_TR) {
-                    cL[s] = __builtin_amdgcn_alignbit(code, cL[s], 1u);
-                    cH[s] = __builtin_amdgcn_alignbit(c >> 2, cH[s], 1u);
-                    // exact ACGT test: the character its own bits 1-2 stand for (byte `code` of "ACTG") vs the character
+                cL[s] = __builtin_amdgcn_alignbit(code, cL[s], 1u);
+                cH[s] = __builtin_amdgcn_alignbit(c >> 2, cH[s], 1u);
+                {   // exact ACGT test: the character its own bits 1-2 stand for (byte `code` of "ACTG") vs the character.
+                    // v_sad_u8 adds the byte differences: bytes 1-3 contribute 3 * 'A' (selector bytes 0 pick 'A', the
+                    // character register is zero there), so with -(3*'A'+1) on top the sum is negative <=> equal
                     const u32 ex = __builtin_amdgcn_perm(0u, 0x47544341u, code);
-                    u64 bal;
-                    asm("v_cmp_ne_u32_sdwa %0, %1, %2 src0_sel:BYTE_0 src1_sel:BYTE_0" : "=s"(bal) : "v"(ex), "v"(c));
-                    inv |= (FULLLEN && s < NS - 1) ? bal : (bal & lowmask64(len_r - 64 * s));
-                } else {   // the four compares first, into four SGPR pairs: a v_writelane right behind the compare
-                    // that produced its operand stalls on the VALU -> SGPR write
-                    u64 b0 = __ballot(c == 'A'), b1 = __ballot(c == 'C'), b2 = __ballot(c == 'G'), b3 = __ballot(c == 'T');
-                    asm volatile("" : "+s"(b0), "+s"(b1), "+s"(b2), "+s"(b3));
-                    SNK_PUT(X[0], b0)
-                    SNK_PUT(X[1], b1)
-                    SNK_PUT(X[2], b2)
-                    SNK_PUT(X[3], b3)
+                    const u32 d = __builtin_amdgcn_sad_u8(ex, c, 0xFFFFFF3Cu);
+                    cV[s] = __builtin_amdgcn_alignbit(cV[s], d, 31u);
                 }
-                const int q = (int)cq[s] - phred;
-                // (with FULLLEN every strip but the last lies inside the read: 64*(NS-1) <= 32*(NW-1) < lcap)
-                if (FULLLEN && s < NS - 1) nlow += __popcll(__ballot(q <= lowQ));
-                else nlow += __popcll(__ballot(q <= lowQ) & lowmask64(len_r - 64 * s));
+                cQ[s] = __builtin_amdgcn_alignbit(cQ[s], qb - klow, 31u);       // sign <=> quality <= lowQual
                 if (FULL) {
+                    const int q = (int)qb - phred;
                     if (P.polyX_num != -1) {
                         // character of the previous position: wave_shr:1, lane 0 keeps `old` = last of the previous strip
                         const u32 pc = (u32)__builtin_amdgcn_update_dpp((int)prev_last, (int)c, 0x138, 0xF, 0xF, false);
@@ -491,11 +476,12 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     }
                 }
                 // raw per-position histograms (src/peprocess.cpp:1145-1201).  N / garbage land in a
-                // wrong base bin here and are moved by the fix-up pass; bin nq = quality overflow.
+                // wrong base bin here and are moved by the fix-up pass.
                 // LDS base rows are ordered by bits 1-2 of the character (A 00, C 01, T 10, G 11, then N):
-                // the row address is one shift-add of (c & 6); the flush swaps rows 2/3 back to ACGT order
-                const u32 qi = min((u32)q, nqu);
-                u32 aB = (code << lgb) + laneB, aQ = (qi << lgb) + laneQ;
+                // the row address is one shift-add of the code; the flush swaps rows 2/3 back to ACGT order
+                u32 qc;
+                asm("v_med3_u32 %0, %1, %2, %3" : "=v"(qc) : "v"(qb), "v"(qlo_v), "s"(qhi));
+                u32 aB = (code << lgb) + laneB, aQ = (qc << lgb) + laneQc;
                 if (!FULLLEN) {
                     const bool valid = pos < len_r;
                     aB = valid ? aB : dumB - 256u * (s >> 1);
@@ -507,9 +493,9 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 lds_add_u32<256 * (s >> 1)>(aQ, (s & 1) ? 0x10000u : 1u);
                 }
             });
-            v_lowq = wl(v_lowq, nlow, r);
-            if (SNK_TR && inv) nf |= 1ull << r;
-            if (has_meanq) {                      // quality sum of the read (mean-quality filter only)
+            int hm = has_meanq;
+            asm volatile("" : "+s"(hm));          // a plain scalar compare + branch per read (hoisted, the flag turns into lane masks)
+            if (hm != 0) {                        // quality sum of the read (mean-quality filter only)
                 int qsum = 0;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) qsum += (64 * s + lane < len_r) ? (int)cq[s] - phred : 0;
@@ -551,6 +537,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     // the chunk reads staging bytes that are never used.
                     constexpr int K = SNK_ABL == 11 ? 0 : 2 * NS;
                     const int nr = min(rb, cnt - k * rb);
+                    if (k * rb == 32) park();              // rb is a power of two <= 32 (launch())
                     u32 sa = lds0 + (u32)(G.stg_off + wave * G.stg_wave + (k & 1) * 2 * G.cba + lane);
                     u32 ac[NS], aq[NS], bc[NS], bq[NS];     // two register sets alternate (no rotation moves)
                     lds_rd(ac, aq, sa);
@@ -586,68 +573,86 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
 #pragma unroll
                         for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
                     }
+                    if (r == 32) park();
                     do_read(FL, r, cc, cq);
                 }
             }
         };
         if (fulllen) run_phase1(std::true_type{});
         else run_phase1(std::false_type{});
-        if ((SNK_ABL == 1 || SNK_ABL >= 11)) {
-#pragma unroll
-            for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(X[0][j]), "v"(X[1][j]), "v"(X[2][j]), "v"(X[3][j]));
-            asm volatile("" ::"v"(v_lowq), "v"(v_sumq));
-            continue;
-        }
-        // ------------------------------------------------------------ phase 2 (this mate)
+        // ------------------------------------------------------------ hand-over: lane = position -> lane = read
         ReadState R;
         rs_init(R, clen_v);
         int v_adja = 0, v_nn = 0, v_bad = 0;
-        bool needfix = false;
-        u32 VAL[NW];                      // SNK_TR: exact-ACGT positions of the reads that went through the fix-up pass
-        if (SNK_TR) {
-            // hand-over lane = position -> lane = read: one 64 x 64 bit transpose per strip and code bit
-            if (cnt < 64) {               // last tile of a batch: the newest read sits on top, move read 0 (32) to bit 0
+        u32 VP[NW], QP[NW];               // exact-ACGT positions, low-quality positions
+        {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {   // sign-collected planes: newest read at the bottom -> on top, like cL
+                cV[s] = __builtin_bitreverse32(cV[s]); pV[s] = __builtin_bitreverse32(pV[s]);
+                cQ[s] = __builtin_bitreverse32(cQ[s]); pQ[s] = __builtin_bitreverse32(pQ[s]);
+            }
+            if (cnt < 64) {               // last tile of a batch: move read 0 (32) down to bit 0
                 if (cnt <= 32) {
+                    const int sh = 32 - cnt;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) { pL[s] = cL[s] >> (32 - cnt); pH[s] = cH[s] >> (32 - cnt); cL[s] = cH[s] = 0; }
+                    for (int s = 0; s < NS; ++s) {
+                        pL[s] = cL[s] >> sh; pH[s] = cH[s] >> sh; pV[s] = cV[s] >> sh; pQ[s] = cQ[s] >> sh;
+                        cL[s] = cH[s] = cV[s] = cQ[s] = 0;
+                    }
                 } else {
+                    const int sh = 64 - cnt;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) { cL[s] >>= (64 - cnt); cH[s] >>= (64 - cnt); }
+                    for (int s = 0; s < NS; ++s) { cL[s] >>= sh; cH[s] >>= sh; cV[s] >>= sh; cQ[s] >>= sh; }
                 }
             }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                u32 l0 = pL[s], l1 = cL[s], h0 = pH[s], h1 = cH[s];
+                u32 l0 = pL[s], l1 = cL[s], h0 = pH[s], h1 = cH[s], v0 = pV[s], v1 = cV[s], q0 = pQ[s], q1 = cQ[s];
+                const int j1 = (2 * s + 1 < NW) ? 2 * s + 1 : 0;
                 if (2 * s + 1 < NW) {
                     bit_transpose64(l0, l1, lane);
                     bit_transpose64(h0, h1, lane);
+                    bit_transpose64(v0, v1, lane);
+                    bit_transpose64(q0, q1, lane);
                 } else {
                     l0 = bit_transpose64_lo(l0, l1, lane);
                     h0 = bit_transpose64_lo(h0, h1, lane);
+                    v0 = bit_transpose64_lo(v0, v1, lane);
+                    q0 = bit_transpose64_lo(q0, q1, lane);
                 }
                 X[0][2 * s] = ~(h0 | l0);
                 X[1][2 * s] = l0 & ~h0;
                 X[2][2 * s] = h0 & l0;
                 X[3][2 * s] = h0 & ~l0;
+                VP[2 * s] = v0;
+                QP[2 * s] = q0;
                 if (2 * s + 1 < NW) {
-                    const int j1 = (2 * s + 1 < NW) ? 2 * s + 1 : 0;
                     X[0][j1] = ~(h1 | l1);
                     X[1][j1] = l1 & ~h1;
                     X[2][j1] = h1 & l1;
                     X[3][j1] = h1 & ~l1;
+                    VP[j1] = v1;
+                    QP[j1] = q1;
                 }
             }
-            needfix = (nf >> lane) & 1ull;
-#pragma unroll
-            for (int j = 0; j < NW; ++j) VAL[j] = 0xFFFFFFFFu;
         }
+        if ((SNK_ABL == 1 || SNK_ABL >= 11)) {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(X[0][j]), "v"(X[1][j]), "v"(X[2][j]), "v"(X[3][j]), "v"(VP[j]), "v"(QP[j]));
+            asm volatile("" ::"v"(v_sumq));
+            continue;
+        }
+        // ------------------------------------------------------------ phase 2 (this mate)
+        bool needfix = false;
+        int nlowq = 0;
         {   // mask the garbage past each read and look for anything that is not ACGT
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 const u32 in = lowmask32(R.len - 32 * j);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) X[k][j] &= in;
-                if (!SNK_TR) needfix = needfix || (in & ~(X[0][j] | X[1][j] | X[2][j] | X[3][j])) != 0;
+                for (int k = 0; k < 4; ++k) X[k][j] &= in & VP[j];      // exact planes: no bit where the character is not that letter
+                needfix = needfix || (in & ~VP[j]) != 0;
+                nlowq += __popc(QP[j] & in);
                 if (FULL) {
                     FG[j] = X[2][j];
                     EQ[j] &= in;
@@ -684,18 +689,10 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                         SNK_PUT(XN, __ballot(valid && c == 'N'))
                         SNK_PUT(FG, __ballot(valid && cu == 'G'))
                     }
-                    if (SNK_TR) SNK_PUT(VAL, __ballot(valid && (c == 'A' || c == 'C' || c == 'G' || c == 'T')))
                 }
                 v_adja = wl(v_adja, adjA, r);
                 v_nn = wl(v_nn, nN, r);
                 v_bad = wl(v_bad, bad, r);
-            }
-            if (SNK_TR && __any(needfix)) {       // the planes are exact: no bit where the character is not that letter
-#pragma unroll
-                for (int j = 0; j < NW; ++j) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) X[k][j] &= VAL[j];
-                }
             }
         }
         const int estat = !lanev ? 0 : (mylen > G.lcap ? SNK_E_TOO_LONG : (mylen == 0 ? SNK_E_EMPTY_SEQ : (v_bad ? SNK_E_BAD_BASE : 0)));
@@ -711,7 +708,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             }
             R.n_a = na + v_adja;
             R.n_n = v_nn;
-            R.lowq = v_lowq;
+            R.lowq = nlowq;
             R.sumq = v_sumq;
         }
         int hix = 0, tix = 0, polyg = 0;
@@ -847,7 +844,10 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         const u32 lds0 = (u32)(uintptr_t)(lds_u32_ptr)lds;
         const u32 remBa = lds0 + ((u32)((m * 2 + 1) * G.SET) + (u32)lane) * 4u, remQa = remBa + (u32)G.WB * 4u;
         const u32 dumR = lds0 + ((u32)(4 * G.SET) + (u32)lane) * 4u;
-        const u32 nqu = (u32)nq;
+        const u32 remQc = remQa - ((u32)phred << lgb);      // clamped character -> quality row, as in phase 1
+        u32 qlo_v = (u32)(phred - 1);
+        asm volatile("" : "+v"(qlo_v));
+        const u32 qhi = (u32)(phred + nq);
         u32 offp[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) offp[s] = (u32)min(64 * s + lane, B.pitch - 1);
@@ -883,19 +883,21 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                         constexpr int s = decltype(sc)::v;
                         const u32 c = cb[b][s];
-                        const u32 qi = min((u32)((int)qb[b][s] - phred), nqu);
+                        u32 qc;
+                        asm("v_med3_u32 %0, %1, %2, %3" : "=v"(qc) : "v"(qb[b][s]), "v"(qlo_v), "s"(qhi));
                         lds_add_u32<256 * (s >> 1)>(((c & 6u) << (lgb - 1)) + remBa, (s & 1) ? 0x10000u : 1u);
-                        lds_add_u32<256 * (s >> 1)>((qi << lgb) + remQa, (s & 1) ? 0x10000u : 1u);
+                        lds_add_u32<256 * (s >> 1)>((qc << lgb) + remQc, (s & 1) ? 0x10000u : 1u);
                     });
                 } else {
                     const u32 span = (u32)(len_r - rm_lo);
                     static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                         constexpr int s = decltype(sc)::v;
                         const u32 c = cb[b][s];
-                        const u32 qi = min((u32)((int)qb[b][s] - phred), nqu);
+                        u32 qc;
+                        asm("v_med3_u32 %0, %1, %2, %3" : "=v"(qc) : "v"(qb[b][s]), "v"(qlo_v), "s"(qhi));
                         const bool inr = (u32)(64 * s + lane - rm_lo) < span;
                         const u32 aB = inr ? ((c & 6u) << (lgb - 1)) + remBa : dumR - 256u * (s >> 1);
-                        const u32 aQ = inr ? (qi << lgb) + remQa : dumR - 256u * (s >> 1);
+                        const u32 aQ = inr ? (qc << lgb) + remQc : dumR - 256u * (s >> 1);
                         lds_add_u32<256 * (s >> 1)>(aB, (s & 1) ? 0x10000u : 1u);
                         lds_add_u32<256 * (s >> 1)>(aQ, (s & 1) ? 0x10000u : 1u);
                     });
@@ -970,8 +972,8 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
                         // slots of positions >= lcap hold the spill-over of lanes past the read end: dropped
                         const int plo = 128 * (pm >> 6) + (pm & 63), phi = plo + 64;
                         const bool lo_ok = plo < G.lcap, hi_ok = phi < G.lcap;
-                        if (w >= G.WB && bin == G.nq) {
-                            if ((alo && lo_ok) || (ahi && hi_ok)) ovf = 1;       // quality outside [0,nq)
+                        if ((w >= G.WB && bin == G.nq) || (w < G.WB && bin == 5)) {
+                            if ((alo && lo_ok) || (ahi && hi_ok)) ovf = 1;       // quality outside [0,nq): overflow / underflow row
                         } else {
                             if (alo && lo_ok) atomicAdd(&fraw[off + plo * stride], (u64)alo);
                             if (alo != blo && lo_ok) atomicAdd(&fcl[off + plo * stride], (u64)alo - (u64)blo);
@@ -1058,6 +1060,13 @@ void go(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const De
     hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), shmem, (hipStream_t)stream, hp, ta, b, st, G, iters, flush_every);
 }
 
+// reads per staging chunk: a power of two <= 32, so that read 32 (where the bit collectors are parked) opens a chunk
+inline int pow2_floor(int v) {
+    int r = 0;
+    for (int p = 1; p <= 32 && p <= v; p <<= 1) r = p;
+    return r;
+}
+
 template <int NW, bool FULL>
 int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, TileGeom G, int n_cu,
            void *stream) {
@@ -1071,13 +1080,13 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
         // bytes per array per buffer: one DMA of (cba/16) lanes x 16 B; the largest chunk that still
         // lets 16 waves share the CU's LDS with the histograms
         for (G.cba = 1024; G.cba >= 256; G.cba -= 256) {
-            G.rb = G.cba / b.pitch;
+            G.rb = pow2_floor(G.cba / b.pitch);
             G.stg_wave = 2 * 2 * G.cba;
             if (G.rb >= 1 && hist + (size_t)W * G.stg_wave + 2048 <= 160 * 1024) break;
             G.rb = 0;
         }
         if (G.rb == 0) {
-            G.cba = 1024; G.rb = G.cba / b.pitch; G.stg_wave = 2 * 2 * G.cba;
+            G.cba = 1024; G.rb = pow2_floor(G.cba / b.pitch); G.stg_wave = 2 * 2 * G.cba;
             while (W > 4 && hist + (size_t)W * G.stg_wave + 2048 > 160 * 1024) W -= 4;
             if (hist + (size_t)W * G.stg_wave + 2048 > 160 * 1024) { G.rb = 0; W = 16; }
         }
@@ -1104,8 +1113,8 @@ int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch
     G.nq = nq;
     G.Lh = 64 * (((lcap + 63) / 64 + 1) / 2);       // dwords per bin row: strips pair up in one dword
     G.lg = G.Lh == 64 ? 6 : 7;
-    G.WB = G.Lh * 5;
-    G.WQ = G.Lh * (nq + 1);          // bin nq collects out-of-range qualities
+    G.WB = G.Lh * 6;                 // A C T G N + the quality underflow row (sits right below quality bin 0)
+    G.WQ = G.Lh * (nq + 1);          // bin nq collects qualities >= nq
     G.SET = G.WB + G.WQ;
     if (((size_t)2 * 2 * G.SET + 64 + 80) * sizeof(u32) > 160 * 1024) return 0;
     G.rb = G.cba = G.stg_off = G.stg_wave = 0;
