@@ -231,22 +231,36 @@ __device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&
         BY[j] = ~lowmask32(len - 32 * j);
     }
     const int steps = min(S - 1, al);
-    const u64 cw0 = A.code4[0], cw1 = A.code4[1], cw2 = A.code4[2], cw3 = A.code4[3];
-    for (int c = 0; c < steps; ++c) {
-        const u64 cw = c < 16 ? cw0 : (c < 32 ? cw1 : (c < 48 ? cw2 : cw3));
-        const int code = (int)((cw >> (4 * (c & 15))) & 15), cr = c & 31;
-#define SNK_STEP(PL)                                                 \
-    if (c < 32) screen_step<NW, 0, NC>(PL, cr, C);                   \
-    else screen_step<NW, 1, NC>(PL, cr, C);
-        switch (code) {
-        case 0: SNK_STEP(X[0]) break;
-        case 1: SNK_STEP(X[1]) break;
-        case 2: SNK_STEP(X[2]) break;
-        case 3: SNK_STEP(X[3]) break;
-        case 5: if (FULL) { SNK_STEP(XN) } else { SNK_STEP(BY) } break;
-        default: SNK_STEP(BY) break;       // matches nothing inside the read
+    // The counters only count, so the order of the steps is free: one loop per plane over the adapter
+    // positions holding that letter (a switch on the letter inside one loop over the positions costs
+    // three times the instructions: register copies at every join of its arms)
+    const u64 sm = lowmask64(steps);
+    auto run = [&](const u32 (&Pl)[NW], u64 m64) {
+        u32 m = __builtin_amdgcn_readfirstlane((u32)m64);
+        while (m) {
+            const int c = __ffs((int)m) - 1;
+            m &= m - 1;
+            screen_step<NW, 0, NC>(Pl, c, C);
         }
-#undef SNK_STEP
+        m = __builtin_amdgcn_readfirstlane((u32)(m64 >> 32));
+        while (m) {
+            const int c = __ffs((int)m) - 1;
+            m &= m - 1;
+            screen_step<NW, 1, NC>(Pl, c, C);
+        }
+    };
+    run(X[0], A.cmask[0] & sm);
+    run(X[1], A.cmask[1] & sm);
+    run(X[2], A.cmask[2] & sm);
+    run(X[3], A.cmask[3] & sm);
+    const u64 other = sm & ~(A.cmask[0] | A.cmask[1] | A.cmask[2] | A.cmask[3]);   // N and anything else in the adapter
+    if (other) {
+        if (FULL) {
+            run(XN, other & A.nmask);
+            run(BY, other & ~A.nmask);      // matches nothing inside the read
+        } else {
+            run(BY, other);
+        }
     }
     // budgets as thermometer planes T_k = [budget >= k]; reject = mis count > budget
     const int rk1 = A.rk[1], rk2 = A.rk[2], rk3 = A.rk[3];
@@ -301,7 +315,7 @@ __device__ int adapter_tile(const TileAdapter &A, const DevAdapter &AG, const u3
     }
     // ---------------- phases B+C screening: candidates p = 0 .. len-edge, bit-sliced
     u32 aliveB[NW], aliveC[NW];
-    if (__any(!done)) {
+    if (SNK_ABL != 7 && __any(!done)) {
         screen_planes<NW, FULL, 4>(A, X, XN, len, done, aliveB, aliveC);
     } else {
 #pragma unroll
@@ -310,7 +324,7 @@ __device__ int adapter_tile(const TileAdapter &A, const DevAdapter &AG, const u3
     // ---------------- exact decision of the survivors, in the reference's order:
     // phase A r1 = 1..5 (-> 0), phase B ascending offset (:743-764), phase C ascending r1 ==
     // descending offset (:765-788).  One candidate per lane per trip; trips are rare.
-    while (__any(!done && (pa != 0 || any_bit(aliveB) || any_bit(aliveC)))) {
+    while (SNK_ABL != 6 && __any(!done && (pa != 0 || any_bit(aliveB) || any_bit(aliveC)))) {
         if (!done) {
             int p = 0, sh = 0, n = 0, budget = 0, res = 0;
             bool have = true, skip_eval = false, skip_ok = false;
