@@ -489,23 +489,14 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                         SNK_PUT(LQT, __ballot(q < P.lq_tail_q))
                     }
                 }
-                // raw per-position histograms (src/peprocess.cpp:1145-1201).  N / garbage land in a
-                // wrong base bin here and are moved by the fix-up pass.
-                // LDS base rows are ordered by bits 1-2 of the character (A 00, C 01, T 10, G 11, then N):
-                // the row address is one shift-add of the code; the flush swaps rows 2/3 back to ACGT order
+                // raw per-position quality histogram (src/peprocess.cpp:1182-1201); the base histogram is
+                // counted from the collected planes once per tile (hand-over)
                 u32 qc;
                 asm("v_med3_u32 %0, %1, %2, %3" : "=v"(qc) : "v"(qb), "v"(qlo_v), "s"(qhi));
-                u32 aB = (code << lgb) + laneB, aQ = (qc << lgb) + laneQc;
-                if (!FULLLEN) {
-                    const bool valid = pos < len_r;
-                    aB = valid ? aB : dumB - 256u * (s >> 1);
-                    aQ = valid ? aQ : dumB - 256u * (s >> 1);
-                }
-                if (SNK_ABL == 11) { asm volatile("" ::"v"(aB), "v"(aQ)); }
-                else {
-                lds_add_u32<256 * (s >> 1)>(aB, (s & 1) ? 0x10000u : 1u);
-                lds_add_u32<256 * (s >> 1)>(aQ, (s & 1) ? 0x10000u : 1u);
-                }
+                u32 aQ = (qc << lgb) + laneQc;
+                if (!FULLLEN) aQ = pos < len_r ? aQ : dumB - 256u * (s >> 1);
+                if (SNK_ABL == 11) { asm volatile("" ::"v"(aQ)); }
+                else lds_add_u32<256 * (s >> 1)>(aQ, (s & 1) ? 0x10000u : 1u);
             });
             int hm = has_meanq;
             asm volatile("" : "+s"(hm));          // a plain scalar compare + branch per read (hoisted, the flag turns into lane masks)
@@ -549,7 +540,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     // prefetch.  Every read is waited for in the same straight-line block that issued it (no
                     // register of an in-flight read crosses a branch).  The prefetch past the last read of
                     // the chunk reads staging bytes that are never used.
-                    constexpr int K = SNK_ABL == 11 ? 0 : 2 * NS;
+                    constexpr int K = SNK_ABL == 11 ? 0 : NS;
                     const int nr = min(rb, cnt - k * rb);
                     if (k * rb == 32) park();              // rb is a power of two <= 32 (launch())
                     u32 sa = lds0 + (u32)(G.stg_off + wave * G.stg_wave + (k & 1) * 2 * G.cba + lane);
@@ -617,6 +608,39 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     const int sh = 64 - cnt;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) { cL[s] >>= sh; cH[s] >>= sh; cV[s] >>= sh; cQ[s] >>= sh; }
+                }
+            }
+            // raw per-position base histogram (src/peprocess.cpp:1145-1180): lane = position holds one bit per
+            // read of each plane, so the count of a letter at its position is a popcount -> one LDS add per
+            // letter, strip and TILE (not per read).  LDS base rows are ordered by the code (A 00, C 01, T 10,
+            // G 11, then N; the flush swaps rows 2/3 back to ACGT order).  Characters that are not exactly ACGT
+            // are not counted here: their reads go through the fix-up pass, which adds them (N, lower case).
+            if (SNK_ABL != 11) {
+                u32 IN[NW];                     // variable lengths: bit r of lane p = position p lies inside read r
+                if (!fulllen) {
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) IN[j] = lanev ? lowmask32(clen_v - 32 * j) : 0u;
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    u32 i0 = 0xFFFFFFFFu, i1 = 0xFFFFFFFFu;
+                    if (!fulllen) {
+                        i0 = IN[2 * s];
+                        i1 = (2 * s + 1 < NW) ? IN[(2 * s + 1 < NW) ? 2 * s + 1 : 0] : 0u;
+                        bit_transpose64(i0, i1, lane);
+                    }
+                    const u32 m0 = pV[s] & i0, m1 = cV[s] & i1;
+                    const u32 l0 = pL[s], l1 = cL[s], h0 = pH[s], h1 = cH[s];
+                    const u32 nA = __popc(m0 & ~(h0 | l0)) + __popc(m1 & ~(h1 | l1));
+                    const u32 nC = __popc(m0 & l0 & ~h0) + __popc(m1 & l1 & ~h1);
+                    const u32 nT = __popc(m0 & h0 & ~l0) + __popc(m1 & h1 & ~l1);
+                    const u32 nG = __popc(m0 & h0 & l0) + __popc(m1 & h1 & l1);
+                    const u32 sh = (s & 1) ? 16u : 0u;
+                    u32 *rowp = lds + rawBw + 64 * (s >> 1) + lane;
+                    atomicAdd(rowp, nA << sh);
+                    atomicAdd(rowp + (1u << G.lg), nC << sh);
+                    atomicAdd(rowp + (2u << G.lg), nT << sh);
+                    atomicAdd(rowp + (3u << G.lg), nG << sh);
                 }
             }
 #pragma unroll
@@ -695,10 +719,9 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     const bool isn = valid && cu == 'N';
                     nN += __popcll(__ballot(isn));
                     if (__any(valid && !(cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T' || cu == 'N'))) bad = 1;
-                    if (isn) {
-                        atomicSub(reinterpret_cast<u32 *>(ldsb + ((c & 6u) << (lgb - 1)) + (laneB - lds0) + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
-                        atomicAdd(reinterpret_cast<u32 *>(ldsb + (4u << lgb) + (laneB - lds0) + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
-                    }
+                    // the hand-over counted exact ACGT only: N -> row 4, lower-case letters -> the row of their bits 1-2
+                    if (valid && !(c == 'A' || c == 'C' || c == 'G' || c == 'T') && (isn || cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T'))
+                        atomicAdd(reinterpret_cast<u32 *>(ldsb + ((isn ? 4u : ((c >> 1) & 3u)) << lgb) + (laneB - lds0) + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
                     if (FULL) {
                         SNK_PUT(XN, __ballot(valid && c == 'N'))
                         SNK_PUT(FG, __ballot(valid && cu == 'G'))
