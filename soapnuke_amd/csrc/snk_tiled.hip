@@ -529,9 +529,9 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 for (int k = 0; k < nchunks; ++k) {
                     if (k + 1 < nchunks) {
                         issue(k + 1);
-                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        if (SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     } else {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
                     // LDS -> register reads run one read ahead of the ballots.  Reads, histogram adds and
                     // their waits are hand-placed asm: the compiler cannot see through the loop-carried LDS
@@ -675,6 +675,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             }
         }
         if ((SNK_ABL == 1 || SNK_ABL >= 11)) {
+            if (SNK_ABL == 14) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(X[0][j]), "v"(X[1][j]), "v"(X[2][j]), "v"(X[3][j]), "v"(VP[j]), "v"(QP[j]));
             asm volatile("" ::"v"(v_sumq));
