@@ -1,14 +1,20 @@
 // snk_tiled.hip -- the wave-tiled fast kernel of the SOAPnuke-filter hot path (gfx950).
 //
-// One wavefront owns a tile of 64 read pairs and walks it in three phases:
+// One wavefront owns a tile of 64 read pairs and walks it in three phases and a hand-over:
 //
 //  phase 1  lane = read POSITION.  The tile's read bytes arrive in LDS by DMA
 //           (global_load_lds, 16 B/lane, next chunk in flight); per read the wave reads
-//           its 64-position strips one read ahead, turns the per-base predicates
-//           (==A/C/G/T, Q<=lowQual, ...) into 64-bit ballots, adds the raw per-position
-//           histograms into LDS (lane l owns positions l, l+64, ... so the adds of one
-//           instruction never collide), and *transposes* the ballots into the lane that
-//           owns the read with v_writelane.  LDS reads / adds / waits are hand-placed asm.
+//           its 64-position strips one read ahead, adds the raw per-position quality
+//           histogram into LDS (lane l owns positions l, l+64, ... so the adds of one
+//           instruction never collide), and shifts one bit per read into four collector
+//           registers per strip: bits 1 and 2 of the character (its 2-bit code), "is exactly
+//           A/C/G/T" and "quality <= lowQual" (v_alignbit on bit 0 or on the sign of a
+//           difference).  LDS reads / adds / waits are hand-placed asm.
+//  hand-over  After 64 reads every lane holds, per strip and plane, 64 bits over the reads of
+//           the tile.  Their popcounts ARE the raw base histogram of the lane's position
+//           (one LDS add per letter, strip and tile), and one 64 x 64 bit-matrix transpose
+//           per strip and plane (snk_bittr.cuh: v_permlane32/16_swap + DPP) turns them into
+//           the per-read bit planes of phase 2.
 //  phase 2  lane = READ.  Each lane now holds its read as bit planes (one bit per
 //           position).  Adapter search (src/read_filter.cpp:707-790) runs bit-sliced over
 //           all candidate offsets at once: for the first S-1 adapter characters (S =
@@ -27,8 +33,9 @@
 // counters packed two per dword (strips 2k and 2k+1 share dwords, so one strip never
 // hits a dword twice); the workgroup flushes them to the global uint64 block before a
 // counter can overflow; the few hot trimming-position counters live in a per-workgroup
-// uint32 copy in HBM.  Everything is integer/byte work: no MFMA, bound by HBM in theory
-// and by instruction issue in practice.
+// uint32 copy in HBM.  Everything is integer/byte work: no MFMA; bound by HBM in theory, in
+// practice by the latency of the few KB per wave that the LDS budget lets the DMA keep in
+// flight.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <utility>
@@ -42,6 +49,20 @@ using namespace snk;
 #ifndef SNK_ABL
 #define SNK_ABL 0
 #endif
+// tile of wave w of this workgroup within one round: 0 = wave-major (neighbouring workgroups take neighbouring
+// tiles), 1 = workgroup-major (the waves of a workgroup take neighbouring tiles: few pages per CU)
+#ifndef SNK_L2SRC
+#define SNK_L2SRC 0      // profiling only: with SNK_ABL == 15
+#endif
+#ifndef SNK_ORDER
+#define SNK_ORDER 1
+#endif
+#if SNK_ORDER
+#define SNK_TILE_OF(w) ((long)blockIdx.x * Wc + (long)(w))
+#else
+#define SNK_TILE_OF(w) ((long)(w) * gridDim.x + blockIdx.x)
+#endif
+
 extern "C" __device__ int __snk_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
 
 namespace {
@@ -372,6 +393,8 @@ struct TileGeom {
     // {bases, qualities} x cba bytes, a chunk = rb consecutive reads.  rb == 0: disabled.
     int rb, cba, stg_off, stg_wave;
 };
+// LDS words behind the four histogram sets: 64 per-lane scratch words, 80 misc counters
+constexpr int SNK_LDS_TAIL = 64 + 80;
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
@@ -399,20 +422,20 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
     int e0 = 0, e1 = 0;
     const bool oobH = (0 - phred) < P.lq_head_q, oobT = (0 - phred) < P.lq_tail_q;
 
+    const uint8_t *const seq0 = B.seq[0], *const seq1 = B.seq[1], *const qual0 = B.qual[0], *const qual1 = B.qual[1];
 #pragma unroll 1
     for (int m = 0; m < mates; ++m) {
         asm volatile("" : "+v"(lane));
-        const uint8_t *seq = B.seq[m], *qual = B.qual[m];
+        const uint8_t *seq = m ? seq1 : seq0, *qual = m ? qual1 : qual0;
         int mylen = 0;
         if (lanev) mylen = B.len[m] ? (int)B.len[m][t0 + lane] : B.fixed_len[m];
         const int clen_v = min(mylen, G.lcap);
         // ------------------------------------------------------------ phase 1
-        // Straight-line per strip: 4 base ballots written into the owning lane with v_writelane,
-        // one quality ballot counted on the scalar unit, two LDS histogram adds.  Nothing else: bits
-        // past a read's end are masked per lane in phase 2, base counts are popcounts of the planes
-        // there, reads containing anything but ACGT (N, lower case, garbage) are detected there and
-        // repaired in a rare fix-up pass, and an out-of-range quality lands in an overflow bin that
-        // the flush checks.  Phase 1 is VALU-issue bound, not HBM bound.
+        // Straight-line per strip: one LDS histogram add (quality) and four one-bit collector updates.
+        // Nothing else: bits past a read's end are masked per lane in phase 2, base and low-quality counts are
+        // popcounts of the planes, reads containing anything but ACGT (N, lower case, garbage) show up in the
+        // "exact ACGT" plane and are repaired in a rare fix-up pass, and an out-of-range quality lands in an
+        // overflow / underflow row that the flush checks.
         u32 X[4][NW], XN[NW], FG[NW], EQ[NW], LQH[NW], LQT[NW];
 #pragma unroll
         for (int j = 0; j < NW; ++j) XN[j] = FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
@@ -515,15 +538,23 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
                 uint8_t *stg = ldsb + G.stg_off + wave * G.stg_wave;
                 const int rb = G.rb, nchunks = (cnt + rb - 1) / rb;
+                // chunk sources advance by scalar adds; the lane offset is the same for every full chunk
+                const int chunkB = rb * B.pitch;
+                // (ablation 15: every wave streams one of 64 tiles over and over -> the DMA hits L2)
+                const long t0s = (SNK_ABL == 15 || SNK_L2SRC) ? (long)((blockIdx.x * 16 + wave) & 63) * 64 : t0;
+                const uint8_t *gs = seq + t0s * (long)B.pitch, *gq = qual + t0s * (long)B.pitch;
+                const int offF = min(lane * 16, chunkB - 16);
+                const bool dlane = lane * 16 < G.cba;
                 auto issue = [&](const int k) {
-                    const long g0 = (t0 + (long)k * rb) * (long)B.pitch;
-                    const int nbytes = min(rb, cnt - k * rb) * B.pitch;
                     uint8_t *dst = stg + (k & 1) * 2 * G.cba;
-                    const int off = min(lane * 16, nbytes - 16);
-                    if (SNK_ABL != 12 && lane * 16 < G.cba) {          // same instruction count every chunk (counted vmcnt below)
-                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(seq + g0 + off), (lds_ptr_t)dst, 16, 0, 0);
-                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(qual + g0 + off), (lds_ptr_t)(dst + G.cba), 16, 0, 0);
+                    int off = offF;
+                    if ((k + 1) * rb > cnt) off = min(lane * 16, (cnt - k * rb) * B.pitch - 16);     // last chunk of the last tile
+                    if (SNK_ABL != 12 && dlane) {          // same instruction count every chunk (counted vmcnt below)
+                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + off), (lds_ptr_t)dst, 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gq + off), (lds_ptr_t)(dst + G.cba), 16, 0, 0);
                     }
+                    gs += chunkB;
+                    gq += chunkB;
                 };
                 issue(0);
                 for (int k = 0; k < nchunks; ++k) {
@@ -974,18 +1005,18 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
     const int lane = threadIdx.x & 63, W = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile index and addresses stay scalar
     const int mates = P.paired ? 2 : 1;
-    const int nwords = 4 * G.SET + 64 + 80;        // histograms, per-lane scratch words, misc counters
+    const int nwords = 4 * G.SET + SNK_LDS_TAIL;    // histograms, per-lane scratch words, misc counters
     for (int i = threadIdx.x; i < nwords; i += blockDim.x) lds[i] = 0;
     __syncthreads();
     // LDS histogram word of (bin b, position p = 64*s + l) = b*Lh + 64*(s>>1) + l, half-word s&1:
     // every address/increment of a strip is lane + compile-time constants (no per-lane tables), and
     // the 64 lanes of one ds_add hit 64 consecutive dwords (conflict-free).
+    const int Wc = W;
     const long GW = (long)gridDim.x * W;
     const long fb = file_block(G.lcap, G.nq);
     int flush_lo = 0;
     for (int it = 0; it < iters; ++it) {
-        // wave-major: the tiles of a partial last round spread over all CUs instead of filling a few
-        const long tile = (long)it * GW + (long)wave * gridDim.x + blockIdx.x;
+        const long tile = (long)it * GW + SNK_TILE_OF(wave);
         const long t0 = tile * 64;
         long rem = B.n - t0;
         const int cnt = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
@@ -1043,7 +1074,7 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
                 // error path: some quality since the last flush was out of range -> find the reads
                 // (the reference corrupts its heap here, src/peprocess.cpp:1196; we report the first)
                 for (int it2 = flush_lo; it2 <= it; ++it2) {
-                    const long t2 = ((long)it2 * GW + (long)wave * gridDim.x + blockIdx.x) * 64;
+                    const long t2 = ((long)it2 * GW + SNK_TILE_OF(wave)) * 64;
                     const long rem2 = B.n - t2;
                     const int cnt2 = rem2 >= 64 ? 64 : (rem2 > 0 ? (int)rem2 : 0);
                     for (int m = 0; m < mates; ++m)
@@ -1108,7 +1139,7 @@ inline int pow2_floor(int v) {
 template <int NW, bool FULL>
 int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, TileGeom G, int n_cu,
            void *stream) {
-    const size_t hist = ((size_t)2 * 2 * G.SET + 64 + 80) * sizeof(u32);
+    const size_t hist = ((size_t)2 * 2 * G.SET + SNK_LDS_TAIL) * sizeof(u32);
     // staging needs 16-byte rows; otherwise the register path is used
     const bool can_stage = (b.pitch % 16 == 0) && b.pitch <= 1024 &&
                            (((uintptr_t)b.seq[0] | (uintptr_t)b.qual[0] | (uintptr_t)b.seq[1] | (uintptr_t)b.qual[1]) % 16 == 0);
@@ -1154,7 +1185,7 @@ int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch
     G.WB = G.Lh * 6;                 // A C T G N + the quality underflow row (sits right below quality bin 0)
     G.WQ = G.Lh * (nq + 1);          // bin nq collects qualities >= nq
     G.SET = G.WB + G.WQ;
-    if (((size_t)2 * 2 * G.SET + 64 + 80) * sizeof(u32) > 160 * 1024) return 0;
+    if (((size_t)2 * 2 * G.SET + SNK_LDS_TAIL) * sizeof(u32) > 160 * 1024) return 0;
     G.rb = G.cba = G.stg_off = G.stg_wave = 0;
     const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq;
     const int nw = (lcap + 31) / 32;        // dwords per bit plane
