@@ -449,11 +449,23 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         // difference (v_alignbit acc, x, 31 = acc << 1 | x >> 31: newest read at the bottom, reversed at the
         // hand-over).  Reads 0..31 are parked in p* when read 32 arrives.
         u32 cL[NS], cH[NS], cV[NS], cQ[NS], pL[NS], pH[NS], pV[NS], pQ[NS];
+        // FULL variant, sign-collected as well: "same character as the previous position" (polyX), quality below
+        // the head / tail thresholds of the low-quality-end trim
+        constexpr int NF = FULL ? NS : 1;
+        u32 cE[NF], cA[NF], cT[NF], pE[NF], pA[NF], pT[NF];
+        const bool has_px = FULL && __builtin_amdgcn_readfirstlane(P.polyX_num) != -1;
+        const bool has_lq = FULL && __builtin_amdgcn_readfirstlane(P.has_lq) != 0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) cL[s] = cH[s] = cV[s] = cQ[s] = pL[s] = pH[s] = pV[s] = pQ[s] = 0;
+#pragma unroll
+        for (int s = 0; s < NF; ++s) cE[s] = cA[s] = cT[s] = pE[s] = pA[s] = pT[s] = 0;
         auto park = [&]() {
 #pragma unroll
             for (int s = 0; s < NS; ++s) { pL[s] = cL[s]; pH[s] = cH[s]; pV[s] = cV[s]; pQ[s] = cQ[s]; }
+            if (FULL) {
+#pragma unroll
+                for (int s = 0; s < NF; ++s) { pE[s] = cE[s]; pA[s] = cA[s]; pT[s] = cT[s]; }
+            }
         };
         const int has_meanq = __builtin_amdgcn_readfirstlane(P.has_meanq);
         const int len0 = rl(clen_v, 0);
@@ -471,6 +483,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         asm volatile("" : "+v"(qlo_v));                                     // v_med3 takes one scalar operand only
         const u32 qhi = (u32)(phred + nq);
         const u32 klow = (u32)(phred + lowQ + 1);
+        const u32 khead = (u32)(phred + P.lq_head_q), ktail = (u32)(phred + P.lq_tail_q);
         const u32 dumB = lds0 + ((u32)(4 * G.SET) + (u32)lane) * 4u;   // per-lane scratch word (variable-length tiles)
         uint8_t *ldsb = reinterpret_cast<uint8_t *>(lds);
         auto do_read = [&](auto FL, const int r, const u32 (&cc)[NS], const u32 (&cq)[NS]) {
@@ -500,16 +513,16 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 }
                 cQ[s] = __builtin_amdgcn_alignbit(cQ[s], qb - klow, 31u);       // sign <=> quality <= lowQual
                 if (FULL) {
-                    const int q = (int)qb - phred;
-                    if (P.polyX_num != -1) {
+                    constexpr int sf = FULL ? s : 0;
+                    if (has_px) {
                         // character of the previous position: wave_shr:1, lane 0 keeps `old` = last of the previous strip
                         const u32 pc = (u32)__builtin_amdgcn_update_dpp((int)prev_last, (int)c, 0x138, 0xF, 0xF, false);
                         prev_last = (u32)rl((int)c, 63);
-                        SNK_PUT(EQ, __ballot(c == pc))
+                        cE[sf] = __builtin_amdgcn_alignbit(cE[sf], __builtin_amdgcn_sad_u8(c, pc, 0xFFFFFFFFu), 31u);   // |c - pc| - 1 < 0 <=> equal
                     }
-                    if (P.has_lq) {
-                        SNK_PUT(LQH, __ballot(q < P.lq_head_q))
-                        SNK_PUT(LQT, __ballot(q < P.lq_tail_q))
+                    if (has_lq) {
+                        cA[sf] = __builtin_amdgcn_alignbit(cA[sf], qb - khead, 31u);      // quality < head threshold
+                        cT[sf] = __builtin_amdgcn_alignbit(cT[sf], qb - ktail, 31u);      // quality < tail threshold
                     }
                 }
                 // raw per-position quality histogram (src/peprocess.cpp:1182-1201); the base histogram is
@@ -621,26 +634,42 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         rs_init(R, clen_v);
         int v_adja = 0, v_nn = 0, v_bad = 0;
         u32 VP[NW], QP[NW];               // exact-ACGT positions, low-quality positions
-        {
+        // collector order -> canonical order (read r at bit r % 32 of word r / 32)
+        auto canon = [&](auto &cur, auto &par, const bool sign_collected) {
+            constexpr int N = sizeof(cur) / sizeof(cur[0]);
+            if (sign_collected) {          // newest read at the bottom -> on top, like cL
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {   // sign-collected planes: newest read at the bottom -> on top, like cL
-                cV[s] = __builtin_bitreverse32(cV[s]); pV[s] = __builtin_bitreverse32(pV[s]);
-                cQ[s] = __builtin_bitreverse32(cQ[s]); pQ[s] = __builtin_bitreverse32(pQ[s]);
+                for (int s = 0; s < N; ++s) { cur[s] = __builtin_bitreverse32(cur[s]); par[s] = __builtin_bitreverse32(par[s]); }
             }
             if (cnt < 64) {               // last tile of a batch: move read 0 (32) down to bit 0
                 if (cnt <= 32) {
-                    const int sh = 32 - cnt;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        pL[s] = cL[s] >> sh; pH[s] = cH[s] >> sh; pV[s] = cV[s] >> sh; pQ[s] = cQ[s] >> sh;
-                        cL[s] = cH[s] = cV[s] = cQ[s] = 0;
-                    }
+                    for (int s = 0; s < N; ++s) { par[s] = cur[s] >> (32 - cnt); cur[s] = 0; }
                 } else {
-                    const int sh = 64 - cnt;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) { cL[s] >>= sh; cH[s] >>= sh; cV[s] >>= sh; cQ[s] >>= sh; }
+                    for (int s = 0; s < N; ++s) cur[s] >>= (64 - cnt);
                 }
             }
+        };
+        // canonical collectors of a plane -> its per-read words (lane = read)
+        auto cross = [&](auto &cur, auto &par, u32 (&out)[NW]) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                u32 w0 = par[s], w1 = cur[s];
+                if (2 * s + 1 < NW) {
+                    bit_transpose64(w0, w1, lane);
+                    out[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = w1;
+                } else {
+                    w0 = bit_transpose64_lo(w0, w1, lane);
+                }
+                out[2 * s] = w0;
+            }
+        };
+        {
+            canon(cL, pL, false);
+            canon(cH, pH, false);
+            canon(cV, pV, true);
+            canon(cQ, pQ, true);
             // raw per-position base histogram (src/peprocess.cpp:1145-1180): lane = position holds one bit per
             // read of each plane, so the count of a letter at its position is a popcount -> one LDS add per
             // letter, strip and TILE (not per read).  LDS base rows are ordered by the code (A 00, C 01, T 10,
@@ -674,34 +703,23 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     atomicAdd(rowp + (3u << G.lg), nG << sh);
                 }
             }
+            u32 LP[NW], HP[NW];
+            cross(cL, pL, LP);
+            cross(cH, pH, HP);
+            cross(cV, pV, VP);
+            cross(cQ, pQ, QP);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                u32 l0 = pL[s], l1 = cL[s], h0 = pH[s], h1 = cH[s], v0 = pV[s], v1 = cV[s], q0 = pQ[s], q1 = cQ[s];
-                const int j1 = (2 * s + 1 < NW) ? 2 * s + 1 : 0;
-                if (2 * s + 1 < NW) {
-                    bit_transpose64(l0, l1, lane);
-                    bit_transpose64(h0, h1, lane);
-                    bit_transpose64(v0, v1, lane);
-                    bit_transpose64(q0, q1, lane);
-                } else {
-                    l0 = bit_transpose64_lo(l0, l1, lane);
-                    h0 = bit_transpose64_lo(h0, h1, lane);
-                    v0 = bit_transpose64_lo(v0, v1, lane);
-                    q0 = bit_transpose64_lo(q0, q1, lane);
-                }
-                X[0][2 * s] = ~(h0 | l0);
-                X[1][2 * s] = l0 & ~h0;
-                X[2][2 * s] = h0 & l0;
-                X[3][2 * s] = h0 & ~l0;
-                VP[2 * s] = v0;
-                QP[2 * s] = q0;
-                if (2 * s + 1 < NW) {
-                    X[0][j1] = ~(h1 | l1);
-                    X[1][j1] = l1 & ~h1;
-                    X[2][j1] = h1 & l1;
-                    X[3][j1] = h1 & ~l1;
-                    VP[j1] = v1;
-                    QP[j1] = q1;
+            for (int j = 0; j < NW; ++j) {
+                X[0][j] = ~(HP[j] | LP[j]);
+                X[1][j] = LP[j] & ~HP[j];
+                X[2][j] = HP[j] & LP[j];
+                X[3][j] = HP[j] & ~LP[j];
+            }
+            if (FULL) {
+                if (has_px) { canon(cE, pE, true); cross(cE, pE, EQ); }
+                if (has_lq) {
+                    canon(cA, pA, true); cross(cA, pA, LQH);
+                    canon(cT, pT, true); cross(cT, pT, LQT);
                 }
             }
         }
