@@ -176,6 +176,8 @@ EXPORTS = [
     "snk_stats_fetch", "snk_stats_allreduce", "snk_set_timing", "snk_last_kernel_ms",
     # include/snk_rmdup.h
     "snk_rmdup_hash_device", "snk_rmdup_bucket_count_device", "snk_rmdup_mark_device", "snk_rmdup_prime",
+    # include/snk_selftest.h
+    "snk_selftest_bit_transpose",
 ]
 
 
@@ -210,4 +212,5 @@ def load_library(path=None):
     lib.snk_rmdup_mark_device.argtypes = [vp, vp, vp, C.c_int64, C.c_uint64, C.c_int64, vp, vp]
     lib.snk_rmdup_prime.argtypes = [C.c_uint64]
     lib.snk_rmdup_prime.restype = C.c_uint32
+    lib.snk_selftest_bit_transpose.argtypes = [i32, vp, i32, vp, vp]
     return lib

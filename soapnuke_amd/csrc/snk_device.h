@@ -126,5 +126,6 @@ int snk_launch_hash(const uint8_t *const seq[2], const uint16_t *const len[2], c
                     int paired, unsigned long long *out, int n_cu, void *stream);
 int snk_launch_bucket_count(const unsigned long long *hash, long n, unsigned prime, const unsigned *flag,
                             unsigned long long *count, void *stream);
+int snk_launch_bittr_selftest(const unsigned *d_in, int n_matrices, unsigned *d_out, unsigned *d_out_lo);   // snk_tiled.hip
 int snk_launch_mark(const unsigned long long *hash, const unsigned *index, long n, unsigned prime, long bucket_total,
                     unsigned char *dup, void *stream);

@@ -17,6 +17,7 @@
 
 #include "snk_device.h"
 #include "../../include/snk_rmdup.h"
+#include "../../include/snk_selftest.h"
 
 namespace {
 
@@ -726,3 +727,20 @@ int snk_rmdup_mark_device(snk_ctx *c, const uint64_t *d_hash, const uint32_t *d_
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- include/snk_selftest.h
+int snk_selftest_bit_transpose(int device, const uint32_t *in, int n_matrices, uint32_t *out, uint32_t *out_lo) {
+    if (!in || !out || !out_lo || n_matrices <= 0) { set_err("snk_selftest_bit_transpose: bad arguments"); return SNK_E_PARAM; }
+    HIP_OK(hipSetDevice(device));
+    const size_t nb = (size_t)n_matrices * 128 * sizeof(uint32_t);
+    uint32_t *d_in = nullptr, *d_out = nullptr, *d_lo = nullptr;
+    HIP_OK(hipMalloc(&d_in, nb));
+    HIP_OK(hipMalloc(&d_out, nb));
+    HIP_OK(hipMalloc(&d_lo, nb / 2));
+    HIP_OK(hipMemcpy(d_in, in, nb, hipMemcpyHostToDevice));
+    if (snk_launch_bittr_selftest(d_in, n_matrices, d_out, d_lo) != 0) { set_err("bit transpose self-test: launch failed"); return SNK_E_HIP; }
+    HIP_OK(hipMemcpy(out, d_out, nb, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(out_lo, d_lo, nb / 2, hipMemcpyDeviceToHost));
+    hipFree(d_in); hipFree(d_out); hipFree(d_lo);
+    return SNK_OK;
+}

@@ -1217,3 +1217,21 @@ int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch
     else { SNK_GO(8) }
 #undef SNK_GO
 }
+
+// ---- include/snk_selftest.h: the hand-over primitive on its own
+namespace {
+__global__ void bittr_selftest_kernel(const u32 *in, u32 *out, u32 *out_lo) {
+    const int lane = threadIdx.x & 63;
+    const size_t m = blockIdx.x;
+    u32 lo = in[(m * 64 + lane) * 2], hi = in[(m * 64 + lane) * 2 + 1];
+    out_lo[m * 64 + lane] = bit_transpose64_lo(lo, hi, lane);
+    bit_transpose64(lo, hi, lane);
+    out[(m * 64 + lane) * 2] = lo;
+    out[(m * 64 + lane) * 2 + 1] = hi;
+}
+}  // namespace
+
+int snk_launch_bittr_selftest(const unsigned *d_in, int n, unsigned *d_out, unsigned *d_out_lo) {
+    hipLaunchKernelGGL(bittr_selftest_kernel, dim3(n), dim3(64), 0, 0, d_in, d_out, d_out_lo);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
