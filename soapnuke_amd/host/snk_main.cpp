@@ -61,6 +61,12 @@ struct Options {
     string trim_fq[2];                                               // trimFq1 / trimFq2 (gz): trimmed, not filtered
     string tile, fov;                                                // reads of these tiles / fovs are dropped (by name)
     string base_convert;
+    // limits on the clean output (src/process_argv.cpp:426-443,1476-1552)
+    uint64_t clean_out_split = 0;        // -w / cleanOutSplit: split.<k>.<cleanFq> files of that many reads
+    float total_reads = 0;               // totalReadsNum as atof() saw it (> 0: set)
+    float total_ratio = 0;               //   < 1: a ratio of the clean reads
+    uint64_t total_num = 0;              //   >= 1: a number of reads
+    bool total_head = false;             //   "<N>head": the first N clean reads; otherwise every k-th read
 };
 
 [[noreturn]] void die(const string &msg) {          // the reference's convention: message, exit(1)
@@ -163,6 +169,29 @@ void read_config(Options &o, const char *path) {             // src/process_argv
         else if (key == "glob_cotm_mR") o.g_mrs = val;
         else if (key == "glob_cotm_mM") o.g_mms = val;
         else if (key == "rmdup") p.rmdup = 1;
+        else if (key == "cleanOutSplit") {                   // src/process_argv.cpp:1537-1554
+            for (char ch : val) if (!isdigit((unsigned char)ch)) die("-w value should be a positive integer");
+            o.clean_out_split = (uint64_t)atoi(val.c_str());
+            if (o.clean_out_split == 0) die("-w value should be a positive integer");
+        }
+        else if (key == "totalReadsNum") {                   // src/process_argv.cpp:1476-1536
+            string t = val;
+            if (t.find("head") == string::npos) {
+                o.total_head = false;
+                for (char ch : t) if (!isdigit((unsigned char)ch) && ch != '.') die("-L value should be a positive integer or float");
+            } else {
+                o.total_head = true;
+                t.erase(t.find("head"), 4);
+                if (t.find(".") != string::npos) die("-L value should be a integer when with head suffix");
+                for (char ch : t) if (!isdigit((unsigned char)ch)) die("-L value should be an integer when with head suffix");
+            }
+            const float tv = (float)atof(val.c_str());
+            if (tv == 0) die("-L value should be a positive integer or float");
+            o.total_reads = tv;
+            if (tv < 1) o.total_ratio = tv;
+            else { std::istringstream is(t); is >> o.total_num; }
+            if (o.total_ratio > 0 && o.total_num > 0) die("reads number and ratio should not be both assigned at the same time");
+        }
         else if (key == "pe_info") o.pe_info = true;
         else if (key == "baseConvert") die("parameter baseConvert is not supported by the GPU filter path yet (the reference converts before its clean statistics)");
         else die("parameter " + key + " is not supported by the GPU filter path yet");
@@ -187,7 +216,7 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
         {"ada_trim", 0, NULL, 'J'}, {"lowQual", 1, NULL, 'l'}, {"qualRate", 1, NULL, 'q'}, {"nRate", 1, NULL, 'n'},
         {"mean", 1, NULL, 'm'}, {"highA", 1, NULL, 'p'}, {"polyG_tail", 1, NULL, 'g'}, {"polyX", 1, NULL, 'X'},
         {"minReadLen", 1, NULL, '4'}, {"trimBadHead", 1, NULL, 'x'}, {"trimBadTail", 1, NULL, 'y'}, {"trim", 1, NULL, 't'},
-        {"thread", 1, NULL, 'T'}, {"help", 0, NULL, 'h'}, {"version", 0, NULL, 'v'}, {NULL, 0, NULL, 0}};
+        {"thread", 1, NULL, 'T'}, {"output_clean", 1, NULL, 'w'}, {"help", 0, NULL, 'h'}, {"version", 0, NULL, 'v'}, {NULL, 0, NULL, 0}};
     snk_params_default(&o.p);
     int c;
     while ((c = getopt_long(argc, argv, shortopts, longopts, NULL)) != -1) {
@@ -215,7 +244,13 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
         case '4': o.p.min_read_length = atoi(optarg); break;
         case 'v': cerr << "SOAPnuke filter tools version 2.1.9 (MI355X hot path)" << endl; exit(1);
         case 'h': usage(); exit(1);
-        case 'j': case 'E': case 'w': die("option not supported by the GPU filter path yet");
+        case 'w': {                                          // src/process_argv.cpp:426-443
+            for (const char *q = optarg; *q; ++q) if (!isdigit((unsigned char)*q)) die("-w value should be a positive integer");
+            o.clean_out_split = (uint64_t)atoi(optarg);
+            if (o.clean_out_split == 0) die("-w value should be a positive integer");
+            break;
+        }
+        case 'j': case 'E': die("option not supported by the GPU filter path yet");
         default: exit(1);
         }
     }
@@ -257,6 +292,14 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
     o.p.g_mms = o.g_mms.empty() ? nullptr : o.g_mms.c_str();
     if (o.log.find("/") == string::npos) o.log = o.out_dir + "/" + o.log;
     if (o.out_file_type != "fastq" && o.out_file_type != "fasta") die("output_file_type value error");
+    // limited clean output (src/process_argv.cpp:614-622,785-789,892-896)
+    if (o.p.paired && (o.clean_out_split > 0 || o.total_reads > 0) && !ends_with_gz(o.clean1) && !ends_with_gz(o.clean2))
+        die("the clean out fastq should be non-gz format when clean output reads are limited");
+    {
+        const uint64_t ps = o.patch_size > 0 ? (uint64_t)o.patch_size : (uint64_t)o.threads * 20000 / 8;
+        if (o.clean_out_split != 0 && o.clean_out_split < ps) die(" output reads in each clean fastq file(-w) should be more than patch size(-e)");
+    }
+    if (o.clean_out_split > 0 && o.total_reads > 0) die("-w and -L cannot be both assigned");
 }
 
 string local_time() {                                   // get_local_time(), src/gc.cpp:186-199 (unpadded)
@@ -637,6 +680,61 @@ struct OutFile {                                        // clean / dup output: b
     }
 };
 
+// totalReadsNum without "head" (src/peprocess.cpp:3198-3320, run_extract_random / sub_extract): after the run
+// every k-th clean read (k = clean reads / wanted reads, integer) until the wanted number is reached goes to a new
+// file that takes the clean file's name; the complete file is kept as total.<cleanFq>.
+void extract_every_kth(const Options &o, int mates, uint64_t total_clean) {
+    unsigned long long want = o.total_num;
+    if (o.total_ratio > 0) {
+        if (o.total_ratio >= 1) die("the ratio extract from clean fq file should not be more than 1");
+        want = (unsigned long long)((float)total_clean * o.total_ratio);
+    }
+    if (total_clean < want) {
+        cerr << "Warning:the reads number in clean fastq file(" << total_clean << ") is less than you assigned to output(" << want << ")" << endl;
+        return;
+    }
+    if (want == 0) { cerr << "Error:assigned reads number should not be 0" << endl; return; }
+    if ((float)total_clean / want < 1.1) return;
+    const int mo = (int)(total_clean / want);
+    const string names[2] = {o.clean1, o.clean2};
+    for (int m = 0; m < mates; ++m) {
+        const string in = o.out_dir + "/" + names[m];
+        const string out = o.out_dir + (o.out_gz ? "/cleanRandomExtractReads.r" : "/cleanRandomExtractReads.r") + std::to_string(m + 1) + (o.out_gz ? ".fq.gz" : ".fq");
+        char buf[1000];                                           // READBUF
+        long line_num = 0, kept_lines = 0;
+        if (o.out_gz) {
+            gzFile fo = gzopen(out.c_str(), "wb"), fi = gzopen(in.c_str(), "rb");
+            if (!fo || !fi) die("cannot open such file," + in);
+            gzsetparams(fo, 2, Z_DEFAULT_STRATEGY);
+            while (gzgets(fi, buf, sizeof buf)) {
+                if (line_num % (4 * mo) <= 3) {
+                    gzwrite(fo, buf, (unsigned)strlen(buf));
+                    ++kept_lines;
+                    if ((unsigned long long)(kept_lines / 4) >= want && kept_lines % 4 == 0) break;
+                }
+                ++line_num;
+            }
+            gzclose(fo);
+            gzclose(fi);
+        } else {
+            FILE *fo = fopen(out.c_str(), "w"), *fi = fopen(in.c_str(), "r");
+            if (!fo || !fi) die("cannot open such file," + in);
+            while (fgets(buf, sizeof buf, fi)) {
+                if (line_num % (4 * mo) <= 3) {
+                    fputs(buf, fo);
+                    ++kept_lines;
+                    if ((unsigned long long)(kept_lines / 4) >= want && kept_lines % 4 == 0) break;
+                }
+                ++line_num;
+            }
+            fclose(fo);
+            fclose(fi);
+        }
+        if (rename(in.c_str(), (o.out_dir + "/total." + names[m]).c_str()) != 0 || rename(out.c_str(), in.c_str()) != 0)
+            die("cannot rename the extracted clean file," + in);
+    }
+}
+
 struct Slot {                                           // one batch in flight
     uint8_t *h_seq[2] = {nullptr, nullptr}, *h_qual[2] = {nullptr, nullptr}, *d_seq[2] = {nullptr, nullptr}, *d_qual[2] = {nullptr, nullptr};
     uint16_t *h_len[2] = {nullptr, nullptr}, *d_len[2] = {nullptr, nullptr};
@@ -834,8 +932,20 @@ int main(int argc, char **argv) {
 
     // ---- main pass: pack+GPU stage (this thread) and write stage (its own thread), NSLOT batches in flight
     OutFile wr[2];
-    wr[0].open(o.out_dir + "/" + o.clean1, o.out_gz);
-    if (mates == 2) wr[1].open(o.out_dir + "/" + o.clean2, o.out_gz);
+    // limited clean output: -w writes split.<k>.<cleanFq> files of clean_out_split reads (the next file is created
+    // the moment one is full, src/peprocess.cpp:2474-2560,2772-2870); "<N>head" keeps the first N clean reads
+    // (:2960-2985); both cut inside a worker's slice, so the slices are compressed after cutting
+    const uint64_t split_n = o.clean_out_split, head_n = o.total_head ? o.total_num : 0;
+    const bool cut_mode = split_n > 0 || head_n > 0;
+    const string clean_name[2] = {o.clean1, o.clean2};
+    uint64_t split_idx = 0, in_split = 0, clean_written = 0, clean_total = 0;
+    auto open_clean = [&](uint64_t k) {
+        for (int m = 0; m < mates; ++m) {
+            wr[m].close();
+            wr[m].open(split_n ? o.out_dir + "/split." + std::to_string(k) + "." + clean_name[m] : o.out_dir + "/" + clean_name[m], o.out_gz);
+        }
+    };
+    if (!split_n) open_clean(0);
     // trimFq1/trimFq2: every read after trimming, before the discard cascade (src/peprocess.cpp:1460-1466,1938-1944)
     const bool trim_out = !o.trim_fq[0].empty();
     OutFile trimw[2];
@@ -851,6 +961,8 @@ int main(int argc, char **argv) {
     std::thread writer([&] {
         Slot *sp;
         std::vector<string> text[2], zbuf[2], ttext[2], tzbuf[2];
+        std::vector<std::vector<uint32_t>> recoff[2];          // cut_mode: start of every kept record in text[m][w]
+        std::vector<uint64_t> kcount;
         struct DupPiece { int vt; string z[2]; };            // one gzip member per (worker slice, virtual thread, mate)
         std::vector<std::vector<DupPiece>> dpieces;
         std::vector<uint64_t> dcount;
@@ -861,9 +973,11 @@ int main(int argc, char **argv) {
             for (int m = 0; m < mates; ++m) {
                 text[m].assign(WK, string()); zbuf[m].assign(WK, string());
                 ttext[m].assign(WK, string()); tzbuf[m].assign(WK, string());
+                recoff[m].assign(WK, std::vector<uint32_t>());
             }
             dpieces.assign(WK, std::vector<DupPiece>());
             dcount.assign(WK, 0);
+            kcount.assign(WK, 0);
             // clean output, input order (src/peprocess.cpp:3383-3484): every worker formats (and deflates) a slice
             parallel_for(WK, n, [&](int w, int lo, int hi) {
                 // one record of mate m in output form; pe_times: how often preOutput ran on the object
@@ -908,14 +1022,18 @@ int main(int argc, char **argv) {
                     string &out = text[m][w];
                     out.reserve((size_t)(hi - lo) * (size_t)(2 * lcap + 64));
                     for (int i = lo; i < hi; ++i)
-                        if (s.h_rec[0][i].reason == SNK_KEEP) put(out, m, i, trim_out ? 2 : 1);
+                        if (s.h_rec[0][i].reason == SNK_KEEP) {
+                            if (m == 0) ++kcount[w];
+                            if (cut_mode) recoff[m][w].push_back((uint32_t)out.size());
+                            put(out, m, i, trim_out ? 2 : 1);
+                        }
                     if (trim_out) {
                         string &tout = ttext[m][w];
                         tout.reserve((size_t)(hi - lo) * (size_t)(2 * lcap + 64));
                         for (int i = lo; i < hi; ++i) put(tout, m, i, 1);
                         if (trimw[m].gz && !tout.empty()) gzip_member(tout, tzbuf[m][w]);
                     }
-                    if (wr[m].gz && !out.empty()) gzip_member(out, zbuf[m][w]);
+                    if (o.out_gz && !cut_mode && !out.empty()) gzip_member(out, zbuf[m][w]);
                 }
                 if (d_dup_all) {                               // C_fastq::toString of the raw records, src/peprocess.cpp:1541
                     string acc[2];
@@ -942,11 +1060,33 @@ int main(int argc, char **argv) {
                     flush_piece();
                 }
             });
-            for (int m = 0; m < mates; ++m)
+            for (int w = 0; w < WK; ++w) clean_total += kcount[w];
+            if (!cut_mode) {
+                for (int m = 0; m < mates; ++m)
+                    for (int w = 0; w < WK; ++w) {
+                        const string &bytes = wr[m].gz ? zbuf[m][w] : text[m][w];
+                        if (!bytes.empty()) fwrite(bytes.data(), 1, bytes.size(), wr[m].fp);
+                    }
+            } else {
                 for (int w = 0; w < WK; ++w) {
-                    const string &bytes = wr[m].gz ? zbuf[m][w] : text[m][w];
-                    if (!bytes.empty()) fwrite(bytes.data(), 1, bytes.size(), wr[m].fp);
+                    const size_t kept = recoff[0][w].size();
+                    size_t pos = 0;
+                    while (pos < kept) {
+                        if (head_n && clean_written >= head_n) break;
+                        if (split_n && !wr[0].fp) open_clean(split_idx);        // the first split file appears with the first clean read
+                        const uint64_t room = split_n ? split_n - in_split : head_n - clean_written;
+                        const size_t take = (size_t)std::min<uint64_t>(room, kept - pos);
+                        for (int m = 0; m < mates; ++m) {
+                            const size_t b = recoff[m][w][pos], e = pos + take < kept ? recoff[m][w][pos + take] : text[m][w].size();
+                            wr[m].write_text(text[m][w].substr(b, e - b));
+                        }
+                        pos += take;
+                        clean_written += take;
+                        in_split += take;
+                        if (split_n && in_split == split_n) { open_clean(++split_idx); in_split = 0; }
+                    }
                 }
+            }
             if (trim_out)
                 for (int m = 0; m < mates; ++m)
                     for (int w = 0; w < WK; ++w) {
@@ -1051,6 +1191,7 @@ int main(int argc, char **argv) {
         sp[t] = sums[t].data();
         mp[t] = maxs[t].data();
     }
+    if (o.total_reads > 0 && !o.total_head) extract_every_kth(o, mates, clean_total);
     char ebuf[512];
     if (snk_write_reports(&o.p, T, sp.data(), mp.data(), o.out_dir.c_str(), ebuf, sizeof ebuf) != 0) { cerr << ebuf << endl; return 1; }
     log << local_time() << "\tAnalysis accomplished!" << endl;

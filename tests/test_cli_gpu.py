@@ -235,3 +235,67 @@ def test_cli_error_surface(tmp_path):
     synth.write_fastq(str(tmp_path / "bad.fq"), d["seq"][0], d["qual"][0], 50, 1)
     r = subprocess.run([CLI, "filter", "-1", str(tmp_path / "bad.fq"), "-C", "c.fq", "-o", str(tmp_path / "o")], capture_output=True)
     assert r.returncode == 1 and b"Error:unrecognized sequence" in r.stderr
+
+
+def _limited_run(tmp_path, paired, n, cfg_lines, extra_cli, seed):
+    """Both binaries on the same .gz input with .gz clean output names (the reference insists on .gz there,
+    src/process_argv.cpp:614-622); returns (ours_dir, ref_dir, report file list)."""
+    L = 100
+    d = synth.make_batch(n, L, paired=paired, seed=seed)
+    work = str(tmp_path)
+    mates = 2 if paired else 1
+    for m in range(mates):
+        synth.write_fastq(os.path.join(work, f"r{m + 1}.fq"), d["seq"][m], d["qual"][m], L, m + 1)
+        subprocess.check_call(["gzip", "-1", "-f", "-k", os.path.join(work, f"r{m + 1}.fq")])
+    open(os.path.join(work, "cfg"), "w").write("\n".join(cfg_lines) + "\n")
+    tail = ["-C", "c1.fq.gz", "-T", "2", "-f", synth.ADAPTER1, "-J", "-c", os.path.join(work, "cfg")] + extra_cli
+    inp = ["-1", os.path.join(work, "r1.fq.gz")]
+    if paired:
+        tail += ["-D", "c2.fq.gz", "-r", synth.ADAPTER2]
+        inp += ["-2", os.path.join(work, "r2.fq.gz")]
+    r = subprocess.run([T.REF_BIN, "filter"] + inp + ["-o", os.path.join(work, "ref")] + tail, capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-300:]
+    r = subprocess.run([CLI, "filter"] + inp + ["-o", os.path.join(work, "ours")] + tail, capture_output=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    return os.path.join(work, "ours"), os.path.join(work, "ref"), (R.REPORT_FILES_PE if paired else R.REPORT_FILES_SE)
+
+
+@pytest.mark.parametrize("paired,split,how", [(True, 700, "-w"), (False, 900, "cfg"), (True, 1000, "cfg")])
+def test_cli_clean_out_split(paired, split, how, tmp_path):
+    """-w / cleanOutSplit: split.<k>.<cleanFq> files of that many reads, in input order (src/peprocess.cpp:2474-2560,
+    2772-2870).  The block of a reference thread (patch * 160 / T reads) stays below the split size here: with
+    bigger blocks the reference binary spins forever in extractReadsToFile (negative head count)."""
+    cfg = ["patch=10"] + ([f"cleanOutSplit={split}"] if how == "cfg" else [])
+    ours, ref, reports = _limited_run(tmp_path, paired, 3000, cfg, ["-w", str(split)] if how == "-w" else [], seed=61)
+    names = sorted(f for f in os.listdir(ref) if f.startswith("split."))
+    assert names and names == sorted(f for f in os.listdir(ours) if f.startswith("split."))
+    for f in names:
+        assert _cat(os.path.join(ours, f)) == _cat(os.path.join(ref, f)), f
+    assert not os.path.exists(os.path.join(ours, "c1.fq.gz"))
+    for f in reports:
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+
+
+@pytest.mark.parametrize("paired,value", [(True, "1000head"), (False, "700head"), (True, "500"), (True, "0.25"), (False, "0.4"),
+                                          (True, "100000head"), (True, "2600")])
+def test_cli_total_reads_num(paired, value, tmp_path):
+    """config key totalReadsNum: "<N>head" keeps the first N clean reads (src/peprocess.cpp:2960-2985); a number or a
+    ratio keeps every k-th clean read in a second pass and leaves the complete file as total.<cleanFq> (:3198-3320;
+    nothing happens when fewer than 1.1 x the wanted reads are there).  Statistics cover the whole input."""
+    ours, ref, reports = _limited_run(tmp_path, paired, 3000, ["patch=10", f"totalReadsNum={value}"], [], seed=62)
+    names = sorted(f for f in os.listdir(ref) if f.endswith(".fq.gz"))
+    assert names == sorted(f for f in os.listdir(ours) if f.endswith(".fq.gz"))
+    for f in names:
+        assert _cat(os.path.join(ours, f)) == _cat(os.path.join(ref, f)), f
+    for f in reports:
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+
+
+def test_cli_limited_output_errors(tmp_path):
+    base = [CLI, "filter", "-1", "/nonexistent.fq", "-2", "/nonexistent2.fq", "-o", str(tmp_path)]
+    r = subprocess.run(base + ["-C", "c1.fq", "-D", "c2.fq", "-w", "100000"], capture_output=True)
+    assert r.returncode == 1 and b"non-gz format when clean output reads are limited" in r.stderr
+    r = subprocess.run(base + ["-C", "c1.fq.gz", "-D", "c2.fq.gz", "-w", "10"], capture_output=True)
+    assert r.returncode == 1 and b"should be more than patch size" in r.stderr
+    r = subprocess.run(base + ["-C", "c1.fq.gz", "-D", "c2.fq.gz", "-w", "abc"], capture_output=True)
+    assert r.returncode == 1 and b"-w value should be a positive integer" in r.stderr
