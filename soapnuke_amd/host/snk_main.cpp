@@ -193,7 +193,7 @@ void read_config(Options &o, const char *path) {             // src/process_argv
             if (o.total_ratio > 0 && o.total_num > 0) die("reads number and ratio should not be both assigned at the same time");
         }
         else if (key == "pe_info") o.pe_info = true;
-        else if (key == "baseConvert") die("parameter baseConvert is not supported by the GPU filter path yet (the reference converts before its clean statistics)");
+        else if (key == "baseConvert") o.base_convert = val;
         else die("parameter " + key + " is not supported by the GPU filter path yet");
     }
 }
@@ -300,6 +300,14 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
         if (o.clean_out_split != 0 && o.clean_out_split < ps) die(" output reads in each clean fastq file(-w) should be more than patch size(-e)");
     }
     if (o.clean_out_split > 0 && o.total_reads > 0) die("-w and -L cannot be both assigned");
+    if (!o.base_convert.empty()) {                               // src/process_argv.cpp:865-890
+        const string acgt = "ACGTacgt", &b = o.base_convert;
+        if (b.find("TO") == string::npos && b.find("2") == string::npos) die("base_convert value format error");
+        if (acgt.find(b[0]) == string::npos || acgt.find(b[b.size() - 1]) == string::npos) die("base_convert value format error");
+        // seProcess::preOutput calls string::replace(npos, ...) for whichever of "TO" / "2" is absent and dies of the
+        // exception (src/seprocess.cpp:923-924): there is no single-end behaviour to reproduce
+        if (!o.p.paired) die("baseConvert aborts the reference in single-end mode (src/seprocess.cpp:923); not supported");
+    }
 }
 
 string local_time() {                                   // get_local_time(), src/gc.cpp:186-199 (unpadded)
@@ -1188,6 +1196,20 @@ int main(int argc, char **argv) {
         if (err.code == SNK_E_EMPTY_SEQ) die("empty sequence");
         if (err.code == SNK_E_QUAL_RANGE) die("quality is too high or too low,please check the quality system parameter or fastq file");
         if (err.code) die("device reported error " + std::to_string(err.code));
+        if (bc_from) {
+            // preOutput converted the clean reads before stat_pe_fqs(..., "clean") counted them (src/peprocess.cpp:1601-1604,1960):
+            // in the clean statistics the letter's counts belong to the letter it became (the switch there is case-insensitive)
+            const string acgt = "ACGT";
+            const size_t from = acgt.find(bc_from), to = acgt.find((char)toupper((unsigned char)bc_to));
+            if (from != string::npos && to != string::npos && from != to)
+                for (int k = 2; k < 2 + mates; ++k) {
+                    uint64_t *f = sums[t].data() + snk_file_off(lcap, nq, k);
+                    f[SNK_GS_A + to] += f[SNK_GS_A + from];
+                    f[SNK_GS_A + from] = 0;
+                    uint64_t *bs = f + snk_bs_off(lcap, nq);
+                    for (int pos = 0; pos < lcap; ++pos) { bs[pos * 5 + to] += bs[pos * 5 + from]; bs[pos * 5 + from] = 0; }
+                }
+        }
         sp[t] = sums[t].data();
         mp[t] = maxs[t].data();
     }

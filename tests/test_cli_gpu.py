@@ -299,3 +299,24 @@ def test_cli_limited_output_errors(tmp_path):
     assert r.returncode == 1 and b"should be more than patch size" in r.stderr
     r = subprocess.run(base + ["-C", "c1.fq.gz", "-D", "c2.fq.gz", "-w", "abc"], capture_output=True)
     assert r.returncode == 1 and b"-w value should be a positive integer" in r.stderr
+
+
+@pytest.mark.parametrize("value", ["T2C", "GTOa", "ATOA"])
+def test_cli_base_convert(value, tmp_path):
+    """config key baseConvert (PE): preOutput rewrites one letter in every clean (and trimmed) read before the clean
+    statistics count it (src/peprocess.cpp:1617-1647); single-end mode aborts the reference (src/seprocess.cpp:923)."""
+    n, L = 6000, 100
+    d = synth.make_batch(n, L, paired=True, seed=97)
+    cfg = [f"baseConvert={value}", "trimFq1=t1.fq.gz", "trimFq2=t2.fq.gz"]
+    cli = ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J"]
+    case = ("bconv", True, L, n, 2, 300, {}, {}, cli, cfg)
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ours = _run_ours(case, work, gz=False)
+    for f in R.REPORT_FILES_PE:
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in ["c1.fq", "c2.fq", "t1.fq.gz", "t2.fq.gz"]:
+        assert _cat(os.path.join(ours, c)) == _cat(os.path.join(ref, c)), c
+    r = subprocess.run([CLI, "filter", "-1", os.path.join(work, "r1.fq"), "-C", "c1.fq", "-o", os.path.join(work, "se"), "-c", os.path.join(work, "cfg")],
+                       capture_output=True)
+    assert r.returncode == 1 and b"single-end" in r.stderr
