@@ -569,34 +569,44 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     gs += chunkB;
                     gq += chunkB;
                 };
+                // LDS -> register reads run one read ahead of the collectors, across chunk boundaries: the read
+                // queue is never drained inside a tile.  Reads, histogram adds and their waits are hand-placed asm:
+                // the compiler cannot see through the loop-carried LDS queue and would drain it (lgkmcnt(0)) right
+                // after issuing the prefetch.  LDS ops return in order, so "all but the newest K" is exact: K = NS
+                // histogram adds follow the prefetch.  Every read is waited for in the same straight-line block
+                // that issued it (no register of an in-flight read crosses a branch).
+                // DMA: chunk k+2 is issued into the buffer of chunk k as soon as its last row sits in registers,
+                // i.e. one read before chunk k+1 is first touched, and the wait there covers chunk k+1.
+                constexpr int K = SNK_ABL == 11 ? 0 : NS;
+                const u32 stg0 = lds0 + (u32)(G.stg_off + wave * G.stg_wave + lane);
                 issue(0);
-                for (int k = 0; k < nchunks; ++k) {
-                    if (k + 1 < nchunks) {
-                        issue(k + 1);
-                        if (SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    } else {
-                        if (SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    // LDS -> register reads run one read ahead of the ballots.  Reads, histogram adds and
-                    // their waits are hand-placed asm: the compiler cannot see through the loop-carried LDS
-                    // queue and would drain it (lgkmcnt(0)) right after issuing the prefetch.  LDS ops return
-                    // in order, so "all but the newest K" is exact: K = 2*NS histogram adds follow the
-                    // prefetch.  Every read is waited for in the same straight-line block that issued it (no
-                    // register of an in-flight read crosses a branch).  The prefetch past the last read of
-                    // the chunk reads staging bytes that are never used.
-                    constexpr int K = SNK_ABL == 11 ? 0 : NS;
+                if (nchunks > 1) issue(1);
+                if (SNK_ABL != 14) {
+                    if (nchunks > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                u32 ac[NS], aq[NS], bc[NS], bq[NS];     // two register sets alternate (no rotation moves)
+                lds_rd(ac, aq, stg0);
+                lds_wait<0>(ac, aq);
+                for (int k = 0; k < nchunks; ++k) {     // `a` holds row 0 of chunk k
                     const int nr = min(rb, cnt - k * rb);
-                    if (k * rb == 32) park();              // rb is a power of two <= 32 (launch())
-                    u32 sa = lds0 + (u32)(G.stg_off + wave * G.stg_wave + (k & 1) * 2 * G.cba + lane);
-                    u32 ac[NS], aq[NS], bc[NS], bq[NS];     // two register sets alternate (no rotation moves)
-                    lds_rd(ac, aq, sa);
-                    lds_wait<0>(ac, aq);
+                    if (k * rb == 32) park();          // rb is a power of two <= 32 (launch())
+                    u32 sa = stg0 + (u32)((k & 1) * 2 * G.cba);
                     for (int rr = 0; rr < nr; rr += 2) {
-                        lds_rd(bc, bq, sa + (u32)B.pitch);
+                        lds_rd(bc, bq, sa + (u32)B.pitch);      // (past the last read of the tile: staging bytes that are never used)
                         do_read(FL, k * rb + rr, ac, aq);
                         lds_wait<K>(bc, bq);
                         sa += 2u * (u32)B.pitch;
                         if (rr + 1 < nr) {
+                            if (rr + 2 >= nr && k + 1 < nchunks) {   // this chunk's rows are all in registers: next DMA, next chunk's row 0
+                                if (k + 2 < nchunks) {
+                                    issue(k + 2);
+                                    if (SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                                } else if (SNK_ABL != 14) {
+                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                }
+                                sa = stg0 + (u32)(((k + 1) & 1) * 2 * G.cba);
+                            }
                             lds_rd(ac, aq, sa);
                             do_read(FL, k * rb + rr + 1, bc, bq);
                             lds_wait<K>(ac, aq);
@@ -1169,13 +1179,13 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
         for (G.cba = 1024; G.cba >= 256; G.cba -= 256) {
             G.rb = pow2_floor(G.cba / b.pitch);
             G.stg_wave = 2 * 2 * G.cba;
-            if (G.rb >= 1 && hist + (size_t)W * G.stg_wave + 2048 <= 160 * 1024) break;
+            if (G.rb >= 2 && hist + (size_t)W * G.stg_wave + 2048 <= 160 * 1024) break;
             G.rb = 0;
         }
         if (G.rb == 0) {
             G.cba = 1024; G.rb = pow2_floor(G.cba / b.pitch); G.stg_wave = 2 * 2 * G.cba;
             while (W > 4 && hist + (size_t)W * G.stg_wave + 2048 > 160 * 1024) W -= 4;
-            if (hist + (size_t)W * G.stg_wave + 2048 > 160 * 1024) { G.rb = 0; W = 16; }
+            if (hist + (size_t)W * G.stg_wave + 2048 > 160 * 1024 || G.rb < 2) { G.rb = 0; W = 16; }   // reads pair up inside a chunk
         }
     }
     const size_t shmem = hist + (G.rb ? (size_t)W * G.stg_wave + 2048 : 0);   // + slack for strip / prefetch over-reads
