@@ -449,22 +449,21 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         // difference (v_alignbit acc, x, 31 = acc << 1 | x >> 31: newest read at the bottom, reversed at the
         // hand-over).  Reads 0..31 are parked in p* when read 32 arrives.
         u32 cL[NS], cH[NS], cV[NS], cQ[NS], pL[NS], pH[NS], pV[NS], pQ[NS];
-        // FULL variant, sign-collected as well: "same character as the previous position" (polyX), quality below
-        // the head / tail thresholds of the low-quality-end trim
+        // FULL variant, sign-collected as well: quality below the head / tail thresholds of the low-quality-end trim
         constexpr int NF = FULL ? NS : 1;
-        u32 cE[NF], cA[NF], cT[NF], pE[NF], pA[NF], pT[NF];
+        u32 cA[NF], cT[NF], pA[NF], pT[NF];
         const bool has_px = FULL && __builtin_amdgcn_readfirstlane(P.polyX_num) != -1;
         const bool has_lq = FULL && __builtin_amdgcn_readfirstlane(P.has_lq) != 0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) cL[s] = cH[s] = cV[s] = cQ[s] = pL[s] = pH[s] = pV[s] = pQ[s] = 0;
 #pragma unroll
-        for (int s = 0; s < NF; ++s) cE[s] = cA[s] = cT[s] = pE[s] = pA[s] = pT[s] = 0;
+        for (int s = 0; s < NF; ++s) cA[s] = cT[s] = pA[s] = pT[s] = 0;
         auto park = [&]() {
 #pragma unroll
             for (int s = 0; s < NS; ++s) { pL[s] = cL[s]; pH[s] = cH[s]; pV[s] = cV[s]; pQ[s] = cQ[s]; }
             if (FULL) {
 #pragma unroll
-                for (int s = 0; s < NF; ++s) { pE[s] = cE[s]; pA[s] = cA[s]; pT[s] = cT[s]; }
+                for (int s = 0; s < NF; ++s) { pA[s] = cA[s]; pT[s] = cT[s]; }
             }
         };
         const int has_meanq = __builtin_amdgcn_readfirstlane(P.has_meanq);
@@ -489,7 +488,6 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         auto do_read = [&](auto FL, const int r, const u32 (&cc)[NS], const u32 (&cq)[NS]) {
             constexpr bool FULLLEN = decltype(FL)::value;
             const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
-            u32 prev_last = 0xFFFFFFFFu;
             static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                 constexpr int s = decltype(sc)::v;
                 const int pos = 64 * s + lane;
@@ -514,12 +512,6 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 cQ[s] = __builtin_amdgcn_alignbit(cQ[s], qb - klow, 31u);       // sign <=> quality <= lowQual
                 if (FULL) {
                     constexpr int sf = FULL ? s : 0;
-                    if (has_px) {
-                        // character of the previous position: wave_shr:1, lane 0 keeps `old` = last of the previous strip
-                        const u32 pc = (u32)__builtin_amdgcn_update_dpp((int)prev_last, (int)c, 0x138, 0xF, 0xF, false);
-                        prev_last = (u32)rl((int)c, 63);
-                        cE[sf] = __builtin_amdgcn_alignbit(cE[sf], __builtin_amdgcn_sad_u8(c, pc, 0xFFFFFFFFu), 31u);   // |c - pc| - 1 < 0 <=> equal
-                    }
                     if (has_lq) {
                         cA[sf] = __builtin_amdgcn_alignbit(cA[sf], qb - khead, 31u);      // quality < head threshold
                         cT[sf] = __builtin_amdgcn_alignbit(cT[sf], qb - ktail, 31u);      // quality < tail threshold
@@ -726,7 +718,16 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 X[3][j] = HP[j] & ~LP[j];
             }
             if (FULL) {
-                if (has_px) { canon(cE, pE, true); cross(cE, pE, EQ); }
+                if (has_px) {
+                    // "same character as the previous position" (polyX) from the planes: same code bits and both exact
+                    // ACGT; reads with anything else get their exact plane in the fix-up pass
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) {
+                        const u32 lp = (LP[j] << 1) | (j ? LP[j ? j - 1 : 0] >> 31 : 0u), hp = (HP[j] << 1) | (j ? HP[j ? j - 1 : 0] >> 31 : 0u);
+                        const u32 vp = (VP[j] << 1) | (j ? VP[j ? j - 1 : 0] >> 31 : 0u);
+                        EQ[j] = ~(LP[j] ^ lp) & ~(HP[j] ^ hp) & VP[j] & vp;
+                    }
+                }
                 if (has_lq) {
                     canon(cA, pA, true); cross(cA, pA, LQH);
                     canon(cT, pT, true); cross(cT, pT, LQT);
@@ -768,12 +769,19 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 const int len_r = rl(clen_v, r);
                 const uint8_t *sp = seq + (t0 + r) * (long)B.pitch;
                 int adjA = 0, nN = 0, bad = 0;
+                u32 prev_last = 0xFFFFFFFFu;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const int pos = 64 * s + lane;
                     const bool valid = pos < len_r;
                     u32 c = 0;
                     if (valid) c = sp[pos];
+                    if (FULL && has_px) {
+                        // character of the previous position: wave_shr:1, lane 0 keeps `old` = last of the previous strip
+                        const u32 pc = (u32)__builtin_amdgcn_update_dpp((int)prev_last, (int)c, 0x138, 0xF, 0xF, false);
+                        prev_last = (u32)rl((int)c, 63);
+                        SNK_PUT(EQ, __ballot(valid && c == pc))
+                    }
                     const u32 cu = c & 0xDFu;
                     adjA += __popcll(__ballot(valid && cu == 'A' && c != 'A'));
                     const bool isn = valid && cu == 'N';
@@ -810,7 +818,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         }
         int hix = 0, tix = 0, polyg = 0;
         if (FULL) {
-            if (P.polyX_num != -1) {        // contig_base >= polyX_num  <=>  run of polyX_num-1 "same as previous"
+            if (SNK_ABL != 8 && P.polyX_num != -1) {        // contig_base >= polyX_num  <=>  run of polyX_num-1 "same as previous"
                 const int need = P.polyX_num - 1;
                 if (need <= 0) R.polyx = 1;
                 else {
@@ -828,7 +836,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     R.polyx = any_bit(EQ) ? 1 : 0;
                 }
             }
-            if (P.has_lq) {                  // src/read_filter.cpp:409-424
+            if (SNK_ABL != 9 && P.has_lq) {                  // src/read_filter.cpp:409-424
                 const int ru = run_up<NW>(LQH);
                 hix = (ru >= 32 * NW && oobH) ? P.lq_head_len : min(ru, P.lq_head_len);
                 hix = max(hix, 0);
@@ -836,7 +844,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 if (rd >= R.len && oobT) rd = 0x7FFFFFFF;           // runs off the front: reads '\0'
                 tix = max(min(rd, P.lq_tail_len), 0);
             }
-            if (P.has_polyG) polyg = run_down<NW>(FG, R.len);     // src/read_filter.cpp:472-482
+            if (SNK_ABL != 9 && P.has_polyG) polyg = run_down<NW>(FG, R.len);     // src/read_filter.cpp:472-482
         }
         const bool good = lanev && !estat;
         int ada_pos = -1;
@@ -849,7 +857,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             if (todo && pp >= 0) ada_pos = pp;
         }
         if (ada_pos >= 0) { R.inc_ada = 1; R.adacut = R.len - ada_pos; }
-        if (P.trim_on) trim_finish(P, m, R, hix, tix, polyg);
+        if (SNK_ABL != 10 && P.trim_on) trim_finish(P, m, R, hix, tix, polyg);
         if (m == 0) { r0 = R; e0 = estat; }
         else { r1 = R; e1 = estat; }
     }

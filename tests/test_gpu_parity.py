@@ -183,6 +183,29 @@ def test_lowercase_and_N_reads(kernel):
     assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), True)
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("polyx", [8, 20, 50])
+def test_polyx_runs_of_every_kind(kernel, polyx):
+    """contig_base is the longest run of identical case-SENSITIVE characters, whatever they are
+    (src/read_filter.cpp:255-269): runs of N, of one lower-case letter, mixed-case runs (two runs), runs
+    across the 64-position strip borders and at the read ends."""
+    L, n = 150, 2048
+    d = synth.make_batch(n, L, paired=True, seed=33)
+    rng = np.random.default_rng(5)
+    for m in range(2):
+        for i in range(0, n, 2):
+            run = int(rng.integers(polyx - 2, polyx + 3))
+            at = int(rng.choice([0, L - run, 64 - run // 2, 128 - run // 2, int(rng.integers(0, L - run))]))
+            kind = i // 2 % 6
+            ch = [b"N", b"a", b"G", b"t", b"C", b"n"][kind]
+            d["seq"][m][i, at:at + run] = np.frombuffer(ch * run, dtype=np.uint8)
+            if kind == 2 and run > 4:                      # mixed case: G..g..G is three runs
+                d["seq"][m][i, at + run // 2] = ord("g")
+    kw = dict(PE_CASES["C2_adatrim_lowq"], polyX_num=polyx, n_ratio=0.9)
+    p = abi.default_params(paired=True, max_read_len=L, **kw)
+    assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), True)
+
+
 def test_full_size_properties():
     """BASELINE configs[1] shape (PE150, adapter-trim + lowQual) at a size the oracle
     cannot follow in seconds: size-independent invariants instead.  Stats are a pure
