@@ -44,8 +44,11 @@
 
 using namespace snk;
 
-// ablation builds for profiling only (tools/ablate.sh): 1 = phase 1 only, 2 = phases 1+2,
-// 3 = no phase 3, 4 = no adapter search.  The shipped library is built with 0.
+// ablation builds for profiling only (tools/ablate.sh, results are wrong by design): 1 = phase 1 + hand-over only,
+// 2 = phases 1+2, 3 = no phase 3, 4 = no adapter search, 5 = no trimming-position counters, 6 = no exact
+// decision of adapter candidates, 7 = no adapter screening, 8 / 9 / 10 = no polyX / no low-quality-end + polyG /
+// no trim_finish (FULL variant), 11 = no LDS histogram adds, 12 = no DMA, 14 = DMA never waited for, 15 = 12-like
+// phase 1 with an L2-resident source (see SNK_L2SRC).  The shipped library is built with 0.
 #ifndef SNK_ABL
 #define SNK_ABL 0
 #endif
