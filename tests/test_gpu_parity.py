@@ -107,10 +107,19 @@ def test_ragged_and_chunked(kernel):
 
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_tiny_batches(kernel):
-    for n in (1, 2, 63, 64, 65):
+    """last tiles of every fill level: the bit collectors of the tiled kernel park after read 32 of a tile and
+    are re-aligned for tiles of fewer than 64 (32) pairs"""
+    for n in (1, 2, 3, 31, 32, 33, 34, 63, 64, 65, 95, 96, 97, 129):
         d = synth.make_batch(n, 150, paired=True, seed=26 + n)
         p = abi.default_params(paired=True, max_read_len=150, **PE_CASES["C2_adatrim_lowq"])
         assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), True)
+        d = synth.make_batch(n, 150, paired=True, var_len=True, seed=126 + n)
+        p = abi.default_params(paired=True, max_read_len=150, **PE_CASES["C3_full"])
+        assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), True)
+        d = synth.make_batch(n, 100, paired=False, seed=226 + n)
+        p = abi.default_params(paired=False, max_read_len=100, **{k: (v[:2] if k == "hard_trim" else v)
+                                                                  for k, v in PE_CASES["C3_full"].items() if k != "adapters2"})
+        assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), False)
 
 
 def test_empty_batch(snk_lib):
