@@ -74,7 +74,7 @@ __device__ __forceinline__ u32 lowmask32(int n) { return n <= 0 ? 0u : (n >= 32 
 __device__ __forceinline__ u64 lowmask64(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); }
 
 // clang exposes readlane but not writelane as a builtin; the LLVM intrinsic is bound above
-// (v_writelane_b32: uniform value -> one lane of a VGPR, the transpose primitive of phase 1).
+// (v_writelane_b32: uniform value -> one lane of a VGPR; per-read scalars and the rare fix-up pass use it).
 __device__ __forceinline__ int wl(int dst, int val, int lane) { return __snk_writelane(val, lane, dst); }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
@@ -348,6 +348,11 @@ __device__ int adapter_tile(const TileAdapter &A, const DevAdapter &AG, const u3
     // ---------------- exact decision of the survivors, in the reference's order:
     // phase A r1 = 1..5 (-> 0), phase B ascending offset (:743-764), phase C ascending r1 ==
     // descending offset (:765-788).  One candidate per lane per trip; trips are rare.
+    if (SNK_ABL == 6) {                   // keep the screening alive, skip the decisions
+#pragma unroll
+        for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(aliveB[j]), "v"(aliveC[j]));
+        asm volatile("" ::"v"(pa));
+    }
     while (SNK_ABL != 6 && __any(!done && (pa != 0 || any_bit(aliveB) || any_bit(aliveC)))) {
         if (!done) {
             int p = 0, sh = 0, n = 0, budget = 0, res = 0;
@@ -542,7 +547,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         auto run_phase1 = [&](auto FL) {
             if (STAGED) {
                 // bytes arrive in LDS by DMA (16 B/lane), the next chunk of rb reads in flight
-                // behind the ballots of the current one
+                // behind the collectors of the current one
                 const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
                 uint8_t *stg = ldsb + G.stg_off + wave * G.stg_wave;
                 const int rb = G.rb, nchunks = (cnt + rb - 1) / rb;

@@ -175,6 +175,18 @@ def test_error_reporting(kernel):
     d["qual"][0][17, 5] = 33 + 60
     got = run_hip_device(p, d, kernel)
     assert got["err"] == (abi.E_QUAL_RANGE, 0, 17)
+    # below the Phred offset (the tiled kernel's underflow row), in each 64-position strip and in both mates
+    for mate, row, pos, ch in ((0, 40, 2, 32), (1, 41, 70, 10), (0, 2999, 149, 0), (1, 7, 64, 31)):
+        d = synth.make_batch(3000, 150, paired=True, seed=29)
+        d["qual"][mate][row, pos] = ch
+        got = run_hip_device(p, d, kernel)
+        assert got["err"] == (abi.E_QUAL_RANGE, mate, row), (mate, row, pos, ch, got["err"])
+    # the first offender wins, whatever the kind of offence
+    d = synth.make_batch(3000, 150, paired=True, seed=29)
+    d["qual"][1][900, 100] = 5
+    d["qual"][0][1500, 3] = 33 + 70
+    got = run_hip_device(p, d, kernel)
+    assert got["err"] == (abi.E_QUAL_RANGE, 1, 900)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
