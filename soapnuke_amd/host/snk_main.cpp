@@ -67,6 +67,7 @@ struct Options {
     float total_ratio = 0;               //   < 1: a ratio of the clean reads
     uint64_t total_num = 0;              //   >= 1: a number of reads
     bool total_head = false;             //   "<N>head": the first N clean reads; otherwise every k-th read
+    std::vector<string> wrong_paras;     // sRNA adapter keys: an error in this module
 };
 
 [[noreturn]] void die(const string &msg) {          // the reference's convention: message, exit(1)
@@ -194,6 +195,15 @@ void read_config(Options &o, const char *path) {             // src/process_argv
         }
         else if (key == "pe_info") o.pe_info = true;
         else if (key == "baseConvert") o.base_convert = val;
+        // accepted without effect on `filter`, as in the reference: `overlap` / `mis` feed whether_over_overlapped(), which nothing
+        // calls (reads_result.over_lapped stays false, src/sequence.cpp:195,364); the stLFR keys and inputAsList are read by other modules
+        else if (key == "overlap" || key == "mis" || key == "barcodeListPath" || key == "barcodeRegionStr" || key == "notCutNoLFR" ||
+                 key == "inputAsList" || key == "tenX") {}
+        else if (key == "adaRCtg") o.wrong_paras.push_back("-S|--adaRCtg");        // src/process_argv.cpp:1446-1470,763-771
+        else if (key == "adaRAr") o.wrong_paras.push_back("-s|--adaRAr");
+        else if (key == "adaRMa") o.wrong_paras.push_back("-U|--adaRMa");
+        else if (key == "adaREr") o.wrong_paras.push_back("-u|--adaREr");
+        else if (key == "adaRMm") o.wrong_paras.push_back("-b|--adaRMm");
         else die("parameter " + key + " is not supported by the GPU filter path yet");
     }
 }
@@ -216,7 +226,7 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
         {"ada_trim", 0, NULL, 'J'}, {"lowQual", 1, NULL, 'l'}, {"qualRate", 1, NULL, 'q'}, {"nRate", 1, NULL, 'n'},
         {"mean", 1, NULL, 'm'}, {"highA", 1, NULL, 'p'}, {"polyG_tail", 1, NULL, 'g'}, {"polyX", 1, NULL, 'X'},
         {"minReadLen", 1, NULL, '4'}, {"trimBadHead", 1, NULL, 'x'}, {"trimBadTail", 1, NULL, 'y'}, {"trim", 1, NULL, 't'},
-        {"thread", 1, NULL, 'T'}, {"output_clean", 1, NULL, 'w'}, {"help", 0, NULL, 'h'}, {"version", 0, NULL, 'v'}, {NULL, 0, NULL, 0}};
+        {"thread", 1, NULL, 'T'}, {"output_clean", 1, NULL, 'w'}, {"ref", 1, NULL, 'E'}, {"streaming", 0, NULL, 'j'}, {"help", 0, NULL, 'h'}, {"version", 0, NULL, 'v'}, {NULL, 0, NULL, 0}};
     snk_params_default(&o.p);
     int c;
     while ((c = getopt_long(argc, argv, shortopts, longopts, NULL)) != -1) {
@@ -250,7 +260,8 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
             if (o.clean_out_split == 0) die("-w value should be a positive integer");
             break;
         }
-        case 'j': case 'E': die("option not supported by the GPU filter path yet");
+        case 'E': break;                                     // --ref: CRAM reference of the Hts module, unused by `filter`
+        case 'j': die("option not supported by the GPU filter path yet");
         default: exit(1);
         }
     }
@@ -300,6 +311,11 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
         if (o.clean_out_split != 0 && o.clean_out_split < ps) die(" output reads in each clean fastq file(-w) should be more than patch size(-e)");
     }
     if (o.clean_out_split > 0 && o.total_reads > 0) die("-w and -L cannot be both assigned");
+    if (!o.wrong_paras.empty()) {
+        string l = o.wrong_paras[0];
+        for (size_t i = 1; i < o.wrong_paras.size(); ++i) l += "," + o.wrong_paras[i];
+        die("these parameters should not appear in the module," + l);
+    }
     if (!o.base_convert.empty()) {                               // src/process_argv.cpp:865-890
         const string acgt = "ACGTacgt", &b = o.base_convert;
         if (b.find("TO") == string::npos && b.find("2") == string::npos) die("base_convert value format error");

@@ -320,3 +320,25 @@ def test_cli_base_convert(value, tmp_path):
     r = subprocess.run([CLI, "filter", "-1", os.path.join(work, "r1.fq"), "-C", "c1.fq", "-o", os.path.join(work, "se"), "-c", os.path.join(work, "cfg")],
                        capture_output=True)
     assert r.returncode == 1 and b"single-end" in r.stderr
+
+
+def test_cli_keys_without_effect_and_module_errors(tmp_path):
+    """`overlap` / `mis` (dead in the reference: nothing sets reads_result.over_lapped), the stLFR keys, inputAsList and -E are
+    accepted without effect; the sRNA adapter keys are an error of this module (src/process_argv.cpp:763-771)."""
+    n, L = 3000, 100
+    d = synth.make_batch(n, L, paired=True, seed=98)
+    cfg = ["overlap=10", "mis=0.1", "tenX", "notCutNoLFR", "inputAsList"]
+    cli = ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-E", "nothing.fa"]
+    case = ("noeffect", True, L, n, 2, 300, {}, {}, cli, cfg)
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ours = _run_ours(case, work, gz=False)
+    for f in R.REPORT_FILES_PE:
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in ["c1.fq", "c2.fq"]:
+        assert _cat(os.path.join(ours, c)) == _cat(os.path.join(ref, c)), c
+    open(os.path.join(work, "cfg2"), "w").write("adaRCtg=3\nadaRMm=2\n")
+    for exe in (T.REF_BIN, CLI):
+        r = subprocess.run([exe, "filter", "-1", os.path.join(work, "r1.fq"), "-2", os.path.join(work, "r2.fq"), "-C", "c1.fq", "-D", "c2.fq",
+                            "-o", os.path.join(work, "bad"), "-c", os.path.join(work, "cfg2")], capture_output=True)
+        assert r.returncode == 1 and b"Error:these parameters should not appear in the module,-S|--adaRCtg,-b|--adaRMm" in r.stderr, (exe, r.stderr[-200:])
