@@ -68,6 +68,7 @@ struct Options {
     uint64_t total_num = 0;              //   >= 1: a number of reads
     bool total_head = false;             //   "<N>head": the first N clean reads; otherwise every k-th read
     std::vector<string> wrong_paras;     // sRNA adapter keys: an error in this module
+    bool streaming = false;              // -j: clean reads and cumulative statistics of every patch on stdout
 };
 
 [[noreturn]] void die(const string &msg) {          // the reference's convention: message, exit(1)
@@ -261,7 +262,7 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
             break;
         }
         case 'E': break;                                     // --ref: CRAM reference of the Hts module, unused by `filter`
-        case 'j': die("option not supported by the GPU filter path yet");
+        case 'j': o.streaming = true; break;
         default: exit(1);
         }
     }
@@ -311,6 +312,8 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
         if (o.clean_out_split != 0 && o.clean_out_split < ps) die(" output reads in each clean fastq file(-w) should be more than patch size(-e)");
     }
     if (o.clean_out_split > 0 && o.total_reads > 0) die("-w and -L cannot be both assigned");
+    if (o.streaming)                                          // one batch = one patch of the reference (src/peprocess.cpp:2137-2148)
+        o.batch_pairs = (int)(o.patch_size > 0 ? o.patch_size : o.threads * 20000 / 8);
     if (!o.wrong_paras.empty()) {
         string l = o.wrong_paras[0];
         for (size_t i = 1; i < o.wrong_paras.size(); ++i) l += "," + o.wrong_paras[i];
@@ -764,6 +767,7 @@ struct Slot {                                           // one batch in flight
     uint16_t *h_len[2] = {nullptr, nullptr}, *d_len[2] = {nullptr, nullptr};
     snk_read_result *h_rec[2] = {nullptr, nullptr}, *d_rec[2] = {nullptr, nullptr};
     uint8_t *h_flags = nullptr, *d_flags = nullptr;      // per-pair host verdicts (tile / fov bits, + the duplicate bit)
+    std::vector<uint64_t> snap_sum, snap_max;            // -j: the owning virtual thread's statistics right after this patch
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     RawChunk *raw[2] = {nullptr, nullptr};
@@ -1010,6 +1014,8 @@ int main(int argc, char **argv) {
                     const snk_read_result &x = s.h_rec[m][i];
                     int li, lsq, lql;
                     const char *id = s.raw[m]->line(4 * i, li), *sq = s.raw[m]->line(4 * i + 1, lsq), *ql = s.raw[m]->line(4 * i + 3, lql);
+                    const bool stream_rec = o.streaming && !fasta;        // ">+\t<id without its first character>\t<mate>\t<seq>\t<qual>" (src/peprocess.cpp:3402-3411)
+                    if (stream_rec) out += ">+\t";
                     const size_t id_at = out.size();
                     if (!o.index_remove) out.append(id, li);
                     else if (o.seq_type == "0") {                 // "@FC:4:1101:1799:2201#GAAGCACG/2": drop '#'..before '/' (src/read_filter.cpp:357-378)
@@ -1030,13 +1036,20 @@ int main(int argc, char **argv) {
                         const size_t at = out.find('@', id_at);
                         if (at != string::npos) out[at] = '>';
                     }
-                    out += '\n';
+                    if (stream_rec) {
+                        if (out.size() > id_at) out.erase(id_at, 1);
+                        out += '\t';
+                        out += (m == 0 ? '1' : '2');
+                        out += '\t';
+                    } else {
+                        out += '\n';
+                    }
                     const size_t sq_at = out.size();
                     out.append(sq + x.clean_start, x.clean_len);
                     if (bc_from)
                         for (size_t k = sq_at; k < out.size(); ++k) if (toupper((unsigned char)out[k]) == bc_from) out[k] = bc_to;
                     if (fasta) { out += '\n'; return; }
-                    out += "\n+\n";
+                    out += stream_rec ? "\t" : "\n+\n";
                     const size_t q_at = out.size();
                     out.append(ql + x.clean_start, x.clean_len);
                     if (dq) for (size_t k = q_at; k < out.size(); ++k) out[k] = (char)(out[k] + dq);
@@ -1057,7 +1070,7 @@ int main(int argc, char **argv) {
                         for (int i = lo; i < hi; ++i) put(tout, m, i, 1);
                         if (trimw[m].gz && !tout.empty()) gzip_member(tout, tzbuf[m][w]);
                     }
-                    if (o.out_gz && !cut_mode && !out.empty()) gzip_member(out, zbuf[m][w]);
+                    if (o.out_gz && !cut_mode && !o.streaming && !out.empty()) gzip_member(out, zbuf[m][w]);
                 }
                 if (d_dup_all) {                               // C_fastq::toString of the raw records, src/peprocess.cpp:1541
                     string acc[2];
@@ -1085,7 +1098,17 @@ int main(int argc, char **argv) {
                 }
             });
             for (int w = 0; w < WK; ++w) clean_total += kcount[w];
-            if (!cut_mode) {
+            if (o.streaming) {
+                // output_fastqs("1", ...), output_fastqs("2", ...), then the thread's statistics (src/peprocess.cpp:1952-1976);
+                // with outFileType=fasta the reference prints no reads at all (they go to a string nobody writes)
+                if (!fasta)
+                    for (int m = 0; m < mates; ++m)
+                        for (int w = 0; w < WK; ++w) fwrite(text[m][w].data(), 1, text[m][w].size(), stdout);
+                string st;
+                snk_streaming_stat_text(&o.p, s.snap_sum.data(), s.snap_max.data(), &st);
+                fwrite(st.data(), 1, st.size(), stdout);
+                fflush(stdout);
+            } else if (!cut_mode) {
                 for (int m = 0; m < mates; ++m)
                     for (int w = 0; w < WK; ++w) {
                         const string &bytes = wr[m].gz ? zbuf[m][w] : text[m][w];
@@ -1185,6 +1208,15 @@ int main(int argc, char **argv) {
         }
         for (int m = 0; m < mates; ++m)
             HIPCHK(hipMemcpyAsync(s.h_rec[m], s.d_rec[m], (size_t)n * sizeof(snk_read_result), hipMemcpyDeviceToHost, s.stream));
+        if (o.streaming) {                                  // the patch's thread, cumulative, before the next patch touches it
+            HIPCHK(hipStreamSynchronize(s.stream));
+            const int vt = (int)((total / (uint64_t)vblock) % (uint64_t)T);
+            s.snap_sum.assign((size_t)nsum, 0);
+            s.snap_max.assign(SNK_MAX_N, 0);
+            snk_error err;
+            if (snk_bind_stats(ctx, d_sum[vt], d_max[vt]) != SNK_OK) die(snk_last_error());
+            if (snk_stats_fetch(ctx, s.snap_sum.data(), s.snap_max.data(), &err, nullptr) != SNK_OK) die(snk_last_error());
+        }
         HIPCHK(hipEventRecord(s.done, s.stream));
         to_write.push(sp);
         total += (uint64_t)n;

@@ -474,3 +474,56 @@ extern "C" int snk_write_reports(const snk_params *P, int T, const uint64_t *con
     if (rc && errbuf && cap > 0) snprintf(errbuf, cap, "%s", err.c_str());
     return rc;
 }
+
+// peStreaming_stat / seStreaming_stat.  As printed by the reference: the rows of the "raw" quality block of fq1 show
+// the CLEAN counters, fq1's quality rows have 40 columns and fq2's 41, both closed by a literal 0.
+extern "C" void snk_streaming_stat_text(const snk_params *P, const uint64_t *sum, const uint64_t *mx, void *out_string) {
+    std::string &o = *static_cast<std::string *>(out_string);
+    const int lcap = P->max_read_len, nq = P->max_base_quality + 1;
+    const bool pe = P->paired != 0;
+    View v[4];
+    for (int k = 0; k < 4; ++k) {
+        v[k].f = sum + snk_file_off(lcap, nq, k);
+        v[k].lcap = lcap;
+        v[k].nq = nq;
+        v[k].read_length = mx[k] & 0xFFFF;
+    }
+    auto num = [&](uint64_t x) { o += std::to_string(x); };
+    const uint64_t *fs = sum;
+    o += "#Total_statistical_information\n";
+    const int total = (int)(fs[SNK_FS_ADAPTER] + fs[SNK_FS_CONTAM] + fs[SNK_FS_LOWQUAL] + fs[SNK_FS_MEANQ] + fs[SNK_FS_NRATE] + fs[SNK_FS_OVERLAP] +
+                            fs[SNK_FS_HIGHA] + fs[SNK_FS_POLYX]);
+    o += std::to_string(total);
+    for (int k : {SNK_FS_ADAPTER, SNK_FS_CONTAM, SNK_FS_LOWQUAL, SNK_FS_MEANQ, SNK_FS_NRATE, SNK_FS_OVERLAP, SNK_FS_HIGHA, SNK_FS_POLYX}) {
+        o += ' ';
+        o += std::to_string((int)fs[k]);
+    }
+    o += '\n';
+    for (int m = 0; m < (pe ? 2 : 1); ++m) {
+        const View &raw = v[m], &clean = v[2 + m];
+        o += m == 0 ? "#Fq1_statistical_information\n" : "#Fq2_statistical_information\n";
+        num(raw.read_length); o += ' '; num(clean.read_length);
+        for (int k : {SNK_GS_READS, SNK_GS_BASES, SNK_GS_A, SNK_GS_C, SNK_GS_G, SNK_GS_T, SNK_GS_N_, SNK_GS_Q20, SNK_GS_Q30}) {
+            o += ' '; num(raw.gs(k)); o += ' '; num(clean.gs(k));
+        }
+        o += '\n';
+        o += "#Base_distributions_by_read_position\n";
+        for (const View *w : {&raw, &clean})
+            for (uint64_t i = 0; i != w->read_length; ++i) {
+                for (int j = 0; j < 4; ++j) { num(w->B(i, j)); o += ' '; }
+                num(w->B(i, 4));
+                o += '\n';
+            }
+        o += "#Raw_Base_quality_value_distribution_by_read_position\n";
+        const int cols = m == 0 ? 40 : 41;
+        const View &first = m == 0 ? clean : raw;              // fq1: the reference reads clean1 here, over raw1's length
+        for (uint64_t i = 0; i != raw.read_length; ++i) {
+            for (int j = 0; j < cols; ++j) { num(first.Q(i, j)); o += ' '; }
+            o += "0\n";
+        }
+        for (uint64_t i = 0; i != clean.read_length; ++i) {
+            for (int j = 0; j < cols; ++j) { num(clean.Q(i, j)); o += ' '; }
+            o += "0\n";
+        }
+    }
+}

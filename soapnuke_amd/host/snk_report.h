@@ -25,6 +25,11 @@ int snk_write_reports(const snk_params *params, int n_threads, const uint64_t *c
 // (src/peprocess.cpp:81,2063,2092; src/process_argv.cpp:541-544).
 int64_t snk_vthread_block(int threads, int patch_size);
 
+// -j / --streaming: the cumulative statistics of one (virtual) reference thread in the text form that
+// peStreaming_stat / seStreaming_stat print behind every patch (src/peprocess.cpp:3485-3594,
+// src/seprocess.cpp:2405-2462), appended to *out (a std::string passed as void*).
+void snk_streaming_stat_text(const snk_params *params, const uint64_t *sum, const uint64_t *max, void *out_string);
+
 #ifdef __cplusplus
 }
 #endif

@@ -342,3 +342,38 @@ def test_cli_keys_without_effect_and_module_errors(tmp_path):
         r = subprocess.run([exe, "filter", "-1", os.path.join(work, "r1.fq"), "-2", os.path.join(work, "r2.fq"), "-C", "c1.fq", "-D", "c2.fq",
                             "-o", os.path.join(work, "bad"), "-c", os.path.join(work, "cfg2")], capture_output=True)
         assert r.returncode == 1 and b"Error:these parameters should not appear in the module,-S|--adaRCtg,-b|--adaRMm" in r.stderr, (exe, r.stderr[-200:])
+
+
+@pytest.mark.parametrize("paired,threads,patch,extra_cfg", [(True, 1, 500, []), (False, 1, 400, []), (True, 2, 50, ["pe_info", "outQualSys=1"]),
+                                                            (True, 1, 700, ["trimBadTail=20,30"])])
+def test_cli_streaming(paired, threads, patch, extra_cfg, tmp_path):
+    """-j / --streaming: every patch's clean reads (">+<TAB>id<TAB>mate<TAB>seq<TAB>qual") and the cumulative statistics of
+    its thread go to stdout (src/peprocess.cpp:1952-1976,3398-3418,3485-3594; seprocess.cpp:2405-2462), the clean files
+    stay empty, the report files are written as usual.  One reference thread, or input inside one thread block: the
+    reference's stdout is then deterministic and must match byte for byte."""
+    n, L = 3000, 100
+    d = synth.make_batch(n, L, paired=paired, seed=99)
+    work = str(tmp_path)
+    mates = 2 if paired else 1
+    for m in range(mates):
+        synth.write_fastq(os.path.join(work, f"r{m + 1}.fq"), d["seq"][m], d["qual"][m], L, m + 1)
+        subprocess.check_call(["gzip", "-1", "-f", "-k", os.path.join(work, f"r{m + 1}.fq")])
+    open(os.path.join(work, "cfg"), "w").write("\n".join([f"patch={patch}"] + extra_cfg) + "\n")
+    tail = ["-C", "c1.fq.gz", "-T", str(threads), "-f", synth.ADAPTER1, "-J", "-j", "-c", os.path.join(work, "cfg")]
+    inp = ["-1", os.path.join(work, "r1.fq.gz")]
+    if paired:
+        tail += ["-D", "c2.fq.gz", "-r", synth.ADAPTER2]
+        inp += ["-2", os.path.join(work, "r2.fq.gz")]
+    ref = subprocess.run([T.REF_BIN, "filter"] + inp + ["-o", os.path.join(work, "ref")] + tail, capture_output=True, timeout=120)
+    assert ref.returncode == 0, ref.stderr[-300:]
+    ours = subprocess.run([CLI, "filter"] + inp + ["-o", os.path.join(work, "ours")] + tail, capture_output=True)
+    assert ours.returncode == 0, ours.stderr[-300:]
+    assert len(ref.stdout) > 100000
+    if ours.stdout != ref.stdout:
+        a, b = ours.stdout.split(b"\n"), ref.stdout.split(b"\n")
+        bad = next((i for i in range(min(len(a), len(b))) if a[i] != b[i]), min(len(a), len(b)))
+        raise AssertionError((len(a), len(b), bad, a[bad][:200] if bad < len(a) else None, b[bad][:200] if bad < len(b) else None))
+    for f in (R.REPORT_FILES_PE if paired else R.REPORT_FILES_SE):
+        assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
+    for c in (["c1.fq.gz", "c2.fq.gz"] if paired else ["c1.fq.gz"]):
+        assert _cat(os.path.join(work, "ours", c)) == b"" == _cat(os.path.join(work, "ref", c))
