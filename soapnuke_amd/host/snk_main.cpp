@@ -216,6 +216,7 @@ void usage() {
             "  -l, --lowQual INT [5]  -q, --qualRate FLOAT [0.5]  -n, --nRate FLOAT [0.05]  -m, --mean INT\n"
             "  -p, --highA FLOAT  -g, --polyG_tail FLOAT  -X, --polyX INT  -4, --minReadLen INT [30]\n"
             "  -x, --trimBadHead Q,LEN  -y, --trimBadTail Q,LEN  -t, --trim H1,T1,H2,T2  -T, --thread INT [6]\n"
+            "  -w, --output_clean INT (reads per split.<k>.<cleanFq> file)  -j, --streaming (reads + statistics on stdout)\n"
             "  -h, --help  -v, --version\n";
 }
 
