@@ -377,3 +377,25 @@ def test_cli_streaming(paired, threads, patch, extra_cfg, tmp_path):
         assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
     for c in (["c1.fq.gz", "c2.fq.gz"] if paired else ["c1.fq.gz"]):
         assert _cat(os.path.join(work, "ours", c)) == b"" == _cat(os.path.join(work, "ref", c))
+
+
+def test_cli_streaming_many_threads(tmp_path):
+    """-j with several reference threads and several blocks per thread: the reference interleaves its threads' patches
+    by timing, so only the set of read lines, the number of statistics dumps and the report files are comparable."""
+    n, L = 4000, 100
+    d = synth.make_batch(n, L, paired=True, seed=101)
+    work = str(tmp_path)
+    for m in range(2):
+        synth.write_fastq(os.path.join(work, f"r{m + 1}.fq"), d["seq"][m], d["qual"][m], L, m + 1)
+        subprocess.check_call(["gzip", "-1", "-f", "-k", os.path.join(work, f"r{m + 1}.fq")])
+    open(os.path.join(work, "cfg"), "w").write("patch=8\n")            # T=4: blocks of 8 * 40 = 320 pairs
+    tail = ["-C", "c1.fq.gz", "-D", "c2.fq.gz", "-T", "4", "-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-j", "-c", os.path.join(work, "cfg")]
+    inp = ["-1", os.path.join(work, "r1.fq.gz"), "-2", os.path.join(work, "r2.fq.gz")]
+    ref = subprocess.run([T.REF_BIN, "filter"] + inp + ["-o", os.path.join(work, "ref")] + tail, capture_output=True, timeout=120)
+    ours = subprocess.run([CLI, "filter"] + inp + ["-o", os.path.join(work, "ours")] + tail, capture_output=True)
+    assert ref.returncode == 0 and ours.returncode == 0, (ref.stderr[-200:], ours.stderr[-200:])
+    a, b = ours.stdout.split(b"\n"), ref.stdout.split(b"\n")
+    assert sorted(x for x in a if x.startswith(b">+")) == sorted(x for x in b if x.startswith(b">+"))
+    assert a.count(b"#Total_statistical_information") == b.count(b"#Total_statistical_information") == n // 8
+    for f in R.REPORT_FILES_PE:
+        assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
