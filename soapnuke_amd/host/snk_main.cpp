@@ -827,6 +827,7 @@ int main(int argc, char **argv) {
     for (int m = 0; m < mates; ++m)
         for (int i = 0; i < first[m]->n; ++i) { int l; first[m]->line(4 * i + 1, l); maxlen = std::max(maxlen, l); }
     if (maxlen > SNK_READ_MAX_LEN) die("read longer than 1000 bases");
+    if (o.streaming) maxlen = std::max(maxlen, 256);      // -j: the first batch is one small patch, a poor sample of the read lengths
     o.p.max_read_len = maxlen;
     const int pitch = (maxlen + 15) / 16 * 16;
 
