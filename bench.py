@@ -102,6 +102,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher -- one rank per GPU under
+        # torch.distributed.run (exactly the command line the driver uses), same arguments
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
     from soapnuke_amd import synth
@@ -110,10 +121,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    if torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} HIP device(s) visible")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus
     torch.cuda.set_device(local_rank)
 
     n_unique = min(PAIRS_UNIQUE, args.pairs)
@@ -189,7 +206,8 @@ def main():
             pass
         out = {
             "metric": "Mreads/s PE150 `filter` (adapter+qual), bit-exact vs ref",
-            "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": f"synthetic PE150 (seed {synth.SEED}+rank): {n_unique} unique pairs x{reps} distinct HBM copies per GPU",

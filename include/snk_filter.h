@@ -73,8 +73,9 @@ typedef struct snk_params {
      * glob_cotm_mR, glob_cotm_mM).  Strings exactly as the reference holds them -- comma-separated
      * lists -- NULL or "" = off.  Only the verdicts matter downstream: with contam_trim == 0 a hit
      * discards the read/pair (src/sequence.cpp:116-127,264-290); the contam trimming itself is
-     * commented out in the reference (src/read_filter.cpp:443-452).  Matchers use gp.adaMis/adaEdge
-     * of mate 1 for both mates (src/read_filter.cpp:513,611). */
+     * commented out in the reference (src/read_filter.cpp:443-452).  Matchers use the mate's own
+     * adaMis/adaEdge: ada_mis[1]/ada_edge[1] for mate 2 of a pair (gp2, src/sequence.cpp:182-189;
+     * src/read_filter.cpp:513,611). */
     const char *contam[2];        /* gp.contam1_seq, gp.contam2_seq */
     const char *ct_match_r;       /* gp.ctMatchR ("0.2"; a list when contam is a list) */
     const char *global_contams;   /* gp.global_contams */
@@ -232,6 +233,14 @@ int snk_filter_batch(snk_ctx *ctx, const snk_batch *batch,
 int snk_stats_finalize(snk_ctx *ctx, void *hip_stream);
 int snk_stats_fetch(snk_ctx *ctx, uint64_t *sum, uint64_t *max, snk_error *err,
                     void *hip_stream);
+
+/* The context's error word (first data error so far: all-ones = none) copied asynchronously on
+ * `hip_stream` into *host_word (pinned host memory): lets a host poll per patch and stop before
+ * it writes anything, as the reference exits at the offending read (src/read_filter.cpp:251,283).
+ * snk_error_decode() turns the word into a snk_error (code SNK_OK when none).               */
+#define SNK_ERR_WORD_NONE 0xFFFFFFFFFFFFFFFFull
+int  snk_error_peek_async(snk_ctx *ctx, uint64_t *host_word, void *hip_stream);
+void snk_error_decode(uint64_t word, snk_error *err);
 
 /* In-place sum/max all-reduce of the bound blocks over an RCCL communicator
  * (ncclComm_t) -- the only collective on this path.             */

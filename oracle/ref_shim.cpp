@@ -13,6 +13,7 @@
  * reference.  The reference exit(1)s on malformed input -- callers must only
  * feed it valid reads.
  */
+#include "gc.h"
 #include "peprocess.h"
 #include "rmdup.h"
 #include "seprocess.h"
@@ -256,6 +257,12 @@ int snkref_filter_batch(const snk_params *P, const snk_batch *B, snk_read_result
 
 
 /* std::hash<std::string> exactly as src/peprocess.cpp:3680 calls it */
+// cal_quar_from_array(), src/gc.cpp:68-119 (data must hold len+1 counters)
+void snkref_cal_quar(uint64_t *data, int len, float out[6]) {
+    const quartile_result q = cal_quar_from_array(data, len);
+    out[0] = q.mean; out[1] = q.median; out[2] = q.lower_quar; out[3] = q.upper_quar; out[4] = q.first10_quar; out[5] = q.last10_quar;
+}
+
 uint64_t snkref_hash(const char *p, uint64_t len) { return (uint64_t)std::hash<std::string>()(std::string(p, len)); }
 
 /* rmdup::markDup of the reference (src/rmdup.cpp:14); the class frees `data` itself */

@@ -343,9 +343,11 @@ static void parse_contams(const snk_params *P, contam_cfg *C) {
 static void contam_flags(const snk_params *P, const contam_cfg *C, int mate, const uint8_t *seq, int len,
                          int *inc_contam, int *inc_global) {
     *inc_contam = *inc_global = 0;
+    /* mate 2 of a pair sees gp2 = gp with adaMis2 / adaEdge2 (src/sequence.cpp:182-189) */
+    const int pm = (P->paired && mate == 1) ? 1 : 0;
     for (int i = 0; i < C->n[mate]; i++) {
         const int pos = snk_oracle_has_contam(seq, len, C->seq[mate][i], C->len[mate][i], C->thr[mate][i],
-                                              P->ada_mis[0], P->ada_edge[0]);
+                                              P->ada_mis[pm], P->ada_edge[pm]);
         if (pos >= 0) { *inc_contam = 1; break; }                 /* later entries cannot change the verdict */
     }
     for (int i = 0; i < C->ng && !*inc_global; i++)

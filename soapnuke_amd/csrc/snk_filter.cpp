@@ -111,9 +111,11 @@ std::string build_contams(const snk_params &P, std::vector<DevContam> &ct, int n
     for (int m = 0; m < 2; ++m) {
         const char *cs = P.contam[m];
         if (!cs || !*cs) continue;
+        // mate 2 of a pair is screened with gp2 = {adaMis2, adaEdge2} (src/sequence.cpp:182-189)
+        const int pm = (P.paired && m == 1) ? 1 : 0;
         if (!strchr(cs, ',')) {                                    // single: hasContam(ref, contam, gp), double ratio (:616)
             const int cl = (int)strlen(cs);
-            if (!build_contam(ct[m * SNK_MAX_CONTAMS], cs, (int)ceil((double)cl * atof(mr)), P.ada_mis[0], P.ada_edge[0]))
+            if (!build_contam(ct[m * SNK_MAX_CONTAMS], cs, (int)ceil((double)cl * atof(mr)), P.ada_mis[pm], P.ada_edge[pm]))
                 return "contaminant longer than 255";
             n_ct[m] = 1;
         } else {                                                   // hasContams (:483-506), float ratios
@@ -122,7 +124,7 @@ std::string build_contams(const snk_params &P, std::vector<DevContam> &ct, int n
             if (seqs.size() > SNK_MAX_CONTAMS) return "too many contaminants";
             for (size_t i = 0; i < seqs.size(); ++i) {
                 const float tmp_mr = (float)atof(mrs[i].c_str());
-                if (!build_contam(ct[m * SNK_MAX_CONTAMS + i], seqs[i], (int)ceilf((float)seqs[i].size() * tmp_mr), P.ada_mis[0], P.ada_edge[0]))
+                if (!build_contam(ct[m * SNK_MAX_CONTAMS + i], seqs[i], (int)ceilf((float)seqs[i].size() * tmp_mr), P.ada_mis[pm], P.ada_edge[pm]))
                     return "contaminant longer than 255";
             }
             n_ct[m] = (int)seqs.size();
@@ -641,11 +643,20 @@ int snk_stats_fetch(snk_ctx *c, uint64_t *sum, uint64_t *maxb, snk_error *err, v
     if (maxb) HIP_OK(hipMemcpyAsync(maxb, c->d_max, SNK_MAX_N * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_OK(hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
-    if (err) {
-        if (e == SNK_ERR_NONE) { err->code = SNK_OK; err->mate = 0; err->index = 0; }
-        else { err->code = (int32_t)(e & 0xF); err->mate = (int32_t)((e >> 4) & 0x1); err->index = e >> 8; }
-    }
+    snk_error_decode(e, err);
     return SNK_OK;
+}
+
+int snk_error_peek_async(snk_ctx *c, uint64_t *host_word, void *stream) {
+    if (!c || !host_word) { set_err("snk_error_peek_async: null argument"); return SNK_E_PARAM; }
+    HIP_OK(hipMemcpyAsync(host_word, c->d_err, sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return SNK_OK;
+}
+
+void snk_error_decode(uint64_t e, snk_error *err) {
+    if (!err) return;
+    if (e == SNK_ERR_NONE) { err->code = SNK_OK; err->mate = 0; err->index = 0; }
+    else { err->code = (int32_t)(e & 0xF); err->mate = (int32_t)((e >> 4) & 0x1); err->index = e >> 8; }
 }
 
 // RCCL is resolved lazily so that the library has no link-time dependency on it:

@@ -12,6 +12,7 @@
 // deflates its slice into its own gzip member, level 2, members concatenated in input order -- the
 // same legal-gzip trick the reference uses for its per-thread part files, src/peprocess.cpp:2386).
 // Three batch slots are in flight, so reading, packing, the GPU and writing overlap.
+#include <dlfcn.h>
 #include <getopt.h>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -54,7 +55,8 @@ struct Options {
     std::vector<string> ada1, ada2;
     snk_params p;
     string trim, trim_bad_head, trim_bad_tail, out_file_type = "fastq";
-    int threads = 6, patch_size = 0, batch_pairs = 1 << 18, device = 0;
+    int threads = 6, patch_size = 0, batch_pairs = 1 << 18;
+    std::vector<int> devices;                                         // --devices 0,1,...: HIP devices the batches go round (default: 0)
     bool in_gz = true, out_gz = true, pe_info = false, index_remove = false;
     string seq_type = "0";
     string contam[2], ct_match_r, global_contams, g_mrs, g_mms;     // kept here: snk_params points into them
@@ -217,6 +219,7 @@ void usage() {
             "  -p, --highA FLOAT  -g, --polyG_tail FLOAT  -X, --polyX INT  -4, --minReadLen INT [30]\n"
             "  -x, --trimBadHead Q,LEN  -y, --trimBadTail Q,LEN  -t, --trim H1,T1,H2,T2  -T, --thread INT [6]\n"
             "  -w, --output_clean INT (reads per split.<k>.<cleanFq> file)  -j, --streaming (reads + statistics on stdout)\n"
+            "      --devices LIST  HIP devices to use, e.g. 0,1,2,3 [0]\n"
             "  -h, --help  -v, --version\n";
 }
 
@@ -228,7 +231,7 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
         {"ada_trim", 0, NULL, 'J'}, {"lowQual", 1, NULL, 'l'}, {"qualRate", 1, NULL, 'q'}, {"nRate", 1, NULL, 'n'},
         {"mean", 1, NULL, 'm'}, {"highA", 1, NULL, 'p'}, {"polyG_tail", 1, NULL, 'g'}, {"polyX", 1, NULL, 'X'},
         {"minReadLen", 1, NULL, '4'}, {"trimBadHead", 1, NULL, 'x'}, {"trimBadTail", 1, NULL, 'y'}, {"trim", 1, NULL, 't'},
-        {"thread", 1, NULL, 'T'}, {"output_clean", 1, NULL, 'w'}, {"ref", 1, NULL, 'E'}, {"streaming", 0, NULL, 'j'}, {"help", 0, NULL, 'h'}, {"version", 0, NULL, 'v'}, {NULL, 0, NULL, 0}};
+        {"thread", 1, NULL, 'T'}, {"output_clean", 1, NULL, 'w'}, {"ref", 1, NULL, 'E'}, {"streaming", 0, NULL, 'j'}, {"devices", 1, NULL, 1000}, {"help", 0, NULL, 'h'}, {"version", 0, NULL, 'v'}, {NULL, 0, NULL, 0}};
     snk_params_default(&o.p);
     int c;
     while ((c = getopt_long(argc, argv, shortopts, longopts, NULL)) != -1) {
@@ -264,9 +267,18 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
         }
         case 'E': break;                                     // --ref: CRAM reference of the Hts module, unused by `filter`
         case 'j': o.streaming = true; break;
+        case 1000:                                           // not a reference option: the GPUs of this node to use
+            for (const string &e : split(optarg, ',')) {
+                if (e.empty() || e.find_first_not_of("0123456789") != string::npos) die("--devices takes a comma separated list of HIP device numbers");
+                o.devices.push_back(atoi(e.c_str()));
+            }
+            break;
         default: exit(1);
         }
     }
+    if (const char *e = getenv("SNK_BATCH_PAIRS")) { const int v = atoi(e); if (v >= 64 && v <= (1 << 24)) o.batch_pairs = v; }   // pairs per pipeline slot (tuning / tests)
+    if (o.devices.empty()) o.devices.push_back(0);
+    if (o.devices.size() > 16) die("--devices: at most 16 devices");
     if (argc != optind + 1) die("please check the options");
     if (string(argv[optind]) != "filter") die("only the filter module is built on this path");
     // check_parameter(), src/process_argv.cpp:554-917 (the checks that matter on this path)
@@ -769,12 +781,99 @@ struct Slot {                                           // one batch in flight
     snk_read_result *h_rec[2] = {nullptr, nullptr}, *d_rec[2] = {nullptr, nullptr};
     uint8_t *h_flags = nullptr, *d_flags = nullptr;      // per-pair host verdicts (tile / fov bits, + the duplicate bit)
     std::vector<uint64_t> snap_sum, snap_max;            // -j: the owning virtual thread's statistics right after this patch
+    uint64_t *h_err = nullptr;                           // the context's error word after this batch (pinned)
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     RawChunk *raw[2] = {nullptr, nullptr};
-    int n = 0;
+    int n = 0, dev = 0, lcap = 0;                        // records; index into the device list; capacity it was packed with
     uint64_t first = 0;
 };
+
+// One-shot sanity check of the quality system on the first patch of fq1 (stat_pe_fqs / stat_se_fqs run it once,
+// on the first patch that reaches them: src/peprocess.cpp:1207-1319, src/seprocess.cpp:745-852): the qualities are
+// scored under qualSys and under the other system; a clearly better fit of the other one is an error, a
+// slightly better one a warning.  Same messages, same exit code.
+void phred_sanity(const Options &o, const RawChunk &fq1) {
+    const int64_t patch = o.patch_size > 0 ? o.patch_size : (int64_t)o.threads * 20000 / 8;
+    const int n = (int)std::min<int64_t>(fq1.n, patch);
+    const int phred = o.p.quality_phred, other = phred == 64 ? 33 : 64, mbq = o.p.max_base_quality;
+    int ex[2] = {0, 0}, normal[2] = {0, 0}, meanq[2] = {0, 0};      // (int accumulators, as there)
+    int64_t bases = 0;
+    for (int i = 0; i < n; ++i) {
+        int ls, lq;
+        fq1.line(4 * i + 1, ls);
+        const char *ql = fq1.line(4 * i + 3, lq);
+        bases += ls;
+        for (int k = 0; k < lq; ++k)
+            for (int w = 0; w < 2; ++w) {
+                const int bq = (int)ql[k] - (w ? other : phred);
+                meanq[w] += bq;
+                if (bq >= 0 && bq <= mbq) ++normal[w];
+                else if (bq < -10 || bq > mbq + 10) ++ex[w];
+            }
+    }
+    if (bases == 0) die("no data");
+    const float ratio[2] = {(float)normal[0] / bases, (float)normal[1] / bases}, mean[2] = {(float)meanq[0] / bases, (float)meanq[1] / bases};
+    int score[2];
+    for (int w = 0; w < 2; ++w) {
+        score[w] = ex[w] ? 0 : 1;
+        score[w] += (ratio[w] > ratio[1 - w] || ratio[w] == ratio[1 - w]) ? 3 : 0;
+        score[w] += (mean[w] < 10 || mean[w] > mbq) ? 0 : 2;
+    }
+    if (score[0] - score[1] < -3) die("base quality seems abnormal,please check the quality system parameter or fastq file");
+    if (score[0] - score[1] < 0) cerr << "Warning:base quality seems abnormal,please check the quality system parameter or fastq file" << endl;
+}
+
+// statistics block of capacity `ls` added into one of capacity `ld` >= ls (include/snk_filter.h layout:
+// fs | 4 files x (gs | bs[L][5] | qs[L][nq] | ts)): the per-position tables grow, everything else is a plain sum
+void widen_add(const uint64_t *src, int ls, uint64_t *dst, int ld, int nq) {
+    if (ls == ld) { for (int64_t k = 0, n = snk_stats_u64(ls, nq); k < n; ++k) dst[k] += src[k]; return; }
+    for (int k = 0; k < SNK_FS_N; ++k) dst[k] += src[k];
+    for (int f = 0; f < 4; ++f) {
+        const uint64_t *s = src + snk_file_off(ls, nq, f);
+        uint64_t *d = dst + snk_file_off(ld, nq, f);
+        for (int k = 0; k < SNK_GS_N; ++k) d[k] += s[k];
+        for (int64_t k = 0; k < (int64_t)ls * 5; ++k) d[snk_bs_off(ld, nq) + k] += s[snk_bs_off(ls, nq) + k];
+        for (int64_t k = 0; k < (int64_t)ls * nq; ++k) d[snk_qs_off(ld, nq) + k] += s[snk_qs_off(ls, nq) + k];
+        const int64_t nts = snk_file_block_u64(ls, nq) - snk_ts_off(ls, nq);
+        for (int64_t k = 0; k < nts; ++k) d[snk_ts_off(ld, nq) + k] += s[snk_ts_off(ls, nq) + k];
+    }
+}
+
+// The path's one collective for a single host process driving several GPUs: one RCCL communicator per
+// device (ncclCommInitAll), one host thread per device, every virtual thread's block sum/max all-reduced in one
+// group.  ctx_of(g, t) binds block t on device g and returns that device's context.  False when RCCL cannot span the
+// list (the same device twice -- a test configuration): the caller then adds the blocks up on the host.
+bool rccl_allreduce_blocks(const std::vector<int> &devices, const std::function<snk_ctx *(int, int)> &ctx_of, int T) {
+    const int G = (int)devices.size();
+    for (int a = 0; a < G; ++a) for (int b = a + 1; b < G; ++b) if (devices[(size_t)a] == devices[(size_t)b]) return false;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) die(string("cannot load RCCL: ") + dlerror());
+    typedef int (*init_all_fn)(void **, int, const int *);
+    typedef int (*comm_fn)(void *);
+    typedef int (*void_fn)(void);
+    init_all_fn init_all = (init_all_fn)dlsym(h, "ncclCommInitAll");
+    comm_fn destroy = (comm_fn)dlsym(h, "ncclCommDestroy");
+    void_fn gstart = (void_fn)dlsym(h, "ncclGroupStart"), gend = (void_fn)dlsym(h, "ncclGroupEnd");
+    if (!init_all || !destroy || !gstart || !gend) die("RCCL symbols missing");
+    std::vector<void *> comms((size_t)G, nullptr);
+    if (init_all(comms.data(), G, devices.data()) != 0) die("ncclCommInitAll failed");
+    std::vector<std::thread> th;
+    std::atomic<int> failed(0);
+    for (int g = 0; g < G; ++g)
+        th.emplace_back([&, g] {
+            if (hipSetDevice(devices[(size_t)g]) != hipSuccess) { failed = 1; return; }
+            // blocks one after the other: every device walks t in the same order, so the collectives pair up
+            for (int t = 0; t < T; ++t)
+                if (snk_stats_allreduce(ctx_of(g, t), comms[(size_t)g], nullptr) != SNK_OK) { failed = 1; return; }
+            if (hipDeviceSynchronize() != hipSuccess) failed = 1;
+        });
+    for (auto &t : th) t.join();
+    for (void *c : comms) destroy(c);
+    if (failed) die(string("stats all-reduce failed: ") + snk_last_error());
+    return true;
+}
 
 }  // namespace
 
@@ -819,49 +918,134 @@ int main(int argc, char **argv) {
         return ok[0];
     };
 
-    // ---- the first batch decides the capacity (longest read) and the pitch
+    // ---- capacity (longest read) and pitch: sized from the first batch, regrown when a longer read appears
     start_readers();
     RawChunk *first[2];
     if (!next_chunks(first)) die("no data");
-    int maxlen = 1;
-    for (int m = 0; m < mates; ++m)
-        for (int i = 0; i < first[m]->n; ++i) { int l; first[m]->line(4 * i + 1, l); maxlen = std::max(maxlen, l); }
-    if (maxlen > SNK_READ_MAX_LEN) die("read longer than 1000 bases");
-    if (o.streaming) maxlen = std::max(maxlen, 256);      // -j: the first batch is one small patch, a poor sample of the read lengths
-    o.p.max_read_len = maxlen;
-    const int pitch = (maxlen + 15) / 16 * 16;
+    auto longest = [&](RawChunk *const c[2]) {
+        int mx = 1;
+        for (int m = 0; m < mates; ++m)
+            for (int i = 0; i < c[m]->n; ++i) { int l; c[m]->line(4 * i + 1, l); mx = std::max(mx, l); }
+        return mx;
+    };
+    phred_sanity(o, *first[0]);
 
-    HIPCHK(hipSetDevice(o.device));
-    snk_ctx *ctx = snk_create(&o.p, o.device);
-    if (!ctx) die(snk_last_error());
-    int32_t lcap, nq; int64_t nsum;
-    snk_stats_geometry(ctx, &lcap, &nq, &nsum);
-    // one accumulator per virtual reference thread
-    const int64_t vblock = snk_vthread_block(T, o.patch_size);
-    std::vector<uint64_t *> d_sum(T), d_max(T);
-    for (int t = 0; t < T; ++t) {
-        HIPCHK(hipMalloc(&d_sum[t], nsum * sizeof(uint64_t)));
-        HIPCHK(hipMalloc(&d_max[t], SNK_MAX_N * sizeof(uint64_t)));
-        HIPCHK(hipMemset(d_sum[t], 0, nsum * sizeof(uint64_t)));
-        HIPCHK(hipMemset(d_max[t], 0, SNK_MAX_N * sizeof(uint64_t)));
-    }
+    // one context + one set of batch slots per device; one accumulator per virtual reference thread
+    //  and device.  A run is a sequence of epochs of constant capacity (normally one).
+    const int G = (int)o.devices.size();
     const int NSLOT = 3;
-    const size_t plane = (size_t)B * pitch;
-    std::vector<Slot> slots(NSLOT);
-    for (Slot &s : slots) {
-        for (int m = 0; m < mates; ++m) {
-            HIPCHK(hipHostMalloc(&s.h_seq[m], plane)); HIPCHK(hipHostMalloc(&s.h_qual[m], plane));
-            HIPCHK(hipHostMalloc(&s.h_len[m], (size_t)B * 2)); HIPCHK(hipHostMalloc(&s.h_rec[m], (size_t)B * sizeof(snk_read_result)));
-            HIPCHK(hipMalloc(&s.d_seq[m], plane)); HIPCHK(hipMalloc(&s.d_qual[m], plane));
-            HIPCHK(hipMalloc(&s.d_len[m], (size_t)B * 2)); HIPCHK(hipMalloc(&s.d_rec[m], (size_t)B * sizeof(snk_read_result)));
-            memset(s.h_seq[m], 0, plane); memset(s.h_qual[m], 0, plane);
+    const int64_t vblock = snk_vthread_block(T, o.patch_size);
+    struct Dev {
+        int id = 0;
+        snk_ctx *ctx = nullptr;
+        std::vector<uint64_t *> d_sum, d_max;
+        std::vector<Slot> slots;
+        std::unique_ptr<Channel<Slot *>> free_slots;
+    };
+    std::vector<Dev> devs((size_t)G);
+    for (int g = 0; g < G; ++g) devs[(size_t)g].id = o.devices[(size_t)g];
+    int32_t lcap = 0, nq = 0;
+    int64_t nsum = 0;
+    int pitch = 0;
+    size_t plane = 0;
+    struct Epoch { int lcap; std::vector<std::vector<uint64_t>> sums, maxs; };
+    std::vector<Epoch> epochs;
+
+    auto setup = [&](int maxlen) {
+        if (maxlen > SNK_READ_MAX_LEN) die("read longer than 1000 bases");
+        o.p.max_read_len = maxlen;
+        pitch = (maxlen + 15) / 16 * 16;
+        plane = (size_t)B * (size_t)pitch;
+        for (Dev &d : devs) {
+            HIPCHK(hipSetDevice(d.id));
+            d.ctx = snk_create(&o.p, d.id);
+            if (!d.ctx) die(snk_last_error());
+            snk_stats_geometry(d.ctx, &lcap, &nq, &nsum);
+            d.d_sum.assign((size_t)T, nullptr);
+            d.d_max.assign((size_t)T, nullptr);
+            for (int t = 0; t < T; ++t) {
+                HIPCHK(hipMalloc(&d.d_sum[t], nsum * sizeof(uint64_t)));
+                HIPCHK(hipMalloc(&d.d_max[t], SNK_MAX_N * sizeof(uint64_t)));
+                HIPCHK(hipMemset(d.d_sum[t], 0, nsum * sizeof(uint64_t)));
+                HIPCHK(hipMemset(d.d_max[t], 0, SNK_MAX_N * sizeof(uint64_t)));
+            }
+            d.slots.assign(NSLOT, Slot());
+            d.free_slots.reset(new Channel<Slot *>(NSLOT + 1));
+            for (Slot &sl : d.slots) {
+                sl.dev = (int)(&d - devs.data());
+                for (int m = 0; m < mates; ++m) {
+                    HIPCHK(hipHostMalloc(&sl.h_seq[m], plane)); HIPCHK(hipHostMalloc(&sl.h_qual[m], plane));
+                    HIPCHK(hipHostMalloc(&sl.h_len[m], (size_t)B * 2)); HIPCHK(hipHostMalloc(&sl.h_rec[m], (size_t)B * sizeof(snk_read_result)));
+                    HIPCHK(hipMalloc(&sl.d_seq[m], plane)); HIPCHK(hipMalloc(&sl.d_qual[m], plane));
+                    HIPCHK(hipMalloc(&sl.d_len[m], (size_t)B * 2)); HIPCHK(hipMalloc(&sl.d_rec[m], (size_t)B * sizeof(snk_read_result)));
+                    memset(sl.h_seq[m], 0, plane); memset(sl.h_qual[m], 0, plane);
+                }
+                HIPCHK(hipHostMalloc(&sl.h_flags, (size_t)B)); HIPCHK(hipMalloc(&sl.d_flags, (size_t)B));
+                HIPCHK(hipHostMalloc(&sl.h_err, sizeof(uint64_t)));
+                HIPCHK(hipStreamCreate(&sl.stream));
+                HIPCHK(hipEventCreate(&sl.done));
+                d.free_slots->push(&sl);
+            }
         }
-        HIPCHK(hipHostMalloc(&s.h_flags, (size_t)B)); HIPCHK(hipMalloc(&s.d_flags, (size_t)B));
-        HIPCHK(hipStreamCreate(&s.stream));
-        HIPCHK(hipEventCreate(&s.done));
-    }
-    // records -> pinned planes (parallel over records)
-    auto pack = [&](Slot &s, bool with_qual) {
+    };
+    auto teardown = [&] {
+        for (Dev &d : devs) {
+            HIPCHK(hipSetDevice(d.id));
+            HIPCHK(hipDeviceSynchronize());
+            for (Slot &sl : d.slots) {
+                for (int m = 0; m < mates; ++m) {
+                    HIPCHK(hipHostFree(sl.h_seq[m])); HIPCHK(hipHostFree(sl.h_qual[m])); HIPCHK(hipHostFree(sl.h_len[m])); HIPCHK(hipHostFree(sl.h_rec[m]));
+                    HIPCHK(hipFree(sl.d_seq[m])); HIPCHK(hipFree(sl.d_qual[m])); HIPCHK(hipFree(sl.d_len[m])); HIPCHK(hipFree(sl.d_rec[m]));
+                }
+                HIPCHK(hipHostFree(sl.h_flags)); HIPCHK(hipFree(sl.d_flags)); HIPCHK(hipHostFree(sl.h_err));
+                HIPCHK(hipStreamDestroy(sl.stream));
+                HIPCHK(hipEventDestroy(sl.done));
+            }
+            d.slots.clear();
+            for (int t = 0; t < T; ++t) { HIPCHK(hipFree(d.d_sum[t])); HIPCHK(hipFree(d.d_max[t])); }
+            snk_destroy(d.ctx);
+            d.ctx = nullptr;
+        }
+    };
+    auto report_device_error = [&](const snk_error &err) {
+        if (err.code == SNK_E_BAD_BASE) die("unrecognized sequence, read " + std::to_string(err.index) + " of fq" + std::to_string(err.mate + 1));
+        if (err.code == SNK_E_EMPTY_SEQ) die("empty sequence");
+        if (err.code == SNK_E_QUAL_RANGE) die("quality is too high or too low,please check the quality system parameter or fastq file");
+        if (err.code) die("device reported error " + std::to_string(err.code));
+    };
+    // end of an epoch: the per-device blocks of every virtual thread become one (the path's only collective,
+    // a sum/max all-reduce over RCCL, issued by one host thread per GPU), then travel to the host
+    auto collect_epoch = [&] {
+        for (Dev &d : devs) { HIPCHK(hipSetDevice(d.id)); HIPCHK(hipDeviceSynchronize()); }
+        bool reduced = false;
+        if (G > 1) reduced = rccl_allreduce_blocks(o.devices, [&](int g, int t) {
+            Dev &d = devs[(size_t)g];
+            if (snk_bind_stats(d.ctx, d.d_sum[(size_t)t], d.d_max[(size_t)t]) != SNK_OK) die(snk_last_error());
+            return d.ctx;
+        }, T);
+        Epoch e;
+        e.lcap = lcap;
+        e.sums.assign((size_t)T, std::vector<uint64_t>((size_t)nsum, 0));
+        e.maxs.assign((size_t)T, std::vector<uint64_t>(SNK_MAX_N, 0));
+        std::vector<uint64_t> ts((size_t)nsum), tm(SNK_MAX_N);
+        for (int g = 0; g < (reduced ? 1 : G); ++g) {       // not reduced (the same device listed twice): summed here
+            Dev &d = devs[(size_t)g];
+            HIPCHK(hipSetDevice(d.id));
+            for (int t = 0; t < T; ++t) {
+                snk_error err;
+                if (snk_bind_stats(d.ctx, d.d_sum[(size_t)t], d.d_max[(size_t)t]) != SNK_OK) die(snk_last_error());
+                if (snk_stats_fetch(d.ctx, ts.data(), tm.data(), &err, nullptr) != SNK_OK) die(snk_last_error());
+                report_device_error(err);
+                for (int64_t k = 0; k < nsum; ++k) e.sums[(size_t)t][(size_t)k] += ts[(size_t)k];
+                for (int k = 0; k < SNK_MAX_N; ++k) e.maxs[(size_t)t][(size_t)k] = std::max(e.maxs[(size_t)t][(size_t)k], tm[(size_t)k]);
+            }
+        }
+        epochs.push_back(std::move(e));
+    };
+    setup(o.streaming ? std::max(longest(first), 256) : longest(first));   // -j: the first batch is one small patch, a poor sample of the read lengths
+
+    // records -> pinned planes (parallel over records); false: a read is longer than the capacity
+    auto pack = [&](Slot &s, bool with_qual) -> bool {
         const int n = s.n;
         std::atomic<int> bad(0);
         parallel_for(WK, n, [&](int, int lo, int hi) {
@@ -869,15 +1053,15 @@ int main(int argc, char **argv) {
                 for (int i = lo; i < hi; ++i) {
                     int ls, lq;
                     const char *sq = s.raw[m]->line(4 * i + 1, ls), *ql = s.raw[m]->line(4 * i + 3, lq);
-                    if (ls > lcap) { bad = 1; continue; }
-                    if (lq != ls) { bad = 2; continue; }
+                    if (ls > lcap) { bad |= 1; continue; }
+                    if (lq != ls) { bad |= 2; continue; }
                     memcpy(s.h_seq[m] + (size_t)i * pitch, sq, ls);
                     if (with_qual) memcpy(s.h_qual[m] + (size_t)i * pitch, ql, lq);
                     s.h_len[m][i] = (uint16_t)ls;
                 }
         });
-        if (bad == 1) die("read longer than the first batch's longest read (" + std::to_string(lcap) + ")");
-        if (bad == 2) die("sequence and quality lengths differ");
+        if (bad & 2) die("sequence and quality lengths differ");
+        return !(bad & 1);
     };
 
     // ---- rmdup pre-pass (src/peprocess.cpp:3071-3152): hash every raw pair on the GPU, keep the hashes
@@ -891,11 +1075,23 @@ int main(int argc, char **argv) {
         uint64_t nall = 0;
         RawChunk *c[2] = {first[0], first[1]};
         bool have = true;
-        Slot &s = slots[0];
+        HIPCHK(hipSetDevice(devs[0].id));                   // the pre-pass runs on the first device (1 ms of kernel per 10 M pairs)
+        snk_ctx *ctx = devs[0].ctx;
         while (have) {
-            s.n = c[0]->n;
-            s.raw[0] = c[0]; s.raw[1] = c[1];
-            pack(s, false);
+            Slot *sp0 = &devs[0].slots[0];
+            sp0->n = c[0]->n;
+            sp0->raw[0] = c[0]; sp0->raw[1] = c[1];
+            if (!pack(*sp0, false)) {                       // a longer read than any before: new capacity (nothing accumulated yet)
+                teardown();
+                setup(longest(c));
+                HIPCHK(hipSetDevice(devs[0].id));
+                ctx = devs[0].ctx;
+                sp0 = &devs[0].slots[0];
+                sp0->n = c[0]->n;
+                sp0->raw[0] = c[0]; sp0->raw[1] = c[1];
+                pack(*sp0, false);
+            }
+            Slot &s = *sp0;
             uint64_t *dh;
             HIPCHK(hipMalloc(&dh, (size_t)s.n * sizeof(uint64_t)));
             snk_batch b;
@@ -954,7 +1150,8 @@ int main(int argc, char **argv) {
             dupw[m].resize(T);
             for (int t = 0; t < T; ++t) dupw[m][t].open(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz", true);
         }
-        for (Slot &sl : slots) for (int m = 0; m < mates; ++m) memset(sl.h_seq[m], 0, plane);
+        for (Dev &d : devs) for (Slot &sl : d.slots) for (int m = 0; m < mates; ++m) memset(sl.h_seq[m], 0, plane);
+        for (Dev &d : devs) for (Slot &sl : d.slots) { sl.raw[0] = sl.raw[1] = nullptr; }
         // second pass over the input
         start_readers();
         if (!next_chunks(first)) die("no data");
@@ -983,8 +1180,8 @@ int main(int argc, char **argv) {
         if (mates == 2 && o.trim_fq[1].empty()) die("trimFq2 is required with trimFq1");
         for (int m = 0; m < mates; ++m) trimw[m].open(o.out_dir + "/" + o.trim_fq[m], ends_with_gz(o.trim_fq[m]));
     }
-    Channel<Slot *> free_slots(NSLOT + 1), to_write(NSLOT + 1);
-    for (Slot &s : slots) free_slots.push(&s);
+    Channel<Slot *> to_write((size_t)NSLOT * (size_t)G + 1);
+    const bool rmdup_on = !dup_host.empty();
     const int dq = o.p.output_quality_phred - o.p.quality_phred;
     const bool fasta = o.out_file_type == "fasta";
     uint64_t ndup_written = 0;
@@ -999,7 +1196,12 @@ int main(int argc, char **argv) {
         while (to_write.pop(sp)) {
             Slot &s = *sp;
             HIPCHK(hipEventSynchronize(s.done));
-            const int n = s.n;
+            if (*s.h_err != SNK_ERR_WORD_NONE) {                    // the reference exits at the offending read: nothing of this batch is written
+                snk_error err;
+                snk_error_decode(*s.h_err, &err);
+                report_device_error(err);
+            }
+            const int n = s.n, lcap = s.lcap;                  // (the capacity this batch was packed with)
             for (int m = 0; m < mates; ++m) {
                 text[m].assign(WK, string()); zbuf[m].assign(WK, string());
                 ttext[m].assign(WK, string()); tzbuf[m].assign(WK, string());
@@ -1047,13 +1249,14 @@ int main(int argc, char **argv) {
                         out += '\n';
                     }
                     const size_t sq_at = out.size();
-                    out.append(sq + x.clean_start, x.clean_len);
+                    const int cs = std::min<int>(x.clean_start, lsq), cl = std::min<int>(x.clean_len, lsq - cs);
+                    out.append(sq + cs, cl);
                     if (bc_from)
                         for (size_t k = sq_at; k < out.size(); ++k) if (toupper((unsigned char)out[k]) == bc_from) out[k] = bc_to;
                     if (fasta) { out += '\n'; return; }
                     out += stream_rec ? "\t" : "\n+\n";
                     const size_t q_at = out.size();
-                    out.append(ql + x.clean_start, x.clean_len);
+                    out.append(ql + cs, cl);
                     if (dq) for (size_t k = q_at; k < out.size(); ++k) out[k] = (char)(out[k] + dq);
                     out += '\n';
                 };
@@ -1074,7 +1277,7 @@ int main(int argc, char **argv) {
                     }
                     if (o.out_gz && !cut_mode && !o.streaming && !out.empty()) gzip_member(out, zbuf[m][w]);
                 }
-                if (d_dup_all) {                               // C_fastq::toString of the raw records, src/peprocess.cpp:1541
+                if (rmdup_on) {                                // C_fastq::toString of the raw records, src/peprocess.cpp:1541
                     string acc[2];
                     int cur_vt = -1;
                     auto flush_piece = [&] {
@@ -1142,7 +1345,7 @@ int main(int argc, char **argv) {
                         const string &bytes = trimw[m].gz ? tzbuf[m][w] : ttext[m][w];
                         if (!bytes.empty()) fwrite(bytes.data(), 1, bytes.size(), trimw[m].fp);
                     }
-            if (d_dup_all)
+            if (rmdup_on)
                 for (int w = 0; w < WK; ++w) {                 // worker order = input order within every side file
                     for (const DupPiece &pc : dpieces[w])
                         for (int m = 0; m < mates; ++m) fwrite(pc.z[m].data(), 1, pc.z[m].size(), dupw[m][pc.vt].fp);
@@ -1150,31 +1353,51 @@ int main(int argc, char **argv) {
                 }
             log << local_time() << " processed_reads:\t" << s.first + (uint64_t)n << endl;
             for (int m = 0; m < mates; ++m) { delete s.raw[m]; s.raw[m] = nullptr; }
-            free_slots.push(sp);
+            devs[(size_t)s.dev].free_slots->push(sp);
         }
     });
 
-    uint64_t total = 0;
+    uint64_t total = 0, batch_no = 0;
     RawChunk *c[2] = {first[0], first[1]};
     bool have = true;
     while (have) {
+        Dev &dv = devs[(size_t)(batch_no++ % (uint64_t)G)];   // batches go round the devices; the writer keeps input order
+        HIPCHK(hipSetDevice(dv.id));
         Slot *sp;
-        free_slots.pop(sp);
+        dv.free_slots->pop(sp);
+        sp->n = c[0]->n;
+        sp->first = total;
+        sp->raw[0] = c[0]; sp->raw[1] = c[1];
+        if (!pack(*sp, true)) {
+            // a read longer than every read before it (the reference takes any read up to 1000 nt at any
+            // position): drain the pipeline, close the epoch, rebuild contexts and slots with the new capacity
+            dv.free_slots->push(sp);
+            for (Dev &d : devs) { Slot *t_[8]; for (int k = 0; k < NSLOT; ++k) d.free_slots->pop(t_[k]); }
+            collect_epoch();
+            teardown();
+            setup(longest(c));
+            HIPCHK(hipSetDevice(dv.id));
+            dv.free_slots->pop(sp);
+            sp->n = c[0]->n;
+            sp->first = total;
+            sp->raw[0] = c[0]; sp->raw[1] = c[1];
+            pack(*sp, true);
+        }
         Slot &s = *sp;
-        s.n = c[0]->n;
-        s.first = total;
-        s.raw[0] = c[0]; s.raw[1] = c[1];
-        pack(s, true);
+        s.lcap = lcap;
         const int n = s.n;
         const bool name_verdicts = !o.tile.empty() || !o.fov.empty();
-        if (name_verdicts) {                                // tile / fov of fq1's read name (src/read_filter.cpp:86-150, src/sequence.cpp:213-231)
+        const bool host_flags = name_verdicts || rmdup_on;
+        if (host_flags) {                                   // tile / fov of fq1's read name (src/read_filter.cpp:86-150, src/sequence.cpp:213-231) + the duplicate bit
             parallel_for(WK, n, [&](int, int lo, int hi) {
                 for (int i = lo; i < hi; ++i) {
-                    int li;
-                    const char *id = s.raw[0]->line(4 * i, li);
-                    uint8_t f = dup_host.empty() ? 0 : (uint8_t)(dup_host[total + (uint64_t)i] & 1);
-                    if (!o.tile.empty() && check_tile_or_fov(read_tile(id, li, o.seq_type), o.tile)) f |= 2;
-                    if (!o.fov.empty() && check_tile_or_fov(read_fov(id, li), o.fov)) f |= 4;
+                    uint8_t f = rmdup_on ? (uint8_t)(dup_host[total + (uint64_t)i] & 1) : 0;
+                    if (name_verdicts) {
+                        int li;
+                        const char *id = s.raw[0]->line(4 * i, li);
+                        if (!o.tile.empty() && check_tile_or_fov(read_tile(id, li, o.seq_type), o.tile)) f |= 2;
+                        if (!o.fov.empty() && check_tile_or_fov(read_fov(id, li), o.fov)) f |= 4;
+                    }
                     s.h_flags[i] = f;
                 }
             });
@@ -1201,23 +1424,23 @@ int main(int argc, char **argv) {
                 b.len[m] = s.d_len[m] + lo;
             }
             b.first_index = g;
-            if (name_verdicts) b.dup = s.d_flags + lo;
-            else if (d_dup_all) b.dup = d_dup_all + g;
-            if (snk_bind_stats(ctx, d_sum[vt], d_max[vt]) != SNK_OK) die(snk_last_error());
-            if (snk_filter_batch_device(ctx, &b, s.d_rec[0] + lo, mates == 2 ? s.d_rec[1] + lo : nullptr, s.stream, 0) != SNK_OK)
+            if (host_flags) b.dup = s.d_flags + lo;
+            if (snk_bind_stats(dv.ctx, dv.d_sum[(size_t)vt], dv.d_max[(size_t)vt]) != SNK_OK) die(snk_last_error());
+            if (snk_filter_batch_device(dv.ctx, &b, s.d_rec[0] + lo, mates == 2 ? s.d_rec[1] + lo : nullptr, s.stream, 0) != SNK_OK)
                 die(snk_last_error());
             lo = hi;
         }
         for (int m = 0; m < mates; ++m)
             HIPCHK(hipMemcpyAsync(s.h_rec[m], s.d_rec[m], (size_t)n * sizeof(snk_read_result), hipMemcpyDeviceToHost, s.stream));
+        if (snk_error_peek_async(dv.ctx, s.h_err, s.stream) != SNK_OK) die(snk_last_error());
         if (o.streaming) {                                  // the patch's thread, cumulative, before the next patch touches it
             HIPCHK(hipStreamSynchronize(s.stream));
             const int vt = (int)((total / (uint64_t)vblock) % (uint64_t)T);
             s.snap_sum.assign((size_t)nsum, 0);
             s.snap_max.assign(SNK_MAX_N, 0);
             snk_error err;
-            if (snk_bind_stats(ctx, d_sum[vt], d_max[vt]) != SNK_OK) die(snk_last_error());
-            if (snk_stats_fetch(ctx, s.snap_sum.data(), s.snap_max.data(), &err, nullptr) != SNK_OK) die(snk_last_error());
+            if (snk_bind_stats(dv.ctx, dv.d_sum[(size_t)vt], dv.d_max[(size_t)vt]) != SNK_OK) die(snk_last_error());
+            if (snk_stats_fetch(dv.ctx, s.snap_sum.data(), s.snap_max.data(), &err, nullptr) != SNK_OK) die(snk_last_error());
         }
         HIPCHK(hipEventRecord(s.done, s.stream));
         to_write.push(sp);
@@ -1229,23 +1452,23 @@ int main(int argc, char **argv) {
     join_readers();
     for (int m = 0; m < mates; ++m) wr[m].close();
     if (trim_out) for (int m = 0; m < mates; ++m) trimw[m].close();
-    if (d_dup_all) {
+    if (rmdup_on) {
         for (int m = 0; m < mates; ++m) for (int t = 0; t < T; ++t) dupw[m][t].close();
         log << "dup number:\t" << ndup_written << endl;
     }
-    HIPCHK(hipDeviceSynchronize());
 
-    // ---- stats: finalize each virtual thread's block, fetch, check errors, write the reports
-    std::vector<std::vector<uint64_t>> sums(T, std::vector<uint64_t>(nsum)), maxs(T, std::vector<uint64_t>(SNK_MAX_N));
+    // ---- stats: reduce over the devices, fold the epochs into the widest geometry, write the reports
+    collect_epoch();
+    const int lfin = epochs.back().lcap;                      // capacities only grow
+    std::vector<std::vector<uint64_t>> sums((size_t)T, std::vector<uint64_t>((size_t)snk_stats_u64(lfin, nq), 0)),
+                                       maxs((size_t)T, std::vector<uint64_t>(SNK_MAX_N, 0));
     std::vector<const uint64_t *> sp(T), mp(T);
+    for (const Epoch &e : epochs)
+        for (int t = 0; t < T; ++t) {
+            widen_add(e.sums[(size_t)t].data(), e.lcap, sums[(size_t)t].data(), lfin, nq);
+            for (int k = 0; k < SNK_MAX_N; ++k) maxs[(size_t)t][(size_t)k] = std::max(maxs[(size_t)t][(size_t)k], e.maxs[(size_t)t][(size_t)k]);
+        }
     for (int t = 0; t < T; ++t) {
-        snk_error err;
-        if (snk_bind_stats(ctx, d_sum[t], d_max[t]) != SNK_OK) die(snk_last_error());
-        if (snk_stats_fetch(ctx, sums[t].data(), maxs[t].data(), &err, nullptr) != SNK_OK) die(snk_last_error());
-        if (err.code == SNK_E_BAD_BASE) die("unrecognized sequence, read " + std::to_string(err.index) + " of fq" + std::to_string(err.mate + 1));
-        if (err.code == SNK_E_EMPTY_SEQ) die("empty sequence");
-        if (err.code == SNK_E_QUAL_RANGE) die("quality is too high or too low,please check the quality system parameter or fastq file");
-        if (err.code) die("device reported error " + std::to_string(err.code));
         if (bc_from) {
             // preOutput converted the clean reads before stat_pe_fqs(..., "clean") counted them (src/peprocess.cpp:1601-1604,1960):
             // in the clean statistics the letter's counts belong to the letter it became (the switch there is case-insensitive)
@@ -1253,11 +1476,11 @@ int main(int argc, char **argv) {
             const size_t from = acgt.find(bc_from), to = acgt.find((char)toupper((unsigned char)bc_to));
             if (from != string::npos && to != string::npos && from != to)
                 for (int k = 2; k < 2 + mates; ++k) {
-                    uint64_t *f = sums[t].data() + snk_file_off(lcap, nq, k);
+                    uint64_t *f = sums[t].data() + snk_file_off(lfin, nq, k);
                     f[SNK_GS_A + to] += f[SNK_GS_A + from];
                     f[SNK_GS_A + from] = 0;
-                    uint64_t *bs = f + snk_bs_off(lcap, nq);
-                    for (int pos = 0; pos < lcap; ++pos) { bs[pos * 5 + to] += bs[pos * 5 + from]; bs[pos * 5 + from] = 0; }
+                    uint64_t *bs = f + snk_bs_off(lfin, nq);
+                    for (int pos = 0; pos < lfin; ++pos) { bs[pos * 5 + to] += bs[pos * 5 + from]; bs[pos * 5 + from] = 0; }
                 }
         }
         sp[t] = sums[t].data();
@@ -1265,8 +1488,9 @@ int main(int argc, char **argv) {
     }
     if (o.total_reads > 0 && !o.total_head) extract_every_kth(o, mates, clean_total);
     char ebuf[512];
+    o.p.max_read_len = lfin;
     if (snk_write_reports(&o.p, T, sp.data(), mp.data(), o.out_dir.c_str(), ebuf, sizeof ebuf) != 0) { cerr << ebuf << endl; return 1; }
     log << local_time() << "\tAnalysis accomplished!" << endl;
-    snk_destroy(ctx);
+    teardown();
     return 0;
 }

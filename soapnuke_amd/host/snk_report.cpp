@@ -68,11 +68,14 @@ void add_ts(FileStat &g, const View &t, uint64_t lo, uint64_t hi_excl) {
 struct Quart { float mean, median, lower, upper, first10, last10; };
 
 // cal_quar_from_array, src/gc.cpp:68-119 (int32 counters and positions on purpose)
-Quart quartiles(FileStat &g, uint64_t row, int len) {
+// *set (optional): bit k = field k was assigned.  A wrapped, negative position matches no bin: the reference then
+// returns that field of its constructor-less quartile_result uninitialised (whatever its stack held); 0 here.
+Quart quartiles_of(const uint64_t *data, int nq, int len, int *set = nullptr) {
+    int mask = 1;
     Quart r = {0, 0, 0, 0, 0, 0};
     unsigned long long total = 0;
     int32_t data_num = 0;
-    auto val = [&](int i) -> uint64_t { return i < g.nq ? g.Q(row, i) : 0; };
+    auto val = [&](int i) -> uint64_t { return i < nq ? data[i] : 0; };      // (one slot past the row reads 0 there)
     for (int i = 0; i <= len; ++i) {
         total += (unsigned long long)i * val(i);
         data_num = (int32_t)((uint32_t)data_num + (uint32_t)val(i));
@@ -84,15 +87,18 @@ Quart quartiles(FileStat &g, uint64_t row, int len) {
     int32_t last = 0, cur = 0;
     for (int i = 0; i <= len; ++i) {
         cur = (int32_t)((uint32_t)cur + (uint32_t)val(i));
-        if (lower_pos >= last && lower_pos <= cur) r.lower = (float)i;
-        if (upper_pos >= last && upper_pos <= cur) r.upper = (float)i;
-        if (first10_pos >= last && first10_pos <= cur) r.first10 = (float)i;
-        if (last10_pos >= last && last10_pos <= cur) r.last10 = (float)i;
-        if (median_pos >= last && median_pos <= cur) r.median = (float)i;
+        if (lower_pos >= last && lower_pos <= cur) { r.lower = (float)i; mask |= 4; }
+        if (upper_pos >= last && upper_pos <= cur) { r.upper = (float)i; mask |= 8; }
+        if (first10_pos >= last && first10_pos <= cur) { r.first10 = (float)i; mask |= 16; }
+        if (last10_pos >= last && last10_pos <= cur) { r.last10 = (float)i; mask |= 32; }
+        if (median_pos >= last && median_pos <= cur) { r.median = (float)i; mask |= 2; }
         last = cur;
     }
+    if (set) *set = mask;
     return r;
 }
+
+Quart quartiles(FileStat &g, uint64_t row, int len) { return quartiles_of(&g.Q(row, 0), g.nq, len); }
 
 std::string pct2(float v) {            // sprintf("%.2f", float)
     char b[64];
@@ -392,6 +398,14 @@ int write_all(const snk_params *P, Gv &gv, const std::string &dir, std::string &
 }
 
 }  // namespace
+
+// test hook: the quartile columns of one quality histogram row (mean, median, lower, upper, first10, last10)
+extern "C" int snk_report_quartiles(const uint64_t *data, int nq, int len, float out[6]) {
+    int set = 0;
+    const Quart q = quartiles_of(data, nq, len, &set);
+    out[0] = q.mean; out[1] = q.median; out[2] = q.lower; out[3] = q.upper; out[4] = q.first10; out[5] = q.last10;
+    return set;
+}
 
 extern "C" int64_t snk_vthread_block(int threads, int patch_size) {
     if (threads < 1) threads = 1;

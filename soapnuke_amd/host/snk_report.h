@@ -30,6 +30,11 @@ int64_t snk_vthread_block(int threads, int patch_size);
 // src/seprocess.cpp:2405-2462), appended to *out (a std::string passed as void*).
 void snk_streaming_stat_text(const snk_params *params, const uint64_t *sum, const uint64_t *max, void *out_string);
 
+// cal_quar_from_array (src/gc.cpp:68-119) on one histogram row of nq counters: mean, median, lower, upper,
+// first10, last10 -- with its 32-bit positions.  Returns a bit mask of the fields the scan assigned
+// (an unassigned field is uninitialised memory in the reference, 0 here).  Exported for the tests.
+int snk_report_quartiles(const uint64_t *data, int nq, int len, float out[6]);
+
 #ifdef __cplusplus
 }
 #endif

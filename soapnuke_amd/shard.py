@@ -12,12 +12,39 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _host_staged(t):
+    """gloo moves host memory only: device tensors are staged through the host there (the CPU tests,
+    and the two-ranks-on-one-GPU test); RCCL (`nccl`) takes the device tensors as they are."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_reduce(t, op):
+    import torch.distributed as dist
+    if _host_staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+
+
+def _all_to_all(out, inp, out_splits=None, in_splits=None):
+    import torch.distributed as dist
+    if _host_staged(inp):
+        ho, hi = out.cpu(), inp.cpu()
+        dist.all_to_all_single(ho, hi, output_split_sizes=out_splits, input_split_sizes=in_splits)
+        out.copy_(ho)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
+
+
 def allreduce_stats(sum_t, max_t):
     """In place.  sum_t / max_t: int64 tensors viewing the uint64 blocks (two's-complement
     addition is the same operation; the max block's keys stay below 2**63)."""
     import torch.distributed as dist
-    dist.all_reduce(sum_t, op=dist.ReduceOp.SUM)
-    dist.all_reduce(max_t, op=dist.ReduceOp.MAX)
+    _all_reduce(sum_t, dist.ReduceOp.SUM)
+    _all_reduce(max_t, dist.ReduceOp.MAX)
 
 
 def rmdup_exchange_mark(hashes, first_index, total_n, mark_fn, bucket_count_fn):
@@ -36,25 +63,25 @@ def rmdup_exchange_mark(hashes, first_index, total_n, mark_fn, bucket_count_fn):
     dev = hashes.device
     # the sentinel quirk needs the population of one bucket over ALL ranks
     cnt = bucket_count_fn(hashes, total_n).clone()
-    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    _all_reduce(cnt, dist.ReduceOp.SUM)
     sentinel_total = int(cnt.item())
     # owner = unsigned(hash) % world, computed on the int64 bit pattern
     owner = (((((hashes >> 1) & 0x7FFFFFFFFFFFFFFF) % world) * 2 + (hashes & 1)) % world) if world > 1 else torch.zeros_like(hashes)
     order = torch.argsort(owner, stable=True)
     send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
     recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts)
+    _all_to_all(recv_counts, send_counts)
     sc, rc = send_counts.tolist(), recv_counts.tolist()
     gidx = (torch.arange(n, device=dev, dtype=torch.int64) + int(first_index))
     send_h = hashes[order].contiguous()
     send_i = gidx[order].contiguous()
     recv_h = torch.empty(sum(rc), dtype=torch.int64, device=dev)
     recv_i = torch.empty(sum(rc), dtype=torch.int64, device=dev)
-    dist.all_to_all_single(recv_h, send_h, output_split_sizes=rc, input_split_sizes=sc)
-    dist.all_to_all_single(recv_i, send_i, output_split_sizes=rc, input_split_sizes=sc)
+    _all_to_all(recv_h, send_h, rc, sc)
+    _all_to_all(recv_i, send_i, rc, sc)
     flags_owned = mark_fn(recv_h, recv_i.to(torch.int32), total_n, sentinel_total)   # indices < 2**32 (reference limit)
     back = torch.empty(n, dtype=torch.uint8, device=dev)
-    dist.all_to_all_single(back, flags_owned.contiguous(), output_split_sizes=sc, input_split_sizes=rc)
+    _all_to_all(back, flags_owned.contiguous(), sc, rc)
     out = torch.empty(n, dtype=torch.uint8, device=dev)
     out[order] = back
     return out

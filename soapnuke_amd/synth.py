@@ -79,13 +79,20 @@ def _mate(rng, n, L, pitch, ins, adapter, polyg_frac, var_len):
 
 
 def make_batch(n, L=150, paired=True, seed=SEED, adapters=(ADAPTER1, ADAPTER2),
-               var_len=False, pitch=None):
-    """Returns dict(seq=[S1,S2], qual=[Q1,Q2], len=[l1,l2] or None, L, pitch, n)."""
+               var_len=False, pitch=None, dimer_frac=0.0):
+    """Returns dict(seq=[S1,S2], qual=[Q1,Q2], len=[l1,l2] or None, L, pitch, n).
+    dimer_frac > 0: that fraction of the pairs are adapter dimers / very short inserts -- insert size in
+    [-12, 40), a negative insert meaning the read starts |insert| characters INTO the adapter (phase A of
+    adapter_pos, src/read_filter.cpp:720-742).  The default stream of random numbers is unchanged by it."""
     rng = np.random.default_rng(seed)
     pitch = pitch or pitch_for(L)
     ins = np.clip(np.rint(rng.normal(350, 100, size=n)), 40, 900).astype(np.int32)
     if L >= 200:                                     # keep ~3 % read-through at PE250 too
         ins = np.clip(np.rint(rng.normal(350 * L / 150, 100 * L / 150, size=n)), 40, 2000).astype(np.int32)
+    if dimer_frac > 0:
+        rng2 = np.random.default_rng([seed, 0xD1AE])
+        sel = np.nonzero(rng2.random(n) < dimer_frac)[0]
+        ins[sel] = rng2.integers(-12, 40, size=len(sel))
     out = {"seq": [], "qual": [], "len": [], "L": L, "pitch": pitch, "n": n, "paired": paired}
     for m in range(2 if paired else 1):
         S, Q, lens = _mate(rng, n, L, pitch, ins, adapters[m], 0.01 if m == 1 else 0.0, var_len)

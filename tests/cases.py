@@ -42,6 +42,8 @@ CONTAM_CASES = {
     "single_default_mr": dict(contam1=CT1 + CT1[:25], ct_match_r="0.2"),
     "list": dict(contam1=CT1 + ",GGGGGGGGGGGGGGGGGGGGGGGG", contam2=CT2 + ",CCCCCCCCCCCCCCCCCCCCCC", ct_match_r="0.6,0.7"),
     "global": dict(global_contams=CT1 + "," + GC1, g_mrs="0.5,0.4", g_mms="1,2"),
+    # mate 2 of a pair is screened with adaMis2 / adaEdge2 (gp2, src/sequence.cpp:182-189)
+    "single_params2": dict(contam1=CT1, contam2=CT2, ct_match_r="0.5", ada_mis=(2, 0), ada_edge=(6, 12)),
     "both_trim": dict(contam1=CT1, ct_match_r="0.4", global_contams=GC1, g_mrs="0.4", g_mms="1", contam_trim=1),
     "both_discard": dict(contam1=CT1, contam2=CT1, ct_match_r="0.4", global_contams=GC1, g_mrs="0.4", g_mms="1",
                          adapters1=[A1], adapters2=[A2], ada_trim=1),

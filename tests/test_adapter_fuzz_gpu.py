@@ -1,0 +1,106 @@
+"""HIP-side adapter search fuzz: random adapter contexts -- adapter 6..64 nt with N inside,
+1..4 adapters per mate, adaMis 0..3, adaMR in {0.3, 0.5, 0.7, 1}, adaEdge 1..8, trim and discard mode -- on reads
+with planted whole / tail-truncated / HEAD-truncated (phase A of adapter_pos: the read starts inside the adapter,
+src/read_filter.cpp:720-742) / mutated adapters; both kernels against the oracle, bit-exact records and counters.
+The bit-sliced screen (screen_planes) and the closed-form early-exit decision (accept_exact) of the tiled kernel
+see every phase with every budget here; the oracle's adapter_pos itself is pinned on the compiled reference by
+tests/test_oracle_vs_ref.py."""
+import numpy as np
+import pytest
+
+import snk_testlib as T
+from soapnuke_amd import abi, synth
+from test_gpu_parity import assert_same, run_hip_device
+
+pytestmark = pytest.mark.gpu
+
+B4 = np.frombuffer(b"ACGT", dtype=np.uint8)
+N_CONTEXTS, READS = 56, 20000
+
+
+def random_adapter(rng, lo=6, hi=64):
+    n = int(rng.integers(lo, hi + 1))
+    a = B4[rng.integers(0, 4, n)].copy()
+    if rng.random() < 0.3:                                   # 'N' inside an adapter: an ordinary character (exact compare)
+        a[rng.integers(0, n, int(rng.integers(1, 3)))] = ord("N")
+    if rng.random() < 0.15:                                  # low-complexity adapters: long runs, many candidate offsets
+        a[:] = B4[rng.integers(0, 4)]
+        a[rng.integers(0, n, 2)] = B4[rng.integers(0, 4, 2)]
+    return bytes(a).decode()
+
+
+def plant(rng, seq, lens, L, adapters, frac):
+    """writes adapter material into `frac` of the rows of seq (n x pitch uint8)"""
+    n = seq.shape[0]
+    rows = rng.choice(n, int(n * frac), replace=False)
+    for r in rows:
+        a = np.frombuffer(adapters[int(rng.integers(0, len(adapters)))].encode(), dtype=np.uint8).copy()
+        la, rl = len(a), int(lens[r]) if lens is not None else L
+        for k in rng.integers(0, la, int(rng.choice([0, 0, 0, 1, 2, 3, 4]))):      # substitutions (also across the budget)
+            a[int(k)] = B4[rng.integers(0, 4)]
+        mode = int(rng.integers(0, 4))
+        if mode == 0 and rl >= la:                          # whole adapter somewhere (phase B), insert >= 0
+            p = int(rng.integers(0, rl - la + 1))
+            seq[r, p:p + la] = a
+        elif mode == 1:                                     # tail-truncated: adapter prefix at the read end (phase C)
+            k = int(rng.integers(1, min(la, rl) + 1))
+            seq[r, rl - k:rl] = a[:k]
+        elif mode == 2:                                     # head-truncated: read starts r1 characters into the adapter (phase A: 1..5)
+            r1 = int(rng.integers(1, 9))
+            k = min(la - r1, rl)
+            if k > 0:
+                seq[r, :k] = a[r1:r1 + k]
+        else:                                               # adapter dimer with a short random insert in front
+            p = int(rng.integers(0, 12))
+            k = min(la, rl - p)
+            if k > 0:
+                seq[r, p:p + k] = a[:k]
+
+
+def context(i):
+    rng = np.random.default_rng(7000 + i)
+    paired = i % 4 != 3
+    L = 150 if i % 2 == 0 else 100
+    var = i % 3 != 0
+    na = [int(rng.integers(1, 5)) for _ in range(2)]
+    if i % 7 == 0:
+        na = [1, 1]
+    ada = [[random_adapter(rng, 6, min(64, L // 2 - 8)) for _ in range(na[m])] for m in range(2)]
+    kw = dict(adapters1=ada[0], ada_trim=int(rng.integers(0, 2)),
+              ada_mis=(int(rng.integers(0, 4)), int(rng.integers(0, 4))),
+              ada_mr=(float(rng.choice([0.3, 0.5, 0.7, 1.0])), float(rng.choice([0.3, 0.5, 0.7, 1.0]))),
+              ada_edge=(int(rng.integers(1, 9)), int(rng.integers(1, 9))),
+              low_qual=10, low_qual_ratio=0.3, min_read_length=int(rng.choice([30, 15, 50])))
+    if paired:
+        kw["adapters2"] = ada[1]
+    d = synth.make_batch(READS, L, paired=paired, var_len=var, seed=9000 + i, dimer_frac=0.02,
+                         adapters=(ada[0][0], ada[1][0]))
+    for m in range(2 if paired else 1):
+        plant(rng, d["seq"][m], d["len"][m], L, ada[m], 0.25)
+    p = abi.default_params(paired=paired, max_read_len=L, **kw)
+    return p, d, paired
+
+
+@pytest.mark.parametrize("i", range(N_CONTEXTS))
+def test_adapter_fuzz(i):
+    p, d, paired = context(i)
+    want = T.run_oracle(p, d)
+    assert int((want["rec"][0]["adacut_pos"] >= 0).sum()) > 100            # adapters are found ...
+    for kernel in (0, 1):
+        assert_same(p, run_hip_device(p, d, kernel, chunks=2), want, paired)
+
+
+def test_phase_a_dimers_reach_the_tiled_kernel():
+    """README adapters, C2 parameters, 5 % adapter dimers with negative inserts: reads whose first base is adapter
+    character r1 = 1..5 must come back with adapter position 0 (phase A) from the tiled kernel."""
+    d = synth.make_batch(40000, 150, paired=True, seed=31, dimer_frac=0.05)
+    p = abi.default_params(paired=True, max_read_len=150, adapters1=[synth.ADAPTER1], adapters2=[synth.ADAPTER2],
+                           ada_trim=1, low_qual=10, low_qual_ratio=0.1)
+    want = T.run_oracle(p, d)
+    got = run_hip_device(p, d, 2)
+    assert_same(p, got, want, True)
+    a1 = np.frombuffer(synth.ADAPTER1.encode(), dtype=np.uint8)
+    phase_a = [r for r in range(d["n"]) if any(np.array_equal(d["seq"][0][r, :20], a1[k:k + 20]) for k in range(1, 6))]
+    assert len(phase_a) > 100
+    # adapter at read position 0 (adacut_pos = length - 0): nothing is left of mate 1
+    assert all(want["rec"][0]["adacut_pos"][r] == 150 and got["rec"][0]["adacut_pos"][r] == 150 for r in phase_a)

@@ -399,3 +399,96 @@ def test_cli_streaming_many_threads(tmp_path):
     assert a.count(b"#Total_statistical_information") == b.count(b"#Total_statistical_information") == n // 8
     for f in R.REPORT_FILES_PE:
         assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
+
+
+# ---- round 2: several devices, capacity regrowth, the quality-system sanity check
+
+def _write_fastq(path, seqs, quals, mate):
+    with open(path, "wb") as f:
+        for i, (s, q) in enumerate(zip(seqs, quals)):
+            f.write(b"@SNK:1:%d:%d:%d/%d\n" % (1101 + i % 7, i, i * 3, mate) + s + b"\n+\n" + q + b"\n")
+    subprocess.check_call(["gzip", "-1", "-f", "-k", path])
+
+
+def _compare_dirs(ours, ref, paired, gz_ours=False):
+    for f in (R.REPORT_FILES_PE if paired else R.REPORT_FILES_SE):
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in (["c1.fq", "c2.fq"] if paired else ["c1.fq"]):
+        assert _cat(os.path.join(ours, c + (".gz" if gz_ours else ""))) == _cat(os.path.join(ref, c)), c
+
+
+@pytest.mark.parametrize("rmdup", [False, True])
+def test_cli_two_device_slots(rmdup, tmp_path):
+    """--devices a,b: batches go round the devices, every device keeps one accumulator per virtual thread, the blocks
+    are merged at the end (RCCL all-reduce between distinct GPUs; the same GPU listed twice -- all a 1-GPU box can
+    offer -- merges on the host), the writer keeps input order.  Output identical to the reference binary."""
+    import torch
+    devs = "0,1" if torch.cuda.device_count() >= 2 else "0,0"
+    n, L, threads, patch = 30000, 150, 3, 250
+    d = synth.make_batch(n, L, paired=True, var_len=True, seed=63)
+    if rmdup:
+        for m in range(2):
+            d["seq"][m][20000:21000] = d["seq"][m][0:1000]
+            d["len"][m][20000:21000] = d["len"][m][0:1000]
+    cli = ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-l", "10", "-q", "0.1"]
+    case = ("devs", True, L, n, threads, patch, {}, {}, cli, ["rmdup"] if rmdup else [])
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    name, paired, L, n, threads, patch, skw, pkw, cli, cfg = case
+    cmd = [CLI, "filter", "-1", os.path.join(work, "r1.fq"), "-2", os.path.join(work, "r2.fq"), "-C", "c1.fq", "-D", "c2.fq",
+           "-o", os.path.join(work, "ours"), "-T", str(threads), "--devices", devs]
+    if os.path.exists(os.path.join(work, "cfg")):
+        cmd += ["-c", os.path.join(work, "cfg")]
+    env = dict(os.environ, SNK_BATCH_PAIRS="4096")                       # 8 batches: 4 per device slot set
+    r = subprocess.run(cmd + cli, capture_output=True, env=env)
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-500:])
+    _compare_dirs(os.path.join(work, "ours"), ref, True)
+
+
+@pytest.mark.parametrize("paired", [True, False])
+def test_cli_longer_read_after_first_batch(paired, tmp_path):
+    """The reference takes any read up to 1000 nt at any position; here the capacity comes from the first batch and is
+    regrown (pipeline drained, statistics folded into the wider geometry) when a longer read shows up later."""
+    rng = np.random.default_rng(9)
+    n = 9000
+    lens = np.concatenate([rng.integers(60, 101, 5000), rng.integers(60, 181, 2000), rng.integers(100, 301, 2000)])
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    work = str(tmp_path)
+    for m in range(2 if paired else 1):
+        seqs = [bytes(B[rng.integers(0, 4, l)]) for l in lens]
+        quals = [bytes((33 + np.clip(rng.normal(34, 6, l), 2, 41)).astype(np.uint8)) for l in lens]
+        _write_fastq(os.path.join(work, f"r{m + 1}.fq"), seqs, quals, m + 1)
+    open(os.path.join(work, "cfg"), "w").write("patch=250\n")
+    tail = ["-C", "c1.fq"] + (["-D", "c2.fq"] if paired else []) + ["-T", "2", "-l", "10", "-q", "0.3", "-c", os.path.join(work, "cfg")]
+    ins = lambda ext: ["-1", os.path.join(work, "r1.fq" + ext)] + (["-2", os.path.join(work, "r2.fq" + ext)] if paired else [])
+    r = subprocess.run([T.REF_BIN, "filter"] + ins(".gz") + ["-o", os.path.join(work, "ref")] + tail, capture_output=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    env = dict(os.environ, SNK_BATCH_PAIRS="2048")
+    r = subprocess.run([CLI, "filter"] + ins("") + ["-o", os.path.join(work, "ours")] + tail, capture_output=True, env=env)
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-500:])
+    _compare_dirs(os.path.join(work, "ours"), os.path.join(work, "ref"), paired)
+
+
+@pytest.mark.parametrize("paired", [True, False])
+@pytest.mark.parametrize("shift,qualsys,expect", [(31, None, "Error"), (0, "1", "Error"), (0, None, None)])
+def test_cli_quality_system_sanity(paired, shift, qualsys, expect, tmp_path):
+    """stat_pe_fqs / stat_se_fqs check the quality system once, on the first patch (src/peprocess.cpp:1207-1319):
+    Phred-64 data under qualSys=2, or Phred-33 data under qualSys=1 -> the same message and exit code as the reference."""
+    n, L = 3000, 100
+    d = synth.make_batch(n, L, paired=paired, seed=73)
+    work = str(tmp_path)
+    for m in range(2 if paired else 1):
+        _write_fastq(os.path.join(work, f"r{m + 1}.fq"), [bytes(x) for x in d["seq"][m][:, :L]],
+                     [bytes(x + shift) for x in d["qual"][m][:, :L]], m + 1)
+    open(os.path.join(work, "cfg"), "w").write("patch=300\n" + (f"qualSys={qualsys}\n" if qualsys else ""))
+    tail = ["-C", "c1.fq"] + (["-D", "c2.fq"] if paired else []) + ["-T", "2", "-c", os.path.join(work, "cfg")]
+    ins = lambda ext: ["-1", os.path.join(work, "r1.fq" + ext)] + (["-2", os.path.join(work, "r2.fq" + ext)] if paired else [])
+    a = subprocess.run([T.REF_BIN, "filter"] + ins(".gz") + ["-o", os.path.join(work, "ref")] + tail, capture_output=True)
+    b = subprocess.run([CLI, "filter"] + ins("") + ["-o", os.path.join(work, "ours")] + tail, capture_output=True)
+    msg = b"base quality seems abnormal,please check the quality system parameter or fastq file"
+    if expect:
+        assert a.returncode == 1 and b.returncode == 1, (a.returncode, b.returncode, a.stderr[-200:], b.stderr[-200:])
+        assert (expect.encode() + b":" + msg) in a.stderr and (expect.encode() + b":" + msg) in b.stderr
+    else:
+        assert a.returncode == 0 and b.returncode == 0
+        assert msg not in a.stderr and msg not in b.stderr

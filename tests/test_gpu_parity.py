@@ -348,3 +348,48 @@ def test_contaminant_list_size_mismatch_is_refused():
     p = abi.default_params(paired=True, max_read_len=150, contam1="ACGTACGTACGT,GGGGGGGGGGGG", ct_match_r="0.5")
     with pytest.raises(FilterError):
         FilterContext(p, device=0)
+
+
+# ---- BASELINE configs at their own sizes
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_config0_se_100k_x150_defaults(kernel):
+    """BASELINE configs[0]: SE 100k x 150 bp, `filter` default parameters -- the whole of it against the oracle."""
+    d = synth.make_batch(100_000, 150, paired=False, seed=synth.SEED)
+    p = abi.default_params(paired=False, max_read_len=150)
+    assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), False)
+
+
+def test_config1_pe_10m_x150_full_size():
+    """BASELINE configs[1] at its full size, laid out as bench.py lays it out: PE 10 M x 150, `-J -l 10 -q 0.1`, one
+    launch over 10 M device-resident pairs (1 M unique pairs x 10 distinct HBM copies).  The 1 M unique pairs are checked
+    against the oracle in full; the 10 M launch through linearity: every counter is 10 x the 1 M block, every replica's
+    records equal the first one's, and the `last read seen` keys name pair 10 M - 1."""
+    import torch
+    from soapnuke_amd.filter import FilterContext, records_to_numpy
+    n1, reps, L = 1_000_000, 10, 150
+    d = synth.make_batch(n1, L, paired=True, seed=synth.SEED)
+    p = abi.default_params(paired=True, max_read_len=L, **PE_CASES["C2_adatrim_lowq"])
+    one = run_hip_device(p, d, 2)
+    assert_same(p, one, T.run_oracle(p, d), True)
+    ctx = FilterContext(p, device=0)
+    dev = ctx.upload(d)
+    dev["seq"] = [x.repeat(reps, 1) for x in dev["seq"]]
+    dev["qual"] = [x.repeat(reps, 1) for x in dev["qual"]]
+    dev["n"] = n1 * reps
+    rec = ctx.alloc_records(n1 * reps)
+    ctx.filter_batch(ctx.make_batch(dev), rec, kernel=2)
+    s, mx, err = ctx.fetch()
+    assert err[0] == 0
+    assert np.array_equal(s, one["sum"] * np.uint64(reps)), T.describe_stats_diff(p, s, one["sum"] * np.uint64(reps))
+    for m in range(2):
+        r = rec[m].view(n1 * reps, 16).reshape(reps, n1, 16)
+        assert bool((r == r[0:1]).all())
+        assert np.array_equal(records_to_numpy(rec[m][:n1]), one["rec"][m])
+    # max block: (index + 1) << 16 | length of the last read of each file (raw files: the last pair)
+    assert int(mx[0]) >> 16 == n1 * reps and int(mx[0]) & 0xFFFF == L
+    kept_last = int(np.nonzero(one["rec"][0]["reason"] == 0)[0][-1]) + (reps - 1) * n1
+    assert int(mx[2]) >> 16 == kept_last + 1
+    ctx.close()
+    del dev, rec
+    torch.cuda.empty_cache()

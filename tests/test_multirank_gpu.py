@@ -1,0 +1,145 @@
+"""The N > 1 path with the HIP kernels, world_size 2.
+
+Every rank runs the tiled kernel on its contiguous shard of one PE150 batch, then the path's one
+collective -- the stats all-reduce -- and, with rmdup, the one exchange step ((hash, global index)
+all-to-all, owner-side marking on the device, flags back).  The reduced block, the concatenated
+records and the duplicate flags must equal the unsharded oracle run bit for bit.
+
+Transports:
+  * `nccl`  -- RCCL, one rank per GPU; needs two visible devices (skipped on a 1-GPU box).  Covers both
+               torch.distributed (what bench.py issues) and the C ABI snk_stats_allreduce() with an
+               ncclComm_t made from a broadcast unique id (what a C++ host issues).
+  * `gloo`  -- both ranks share cuda:0: the kernels, the sharding and the exchange run on the device at
+               world 2 on any box; only the wire is the host (RCCL refuses two ranks on one device).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import snk_testlib as T
+from cases import PE_CASES
+from soapnuke_amd import abi, synth
+from soapnuke_amd.shard import allreduce_stats, rmdup_exchange_mark, shard_bounds
+
+pytestmark = pytest.mark.gpu
+
+N, L, SEED = 30011, 150, 4242
+
+
+def _data():
+    d = synth.make_batch(N, L, paired=True, var_len=True, seed=SEED)
+    # 8 % exact duplicate pairs, spread so that most duplicates sit on the other rank's shard
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, N, N // 12)
+    dst = rng.integers(0, N, N // 12)
+    for m in range(2):
+        d["seq"][m][dst] = d["seq"][m][src]
+        d["qual"][m][dst] = d["qual"][m][src]
+        d["len"][m][dst] = d["len"][m][src]
+    return d
+
+
+def _params(rmdup):
+    return abi.default_params(paired=True, max_read_len=L, rmdup=1 if rmdup else 0, **PE_CASES["C3_full"])
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+def _worker(rank, world, port, backend, rmdup, c_abi, tmp):
+    from soapnuke_amd.filter import FilterContext, records_to_numpy
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    device = rank if backend == "nccl" else 0
+    torch.cuda.set_device(device)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert dist.get_world_size() == world
+    d = _data()
+    p = _params(rmdup)
+    lo, hi = shard_bounds(N, rank, world)
+    sub = dict(n=hi - lo, L=L, pitch=d["pitch"], paired=True, seq=[x[lo:hi] for x in d["seq"]],
+               qual=[x[lo:hi] for x in d["qual"]], len=[x[lo:hi] for x in d["len"]])
+    ctx = FilterContext(p, device=device)
+    dev = ctx.upload(sub)
+    dup = None
+    if rmdup:
+        h = ctx.hash_batch(ctx.make_batch(dev))
+        dup = rmdup_exchange_mark(h, lo, N, ctx.mark_dups, ctx.bucket_count)
+        np.save(os.path.join(tmp, f"dup{rank}.npy"), dup.cpu().numpy())
+    rec = ctx.alloc_records(hi - lo)
+    ctx.filter_batch(ctx.make_batch(dev, first_index=lo, dup=dup), rec, kernel=2)
+    if c_abi:
+        # a C++ host's route: ncclComm_t from a broadcast unique id, snk_stats_allreduce() on the stream
+        rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+        uid = _UniqueId()
+        if rank == 0:
+            assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+        raw = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            raw.copy_(torch.frombuffer(bytearray(C.string_at(C.addressof(uid), 128)), dtype=torch.uint8))
+        dist.broadcast(raw, src=0)
+        C.memmove(C.addressof(uid), bytes(raw.cpu().numpy().tobytes()), 128)
+        comm = C.c_void_p()
+        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        assert rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+        ctx.lib.snk_stats_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        assert ctx.lib.snk_stats_allreduce(ctx.ctx, comm, ctx._stream()) == 0, ctx.lib.snk_last_error()
+        torch.cuda.synchronize()
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+    else:
+        ctx.finalize()
+        allreduce_stats(ctx.sum, ctx.max)
+    s, mx, err = ctx.fetch()
+    assert err[0] == 0, err
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), sum=s, max=mx,
+             rec=np.stack([records_to_numpy(r).view(np.uint8).reshape(-1, 16) for r in rec]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(tmp_path, backend, rmdup, c_abi=False):
+    world = 2
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank; this box has %d" % torch.cuda.device_count())
+    port = 30100 + os.getpid() % 1500 + (7 if rmdup else 0) + (13 if c_abi else 0)
+    mp.spawn(_worker, args=(world, port, backend, rmdup, c_abi, str(tmp_path)), nprocs=world, join=True)
+    d = _data()
+    p = _params(rmdup)
+    dup = None
+    if rmdup:
+        dup = T.oracle_markdup(T.oracle_hash_batch(d, True))
+        got = np.concatenate([np.load(tmp_path / f"dup{r}.npy") for r in range(world)])
+        assert np.array_equal(got, dup)
+        assert dup.sum() > N // 20
+    whole = T.run_oracle(p, d, dup=dup)
+    z = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r in range(world):      # every rank holds the reduced block
+        assert np.array_equal(z[r]["sum"], whole["sum"]), T.describe_stats_diff(p, z[r]["sum"], whole["sum"])
+        assert np.array_equal(z[r]["max"], whole["max"])
+    rec = np.concatenate([x["rec"] for x in z], axis=1)
+    for m in range(2):
+        assert np.array_equal(rec[m].reshape(-1).view(abi.record_dtype()), whole["rec"][m])
+
+
+@pytest.mark.parametrize("rmdup", [False, True])
+def test_two_ranks_one_gpu_gloo_wire(tmp_path, rmdup):
+    _run(tmp_path, "gloo", rmdup)
+
+
+@pytest.mark.parametrize("rmdup", [False, True])
+def test_two_ranks_two_gpus_rccl(tmp_path, rmdup):
+    _run(tmp_path, "nccl", rmdup)
+
+
+def test_two_ranks_two_gpus_rccl_c_abi(tmp_path):
+    _run(tmp_path, "nccl", False, c_abi=True)

@@ -76,3 +76,52 @@ def test_reports_from_hip_stats(case, tmp_path):
     # gs a/c/g/t/n/bases/q20/q30 are derived per block by the finalize kernel: sums of sums stay exact
     R.write_reports(p, stats, str(tmp_path / "ours"))
     _compare(case, str(tmp_path / "ours"), os.path.join(GOLD, case[0]))
+
+
+# ---- cal_quar_from_array keeps its positions in 32-bit ints; data_num*3 wraps past 715 M counts,
+# data_num*9 past 238 M -- exactly what BASELINE configs[2]/[3] (628 M reads) feed it.
+
+def _quartiles_ours(data, nq, length):
+    import ctypes as C
+    import numpy as np
+    lib = C.CDLL(os.path.join(T.ROOT, "soapnuke_amd", "libsnk_report.so"))
+    lib.snk_report_quartiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    out = np.zeros(6, dtype=np.float32)
+    mask = lib.snk_report_quartiles(data.ctypes.data, nq, length, out.ctypes.data)
+    return out, np.array([(mask >> k) & 1 for k in range(6)], dtype=bool)
+
+
+def _quartiles_ref(data, length):
+    import ctypes as C
+    import numpy as np
+    lib = T.ref_lib()
+    lib.snkref_cal_quar.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    out = np.zeros(6, dtype=np.float32)
+    padded = np.concatenate([data, np.zeros(2, dtype=np.uint64)])       # the reference reads data[len] (one past a PE row)
+    lib.snkref_cal_quar(padded.ctypes.data, length, out.ctypes.data)
+    return out
+
+
+@pytest.mark.skipif(not T.have_ref(), reason="oracle/_ref/libsnkref.so not built")
+def test_quartiles_int32_wrap_vs_reference():
+    import numpy as np
+    rng = np.random.default_rng(12)
+    nq = 43
+    totals = [1000, 2.0e8, 2.38e8, 2.39e8, 4.0e8, 6.28e8, 7.15e8, 7.2e8, 1.0e9, 2.1e9, 2.2e9, 3.5e9, 4.4e9, 7.0e8 * 9]
+    seen_wrap = 0
+    for total in totals:
+        for shape in range(4):
+            w = rng.random(nq) ** (1 + 2 * shape)
+            if shape == 3:
+                w[:] = 0
+                w[[2, 14, 36, 41]] = [0.1, 0.2, 0.5, 0.2]                  # Illumina-style binned qualities
+            data = np.floor(w / w.sum() * total).astype(np.uint64)
+            for length in (nq - 1, nq):                                    # PE passes max_qual, SE max_qual + 1
+                (a, defined), b = _quartiles_ours(data, nq, length), _quartiles_ref(data, length)
+                # a wrapped, negative position matches no bin: that field is uninitialised memory in the reference
+                assert np.array_equal(a[defined], b[defined]), (total, shape, length, a, b, defined)
+                assert defined[:3].all() or int(data.sum()) >= 2**31
+            n = int(data.sum())
+            if (n * 9) % 2**32 != n * 9:
+                seen_wrap += 1
+    assert seen_wrap > 10
