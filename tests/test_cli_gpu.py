@@ -425,11 +425,10 @@ def test_cli_two_device_slots(rmdup, tmp_path):
     import torch
     devs = "0,1" if torch.cuda.device_count() >= 2 else "0,0"
     n, L, threads, patch = 30000, 150, 3, 250
-    d = synth.make_batch(n, L, paired=True, var_len=True, seed=63)
+    d = synth.make_batch(n, L, paired=True, seed=63)
     if rmdup:
         for m in range(2):
             d["seq"][m][20000:21000] = d["seq"][m][0:1000]
-            d["len"][m][20000:21000] = d["len"][m][0:1000]
     cli = ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-l", "10", "-q", "0.1"]
     case = ("devs", True, L, n, threads, patch, {}, {}, cli, ["rmdup"] if rmdup else [])
     work = str(tmp_path)
