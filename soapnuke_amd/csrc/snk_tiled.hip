@@ -88,23 +88,39 @@ __device__ __forceinline__ void lds_add_u32(u32 addr, u32 val) {
     asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(OFF));
 }
 typedef __attribute__((address_space(3))) u32 *lds_u32_ptr;
-// asynchronous byte reads of one read's strips (bases at addr, qualities at addrq); pair with lds_wait
+// asynchronous LDS reads of one read's row: its bases and qualities as dwords (lane l: positions 4l..4l+3, for the
+// bit collectors) and its qualities once more as one byte per lane and 64-position strip (lane = position, for the
+// per-position histogram); pair with lds_wait
 template <int S, int NS>
-__device__ __forceinline__ void lds_read_strips(u32 (&c)[NS], u32 (&q)[NS], u32 addr, u32 addrq) {
+__device__ __forceinline__ void lds_read_qstrips(u32 (&q)[NS], u32 addrq) {
     if constexpr (S < NS) {
-        asm volatile("ds_read_u8 %0, %1 offset:%2" : "=&v"(c[S]) : "v"(addr), "n"(64 * S));
         asm volatile("ds_read_u8 %0, %1 offset:%2" : "=&v"(q[S]) : "v"(addrq), "n"(64 * S));
-        lds_read_strips<S + 1>(c, q, addr, addrq);
+        lds_read_qstrips<S + 1>(q, addrq);
     }
 }
+__device__ __forceinline__ void lds_read_b32(u32 &d, u32 addr) { asm volatile("ds_read_b32 %0, %1" : "=&v"(d) : "v"(addr)); }
 // wait until at most N LDS ops are outstanding; the registers of the (asm) reads being waited for
 // are tied to the wait so that no use can be scheduled above it
 template <int N, int NS>
-__device__ __forceinline__ void lds_wait(u32 (&c)[NS], u32 (&q)[NS]) {
+__device__ __forceinline__ void lds_wait(u32 &c4, u32 &q4, u32 (&q)[NS]) {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+    asm volatile("" : "+v"(c4), "+v"(q4));
 #pragma unroll
-    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(c[s]), "+v"(q[s]));
+    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(q[s]));
 }
+// 4 x 4 byte transpose: out[k] = bytes k of in[0..3] (8 v_perm)
+__device__ __forceinline__ void byte_tr4(u32 i0, u32 i1, u32 i2, u32 i3, u32 (&o)[4]) {
+    const u32 t0 = __builtin_amdgcn_perm(i1, i0, 0x05010400u), t1 = __builtin_amdgcn_perm(i1, i0, 0x07030602u);
+    const u32 t2 = __builtin_amdgcn_perm(i3, i2, 0x05010400u), t3 = __builtin_amdgcn_perm(i3, i2, 0x07030602u);
+    o[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u);
+    o[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    o[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u);
+    o[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+}
+typedef u32 v4u __attribute__((ext_vector_type(4)));
+typedef u32 v2u __attribute__((ext_vector_type(2)));
+typedef u32 v16u __attribute__((ext_vector_type(16)));
+typedef u32 v8u __attribute__((ext_vector_type(8)));
 
 // compile-time strip loop (the strip number feeds immediate offsets of the asm above)
 template <int V> struct IntC { static constexpr int v = V; };
@@ -120,6 +136,18 @@ __device__ __forceinline__ int wave_sum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);    // row_bcast:15 into rows 1 and 3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);    // row_bcast:31 into rows 2 and 3
     return rl(v, 63);
+}
+
+// OR over the 64 lanes, uniform result
+__device__ __forceinline__ u32 wave_or(u32 x) {
+    int v = (int)x;
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);
+    return (u32)rl(v, 63);
 }
 
 // Exact outcome of one alignment of the reference's scan (src/read_filter.cpp:726-741 and
@@ -400,6 +428,8 @@ struct TileGeom {
     // LDS staging of the read bytes (global_load_lds, 16 B/lane): per wave 2 buffers x
     // {bases, qualities} x cba bytes, a chunk = rb consecutive reads.  rb == 0: disabled.
     int rb, cba, stg_off, stg_wave;
+    // hand-over scratch: 2 KB per wave (8 rows of 256 B); the wave's own staging buffers when they exist (idle by then)
+    int scr_off, scr_wave;
 };
 // LDS words behind the four histogram sets: 64 per-lane scratch words, 80 misc counters
 constexpr int SNK_LDS_TAIL = 64 + 80;
@@ -448,37 +478,28 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
 #pragma unroll
         for (int j = 0; j < NW; ++j) XN[j] = FG[j] = EQ[j] = LQH[j] = LQT[j] = 0;
         int v_sumq = 0;
-        // Four bit planes per strip are collected by the lane that owns the POSITION, one bit per read, and
-        // cross over to lane = read in the hand-over below (64 x 64 bit transposes):
-        //   cL / cH  bits 1 / 2 of the character (A 00, C 01, T 10, G 11)
-        //   cV       the character is exactly A, C, G or T
-        //   cQ       quality <= lowQual
-        // cL takes bit 0 of its source (v_alignbit ..., 1: newest read on top); the others take the SIGN of a
-        // difference (v_alignbit acc, x, 31 = acc << 1 | x >> 31: newest read at the bottom, reversed at the
-        // hand-over).  Reads 0..31 are parked in p* when read 32 arrives.
-        u32 cL[NS], cH[NS], cV[NS], cQ[NS], pL[NS], pH[NS], pV[NS], pQ[NS];
-        // FULL variant, sign-collected as well: quality below the head / tail thresholds of the low-quality-end trim
-        constexpr int NF = FULL ? NS : 1;
-        u32 cA[NF], cT[NF], pA[NF], pT[NF];
+        // Bit collectors, FOUR POSITIONS PER LANE: lane l holds bases / qualities 4l..4l+3 of the current read as one dword
+        // each (one ds_read_b32), every predicate is evaluated on the four bytes at once and shifted into a packed
+        // accumulator -- one bit (or bit pair) per byte and read:
+        //   aC   2-bit code of the character (bits 1-2: A 00, C 01, T 10, G 11): aC = aC << 2 | code, parked every 4 reads
+        //   aQ   quality >= lowQual + 1 (bit 7 of quality + 128 - threshold; no carry between valid bytes, which are
+        //        < 128): aQ = aQ >> 1 | bit 7, parked every 8 reads
+        //   aA / aT (FULL)  quality >= head / tail threshold of the low-quality-end trim, like aQ
+        //   badv one bit per READ: some character of this lane's dword is not exactly the letter its code stands for
+        //        (v_perm picks that letter for the four bytes at once), shifted in through the carry
+        // The parked dwords (PC: 16, PQ / PA / PT: 8) cross over to lane = read in the hand-over below.  Bytes past the
+        // read's end are forced to 'A' first, so they raise no flag and count as code 00 (subtracted at the hand-over).
+        v16u PC = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // (16-element vectors: the compiler parks into them with s_set_gpr_idx; 8-element ones get a v_cndmask chain)
+        v16u PQA = PC, PTT = PC;           // [0,8): aQ, [8,16): aA ; [0,8): aT
+        u32 aC = 0, aQ = 0, aA = 0, aT = 0, badv = 0, bad0 = 0;
         const bool has_px = FULL && __builtin_amdgcn_readfirstlane(P.polyX_num) != -1;
         const bool has_lq = FULL && __builtin_amdgcn_readfirstlane(P.has_lq) != 0;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) cL[s] = cH[s] = cV[s] = cQ[s] = pL[s] = pH[s] = pV[s] = pQ[s] = 0;
-#pragma unroll
-        for (int s = 0; s < NF; ++s) cA[s] = cT[s] = pA[s] = pT[s] = 0;
-        auto park = [&]() {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) { pL[s] = cL[s]; pH[s] = cH[s]; pV[s] = cV[s]; pQ[s] = cQ[s]; }
-            if (FULL) {
-#pragma unroll
-                for (int s = 0; s < NF; ++s) { pA[s] = cA[s]; pT[s] = cT[s]; }
-            }
-        };
         const int has_meanq = __builtin_amdgcn_readfirstlane(P.has_meanq);
         const int len0 = rl(clen_v, 0);
         const bool fixed = __all(!lanev || clen_v == len0);
         // every read of the tile fills the whole capacity: lanes past the end fall into histogram
-        // slots of positions >= lcap, which are never flushed -> no validity masking at all
+        // slots of positions >= lcap, which are never flushed -> no validity masking of the histogram adds
         const bool fulllen = fixed && len0 == G.lcap;
         const u32 rawBw = (u32)((m * 2 + 0) * G.SET), rawQw = rawBw + (u32)G.WB;
         const u32 lds0 = (u32)(uintptr_t)(lds_u32_ptr)lds;                   // absolute LDS address of the histograms
@@ -489,50 +510,54 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         u32 qlo_v = (u32)(phred - 1);
         asm volatile("" : "+v"(qlo_v));                                     // v_med3 takes one scalar operand only
         const u32 qhi = (u32)(phred + nq);
-        const u32 klow = (u32)(phred + lowQ + 1);
-        const u32 khead = (u32)(phred + P.lq_head_q), ktail = (u32)(phred + P.lq_tail_q);
+        // byte-parallel thresholds: bit 7 of (quality + 128 - k) <=> quality >= k, for k in [0, 128]
+        auto kbytes = [](int k) { return (u32)(128 - min(max(k, 0), 128)) * 0x01010101u; };
+        const u32 KQ = kbytes(phred + lowQ + 1), KA = kbytes(phred + P.lq_head_q), KT = kbytes(phred + P.lq_tail_q);
         const u32 dumB = lds0 + ((u32)(4 * G.SET) + (u32)lane) * 4u;   // per-lane scratch word (variable-length tiles)
         uint8_t *ldsb = reinterpret_cast<uint8_t *>(lds);
-        auto do_read = [&](auto FL, const int r, const u32 (&cc)[NS], const u32 (&cq)[NS]) {
+        const int lane4 = 4 * lane;
+        auto bytemask = [&](const int len_r) -> u32 {      // bytes k of this lane's dword with 4*lane + k < len_r
+            const int d = len_r - lane4;
+            return d >= 4 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << (8 * d)) - 1u));
+        };
+        const u32 padm = bytemask(fixed ? len0 : G.lcap);                    // constant over a fixed-length tile
+        auto do_read = [&](auto FL, const int r, u32 c4, const u32 q4, const u32 (&cq)[NS]) {
             constexpr bool FULLLEN = decltype(FL)::value;
             const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
+            {   // ---- collectors (4 positions per lane)
+                u32 vm = padm;
+                if (!FULLLEN && !fixed) {                  // variable-length tile: the partial dword's mask is uniform
+                    const int lr4 = len_r & ~3;
+                    const u32 pm = (1u << (8 * (len_r & 3))) - 1u;
+                    vm = lane4 < lr4 ? 0xFFFFFFFFu : (lane4 == lr4 ? pm : 0u);
+                }
+                c4 = (c4 & vm) | (0x41414141u & ~vm);                          // v_bfi: 'A' past the end
+                const u32 code = (c4 >> 1) & 0x03030303u;
+                aC = (aC << 2) | code;                                         // v_lshl_or
+                const u32 ex = __builtin_amdgcn_perm(0u, 0x47544341u, code);   // the letter each code stands for ("ACTG")
+                u32 carry_out;
+                asm("v_cmp_ne_u32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %1, %1, vcc" : "=v"(carry_out) : "v"(badv), "v"(ex), "v"(c4) : "vcc");
+                badv = carry_out;                                              // badv = 2 * badv + (ex != c4)
+                aQ = (aQ >> 1) | ((q4 + KQ) & 0x80808080u);                   // v_add, v_lshrrev, v_and_or
+                if (FULL) {
+                    if (has_lq) {
+                        aA = (aA >> 1) | ((q4 + KA) & 0x80808080u);
+                        aT = (aT >> 1) | ((q4 + KT) & 0x80808080u);
+                    }
+                }
+            }
+            // ---- raw per-position quality histogram (src/peprocess.cpp:1182-1201), lane = position; the base histogram
+            // is counted from the collected planes once per tile (hand-over)
             static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                 constexpr int s = decltype(sc)::v;
                 const int pos = 64 * s + lane;
-                const u32 c = cc[s], qb = cq[s];
-                u32 code = __builtin_amdgcn_ubfe(c, 1u, 2u);
-                asm("" : "+v"(code));     // one v_bfe feeds the row address, the bit collector and the ACGT test
-#define SNK_PUT(PL, VAL)                                                                   \
-    {                                                                                      \
-        const u64 val_ = (VAL);                                                            \
-        PL[2 * s] = wl(PL[2 * s], (int)(u32)val_, r);                                      \
-        if (2 * s + 1 < NW) PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = wl(PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0], (int)(u32)(val_ >> 32), r); \
-    }
-                cL[s] = __builtin_amdgcn_alignbit(code, cL[s], 1u);
-                cH[s] = __builtin_amdgcn_alignbit(c >> 2, cH[s], 1u);
-                {   // exact ACGT test: the character its own bits 1-2 stand for (byte `code` of "ACTG") vs the character.
-                    // v_sad_u8 adds the byte differences: bytes 1-3 contribute 3 * 'A' (selector bytes 0 pick 'A', the
-                    // character register is zero there), so with -(3*'A'+1) on top the sum is negative <=> equal
-                    const u32 ex = __builtin_amdgcn_perm(0u, 0x47544341u, code);
-                    const u32 d = __builtin_amdgcn_sad_u8(ex, c, 0xFFFFFF3Cu);
-                    cV[s] = __builtin_amdgcn_alignbit(cV[s], d, 31u);
-                }
-                cQ[s] = __builtin_amdgcn_alignbit(cQ[s], qb - klow, 31u);       // sign <=> quality <= lowQual
-                if (FULL) {
-                    constexpr int sf = FULL ? s : 0;
-                    if (has_lq) {
-                        cA[sf] = __builtin_amdgcn_alignbit(cA[sf], qb - khead, 31u);      // quality < head threshold
-                        cT[sf] = __builtin_amdgcn_alignbit(cT[sf], qb - ktail, 31u);      // quality < tail threshold
-                    }
-                }
-                // raw per-position quality histogram (src/peprocess.cpp:1182-1201); the base histogram is
-                // counted from the collected planes once per tile (hand-over)
+                const u32 qb = cq[s];
                 u32 qc;
                 asm("v_med3_u32 %0, %1, %2, %3" : "=v"(qc) : "v"(qb), "v"(qlo_v), "s"(qhi));
-                u32 aQ = (qc << lgb) + laneQc;
-                if (!FULLLEN) aQ = pos < len_r ? aQ : dumB - 256u * (s >> 1);
-                if (SNK_ABL == 11) { asm volatile("" ::"v"(aQ)); }
-                else lds_add_u32<256 * (s >> 1)>(aQ, (s & 1) ? 0x10000u : 1u);
+                u32 aQa = (qc << lgb) + laneQc;
+                if (!FULLLEN) aQa = pos < len_r ? aQa : dumB - 256u * (s >> 1);
+                if (SNK_ABL == 11) { asm volatile("" ::"v"(aQa)); }
+                else lds_add_u32<256 * (s >> 1)>(aQa, (s & 1) ? 0x10000u : 1u);
             });
             int hm = has_meanq;
             asm volatile("" : "+s"(hm));          // a plain scalar compare + branch per read (hoisted, the flag turns into lane masks)
@@ -543,8 +568,27 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 v_sumq = wl(v_sumq, wave_sum(qsum), r);
             }
         };
-        auto lds_rd = [&](u32 (&c)[NS], u32 (&q)[NS], const u32 addr) { lds_read_strips<0>(c, q, addr, addr + (u32)G.cba); };
-        auto run_phase1 = [&](auto FL) {
+        // a read that does not exist (last tile of a batch): keep the collectors aligned
+        auto skip_read = [&]() {
+            aC <<= 2; aQ >>= 1; badv <<= 1;
+            if (FULL) { aA >>= 1; aT >>= 1; }
+        };
+        // parks after reads 8o+3 and 8o+7 (uniform o); read 32 starts the second flag word
+        auto park4 = [&](const int slot) {
+            PC[slot] = aC;
+            aC = 0;
+        };
+        auto park8 = [&](const int o) {
+            PQA[o] = aQ;
+            aQ = 0;
+            if (FULL) {
+                if (has_lq) { PQA[8 + o] = aA; PTT[o] = aT; aA = aT = 0; }
+            }
+            if (o == 3) { bad0 = badv; badv = 0; }
+        };
+        auto run_phase1 = [&](auto FL, auto C64) {
+            constexpr bool CNT64 = decltype(C64)::value;      // a whole tile: no per-read existence test
+            const int nocts = CNT64 ? 8 : (cnt + 7) >> 3;
             if (STAGED) {
                 // bytes arrive in LDS by DMA (16 B/lane), the next chunk of rb reads in flight
                 // behind the collectors of the current one
@@ -578,62 +622,91 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 // DMA: chunk k+2 is issued into the buffer of chunk k as soon as its last row sits in registers,
                 // i.e. one read before chunk k+1 is first touched, and the wait there covers chunk k+1.
                 constexpr int K = SNK_ABL == 11 ? 0 : NS;
-                const u32 stg0 = lds0 + (u32)(G.stg_off + wave * G.stg_wave + lane);
+                const u32 stgA = lds0 + (u32)(G.stg_off + wave * G.stg_wave);
+                const u32 l4 = (u32)lane4, l1 = (u32)G.cba + (u32)lane, lq4 = (u32)G.cba + (u32)lane4;
                 issue(0);
                 if (nchunks > 1) issue(1);
                 if (SNK_ABL != 14) {
                     if (nchunks > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                u32 ac[NS], aq[NS], bc[NS], bq[NS];     // two register sets alternate (no rotation moves)
-                lds_rd(ac, aq, stg0);
-                lds_wait<0>(ac, aq);
-                for (int k = 0; k < nchunks; ++k) {     // `a` holds row 0 of chunk k
-                    const int nr = min(rb, cnt - k * rb);
-                    if (k * rb == 32) park();          // rb is a power of two <= 32 (launch())
-                    u32 sa = stg0 + (u32)((k & 1) * 2 * G.cba);
-                    for (int rr = 0; rr < nr; rr += 2) {
-                        lds_rd(bc, bq, sa + (u32)B.pitch);      // (past the last read of the tile: staging bytes that are never used)
-                        do_read(FL, k * rb + rr, ac, aq);
-                        lds_wait<K>(bc, bq);
-                        sa += 2u * (u32)B.pitch;
-                        if (rr + 1 < nr) {
-                            if (rr + 2 >= nr && k + 1 < nchunks) {   // this chunk's rows are all in registers: next DMA, next chunk's row 0
-                                if (k + 2 < nchunks) {
-                                    issue(k + 2);
-                                    if (SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                                } else if (SNK_ABL != 14) {
-                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                }
-                                sa = stg0 + (u32)(((k + 1) & 1) * 2 * G.cba);
+                auto lds_rd = [&](u32 &c4, u32 &q4, u32 (&q)[NS], const u32 row) {
+                    lds_read_b32(c4, row + l4);
+                    lds_read_b32(q4, row + lq4);
+                    lds_read_qstrips<0>(q, row + l1);
+                };
+                u32 ac4, aq4, aq[NS], bc4, bq4, bq[NS];     // two register sets alternate (no rotation moves)
+                u32 row = stgA;                             // LDS address of the row being prefetched (scalar)
+                const int rbm = rb - 1, lgrb = 31 - __builtin_clz((unsigned)rb);     // rb is a power of two (launch())
+                lds_rd(ac4, aq4, aq, row);
+                lds_wait<0>(ac4, aq4, aq);
+                // the row after read r: next row of the chunk, or -- when r closes chunk k -- row 0 of chunk k+1
+                // (its DMA is waited for here, and chunk k+2 goes into the buffer that just became free)
+                auto next_row = [&](const int r) {
+                    if (((r + 1) & rbm) == 0) {
+                        const int k = ((r + 1) >> lgrb) - 1;
+                        if (k + 1 < nchunks) {
+                            if (k + 2 < nchunks) {
+                                issue(k + 2);
+                                if (SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                            } else if (SNK_ABL != 14) {
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             }
-                            lds_rd(ac, aq, sa);
-                            do_read(FL, k * rb + rr + 1, bc, bq);
-                            lds_wait<K>(ac, aq);
                         }
+                        row = stgA + (u32)(((k + 1) & 1) * 2 * G.cba);
+                    } else {
+                        row += (u32)B.pitch;
                     }
+                };
+                for (int o = 0; o < nocts; ++o) {           // reads 8o .. 8o+7; `a` holds row 8o
+                    static_for(std::make_integer_sequence<int, 4>{}, [&](auto jc) {
+                        constexpr int j = 2 * decltype(jc)::v;
+                        const int r = 8 * o + j;
+                        if (CNT64 || r < cnt) {
+                            next_row(r);                    // (past the last read of the tile: staging bytes that are never used)
+                            lds_rd(bc4, bq4, bq, row);
+                            do_read(FL, r, ac4, aq4, aq);
+                            lds_wait<K>(bc4, bq4, bq);
+                        } else skip_read();
+                        if (CNT64 || r + 1 < cnt) {
+                            next_row(r + 1);
+                            lds_rd(ac4, aq4, aq, row);
+                            do_read(FL, r + 1, bc4, bq4, bq);
+                            lds_wait<K>(ac4, aq4, aq);
+                        } else skip_read();
+                        if (j == 2) park4(2 * o);
+                        if (j == 6) { park4(2 * o + 1); park8(o); }
+                    });
                 }
             } else {
-                // register path (pitch not a multiple of 16): strip loads run one read ahead
-                u32 offc[NS], nc[NS], nqb[NS];
+                // register path (pitch not a multiple of 16): loads run one read ahead
+                u32 offq[NS], nc4, nq4, nqb[NS];
+                const bool l4ok = lane4 < B.pitch;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) offc[s] = (u32)min(64 * s + lane, B.pitch - 1);
-                {
-                    const uint8_t *sp = seq + t0 * (long)B.pitch, *qp = qual + t0 * (long)B.pitch;
+                for (int s = 0; s < NS; ++s) offq[s] = (u32)min(64 * s + lane, B.pitch - 1);
+                auto load = [&](const long rd) {
+                    const uint8_t *sp = seq + rd * (long)B.pitch, *qp = qual + rd * (long)B.pitch;
+                    nc4 = l4ok ? *reinterpret_cast<const u32 *>(sp + lane4) : 0u;
+                    nq4 = l4ok ? *reinterpret_cast<const u32 *>(qp + lane4) : 0u;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
-                }
-                for (int r = 0; r < cnt; ++r) {
-                    u32 cc[NS], cq[NS];
+                    for (int s = 0; s < NS; ++s) nqb[s] = qp[offq[s]];
+                };
+                load(t0);
+                for (int o = 0; o < nocts; ++o) {
+                    static_for(std::make_integer_sequence<int, 8>{}, [&](auto jc) {
+                        constexpr int j = decltype(jc)::v;
+                        const int r = 8 * o + j;
+                        if (CNT64 || r < cnt) {
+                            u32 cq[NS];
+                            const u32 c4 = nc4, q4 = nq4;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) { cc[s] = nc[s]; cq[s] = nqb[s]; }
-                    if (r + 1 < cnt) {
-                        const uint8_t *sp = seq + (t0 + r + 1) * (long)B.pitch, *qp = qual + (t0 + r + 1) * (long)B.pitch;
-#pragma unroll
-                        for (int s = 0; s < NS; ++s) { nc[s] = sp[offc[s]]; nqb[s] = qp[offc[s]]; }
-                    }
-                    if (r == 32) park();
-                    do_read(FL, r, cc, cq);
+                            for (int s = 0; s < NS; ++s) cq[s] = nqb[s];
+                            if (r + 1 < cnt) load(t0 + r + 1);
+                            do_read(FL, r, c4, q4, cq);
+                        } else skip_read();
+                        if (j == 3) park4(2 * o);
+                        if (j == 7) { park4(2 * o + 1); park8(o); }
+                    });
                 }
             }
         };
@@ -641,55 +714,79 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         // phases, and the arbiter's default (oldest first) lets the ALU-dense phases of some waves starve the LDS
         // round trips of the waves in phase 1.  Phase 1 first, phase 3 last: 3.78 -> 3.36 ms.
         __builtin_amdgcn_s_setprio(3);
-        if (fulllen) run_phase1(std::true_type{});
-        else run_phase1(std::false_type{});
+        if (cnt == 64) {
+            if (fulllen) run_phase1(std::true_type{}, std::true_type{});
+            else run_phase1(std::false_type{}, std::true_type{});
+        } else {
+            run_phase1(std::false_type{}, std::false_type{});
+        }
+        if (cnt < 64) {                           // fewer than 8 octets: move the read flags to where 64 reads would have put them
+            const int nocts = (cnt + 7) >> 3;
+            if (nocts < 4) { bad0 = badv << (8 * (4 - nocts)); badv = 0; }
+            else if (nocts > 4 && nocts < 8) badv <<= 8 * (8 - nocts);
+        }
         __builtin_amdgcn_s_setprio(2);            // hand-over, planes, fix-up
-        // ------------------------------------------------------------ hand-over: lane = position -> lane = read
+        // ------------------------------------------------------------ hand-over: lane = 4 positions -> lane = read
         ReadState R;
         rs_init(R, clen_v);
         int v_adja = 0, v_nn = 0, v_bad = 0;
         u32 VP[NW], QP[NW];               // exact-ACGT positions, low-quality positions
-        // collector order -> canonical order (read r at bit r % 32 of word r / 32)
-        auto canon = [&](auto &cur, auto &par, const bool sign_collected) {
-            constexpr int N = sizeof(cur) / sizeof(cur[0]);
-            if (sign_collected) {          // newest read at the bottom -> on top, like cL
-#pragma unroll
-                for (int s = 0; s < N; ++s) { cur[s] = __builtin_bitreverse32(cur[s]); par[s] = __builtin_bitreverse32(par[s]); }
-            }
-            if (cnt < 64) {               // last tile of a batch: move read 0 (32) down to bit 0
-                if (cnt <= 32) {
-#pragma unroll
-                    for (int s = 0; s < N; ++s) { par[s] = cur[s] >> (32 - cnt); cur[s] = 0; }
-                } else {
-#pragma unroll
-                    for (int s = 0; s < N; ++s) cur[s] >>= (64 - cnt);
-                }
-            }
-        };
-        // canonical collectors of a plane -> its per-read words (lane = read)
-        auto cross = [&](auto &cur, auto &par, u32 (&out)[NW]) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                u32 w0 = par[s], w1 = cur[s];
-                if (2 * s + 1 < NW) {
-                    bit_transpose64(w0, w1, lane);
-                    out[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = w1;
-                } else {
-                    w0 = bit_transpose64_lo(w0, w1, lane);
-                }
-                out[2 * s] = w0;
-            }
-        };
+        bool badread;
         {
-            canon(cL, pL, false);
-            canon(cH, pH, false);
-            canon(cV, pV, true);
-            canon(cQ, pQ, true);
-            // raw per-position base histogram (src/peprocess.cpp:1145-1180): lane = position holds one bit per
-            // read of each plane, so the count of a letter at its position is a popcount -> one LDS add per
-            // letter, strip and TILE (not per read).  LDS base rows are ordered by the code (A 00, C 01, T 10,
-            // G 11, then N; the flush swaps rows 2/3 back to ACGT order).  Characters that are not exactly ACGT
-            // are not counted here: their reads go through the fix-up pass, which adds them (N, lower case).
+            // Parked dwords go to the wave's LDS scratch, one 256-byte row each: byte p of row g = the bits of position
+            // p for reads 8g..8g+7 (code planes: reads 4g..4g+3, two bits each).  A lane = position gathers its byte of
+            // 8 rows into 64 read bits, and the 64 x 64 bit transposes (snk_bittr.cuh) turn them into per-read planes.
+            const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            // Hand-over scratch of the wave (2 KB): 8 bytes per position.  The owner of positions 4l..4l+3 turns its 8 parked
+            // dwords (byte k = 8 read bits of position 4l+k) into four 8-byte rows by two 4 x 4 byte transposes and stores
+            // them with two 16-byte writes; the lane = position reads its 64 read bits back with one 8-byte read.
+            uint8_t *scr = ldsb + G.scr_off + wave * G.scr_wave;
+            auto write8 = [&](const v8u &V) {
+                u32 lo[4], hi[4];
+                byte_tr4(V[0], V[1], V[2], V[3], lo);
+                byte_tr4(V[4], V[5], V[6], V[7], hi);
+                v4u *dst = reinterpret_cast<v4u *>(scr + 32 * lane);
+                dst[0] = v4u{lo[0], hi[0], lo[1], hi[1]};
+                dst[1] = v4u{lo[2], hi[2], lo[3], hi[3]};
+            };
+            auto gather = [&](const int s, u32 &w0, u32 &w1) {
+                const v2u v = *reinterpret_cast<const v2u *>(scr + 8 * (64 * s + lane));
+                w0 = v[0];
+                w1 = v[1];
+            };
+            // one-bit planes (8 parked dwords): gather + transpose per strip -> out[NW], lane = read, bit = position
+            auto cross1 = [&](const v8u &V, u32 (&out)[NW]) {
+                write8(V);
+                static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
+                    constexpr int s = decltype(sc)::v;
+                    u32 w0, w1;
+                    gather(s, w0, w1);
+                    if (2 * s + 1 < NW) {
+                        bit_transpose64(w0, w1, lane);
+                        out[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = w1;
+                    } else {
+                        w0 = bit_transpose64_lo(w0, w1, lane);
+                    }
+                    out[2 * s] = w0;
+                });
+            };
+            // code planes: rows 0..7 hold reads 0..31 (matrix A), rows 8..15 reads 32..63 (matrix B), two bits per read
+            u32 cw[NS][4];                 // lane = position: its 128 code bits
+            {
+                v8u lo8, hi8;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) { lo8[g] = PC[g]; hi8[g] = PC[8 + g]; }
+                write8(lo8);
+                static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) { constexpr int s = decltype(sc)::v; gather(s, cw[s][0], cw[s][1]); });
+                write8(hi8);
+                static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) { constexpr int s = decltype(sc)::v; gather(s, cw[s][2], cw[s][3]); });
+            }
+            // raw per-position base histogram (src/peprocess.cpp:1145-1180): lane = position holds the codes of all
+            // reads at its position, so the count of a letter is a popcount -> one LDS add per letter, strip and TILE.
+            // LDS base rows are ordered by the code (A 00, C 01, T 10, G 11, then N; the flush swaps rows 2/3 back to
+            // ACGT order).  Every character is counted by its code here (N and n as G, lower case as its letter, bytes
+            // past a read's end as the 'A' they were replaced by): A = reads covering the position - C - T - G, and
+            // the fix-up pass moves the N of the reads that have any.
             if (SNK_ABL != 11) {
                 u32 IN[NW];                     // variable lengths: bit r of lane p = position p lies inside read r
                 if (!fulllen) {
@@ -698,18 +795,21 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 }
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    u32 i0 = 0xFFFFFFFFu, i1 = 0xFFFFFFFFu;
+                    u32 cover = (u32)cnt;
                     if (!fulllen) {
-                        i0 = IN[2 * s];
-                        i1 = (2 * s + 1 < NW) ? IN[(2 * s + 1 < NW) ? 2 * s + 1 : 0] : 0u;
+                        u32 i0 = IN[2 * s], i1 = (2 * s + 1 < NW) ? IN[(2 * s + 1 < NW) ? 2 * s + 1 : 0] : 0u;
                         bit_transpose64(i0, i1, lane);
+                        cover = __popc(i0) + __popc(i1);
                     }
-                    const u32 m0 = pV[s] & i0, m1 = cV[s] & i1;
-                    const u32 l0 = pL[s], l1 = cL[s], h0 = pH[s], h1 = cH[s];
-                    const u32 nA = __popc(m0 & ~(h0 | l0)) + __popc(m1 & ~(h1 | l1));
-                    const u32 nC = __popc(m0 & l0 & ~h0) + __popc(m1 & l1 & ~h1);
-                    const u32 nT = __popc(m0 & h0 & ~l0) + __popc(m1 & h1 & ~l1);
-                    const u32 nG = __popc(m0 & h0 & l0) + __popc(m1 & h1 & l1);
+                    u32 nC = 0, nT = 0, nG = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const u32 x = cw[s][w], l = x & 0x55555555u, h = (x >> 1) & 0x55555555u;
+                        nC += __popc(l & ~h);
+                        nT += __popc(h & ~l);
+                        nG += __popc(l & h);
+                    }
+                    const u32 nA = cover - nC - nT - nG;
                     const u32 sh = (s & 1) ? 16u : 0u;
                     u32 *rowp = lds + rawBw + 64 * (s >> 1) + lane;
                     atomicAdd(rowp, nA << sh);
@@ -718,17 +818,51 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     atomicAdd(rowp + (3u << G.lg), nG << sh);
                 }
             }
+            // transposes: lane i of matrix A / B then holds 64 positions of ONE plane of ONE read -- bit i of a code word
+            // is plane (i & 1) of read 4 * (i >> 3) + 3 - ((i & 7) >> 1) (+ 32 for B: the newest read sits in the low bit
+            // pair) -- and lane = read fetches its two planes from there (ds_bpermute)
             u32 LP[NW], HP[NW];
-            cross(cL, pL, LP);
-            cross(cH, pH, HP);
-            cross(cV, pV, VP);
-            cross(cQ, pQ, QP);
+            {
+                const int rr = lane & 31;
+                const int srcL = 4 * (8 * (rr >> 2) + 2 * (3 - (rr & 3)));     // byte address of the source lane
+                const bool fromB = lane >= 32;
+                static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
+                    constexpr int s = decltype(sc)::v;
+                    u32 a0 = cw[s][0], a1 = cw[s][1], b0 = cw[s][2], b1 = cw[s][3];
+                    if (2 * s + 1 < NW) {
+                        bit_transpose64(a0, a1, lane);
+                        bit_transpose64(b0, b1, lane);
+                        const u32 la = (u32)__builtin_amdgcn_ds_bpermute(srcL, (int)a1), lb = (u32)__builtin_amdgcn_ds_bpermute(srcL, (int)b1);
+                        const u32 ha = (u32)__builtin_amdgcn_ds_bpermute(srcL + 4, (int)a1), hb = (u32)__builtin_amdgcn_ds_bpermute(srcL + 4, (int)b1);
+                        LP[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = fromB ? lb : la;
+                        HP[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = fromB ? hb : ha;
+                    } else {
+                        a0 = bit_transpose64_lo(a0, a1, lane);
+                        b0 = bit_transpose64_lo(b0, b1, lane);
+                    }
+                    const u32 la = (u32)__builtin_amdgcn_ds_bpermute(srcL, (int)a0), lb = (u32)__builtin_amdgcn_ds_bpermute(srcL, (int)b0);
+                    const u32 ha = (u32)__builtin_amdgcn_ds_bpermute(srcL + 4, (int)a0), hb = (u32)__builtin_amdgcn_ds_bpermute(srcL + 4, (int)b0);
+                    LP[2 * s] = fromB ? lb : la;
+                    HP[2 * s] = fromB ? hb : ha;
+                });
+            }
+            v8u PQ, PA, PT;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { PQ[g] = PQA[g]; PA[g] = PQA[8 + g]; PT[g] = PTT[g]; }
+            cross1(PQ, QP);
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
+                QP[j] = ~QP[j];                 // collected: quality > lowQual
+                VP[j] = 0xFFFFFFFFu;            // exact ACGT everywhere, unless the read is flagged (fix-up pass)
                 X[0][j] = ~(HP[j] | LP[j]);
                 X[1][j] = LP[j] & ~HP[j];
                 X[2][j] = HP[j] & LP[j];
                 X[3][j] = HP[j] & ~LP[j];
+            }
+            // reads with a character that is not exactly A/C/G/T: flag word bit 31 - (r & 31), OR over the lanes
+            {
+                const u32 f0 = wave_or(bad0), f1 = wave_or(badv);
+                badread = (((lane < 32 ? f0 : f1) >> (31 - (lane & 31))) & 1u) != 0;
             }
             if (FULL) {
                 if (has_px) {
@@ -737,15 +871,17 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
 #pragma unroll
                     for (int j = 0; j < NW; ++j) {
                         const u32 lp = (LP[j] << 1) | (j ? LP[j ? j - 1 : 0] >> 31 : 0u), hp = (HP[j] << 1) | (j ? HP[j ? j - 1 : 0] >> 31 : 0u);
-                        const u32 vp = (VP[j] << 1) | (j ? VP[j ? j - 1 : 0] >> 31 : 0u);
-                        EQ[j] = ~(LP[j] ^ lp) & ~(HP[j] ^ hp) & VP[j] & vp;
+                        EQ[j] = ~(LP[j] ^ lp) & ~(HP[j] ^ hp) & (j ? 0xFFFFFFFFu : 0xFFFFFFFEu);
                     }
                 }
                 if (has_lq) {
-                    canon(cA, pA, true); cross(cA, pA, LQH);
-                    canon(cT, pT, true); cross(cT, pT, LQT);
+                    cross1(PA, LQH);
+                    cross1(PT, LQT);
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) { LQH[j] = ~LQH[j]; LQT[j] = ~LQT[j]; }   // collected: quality >= threshold
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the scratch may be the next mate's DMA target
         }
         if ((SNK_ABL == 1 || SNK_ABL >= 11)) {
             if (SNK_ABL == 14) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -755,27 +891,16 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             continue;
         }
         // ------------------------------------------------------------ phase 2 (this mate)
-        bool needfix = false;
-        int nlowq = 0;
-        {   // mask the garbage past each read and look for anything that is not ACGT
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const u32 in = lowmask32(R.len - 32 * j);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) X[k][j] &= in & VP[j];      // exact planes: no bit where the character is not that letter
-                needfix = needfix || (in & ~VP[j]) != 0;
-                nlowq += __popc(QP[j] & in);
-                if (FULL) {
-                    FG[j] = X[2][j];
-                    EQ[j] &= in;
-                    LQH[j] = (LQH[j] & in) | (oobH ? ~in : 0u);
-                }
-            }
-        }
-        // fix-up pass (rare): reads with N / lower case / garbage.  Exact counts, the N plane,
-        // the folded-G plane, and the histogram move "wrong base bin -> N bin".
+#define SNK_PUT(PL, VAL)                                                                   \
+    {                                                                                      \
+        const u64 val_ = (VAL);                                                            \
+        PL[2 * s] = wl(PL[2 * s], (int)(u32)val_, r);                                      \
+        if (2 * s + 1 < NW) PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0] = wl(PL[(2 * s + 1 < NW) ? 2 * s + 1 : 0], (int)(u32)(val_ >> 32), r); \
+    }
+        // fix-up pass (rare): reads with N / lower case / garbage.  Their exact-ACGT plane, exact counts, the N plane,
+        // the folded-G plane, and the histogram move "bin of the code -> N bin".
         {
-            u64 fix = __ballot(needfix && lanev);
+            u64 fix = __ballot(badread && lanev);
             while (fix) {
                 const int r = __ffsll((long long)fix) - 1;
                 fix &= fix - 1;
@@ -796,13 +921,19 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                         SNK_PUT(EQ, __ballot(valid && c == pc))
                     }
                     const u32 cu = c & 0xDFu;
+                    const bool exact = c == 'A' || c == 'C' || c == 'G' || c == 'T';
+                    SNK_PUT(VP, __ballot(!valid || exact))
                     adjA += __popcll(__ballot(valid && cu == 'A' && c != 'A'));
                     const bool isn = valid && cu == 'N';
                     nN += __popcll(__ballot(isn));
                     if (__any(valid && !(cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T' || cu == 'N'))) bad = 1;
-                    // the hand-over counted exact ACGT only: N -> row 4, lower-case letters -> the row of their bits 1-2
-                    if (valid && !(c == 'A' || c == 'C' || c == 'G' || c == 'T') && (isn || cu == 'A' || cu == 'C' || cu == 'G' || cu == 'T'))
-                        atomicAdd(reinterpret_cast<u32 *>(ldsb + ((isn ? 4u : ((c >> 1) & 3u)) << lgb) + (laneB - lds0) + 256u * (s >> 1)), (s & 1) ? 0x10000u : 1u);
+                    // the hand-over counted every character in the row of its bits 1-2: N / n sit in row 3 and belong in row 4
+                    // (lower-case letters share the row of their upper-case form, as the reference's switch does)
+                    if (isn) {
+                        u32 *rowp = reinterpret_cast<u32 *>(ldsb + (laneB - lds0) + 256u * (s >> 1));
+                        atomicSub(rowp + (3u << G.lg), (s & 1) ? 0x10000u : 1u);
+                        atomicAdd(rowp + (4u << G.lg), (s & 1) ? 0x10000u : 1u);
+                    }
                     if (FULL) {
                         SNK_PUT(XN, __ballot(valid && c == 'N'))
                         SNK_PUT(FG, __ballot(valid && cu == 'G'))
@@ -811,6 +942,21 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 v_adja = wl(v_adja, adjA, r);
                 v_nn = wl(v_nn, nN, r);
                 v_bad = wl(v_bad, bad, r);
+            }
+        }
+        int nlowq = 0;
+        {   // mask the garbage past each read; exact planes: no bit where the character is not that letter
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const u32 in = lowmask32(R.len - 32 * j);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) X[k][j] &= in & VP[j];
+                nlowq += __popc(QP[j] & in);
+                if (FULL) {
+                    FG[j] = badread ? FG[j] : X[2][j];
+                    EQ[j] &= in;
+                    LQH[j] = (LQH[j] & in) | (oobH ? ~in : 0u);
+                }
             }
         }
         const int estat = !lanev ? 0 : (mylen > G.lcap ? SNK_E_TOO_LONG : (mylen == 0 ? SNK_E_EMPTY_SEQ : (v_bad ? SNK_E_BAD_BASE : 0)));
@@ -1196,10 +1342,12 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
                            (((uintptr_t)b.seq[0] | (uintptr_t)b.qual[0] | (uintptr_t)b.seq[1] | (uintptr_t)b.qual[1]) % 16 == 0);
     int W = 16;
     G.rb = 0; G.cba = 0; G.stg_off = (int)hist; G.stg_wave = 0;
+    constexpr int SCR = 2048;          // hand-over scratch per wave: 8 rows of 256 B
     if (can_stage) {
         // bytes per array per buffer: one DMA of (cba/16) lanes x 16 B; the largest chunk that still
-        // lets 16 waves share the CU's LDS with the histograms
-        for (G.cba = 1024; G.cba >= 256; G.cba -= 256) {
+        // lets 16 waves share the CU's LDS with the histograms.  The wave's staging buffers double as its
+        // hand-over scratch, so they are at least that large.
+        for (G.cba = 1024; G.cba >= 512; G.cba -= 256) {
             G.rb = pow2_floor(G.cba / b.pitch);
             G.stg_wave = 2 * 2 * G.cba;
             if (G.rb >= 2 && hist + (size_t)W * G.stg_wave + 2048 <= 160 * 1024) break;
@@ -1211,7 +1359,13 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
             if (hist + (size_t)W * G.stg_wave + 2048 > 160 * 1024 || G.rb < 2) { G.rb = 0; W = 16; }   // reads pair up inside a chunk
         }
     }
-    const size_t shmem = hist + (G.rb ? (size_t)W * G.stg_wave + 2048 : 0);   // + slack for strip / prefetch over-reads
+    if (G.rb) { G.scr_off = G.stg_off; G.scr_wave = G.stg_wave; }
+    else {
+        G.scr_off = (int)hist; G.scr_wave = SCR;
+        while (W > 4 && hist + (size_t)W * SCR > 160 * 1024) W -= 4;
+        if (hist + (size_t)W * SCR > 160 * 1024) return 0;
+    }
+    const size_t shmem = hist + (G.rb ? (size_t)W * G.stg_wave + 2048 : (size_t)W * SCR);   // + slack for strip / prefetch over-reads
     const long tiles = (b.n + 63) / 64;
     long wgs = (tiles + W - 1) / W;
     if (wgs > n_cu) wgs = n_cu;
@@ -1237,7 +1391,7 @@ int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch
     G.WQ = G.Lh * (nq + 1);          // bin nq collects qualities >= nq
     G.SET = G.WB + G.WQ;
     if (((size_t)2 * 2 * G.SET + SNK_LDS_TAIL) * sizeof(u32) > 160 * 1024) return 0;
-    G.rb = G.cba = G.stg_off = G.stg_wave = 0;
+    G.rb = G.cba = G.stg_off = G.stg_wave = G.scr_off = G.scr_wave = 0;
     const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq;
     const int nw = (lcap + 31) / 32;        // dwords per bit plane
 #define SNK_GO(NW_)                                                                    \
