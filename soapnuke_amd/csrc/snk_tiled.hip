@@ -500,7 +500,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         const bool fixed = __all(!lanev || clen_v == len0);
         // every read of the tile fills the whole capacity: lanes past the end fall into histogram
         // slots of positions >= lcap, which are never flushed -> no validity masking of the histogram adds
-        const bool fulllen = fixed && len0 == G.lcap;
+        const bool fulllen = fixed && len0 == G.lcap && G.lcap >= 4;
         const u32 rawBw = (u32)((m * 2 + 0) * G.SET), rawQw = rawBw + (u32)G.WB;
         const u32 lds0 = (u32)(uintptr_t)(lds_u32_ptr)lds;                   // absolute LDS address of the histograms
         const u32 laneB = lds0 + (rawBw + (u32)lane) * 4u;                   // base bin row 0
@@ -521,20 +521,30 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             return d >= 4 ? 0xFFFFFFFFu : (d <= 0 ? 0u : ((1u << (8 * d)) - 1u));
         };
         const u32 padm = bytemask(fixed ? len0 : G.lcap);                    // constant over a fixed-length tile
-        auto do_read = [&](auto FL, const int r, u32 c4, const u32 q4, const u32 (&cq)[NS]) {
+        // (moving the dword reads of the lanes at and past the end of a fixed-length read back onto its last four characters
+        // would save the mask, but the unaligned ds_read_b32 of those lanes costs far more: 2.9 -> 3.8 ms)
+        const int lenF = fixed ? len0 : G.lcap;
+        constexpr bool nomask = false;
+        const int l4 = lane4;                                                // byte offset of this lane's dword in a row
+        const u32 fixsh = 0u;
+        auto do_read = [&](auto FL, auto JC, const int r, u32 c4, const u32 q4, const u32 (&cq)[NS]) {
             constexpr bool FULLLEN = decltype(FL)::value;
+            constexpr int jq = decltype(JC)::v & 3;        // place of the read in its group of four
             const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
             {   // ---- collectors (4 positions per lane)
-                u32 vm = padm;
-                if (!FULLLEN && !fixed) {                  // variable-length tile: the partial dword's mask is uniform
-                    const int lr4 = len_r & ~3;
-                    const u32 pm = (1u << (8 * (len_r & 3))) - 1u;
-                    vm = lane4 < lr4 ? 0xFFFFFFFFu : (lane4 == lr4 ? pm : 0u);
+                {
+                    u32 vm = padm;
+                    if (!FULLLEN && !fixed) {                          // variable-length tile: the partial dword's mask is uniform
+                        const int lr4 = len_r & ~3;
+                        const u32 pm = (1u << (8 * (len_r & 3))) - 1u;
+                        vm = lane4 < lr4 ? 0xFFFFFFFFu : (lane4 == lr4 ? pm : 0u);
+                    }
+                    c4 = (c4 & vm) | (0x41414141u & ~vm);                      // v_bfi: 'A' past the end
                 }
-                c4 = (c4 & vm) | (0x41414141u & ~vm);                          // v_bfi: 'A' past the end
-                const u32 code = (c4 >> 1) & 0x03030303u;
-                aC = (aC << 2) | code;                                         // v_lshl_or
-                const u32 ex = __builtin_amdgcn_perm(0u, 0x47544341u, code);   // the letter each code stands for ("ACTG")
+                const u32 t = c4 & 0x06060606u;                                // 2 * code of every byte (A 0, C 2, T 4, G 6)
+                if (jq == 0) aC = t >> 1;                                      // read j of the group: bits 2j, 2j+1 of every byte
+                else aC = (t << (2 * jq - 1)) | aC;                            // v_lshl_or
+                const u32 ex = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);   // the letter each code stands for
                 u32 carry_out;
                 asm("v_cmp_ne_u32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %1, %1, vcc" : "=v"(carry_out) : "v"(badv), "v"(ex), "v"(c4) : "vcc");
                 badv = carry_out;                                              // badv = 2 * badv + (ex != c4)
@@ -559,9 +569,9 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 if (SNK_ABL == 11) { asm volatile("" ::"v"(aQa)); }
                 else lds_add_u32<256 * (s >> 1)>(aQa, (s & 1) ? 0x10000u : 1u);
             });
-            int hm = has_meanq;
+            int hm = FULL ? has_meanq : 0;        // (the mean-quality filter selects the FULL variant)
             asm volatile("" : "+s"(hm));          // a plain scalar compare + branch per read (hoisted, the flag turns into lane masks)
-            if (hm != 0) {                        // quality sum of the read (mean-quality filter only)
+            if (FULL && hm != 0) {                // quality sum of the read (mean-quality filter only)
                 int qsum = 0;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) qsum += (64 * s + lane < len_r) ? (int)cq[s] - phred : 0;
@@ -570,7 +580,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         };
         // a read that does not exist (last tile of a batch): keep the collectors aligned
         auto skip_read = [&]() {
-            aC <<= 2; aQ >>= 1; badv <<= 1;
+            aQ >>= 1; badv <<= 1;
             if (FULL) { aA >>= 1; aT >>= 1; }
         };
         // parks after reads 8o+3 and 8o+7 (uniform o); read 32 starts the second flag word
@@ -623,7 +633,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 // i.e. one read before chunk k+1 is first touched, and the wait there covers chunk k+1.
                 constexpr int K = SNK_ABL == 11 ? 0 : NS;
                 const u32 stgA = lds0 + (u32)(G.stg_off + wave * G.stg_wave);
-                const u32 l4 = (u32)lane4, l1 = (u32)G.cba + (u32)lane, lq4 = (u32)G.cba + (u32)lane4;
+                const u32 lc4 = (u32)l4, l1 = (u32)G.cba + (u32)lane, lq4 = (u32)G.cba + (u32)l4;
                 issue(0);
                 if (nchunks > 1) issue(1);
                 if (SNK_ABL != 14) {
@@ -631,7 +641,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 auto lds_rd = [&](u32 &c4, u32 &q4, u32 (&q)[NS], const u32 row) {
-                    lds_read_b32(c4, row + l4);
+                    lds_read_b32(c4, row + lc4);
                     lds_read_b32(q4, row + lq4);
                     lds_read_qstrips<0>(q, row + l1);
                 };
@@ -642,8 +652,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 lds_wait<0>(ac4, aq4, aq);
                 // the row after read r: next row of the chunk, or -- when r closes chunk k -- row 0 of chunk k+1
                 // (its DMA is waited for here, and chunk k+2 goes into the buffer that just became free)
-                auto next_row = [&](const int r) {
-                    if (((r + 1) & rbm) == 0) {
+                auto next_row = [&](const int r, const bool closes) {
+                    if (closes) {
                         const int k = ((r + 1) >> lgrb) - 1;
                         if (k + 1 < nchunks) {
                             if (k + 2 < nchunks) {
@@ -659,19 +669,21 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     }
                 };
                 for (int o = 0; o < nocts; ++o) {           // reads 8o .. 8o+7; `a` holds row 8o
+                    // which reads of this octet close a chunk (rb is a power of two): one bit test per read
+                    const u32 evm = rb == 2 ? 0xAAu : rb == 4 ? 0x88u : ((((8 * (o + 1)) & rbm) == 0) ? 0x80u : 0u);
                     static_for(std::make_integer_sequence<int, 4>{}, [&](auto jc) {
                         constexpr int j = 2 * decltype(jc)::v;
                         const int r = 8 * o + j;
                         if (CNT64 || r < cnt) {
-                            next_row(r);                    // (past the last read of the tile: staging bytes that are never used)
+                            next_row(r, (evm >> j) & 1u);   // (past the last read of the tile: staging bytes that are never used)
                             lds_rd(bc4, bq4, bq, row);
-                            do_read(FL, r, ac4, aq4, aq);
+                            do_read(FL, IntC<j>{}, r, ac4, aq4, aq);
                             lds_wait<K>(bc4, bq4, bq);
                         } else skip_read();
                         if (CNT64 || r + 1 < cnt) {
-                            next_row(r + 1);
+                            next_row(r + 1, (evm >> (j + 1)) & 1u);
                             lds_rd(ac4, aq4, aq, row);
-                            do_read(FL, r + 1, bc4, bq4, bq);
+                            do_read(FL, IntC<j + 1>{}, r + 1, bc4, bq4, bq);
                             lds_wait<K>(ac4, aq4, aq);
                         } else skip_read();
                         if (j == 2) park4(2 * o);
@@ -681,13 +693,13 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             } else {
                 // register path (pitch not a multiple of 16): loads run one read ahead
                 u32 offq[NS], nc4, nq4, nqb[NS];
-                const bool l4ok = lane4 < B.pitch;
+                const bool l4ok = l4 < B.pitch;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) offq[s] = (u32)min(64 * s + lane, B.pitch - 1);
                 auto load = [&](const long rd) {
                     const uint8_t *sp = seq + rd * (long)B.pitch, *qp = qual + rd * (long)B.pitch;
-                    nc4 = l4ok ? *reinterpret_cast<const u32 *>(sp + lane4) : 0u;
-                    nq4 = l4ok ? *reinterpret_cast<const u32 *>(qp + lane4) : 0u;
+                    nc4 = l4ok ? *reinterpret_cast<const u32 *>(sp + l4) : 0u;
+                    nq4 = l4ok ? *reinterpret_cast<const u32 *>(qp + l4) : 0u;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) nqb[s] = qp[offq[s]];
                 };
@@ -702,7 +714,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
 #pragma unroll
                             for (int s = 0; s < NS; ++s) cq[s] = nqb[s];
                             if (r + 1 < cnt) load(t0 + r + 1);
-                            do_read(FL, r, c4, q4, cq);
+                            do_read(FL, IntC<j>{}, r, c4, q4, cq);
                         } else skip_read();
                         if (j == 3) park4(2 * o);
                         if (j == 7) { park4(2 * o + 1); park8(o); }
@@ -743,8 +755,9 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             uint8_t *scr = ldsb + G.scr_off + wave * G.scr_wave;
             auto write8 = [&](const v8u &V) {
                 u32 lo[4], hi[4];
-                byte_tr4(V[0], V[1], V[2], V[3], lo);
-                byte_tr4(V[4], V[5], V[6], V[7], hi);
+                // (the lane whose slot straddles the end of a fixed-length read collected its last characters in the upper bytes)
+                byte_tr4(V[0] >> fixsh, V[1] >> fixsh, V[2] >> fixsh, V[3] >> fixsh, lo);
+                byte_tr4(V[4] >> fixsh, V[5] >> fixsh, V[6] >> fixsh, V[7] >> fixsh, hi);
                 v4u *dst = reinterpret_cast<v4u *>(scr + 32 * lane);
                 dst[0] = v4u{lo[0], hi[0], lo[1], hi[1]};
                 dst[1] = v4u{lo[2], hi[2], lo[3], hi[3]};
@@ -809,6 +822,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                         nT += __popc(h & ~l);
                         nG += __popc(l & h);
                     }
+                    if (!fulllen && nomask && 64 * s + lane >= lenF) nC = nT = nG = 0;   // (fixed-length tile: duplicates past the end)
                     const u32 nA = cover - nC - nT - nG;
                     const u32 sh = (s & 1) ? 16u : 0u;
                     u32 *rowp = lds + rawBw + 64 * (s >> 1) + lane;
@@ -819,12 +833,11 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 }
             }
             // transposes: lane i of matrix A / B then holds 64 positions of ONE plane of ONE read -- bit i of a code word
-            // is plane (i & 1) of read 4 * (i >> 3) + 3 - ((i & 7) >> 1) (+ 32 for B: the newest read sits in the low bit
-            // pair) -- and lane = read fetches its two planes from there (ds_bpermute)
+            // is plane (i & 1) of read i >> 1 (+ 32 for B) -- and lane = read fetches its two planes from there (ds_bpermute)
             u32 LP[NW], HP[NW];
             {
                 const int rr = lane & 31;
-                const int srcL = 4 * (8 * (rr >> 2) + 2 * (3 - (rr & 3)));     // byte address of the source lane
+                const int srcL = 4 * (2 * rr);                                 // byte address of the source lane
                 const bool fromB = lane >= 32;
                 static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                     constexpr int s = decltype(sc)::v;
@@ -1392,7 +1405,7 @@ int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch
     G.SET = G.WB + G.WQ;
     if (((size_t)2 * 2 * G.SET + SNK_LDS_TAIL) * sizeof(u32) > 160 * 1024) return 0;
     G.rb = G.cba = G.stg_off = G.stg_wave = G.scr_off = G.scr_wave = 0;
-    const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq;
+    const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq || hp.has_meanq;
     const int nw = (lcap + 31) / 32;        // dwords per bit plane
 #define SNK_GO(NW_)                                                                    \
     return full ? launch<NW_, true>(hp, ta, b, st, G, n_cu, stream)                    \
