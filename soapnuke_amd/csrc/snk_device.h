@@ -60,7 +60,7 @@ struct TileAdapter {
     int32_t len, S, mis, edge, negC;
     int32_t budgetA[6];
     int32_t rk[4];
-    int32_t pad_;
+    int32_t maxb;               // DevAdapter::maxBudget over phases B and C (the screen needs maxb + 1 counter planes)
 };
 struct TileAdapters { TileAdapter a[2][SNK_TILE_MAX_ADA]; };
 

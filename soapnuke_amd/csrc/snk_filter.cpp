@@ -364,6 +364,8 @@ static int build_ctx(snk_ctx *c) {
                 T.nmask = A.nmask;
                 for (int ci = 0; ci < 64 && ci < A.len; ++ci) T.code4[ci >> 4] |= (uint64_t)(A.code[ci] & 15) << (4 * (ci & 15));
                 T.len = A.len; T.S = A.S; T.mis = A.mis; T.edge = A.edge; T.negC = A.negC;
+                T.maxb = A.mis > 0 ? A.mis : 0;
+                for (int r1 = 0; r1 < A.nC && r1 < SNK_DEV_MAX_ADA_LEN; ++r1) if (A.budgetC[r1] > T.maxb) T.maxb = A.budgetC[r1];
                 for (int k = 0; k < 6; ++k) T.budgetA[k] = A.budgetA[k];
                 for (int k = 0; k < 4; ++k) T.rk[k] = A.rk[k];
             }

@@ -255,7 +255,7 @@ __device__ __forceinline__ void shr_plane(u32 (&R)[NW], int st) {
     for (int j = 0; j < NW; ++j) R[j] = __builtin_amdgcn_alignbit(T[j + 1], T[j], r);
 }
 
-// one screening step: D = plane >> c (ones shifted in), C_k |= C_{k-1} & ~D  (NC unary counter planes)
+// one screening step: x = ~(plane >> c) (ones shifted in), C_k |= C_{k-1} & x  (NC unary counter planes)
 template <int NW, int CQ, int NC>
 __device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C)[NC][NW]) {
 #pragma unroll
@@ -271,8 +271,9 @@ __device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C
 
 // Bit-sliced screening of the candidates p = 0 .. len-edge of phases B and C over the first S-1 adapter
 // characters with NC unary mismatch-counter planes (4: budgets up to 3, the tiled kernel's limit).
+// NC = largest budget + 1 counter planes (4: budgets up to 3, the tiled kernel's limit).
 template <int NW, bool FULL, int NC>
-__device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool done,
+__device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&NX)[4][NW], const u32 (&NXN)[NW], int len, bool done,
                                               u32 (&aliveB)[NW], u32 (&aliveC)[NW]) {
     const int al = A.len, S = max(A.S, 1), edge = A.edge, mis = A.mis;
     u32 C[NC][NW], BY[NW];
@@ -280,7 +281,7 @@ __device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&
     for (int j = 0; j < NW; ++j) {
 #pragma unroll
         for (int k = 0; k < NC; ++k) C[k][j] = 0;
-        BY[j] = ~lowmask32(len - 32 * j);
+        BY[j] = ~lowmask32(len - 32 * j);                 // a character that matches nothing inside the read
     }
     const int steps = min(S - 1, al);
     // The counters only count, so the order of the steps is free: one loop per plane over the adapter
@@ -301,15 +302,15 @@ __device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&
             screen_step<NW, 1, NC>(Pl, c, C);
         }
     };
-    run(X[0], A.cmask[0] & sm);
-    run(X[1], A.cmask[1] & sm);
-    run(X[2], A.cmask[2] & sm);
-    run(X[3], A.cmask[3] & sm);
+    run(NX[0], A.cmask[0] & sm);
+    run(NX[1], A.cmask[1] & sm);
+    run(NX[2], A.cmask[2] & sm);
+    run(NX[3], A.cmask[3] & sm);
     const u64 other = sm & ~(A.cmask[0] | A.cmask[1] | A.cmask[2] | A.cmask[3]);   // N and anything else in the adapter
     if (other) {
         if (FULL) {
-            run(XN, other & A.nmask);
-            run(BY, other & ~A.nmask);      // matches nothing inside the read
+            run(NXN, other & A.nmask);
+            run(BY, other & ~A.nmask);
         } else {
             run(BY, other);
         }
@@ -321,14 +322,16 @@ __device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&
         const u32 valid = lowmask32(len - edge + 1 - 32 * j);
         const u32 bm = lowmask32(len - al + 1 - 32 * j);                    // phase B region
         const u32 t1 = lowmask32(len - edge - rk1 + 1 - 32 * j) & (mis >= 1 ? 0xFFFFFFFFu : ~bm);
-        u32 rej;
-        if (NC == 2) {
-            rej = (C[0][j] & ~t1) | C[1][j];
-        } else {
+        u32 rej = C[0][j] & ~t1;
+        if (NC >= 3) {
             const u32 t2 = lowmask32(len - edge - rk2 + 1 - 32 * j) & (mis >= 2 ? 0xFFFFFFFFu : ~bm);
-            const u32 t3 = lowmask32(len - edge - rk3 + 1 - 32 * j) & (mis >= 3 ? 0xFFFFFFFFu : ~bm);
-            rej = (C[0][j] & ~t1) | (C[1][j] & ~t2) | (C[2 < NC ? 2 : 0][j] & ~t3) | C[3 < NC ? 3 : 0][j];
+            rej |= C[1][j] & ~t2;
         }
+        if (NC >= 4) {
+            const u32 t3 = lowmask32(len - edge - rk3 + 1 - 32 * j) & (mis >= 3 ? 0xFFFFFFFFu : ~bm);
+            rej |= C[NC >= 4 ? 2 : 0][j] & ~t3;
+        }
+        rej |= C[NC - 1][j];                                                 // more mismatches than any budget of this adapter
         const u32 alive = done ? 0u : (valid & ~rej);
         aliveB[j] = alive & bm;
         aliveC[j] = alive & ~bm;
@@ -368,7 +371,9 @@ __device__ int adapter_tile(const TileAdapter &A, const DevAdapter &AG, const u3
     // ---------------- phases B+C screening: candidates p = 0 .. len-edge, bit-sliced
     u32 aliveB[NW], aliveC[NW];
     if (SNK_ABL != 7 && __any(!done)) {
-        screen_planes<NW, FULL, 4>(A, X, XN, len, done, aliveB, aliveC);
+        if (A.maxb <= 1) screen_planes<NW, FULL, 2>(A, X, XN, len, done, aliveB, aliveC);
+        else if (A.maxb == 2) screen_planes<NW, FULL, 3>(A, X, XN, len, done, aliveB, aliveC);
+        else screen_planes<NW, FULL, 4>(A, X, XN, len, done, aliveB, aliveC);
     } else {
 #pragma unroll
         for (int j = 0; j < NW; ++j) aliveB[j] = aliveC[j] = 0;
@@ -526,28 +531,25 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         const int lenF = fixed ? len0 : G.lcap;
         constexpr bool nomask = false;
         const int l4 = lane4;                                                // byte offset of this lane's dword in a row
-        const u32 fixsh = 0u;
         auto do_read = [&](auto FL, auto JC, const int r, u32 c4, const u32 q4, const u32 (&cq)[NS]) {
             constexpr bool FULLLEN = decltype(FL)::value;
             constexpr int jq = decltype(JC)::v & 3;        // place of the read in its group of four
             const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
             {   // ---- collectors (4 positions per lane)
-                {
-                    u32 vm = padm;
-                    if (!FULLLEN && !fixed) {                          // variable-length tile: the partial dword's mask is uniform
-                        const int lr4 = len_r & ~3;
-                        const u32 pm = (1u << (8 * (len_r & 3))) - 1u;
-                        vm = lane4 < lr4 ? 0xFFFFFFFFu : (lane4 == lr4 ? pm : 0u);
-                    }
-                    c4 = (c4 & vm) | (0x41414141u & ~vm);                      // v_bfi: 'A' past the end
+                u32 vm = padm;                             // bytes of this lane's dword inside the read
+                if (!FULLLEN && !fixed) {                  // variable-length tile: the partial dword's mask is uniform
+                    const int lr4 = len_r & ~3;
+                    const u32 pm = (1u << (8 * (len_r & 3))) - 1u;
+                    vm = lane4 < lr4 ? 0xFFFFFFFFu : (lane4 == lr4 ? pm : 0u);
                 }
-                const u32 t = c4 & 0x06060606u;                                // 2 * code of every byte (A 0, C 2, T 4, G 6)
+                const u32 t = c4 & vm & 0x06060606u;                           // 2 * code of every byte (A 0, C 2, T 4, G 6); past the end: A
                 if (jq == 0) aC = t >> 1;                                      // read j of the group: bits 2j, 2j+1 of every byte
                 else aC = (t << (2 * jq - 1)) | aC;                            // v_lshl_or
                 const u32 ex = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);   // the letter each code stands for
+                const u32 df = (ex ^ c4) & vm;                                 // one v_bitop3
                 u32 carry_out;
-                asm("v_cmp_ne_u32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %1, %1, vcc" : "=v"(carry_out) : "v"(badv), "v"(ex), "v"(c4) : "vcc");
-                badv = carry_out;                                              // badv = 2 * badv + (ex != c4)
+                asm("v_cmp_ne_u32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %1, %1, vcc" : "=v"(carry_out) : "v"(badv), "v"(df) : "vcc");
+                badv = carry_out;                                              // badv = 2 * badv + (some byte is not the letter of its code)
                 aQ = (aQ >> 1) | ((q4 + KQ) & 0x80808080u);                   // v_add, v_lshrrev, v_and_or
                 if (FULL) {
                     if (has_lq) {
@@ -623,15 +625,18 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     gs += chunkB;
                     gq += chunkB;
                 };
-                // LDS -> register reads run one read ahead of the collectors, across chunk boundaries: the read
-                // queue is never drained inside a tile.  Reads, histogram adds and their waits are hand-placed asm:
-                // the compiler cannot see through the loop-carried LDS queue and would drain it (lgkmcnt(0)) right
-                // after issuing the prefetch.  LDS ops return in order, so "all but the newest K" is exact: K = NS
-                // histogram adds follow the prefetch.  Every read is waited for in the same straight-line block
-                // that issued it (no register of an in-flight read crosses a branch).
-                // DMA: chunk k+2 is issued into the buffer of chunk k as soon as its last row sits in registers,
-                // i.e. one read before chunk k+1 is first touched, and the wait there covers chunk k+1.
-                constexpr int K = SNK_ABL == 11 ? 0 : NS;
+                // LDS -> register reads run TWO reads ahead of the collectors, across chunk boundaries: the read
+                // queue is never drained inside a tile (four register sets rotate, no moves).  Reads, histogram adds and
+                // their waits are hand-placed asm: the compiler cannot see through the loop-carried LDS queue and would
+                // drain it (lgkmcnt(0)) right after issuing the prefetch.  LDS ops return in order, so "all but the newest
+                // K" is exact: behind the row of read r+1 come the row of read r+2 (2 + NS reads) and the NS histogram
+                // adds of read r.  Every step issues the same ops (rows past the tile's last read are staging bytes that
+                // are never used).
+                // DMA: when the row of the last read of chunk k has been ISSUED (two reads before it is used), the next
+                // row to fetch is row 0 of chunk k+1, whose DMA is waited for there; one step later that last row sits in
+                // registers, and the DMA of chunk k+2 goes into the buffer of chunk k.
+                constexpr int ROWOPS = 2 + NS;
+                constexpr int K = (SNK_ABL == 11 ? 0 : NS) + ROWOPS;
                 const u32 stgA = lds0 + (u32)(G.stg_off + wave * G.stg_wave);
                 const u32 lc4 = (u32)l4, l1 = (u32)G.cba + (u32)lane, lq4 = (u32)G.cba + (u32)l4;
                 issue(0);
@@ -645,51 +650,43 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     lds_read_b32(q4, row + lq4);
                     lds_read_qstrips<0>(q, row + l1);
                 };
-                u32 ac4, aq4, aq[NS], bc4, bq4, bq[NS];     // two register sets alternate (no rotation moves)
-                u32 row = stgA;                             // LDS address of the row being prefetched (scalar)
-                const int rbm = rb - 1, lgrb = 31 - __builtin_clz((unsigned)rb);     // rb is a power of two (launch())
-                lds_rd(ac4, aq4, aq, row);
-                lds_wait<0>(ac4, aq4, aq);
-                // the row after read r: next row of the chunk, or -- when r closes chunk k -- row 0 of chunk k+1
-                // (its DMA is waited for here, and chunk k+2 goes into the buffer that just became free)
-                auto next_row = [&](const int r, const bool closes) {
-                    if (closes) {
-                        const int k = ((r + 1) >> lgrb) - 1;
-                        if (k + 1 < nchunks) {
-                            if (k + 2 < nchunks) {
-                                issue(k + 2);
-                                if (SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                            } else if (SNK_ABL != 14) {
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            }
-                        }
-                        row = stgA + (u32)(((k + 1) & 1) * 2 * G.cba);
-                    } else {
-                        row += (u32)B.pitch;
-                    }
-                };
-                for (int o = 0; o < nocts; ++o) {           // reads 8o .. 8o+7; `a` holds row 8o
-                    // which reads of this octet close a chunk (rb is a power of two): one bit test per read
+                u32 C4[4], Q4[4], QS[4][NS];                // register set of read r: r & 3
+                u32 row = stgA;                             // LDS address of the newest prefetched row (scalar)
+                const int rbm = rb - 1, lgrb = 31 - __builtin_clz((unsigned)rb);     // rb is a power of two >= 2 (launch())
+                lds_rd(C4[0], Q4[0], QS[0], row);
+                row += (u32)B.pitch;                        // (row 1 is in chunk 0: rb >= 2)
+                lds_rd(C4[1], Q4[1], QS[1], row);
+                lds_wait<ROWOPS>(C4[0], Q4[0], QS[0]);
+                for (int o = 0; o < nocts; ++o) {           // reads 8o .. 8o+7
+                    // which reads of this octet are the last of a chunk (rb is a power of two): one bit test per read
                     const u32 evm = rb == 2 ? 0xAAu : rb == 4 ? 0x88u : ((((8 * (o + 1)) & rbm) == 0) ? 0x80u : 0u);
-                    static_for(std::make_integer_sequence<int, 4>{}, [&](auto jc) {
-                        constexpr int j = 2 * decltype(jc)::v;
+                    static_for(std::make_integer_sequence<int, 8>{}, [&](auto jc) {
+                        constexpr int j = decltype(jc)::v;
                         const int r = 8 * o + j;
                         if (CNT64 || r < cnt) {
-                            next_row(r, (evm >> j) & 1u);   // (past the last read of the tile: staging bytes that are never used)
-                            lds_rd(bc4, bq4, bq, row);
-                            do_read(FL, IntC<j>{}, r, ac4, aq4, aq);
-                            lds_wait<K>(bc4, bq4, bq);
+                            // read r+1 is the last of chunk k (never for j = 7: read 0 of an octet closes no chunk)
+                            const bool closes = j < 7 && ((evm >> ((j + 1) & 7)) & 1u);
+                            const int k = ((r + 2) >> lgrb) - 1;
+                            if (closes) {                   // row of read r+2 = row 0 of chunk k+1
+                                if (k + 1 < nchunks && SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                row = stgA + (u32)(((k + 1) & 1) * 2 * G.cba);
+                            } else {
+                                row += (u32)B.pitch;
+                            }
+                            lds_rd(C4[(j + 2) & 3], Q4[(j + 2) & 3], QS[(j + 2) & 3], row);
+                            do_read(FL, IntC<j>{}, r, C4[j & 3], Q4[j & 3], QS[j & 3]);
+                            lds_wait<K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
+                            if (closes && k + 2 < nchunks) issue(k + 2);     // every row of chunk k sits in registers now
                         } else skip_read();
-                        if (CNT64 || r + 1 < cnt) {
-                            next_row(r + 1, (evm >> (j + 1)) & 1u);
-                            lds_rd(ac4, aq4, aq, row);
-                            do_read(FL, IntC<j + 1>{}, r + 1, bc4, bq4, bq);
-                            lds_wait<K>(ac4, aq4, aq);
-                        } else skip_read();
-                        if (j == 2) park4(2 * o);
-                        if (j == 6) { park4(2 * o + 1); park8(o); }
+                        if (j == 3) park4(2 * o);
+                        if (j == 7) { park4(2 * o + 1); park8(o); }
                     });
                 }
+                // the two rows fetched past the last read: nothing may be in flight into registers the compiler reuses
+                lds_wait<0>(C4[0], Q4[0], QS[0]);
+                lds_wait<0>(C4[1], Q4[1], QS[1]);
+                lds_wait<0>(C4[2], Q4[2], QS[2]);
+                lds_wait<0>(C4[3], Q4[3], QS[3]);
             } else {
                 // register path (pitch not a multiple of 16): loads run one read ahead
                 u32 offq[NS], nc4, nq4, nqb[NS];
@@ -755,9 +752,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             uint8_t *scr = ldsb + G.scr_off + wave * G.scr_wave;
             auto write8 = [&](const v8u &V) {
                 u32 lo[4], hi[4];
-                // (the lane whose slot straddles the end of a fixed-length read collected its last characters in the upper bytes)
-                byte_tr4(V[0] >> fixsh, V[1] >> fixsh, V[2] >> fixsh, V[3] >> fixsh, lo);
-                byte_tr4(V[4] >> fixsh, V[5] >> fixsh, V[6] >> fixsh, V[7] >> fixsh, hi);
+                byte_tr4(V[0], V[1], V[2], V[3], lo);
+                byte_tr4(V[4], V[5], V[6], V[7], hi);
                 v4u *dst = reinterpret_cast<v4u *>(scr + 32 * lane);
                 dst[0] = v4u{lo[0], hi[0], lo[1], hi[1]};
                 dst[1] = v4u{lo[2], hi[2], lo[3], hi[3]};
