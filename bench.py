@@ -92,6 +92,18 @@ def cpu_baseline(data, n_sample):
         subprocess.call(["rm", "-rf", tmp])
 
 
+def end_to_end(n_pairs, threads=16):
+    """This repo's CLI and the reference binary on the same /dev/shm FASTQ, plain -> plain and .gz -> .gz, whole-process
+    wall clock (tools/bench_e2e.py).  The reference's plain run doubles as the cpu_baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_e2e
+    tmp = tempfile.mkdtemp(prefix="snkbench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        return bench_e2e.measure(tmp, n_pairs, threads, ["plain", "gz"])
+    finally:
+        subprocess.call(["rm", "-rf", tmp])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,7 +111,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=PAIRS_TOTAL, help="pairs per GPU per step")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 tiled")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-side legs (cpu_baseline, end_to_end)")
+    ap.add_argument("--e2e-pairs", type=int, default=4_000_000, help="pairs of the end_to_end leg (0: only the cpu_baseline sample)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -221,7 +234,21 @@ def main():
                          "kernel_ms": round(k_ms, 4), "bytes_per_launch": BYTES_PER_PAIR * n, **extra},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(data, min(n_unique, 1_000_000))
+            e2e = None
+            if args.e2e_pairs > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "SOAPnuke")):
+                try:
+                    e2e = end_to_end(args.e2e_pairs)
+                except Exception as ex:          # the host legs must never take the kernel line down
+                    e2e = {"error": repr(ex)[:200]}
+            ref_plain = (e2e or {}).get("modes", {}).get("plain", {}).get("reference")
+            if ref_plain and ref_plain.get("rc") == 0:
+                out["cpu_baseline"] = {"value": ref_plain["Mreads_per_s"], "unit": "Mreads/s", "cores": 16, "kind": "reference",
+                                       "sample": f"{args.e2e_pairs} PE150 pairs, plain FASTQ in /dev/shm, `SOAPnuke filter -J -l 10 -q 0.1 -T 16`, "
+                                                 f"whole-process wall {ref_plain['wall_s']}s (includes its 5 s merge-poll quantum)"}
+            else:
+                out["cpu_baseline"] = cpu_baseline(data, min(n_unique, 1_000_000))
+            if e2e is not None:
+                out["end_to_end"] = e2e
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -37,7 +37,7 @@ REPORT_LIB = os.path.join(HERE, "libsnk_report.so")
 def build_host(force=False, verbose=False):
     """The C++ host side: report writer library (plain g++) and the `SOAPnuke filter` CLI (links the
     C-ABI library with an $ORIGIN rpath)."""
-    srcs = [os.path.join(HOST, f) for f in ("snk_main.cpp", "snk_report.cpp", "snk_report.h", "snk_inflate.h")]
+    srcs = [os.path.join(HOST, f) for f in ("snk_main.cpp", "snk_report.cpp", "snk_report.h", "snk_inflate.h", "snk_pgunzip.h")]
     newest = max(os.path.getmtime(f) for f in srcs + [LIB])
     if force or not os.path.exists(REPORT_LIB) or os.path.getmtime(REPORT_LIB) < newest:
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", REPORT_LIB, "snk_report.cpp"]
@@ -45,7 +45,7 @@ def build_host(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=HOST)
     if force or not os.path.exists(CLI) or os.path.getmtime(CLI) < newest:
-        cmd = [HIPCC, "-O2", "-std=c++17", "-o", CLI, "snk_main.cpp", "snk_report.cpp", "-L" + HERE, "-lsnk_filter", "-lz",
+        cmd = [HIPCC, "-O2", "-std=c++17", "-o", CLI, "snk_main.cpp", "snk_report.cpp", "-L" + HERE, "-lsnk_filter", "-lz", "-pthread",
                "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

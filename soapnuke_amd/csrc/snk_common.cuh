@@ -103,49 +103,89 @@ __device__ inline int has_contam_seq(const uint8_t *s, int len, const DevContam 
     return -1;
 }
 
-// global_contam_pos(), src/read_filter.cpp:961-1062 (score / overlap carried across alignments of a section)
-__device__ inline int global_contam_pos_seq(const uint8_t *ref, int rl, const uint8_t *gc, int cl, int min_match_len, int mmn) {
-    const int mismatch_score = -200, tms = mmn * mismatch_score, lower = (min_match_len - mmn) + tms;
-    int total = -1000, overlap = 0;
-    for (int i = cl - min_match_len; i >= 0; --i) {
-        const int j_max = cl - i > rl ? rl : cl - i;
-        for (int j = 0; j != j_max; ++j) {
-            if (ref[j] == gc[i + j]) {
-                if (total > tms) { total += 1; ++overlap; }
-                else { if (j_max - j < min_match_len) break; total = 1; overlap = 1; }
-            } else {
-                if (total > tms) { total += mismatch_score; ++overlap; }
-                else if (j_max - j < min_match_len) break;
+// ---- global contaminants: the verdict of global_contam_pos() (src/read_filter.cpp:961-1062; only ">= 0" is ever used,
+// src/read_filter.cpp:229-262).
+//
+// What the reference's three scans compute, in other words: the read and the contaminant are laid on each other at every
+// offset of a section (contaminant hanging off the front / inside / hanging off the end); the cells of one lay are
+// walked in order, the lays of a section one after the other WITHOUT resetting the state in between.  The state is a
+// window: it opens on a matching cell (score 1, span 1) provided at least min_match_len cells of the lay remain (in the
+// last section the window opens first and the lay is then abandoned), every later cell extends it (score +1 / -200),
+// it is dead once the score is down to -200 * mismatches, and the verdict is "hit" as soon as a window spans
+// min_match_len cells with its score at (min_match_len - mismatches) - 200 * mismatches or better.
+//
+// Here: one equality bit per cell of a lay (up to 4 words), and an event walk over them -- a live window jumps over a
+// whole run of matches (count-trailing-zeros; the hit test inside the run is a closed form), a dead one jumps to the
+// next match.  Valid for the parameter range snk_create() admits: 0 <= mismatches <= 4 < ... < min_match_len, for which
+// a dead window can never pass the hit test.
+struct GcWindow { int score, span; };
+
+__device__ inline int gc_next(const unsigned long long (&e)[4], int pos, int n, bool ones) {   // first cell >= pos that is a match (ones) / a mismatch, n if none
+    while (pos < n) {
+        const int w = pos >> 6;
+        unsigned long long x = ones ? e[w] : ~e[w];
+        x &= ~0ull << (pos & 63);
+        if (x) { const int p = (w << 6) + __ffsll((long long)x) - 1; return p < n ? p : n; }
+        pos = (w + 1) << 6;
+    }
+    return n;
+}
+
+// one lay of n cells: cell j compares a[j] with b[j].  early_stop: sections 1 and 2 (a dead window meeting a cell with
+// fewer than mml cells left abandons the lay); otherwise section 3 (a mismatch there abandons it, a match opens the
+// window first).  True = hit.
+__device__ inline bool gc_lay(GcWindow &st, const uint8_t *a, const uint8_t *b, int n, int mml, int tms, int lower, bool early_stop) {
+    if (n <= 0) return false;
+    unsigned long long e[4] = {0, 0, 0, 0};
+    for (int j = 0; j < n; ++j) e[j >> 6] |= (unsigned long long)(a[j] == b[j]) << (j & 63);
+    const int last_ok = n - mml;                 // cells j <= last_ok still have mml cells of the lay in front of them
+    int pos = 0;
+    while (pos < n) {
+        if (st.score > tms) {                    // live window
+            const int z = gc_next(e, pos, n, false);
+            const int run = z - pos;
+            if (run > 0) {
+                const int need = max(max(lower - st.score, mml - st.span), 1);     // matches until the hit test passes
+                if (need <= run) return true;
+                st.score += run;
+                st.span += run;
+                pos = z;
+                if (pos == n) break;
             }
-            if (total >= lower && overlap >= min_match_len) return 0;
+            st.score -= 200;                     // the mismatch at pos
+            st.span += 1;
+            if (st.score >= lower && st.span >= mml) return true;
+            ++pos;
+        } else {                                 // dead: nothing happens until the next match
+            const int o = gc_next(e, pos, n, true);
+            if (o >= n) break;
+            if (early_stop) {
+                if (o > last_ok) break;
+            } else {
+                if (max(pos, last_ok + 1) < o) break;        // a mismatch without room comes first
+            }
+            st.score = 1;
+            st.span = 1;
+            if (!early_stop && n - o < mml) break;          // opened, and the lay is abandoned (the window lives on)
+            if (st.score >= lower && st.span >= mml) return true;
+            pos = o + 1;
         }
     }
-    total = -1000; overlap = 0;
-    for (int i = 0; i <= rl - cl; ++i)
-        for (int j = 0; j != cl; ++j) {
-            if (ref[i + j] == gc[j]) {
-                if (total > tms) { total += 1; ++overlap; }
-                else { if (cl - j < min_match_len) break; total = 1; overlap = 1; }
-            } else {
-                if (total > tms) { total += mismatch_score; ++overlap; }
-                else if (cl - j < min_match_len) break;
-            }
-            if (total >= lower && overlap >= min_match_len) return i + j - overlap + 1;
-        }
-    total = -1000; overlap = 0;
-    const int i_min = cl > rl ? cl - rl : 0;
-    for (int i = i_min; i <= cl - min_match_len; ++i)
-        for (int j = 0; j != cl - i; ++j) {
-            if (ref[rl - (cl - i) + j] == gc[j]) {
-                if (total > tms) { total += 1; ++overlap; }
-                else { total = 1; overlap = 1; if (cl - i - j < min_match_len) break; }
-            } else {
-                if (total > tms) { total += mismatch_score; ++overlap; }
-                else if (cl - i - j < min_match_len) break;
-            }
-            if (total >= lower && overlap >= min_match_len) return rl - cl + i + j - overlap + 1;
-        }
-    return -1;
+    return false;
+}
+
+__device__ inline bool global_contam_hit(const uint8_t *ref, int rl, const uint8_t *gc, int cl, int mml, int mmn) {
+    const int tms = -200 * mmn, lower = (mml - mmn) + tms;
+    GcWindow st = {-1000, 0};
+    for (int i = cl - mml; i >= 0; --i)                                    // contaminant hanging off the front, less and less
+        if (gc_lay(st, ref, gc + i, min(cl - i, rl), mml, tms, lower, true)) return true;
+    st = GcWindow{-1000, 0};
+    for (int i = 0; i <= rl - cl; ++i)                                     // contaminant inside the read
+        if (gc_lay(st, ref + i, gc, cl, mml, tms, lower, true)) return true;
+    st = GcWindow{-1000, 0};
+    for (int i = cl > rl ? cl - rl : 0; i <= cl - mml; ++i)                // hanging off the end, more and more
+        if (gc_lay(st, ref + rl - (cl - i), gc, cl - i, mml, tms, lower, false)) return true;
+    return false;
 }
 
 // include_contam (bit 0) / include_global_contam (bit 1) of one read, src/read_filter.cpp:189-248.
@@ -156,7 +196,7 @@ __device__ inline int contam_flags(const DevContam *ct, int n_ct, const DevGCont
         if (has_contam_seq(s, len, ct[i]) >= 0) f |= 1;
     for (int i = 0; i < n_gct && !(f & 2); ++i)
         for (int d = 0; d < 2 && !(f & 2); ++d)
-            if (global_contam_pos_seq(s, len, gct[i].seq[d], gct[i].len, gct[i].min_match_len, gct[i].mm) >= 0) f |= 2;
+            if (global_contam_hit(s, len, gct[i].seq[d], gct[i].len, gct[i].min_match_len, gct[i].mm)) f |= 2;
     return f;
 }
 

@@ -143,6 +143,9 @@ std::string build_contams(const snk_params &P, std::vector<DevContam> &ct, int n
             G.len = cl;
             G.min_match_len = (int)((float)cl * (float)atof(mrs[i].c_str()));           // :969
             G.mm = atoi(mms[i].c_str());
+            // the window walk of the kernels (snk_common.cuh) covers the sensible range; outside it the reference's score
+            // arithmetic degenerates (a window that is "dead" can pass the hit test)
+            if (G.mm < 0 || G.mm > 4 || G.min_match_len <= G.mm) return "global contaminant: mismatch number must be 0..4 and smaller than the match length";
             memcpy(G.seq[0], seqs[i].data(), cl);
             for (int k = 0; k < cl; ++k) {                           // reversecomplementary(), :1068-1090
                 const int ch = toupper((unsigned char)seqs[i][cl - 1 - k]);

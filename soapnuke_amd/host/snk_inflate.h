@@ -30,6 +30,7 @@ public:
     void set_verify_crc(bool v) { verify_crc_ = v; }
     const std::vector<MemberEnd> &member_ends() const { return ends_; }
     void init(const uint8_t *in, size_t n) {
+        base_ = in;
         in_ = in; in_end_ = in + n;
         bitbuf_ = 0; bitcnt_ = 0;
         state_ = MEMBER_HEADER;
@@ -39,7 +40,29 @@ public:
         crc_ = 0;
         pend_len_ = 0;
         members_ = 0;
+        partial_member_ = false;
+        stop_bit_ = ~0ull;
+        stopped_ = false;
     }
+    // ---- mid-stream use (snk_pgunzip.h): start at the block header at bit offset `bit` of the input given to init();
+    // the member it belongs to started earlier, so its length is unknown (no distance / ISIZE checks for it) and its
+    // CRC is the caller's business (member_ends()).  The usual contract on `out` holds: the 32 KiB before it are the
+    // stream's previous bytes.
+    void start_at_block(uint64_t bit) {
+        in_ = base_ + (bit >> 3);
+        bitbuf_ = 0; bitcnt_ = 0;
+        if (bit & 7) { refill(); take((int)(bit & 7)); }
+        state_ = BLOCK_HEADER;
+        member_out_ = 1ull << 40;
+        partial_member_ = true;
+        members_ = 1;
+        verify_crc_ = false;
+    }
+    // run() returns (stopped() true) in front of the first block header at or past this bit offset
+    void set_stop_bit(uint64_t b) { stop_bit_ = b; stopped_ = false; }
+    bool stopped() const { return stopped_; }
+    uint64_t bitpos() const { return (uint64_t)(in_ - base_) * 8 - (uint64_t)bitcnt_; }
+    void set_strict(bool v) { strict_ = v; }
     const char *error() const { return err_; }
     bool done() const { return state_ == DONE; }
     uint64_t total_out() const { return total_out_; }
@@ -57,6 +80,7 @@ public:
                 continue;
             }
             if (state_ == MEMBER_HEADER) { member_header(); continue; }
+            if (state_ == BLOCK_HEADER && bitpos() >= stop_bit_) { stopped_ = true; break; }
             if (out == out_end) break;
             if (state_ == BLOCK_HEADER) { block_header(); continue; }
             if (state_ == STORED) {
@@ -74,8 +98,11 @@ public:
         return (size_t)(out - out0);
     }
 
-private:
+protected:
     enum State { MEMBER_HEADER, BLOCK_HEADER, STORED, CODES, MEMBER_TRAILER, DONE };
+    const uint8_t *base_ = nullptr;
+    bool partial_member_ = false, stopped_ = false, strict_ = false;
+    uint64_t stop_bit_ = ~0ull;
     enum { LIT_BITS = 11, DIST_BITS = 8, T_LIT = 1, T_LEN = 2, T_EOB = 3, T_SUB = 4 };
     const uint8_t *in_ = nullptr, *in_end_ = nullptr;
     uint64_t bitbuf_ = 0;
@@ -175,7 +202,8 @@ private:
         ++members_;
         if (verify_crc_) { if (crc != crc_) { err_ = "gzip CRC mismatch"; return false; } }
         else ends_.push_back(MemberEnd{(size_t)(acc_from_ - run_out0_), crc, isz});
-        if (isz != (uint32_t)member_out_) { err_ = "gzip length mismatch"; return false; }
+        if (!partial_member_ && isz != (uint32_t)member_out_) { err_ = "gzip length mismatch"; return false; }
+        partial_member_ = false;
         state_ = MEMBER_HEADER;
         return true;
     }
@@ -187,8 +215,10 @@ private:
         return r;
     }
     // entry = value << 16 | extra << 12 | type << 8 | code length; sym_entry(sym) gives the payload (without length)
+    // strict_ (block-start search): codes must be complete as zlib demands -- literal/length and code-length codes
+    // always, distance codes unless there is a single code or none
     template <class F>
-    bool build(uint32_t *tab, int tab_cap, int pbits, const uint8_t *lens, int nsym, F sym_entry) {
+    bool build(uint32_t *tab, int tab_cap, int pbits, const uint8_t *lens, int nsym, F sym_entry, bool dist_code = false) {
         int count[16] = {0};
         for (int s = 0; s < nsym; ++s) count[lens[s]]++;
         count[0] = 0;
@@ -206,6 +236,7 @@ private:
             code = (code + (l > 1 ? (uint32_t)count[l - 1] : 0)) << 1;
             next[l] = code;
         }
+        if (strict_ && left > 0 && !(dist_code && used == 1)) return false;   // incomplete
         // (incomplete codes are legal only for a single distance code; tolerated: unused entries stay invalid)
         // subtable sizes: per primary prefix the longest code
         int sub_bits[1 << LIT_BITS];
@@ -332,7 +363,7 @@ private:
             return false;
         }
         if (!build(lit_, (int)(sizeof(lit_) / 4), LIT_BITS, lens, nlit, litlen_entry)) { err_ = "invalid literal/lengths set"; return false; }
-        if (!build(dist_, (int)(sizeof(dist_) / 4), DIST_BITS, lens + 288, ndist, dist_entry)) { err_ = "invalid distances set"; return false; }
+        if (!build(dist_, (int)(sizeof(dist_) / 4), DIST_BITS, lens + 288, ndist, dist_entry, true)) { err_ = "invalid distances set"; return false; }
         state_ = CODES;
         return true;
     }

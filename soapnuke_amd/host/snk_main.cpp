@@ -20,6 +20,7 @@
 #include <string.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <time.h>
@@ -40,6 +41,7 @@
 
 #include "../../include/snk_filter.h"
 #include "snk_inflate.h"
+#include "snk_pgunzip.h"
 #include "snk_report.h"
 #include "../../include/snk_rmdup.h"
 
@@ -429,15 +431,110 @@ public:
     }
 };
 
+// Host worker pool: parallel_for() cuts [0, n) into `workers` slices and runs them on the pool's threads (several
+// pipeline stages call it concurrently; the caller takes slices too, so a busy pool never blocks it).
+class Pool {
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+    std::vector<std::thread> th_;
+    bool quit_ = false;
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return quit_ || !q_.empty(); });
+                if (q_.empty()) return;
+                job = std::move(q_.front());
+                q_.pop_front();
+            }
+            job();
+        }
+    }
+public:
+    void start(int n) { for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); }); }
+    ~Pool() {
+        { std::lock_guard<std::mutex> l(m_); quit_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    bool try_run_one() {
+        std::function<void()> job;
+        {
+            std::lock_guard<std::mutex> l(m_);
+            if (q_.empty()) return false;
+            job = std::move(q_.front());
+            q_.pop_front();
+        }
+        job();
+        return true;
+    }
+    void push(std::function<void()> j) {
+        { std::lock_guard<std::mutex> l(m_); q_.push_back(std::move(j)); }
+        cv_.notify_one();
+    }
+};
+Pool g_pool;
+int g_host_threads = 1;
+
+// CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota (a container with 256
+// visible hardware threads and a quota of 16 CPUs only gets slower with more than 16 busy threads)
+int usable_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n > 0 ? n : 1 << 20, CPU_COUNT(&set));
+    auto quota = [](const char *path, const char *path_period) -> double {
+        FILE *f = fopen(path, "r");
+        if (!f) return 0;
+        char a[64] = "", b[64] = "";
+        const int k = fscanf(f, "%63s %63s", a, b);
+        fclose(f);
+        if (k < 1 || !strcmp(a, "max") || atof(a) <= 0) return 0;
+        double period = k == 2 ? atof(b) : 0;
+        if (path_period) {
+            FILE *g = fopen(path_period, "r");
+            if (g) { if (fscanf(g, "%63s", b) == 1) period = atof(b); fclose(g); }
+        }
+        return period > 0 ? atof(a) / period : 0;
+    };
+    double q = quota("/sys/fs/cgroup/cpu.max", nullptr);                                             // cgroup v2
+    if (q <= 0) q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");   // v1
+    if (q > 0) n = std::min(n, std::max(1, (int)(q + 0.5)));
+    return n > 0 ? n : 1;
+}
+
+// SNK_TIMING=1: where the wall clock of the host pipeline goes (seconds per stage, printed at the end)
+struct StageClock {
+    std::atomic<long long> ns[12];
+    const char *name[12] = {"reader: inflate/copy", "reader: newline index", "reader: push wait", "main: input wait", "main: slot wait",
+                            "main: pack", "main: submit", "writer: slot wait", "writer: gpu wait", "writer: format+deflate", "writer: write", "other"};
+    bool on = false;
+    StageClock() { for (auto &x : ns) x = 0; }
+    static long long now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (long long)t.tv_sec * 1000000000ll + t.tv_nsec; }
+    void report() const {
+        if (!on) return;
+        for (int i = 0; i < 11; ++i) fprintf(stderr, "[timing] %-24s %8.3f s\n", name[i], (double)ns[i].load() * 1e-9);
+    }
+};
+StageClock g_clk;
+struct Tick {
+    int k; long long t0;
+    explicit Tick(int k_) : k(k_), t0(g_clk.on ? StageClock::now() : 0) {}
+    ~Tick() { if (g_clk.on) g_clk.ns[k] += StageClock::now() - t0; }
+};
+
 void parallel_for(int workers, int n, const std::function<void(int, int, int)> &f) {   // f(worker, lo, hi)
     workers = std::max(1, std::min(workers, n));
     if (workers == 1) { f(0, 0, n); return; }
-    std::vector<std::thread> th;
-    for (int w = 0; w < workers; ++w) {
+    std::atomic<int> left(workers - 1);
+    for (int w = 1; w < workers; ++w) {
         const int lo = (int)((long)n * w / workers), hi = (int)((long)n * (w + 1) / workers);
-        th.emplace_back([&f, w, lo, hi] { f(w, lo, hi); });
+        g_pool.push([&f, &left, w, lo, hi] { f(w, lo, hi); left.fetch_sub(1, std::memory_order_release); });
     }
-    for (auto &t : th) t.join();
+    f(0, 0, (int)((long)n / workers));
+    while (left.load(std::memory_order_acquire) > 0)
+        if (!g_pool.try_run_one()) std::this_thread::yield();
 }
 
 // n whole FASTQ records of one file as they were read, plus the index of their 4n lines
@@ -455,6 +552,23 @@ struct RawChunk {
     std::vector<uint32_t> ls, le;                      // line start / end (end excludes the line terminator)
     int n = 0;
     const char *line(int k, int &len) const { len = (int)(le[k] - ls[k]); return base + ls[k]; }
+    // chunks are recycled: a fresh 100 MB buffer per batch means 100 MB of page faults per batch (and one mmap lock
+    // for all threads of the process)
+    static std::mutex &pool_mutex() { static std::mutex m; return m; }
+    static std::vector<RawChunk *> &pool() { static std::vector<RawChunk *> p; return p; }
+    static RawChunk *get() {
+        std::lock_guard<std::mutex> l(pool_mutex());
+        if (pool().empty()) return new RawChunk;
+        RawChunk *c = pool().back();
+        pool().pop_back();
+        return c;
+    }
+    static void put(RawChunk *c) {
+        if (!c) return;
+        c->ls.clear(); c->le.clear(); c->n = 0; c->base = nullptr;
+        std::lock_guard<std::mutex> l(pool_mutex());
+        if (pool().size() < 16) pool().push_back(c); else delete c;
+    }
 };
 
 // gz input (multi-member ok): inflate (snk_inflate.h, from the mapped file) + line index on one thread per
@@ -488,31 +602,15 @@ void reader_gz(const string path, int batch, int space_num, int workers, Channel
     const uint8_t *zin = (const uint8_t *)mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (zin == MAP_FAILED) die("cannot map file," + path);
     madvise((void *)zin, (size_t)st.st_size, MADV_SEQUENTIAL);
-    snk::GzipInflate z;
-    z.init(zin, (size_t)st.st_size);
-    z.set_verify_crc(false);
-    // the CRC-32 of the members is checked by a helper thread, one decoded block behind the decoder
-    struct CrcJob { const uint8_t *p; size_t n; std::vector<snk::GzipInflate::MemberEnd> ends; };
-    Channel<CrcJob> crc_q(64);
-    std::atomic<int> crc_pending(0);
-    std::thread crc_thread([&] {
-        CrcJob j;
-        uint32_t crc = 0;
-        while (crc_q.pop(j)) {
-            size_t pos = 0;
-            for (const auto &e : j.ends) {
-                crc = (uint32_t)crc32_z(crc, j.p + pos, e.out_off - pos);
-                if (crc != e.crc) die("read error in input fastq (gzip CRC mismatch)," + path);
-                crc = 0;
-                pos = e.out_off;
-            }
-            crc = (uint32_t)crc32_z(crc, j.p + pos, j.n - pos);
-            --crc_pending;
-        }
-    });
-    auto crc_drain = [&] { while (crc_pending.load() > 0) std::this_thread::yield(); };   // before a buffer changes hands
+    // One gzip stream, decoded by `workers` threads (snk_pgunzip.h: block-start search, marker decoding, window
+    // resolution; CRC-32 and ISIZE of every member are checked there).  The reference decodes with one zlib stream
+    // per reading thread (src/peprocess.cpp:2089-2113).
+    size_t pg_chunk = (size_t)2 << 20;
+    if (const char *e = getenv("SNK_GZ_CHUNK")) { const long v = atol(e); if (v >= 65536) pg_chunk = (size_t)v; }
+    snk::ParallelGunzip z(zin, (size_t)st.st_size, workers, pg_chunk);
+    auto crc_drain = [] {};
     const size_t H = snk::GzipInflate::HIST, block = (size_t)1 << 24;
-    RawChunk *cur = new RawChunk;
+    RawChunk *cur = RawChunk::get();
     const size_t cap0 = H + (size_t)batch * 400 + 2 * block;      // a whole batch of ~150 bp records without regrowth
     cur->reserve(cap0);
     memset(cur->own, 0, H);
@@ -528,7 +626,7 @@ void reader_gz(const string path, int batch, int space_num, int workers, Channel
     for (;;) {
         char *data = cur->own + H;
         if (scan < fill && cur->ls.size() < want) {     // index the new text (the inflate thread only waits for the scan)
-            parallel_newlines(data + scan, fill - scan, workers, nlpos);
+            { Tick t_(1); parallel_newlines(data + scan, fill - scan, workers, nlpos); }
             const size_t base_off = scan;
             scan = fill;
             for (uint32_t rel : nlpos) {
@@ -539,14 +637,14 @@ void reader_gz(const string path, int batch, int space_num, int workers, Channel
             }
         }
         if (cur->ls.size() == want) {                  // a full batch: hand it over, keep the unread tail + window
-            RawChunk *next = new RawChunk;
+            RawChunk *next = RawChunk::get();
             next->reserve(std::max(cur->own_cap, cap0));
             const size_t left = fill - line_start;
             memcpy(next->own, data + line_start - H, H + left);   // (reaches into cur's own window area: valid)
             cur->n = batch;
             cur->base = data;
             crc_drain();
-            out->push(cur);
+            { Tick t_(2); out->push(cur); }
             cur = next;
             fill = left;
             scan = 0;
@@ -559,19 +657,17 @@ void reader_gz(const string path, int batch, int space_num, int workers, Channel
             cur->n = (int)(cur->ls.size() / 4);
             cur->base = data;
             crc_drain();
-            if (cur->n) out->push(cur); else delete cur;
+            if (cur->n) out->push(cur); else RawChunk::put(cur);
             break;
         }
         if (H + fill + block > cur->own_cap) { crc_drain(); cur->reserve(cur->own_cap * 2); data = cur->own + H; }
-        const size_t got = z.run((uint8_t *)data + fill, block);
+        size_t got;
+        { Tick t_(0); got = z.run((uint8_t *)data + fill, block); }
         if (z.error()) die(string("read error in input fastq (") + z.error() + ")," + path);
-        if (got) { ++crc_pending; crc_q.push(CrcJob{(const uint8_t *)data + fill, got, z.member_ends()}); }
         if (got == 0 && z.done()) eof = true;
         fill += got;
         if (fill > 0xF0000000ull) die("batch larger than 4 GB: lower the batch size");
     }
-    crc_q.close();
-    crc_thread.join();
     munmap((void *)zin, (size_t)st.st_size);
     close(fd);
     out->close();
@@ -616,7 +712,7 @@ void reader_plain(const string path, int batch, int space_num, int workers, Chan
             win_end = ext_end;
             if (total) per_line = (double)(win_end - pos) / (double)total;
         }
-        RawChunk *c = new RawChunk;
+        RawChunk *c = RawChunk::get();
         c->base = base + pos;
         const size_t take = std::min(total, want);
         c->ls.reserve(take + 1);
@@ -643,7 +739,7 @@ void reader_plain(const string path, int batch, int space_num, int workers, Chan
         if (c->ls.size() % 4) die("truncated fastq record");
         c->n = (int)(c->ls.size() / 4);
         pos += consumed;
-        if (c->n) out->push(c); else { delete c; break; }
+        if (c->n) out->push(c); else { RawChunk::put(c); break; }
     }
     out->close();                                        // the mapping stays until exit: chunks point into it
     close(fd);
@@ -698,25 +794,56 @@ void gzip_member(const string &in, string &out) {
 }
 
 struct OutFile {                                        // clean / dup output: bytes are produced by the workers
-    FILE *fp = nullptr;
+    int fd = -1;
+    off_t pos = 0;
     bool gz = false;
+    bool is_open() const { return fd >= 0; }
     void open(const string &path, bool gzip) {
-        fp = fopen(path.c_str(), "wb");
-        if (!fp) die("cannot write to the file," + path);
+        fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) die("cannot write to the file," + path);
+        pos = 0;
         gz = gzip;
+    }
+    static void put_at(int fd, const char *p, size_t n, off_t at) {
+        while (n) {
+            const ssize_t w = pwrite(fd, p, n, at);
+            if (w <= 0) die("write error (disk full?)");
+            p += w; n -= (size_t)w; at += w;
+        }
+    }
+    void write_bytes(const string &b) {
+        if (b.empty()) return;
+        put_at(fd, b.data(), b.size(), pos);
+        pos += (off_t)b.size();
+    }
+    // the pieces of one batch, in order: every piece goes to its own offset, written by the pool's threads
+    void write_parts(const std::vector<string> &parts) {
+        std::vector<off_t> at(parts.size());
+        off_t p = pos;
+        size_t total = 0;
+        for (size_t i = 0; i < parts.size(); ++i) { at[i] = p; p += (off_t)parts[i].size(); total += parts[i].size(); }
+        if (total < ((size_t)8 << 20) || parts.size() < 2) {
+            for (size_t i = 0; i < parts.size(); ++i) if (!parts[i].empty()) put_at(fd, parts[i].data(), parts[i].size(), at[i]);
+        } else {
+            const int fdc = fd;
+            parallel_for(std::min<int>(8, (int)parts.size()), (int)parts.size(), [&](int, int lo, int hi) {     // (tmpfs page allocation does not scale past a few writers)
+                for (int i = lo; i < hi; ++i) if (!parts[(size_t)i].empty()) put_at(fdc, parts[(size_t)i].data(), parts[(size_t)i].size(), at[(size_t)i]);
+            });
+        }
+        pos = p;
     }
     void write_text(const string &text) {               // serial path (dup side files): compress here if needed
         if (text.empty()) return;
-        if (!gz) { fwrite(text.data(), 1, text.size(), fp); return; }
+        if (!gz) { write_bytes(text); return; }
         string z;
         gzip_member(text, z);
-        fwrite(z.data(), 1, z.size(), fp);
+        write_bytes(z);
     }
     void close() {
-        if (!fp) return;
-        if (gz && ftell(fp) == 0) { string z; gzip_member(string(), z); fwrite(z.data(), 1, z.size(), fp); }   // valid empty .gz
-        fclose(fp);
-        fp = nullptr;
+        if (fd < 0) return;
+        if (gz && pos == 0) { string z; gzip_member(string(), z); write_bytes(z); }   // valid empty .gz
+        ::close(fd);
+        fd = -1;
     }
 };
 
@@ -886,7 +1013,13 @@ int main(int argc, char **argv) {
     std::ofstream log(o.log.c_str());
     if (!log) die("cannot open such file," + o.log);
     log << local_time() << "\tAnalysis start!" << endl;
-    const int B = o.batch_pairs, T = o.threads, WK = std::max(1, o.threads);
+    // host workers: not tied to -T (which only decides how the reference would have dealt the reads to its threads)
+    int ht = std::max(1, std::min(64, usable_cpus()));
+    if (const char *e = getenv("SNK_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) ht = v; }
+    g_host_threads = ht;
+    g_pool.start(ht);
+    g_clk.on = getenv("SNK_TIMING") != nullptr;
+    const int B = o.batch_pairs, T = o.threads, WK = ht;
     const string inputs[2] = {o.fq1, o.fq2};
     { struct stat st; for (int m = 0; m < mates; ++m) if (stat(inputs[m].c_str(), &st) != 0 || st.st_size == 0) die("cannot open file or empty file," + inputs[m]); }
     const int space_num = first_line_space_num(o.fq1);
@@ -1108,7 +1241,7 @@ int main(int argc, char **argv) {
             chunks.push_back(dh);
             chunk_n.push_back(s.n);
             nall += (uint64_t)s.n;
-            for (int m = 0; m < mates; ++m) delete c[m];
+            for (int m = 0; m < mates; ++m) RawChunk::put(c[m]);
             have = next_chunks(c);
         }
         join_readers();
@@ -1193,24 +1326,25 @@ int main(int argc, char **argv) {
         struct DupPiece { int vt; string z[2]; };            // one gzip member per (worker slice, virtual thread, mate)
         std::vector<std::vector<DupPiece>> dpieces;
         std::vector<uint64_t> dcount;
-        while (to_write.pop(sp)) {
+        for (;;) {
+            { Tick t_(7); if (!to_write.pop(sp)) break; }
             Slot &s = *sp;
-            HIPCHK(hipEventSynchronize(s.done));
+            { Tick t_(8); HIPCHK(hipEventSynchronize(s.done)); }
             if (*s.h_err != SNK_ERR_WORD_NONE) {                    // the reference exits at the offending read: nothing of this batch is written
                 snk_error err;
                 snk_error_decode(*s.h_err, &err);
                 report_device_error(err);
             }
             const int n = s.n, lcap = s.lcap;                  // (the capacity this batch was packed with)
-            for (int m = 0; m < mates; ++m) {
-                text[m].assign(WK, string()); zbuf[m].assign(WK, string());
-                ttext[m].assign(WK, string()); tzbuf[m].assign(WK, string());
-                recoff[m].assign(WK, std::vector<uint32_t>());
+            for (int m = 0; m < mates; ++m) {               // (buffers keep their capacity from batch to batch: no page faults after the first)
+                text[m].resize(WK); zbuf[m].resize(WK); ttext[m].resize(WK); tzbuf[m].resize(WK); recoff[m].resize(WK);
+                for (int w = 0; w < WK; ++w) { text[m][w].clear(); zbuf[m][w].clear(); ttext[m][w].clear(); tzbuf[m][w].clear(); recoff[m][w].clear(); }
             }
             dpieces.assign(WK, std::vector<DupPiece>());
             dcount.assign(WK, 0);
             kcount.assign(WK, 0);
             // clean output, input order (src/peprocess.cpp:3383-3484): every worker formats (and deflates) a slice
+            const long long t_fmt0 = g_clk.on ? StageClock::now() : 0;
             parallel_for(WK, n, [&](int w, int lo, int hi) {
                 // one record of mate m in output form; pe_times: how often preOutput ran on the object
                 // (twice for clean reads when the trim files are on)
@@ -1302,6 +1436,8 @@ int main(int argc, char **argv) {
                     flush_piece();
                 }
             });
+            if (g_clk.on) g_clk.ns[9] += StageClock::now() - t_fmt0;
+            Tick t_write_(10);
             for (int w = 0; w < WK; ++w) clean_total += kcount[w];
             if (o.streaming) {
                 // output_fastqs("1", ...), output_fastqs("2", ...), then the thread's statistics (src/peprocess.cpp:1952-1976);
@@ -1314,18 +1450,14 @@ int main(int argc, char **argv) {
                 fwrite(st.data(), 1, st.size(), stdout);
                 fflush(stdout);
             } else if (!cut_mode) {
-                for (int m = 0; m < mates; ++m)
-                    for (int w = 0; w < WK; ++w) {
-                        const string &bytes = wr[m].gz ? zbuf[m][w] : text[m][w];
-                        if (!bytes.empty()) fwrite(bytes.data(), 1, bytes.size(), wr[m].fp);
-                    }
+                for (int m = 0; m < mates; ++m) wr[m].write_parts(wr[m].gz ? zbuf[m] : text[m]);
             } else {
                 for (int w = 0; w < WK; ++w) {
                     const size_t kept = recoff[0][w].size();
                     size_t pos = 0;
                     while (pos < kept) {
                         if (head_n && clean_written >= head_n) break;
-                        if (split_n && !wr[0].fp) open_clean(split_idx);        // the first split file appears with the first clean read
+                        if (split_n && !wr[0].is_open()) open_clean(split_idx);        // the first split file appears with the first clean read
                         const uint64_t room = split_n ? split_n - in_split : head_n - clean_written;
                         const size_t take = (size_t)std::min<uint64_t>(room, kept - pos);
                         for (int m = 0; m < mates; ++m) {
@@ -1340,19 +1472,15 @@ int main(int argc, char **argv) {
                 }
             }
             if (trim_out)
-                for (int m = 0; m < mates; ++m)
-                    for (int w = 0; w < WK; ++w) {
-                        const string &bytes = trimw[m].gz ? tzbuf[m][w] : ttext[m][w];
-                        if (!bytes.empty()) fwrite(bytes.data(), 1, bytes.size(), trimw[m].fp);
-                    }
+                for (int m = 0; m < mates; ++m) trimw[m].write_parts(trimw[m].gz ? tzbuf[m] : ttext[m]);
             if (rmdup_on)
                 for (int w = 0; w < WK; ++w) {                 // worker order = input order within every side file
                     for (const DupPiece &pc : dpieces[w])
-                        for (int m = 0; m < mates; ++m) fwrite(pc.z[m].data(), 1, pc.z[m].size(), dupw[m][pc.vt].fp);
+                        for (int m = 0; m < mates; ++m) dupw[m][pc.vt].write_bytes(pc.z[m]);
                     ndup_written += dcount[w];
                 }
             log << local_time() << " processed_reads:\t" << s.first + (uint64_t)n << endl;
-            for (int m = 0; m < mates; ++m) { delete s.raw[m]; s.raw[m] = nullptr; }
+            for (int m = 0; m < mates; ++m) { RawChunk::put(s.raw[m]); s.raw[m] = nullptr; }
             devs[(size_t)s.dev].free_slots->push(sp);
         }
     });
@@ -1364,11 +1492,13 @@ int main(int argc, char **argv) {
         Dev &dv = devs[(size_t)(batch_no++ % (uint64_t)G)];   // batches go round the devices; the writer keeps input order
         HIPCHK(hipSetDevice(dv.id));
         Slot *sp;
-        dv.free_slots->pop(sp);
+        { Tick t_(4); dv.free_slots->pop(sp); }
         sp->n = c[0]->n;
         sp->first = total;
         sp->raw[0] = c[0]; sp->raw[1] = c[1];
-        if (!pack(*sp, true)) {
+        bool packed;
+        { Tick t_(5); packed = pack(*sp, true); }
+        if (!packed) {
             // a read longer than every read before it (the reference takes any read up to 1000 nt at any
             // position): drain the pipeline, close the epoch, rebuild contexts and slots with the new capacity
             dv.free_slots->push(sp);
@@ -1445,7 +1575,7 @@ int main(int argc, char **argv) {
         HIPCHK(hipEventRecord(s.done, s.stream));
         to_write.push(sp);
         total += (uint64_t)n;
-        have = next_chunks(c);
+        { Tick t_(3); have = next_chunks(c); }
     }
     to_write.close();
     writer.join();
@@ -1491,6 +1621,7 @@ int main(int argc, char **argv) {
     o.p.max_read_len = lfin;
     if (snk_write_reports(&o.p, T, sp.data(), mp.data(), o.out_dir.c_str(), ebuf, sizeof ebuf) != 0) { cerr << ebuf << endl; return 1; }
     log << local_time() << "\tAnalysis accomplished!" << endl;
+    g_clk.report();
     teardown();
     return 0;
 }

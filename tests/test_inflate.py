@@ -17,7 +17,7 @@ SRC = os.path.join(T.ROOT, "tools", "micro", "inflate_test.cpp")
 @pytest.fixture(scope="module")
 def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("inf") / "inflate_test")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", out, SRC, "-lz"])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, SRC, "-lz"])
     return out
 
 
@@ -50,6 +50,10 @@ def test_identical_to_zlib(exe, tmp_path):
         for chunk in ("4194304", "777"):                                          # big blocks; tiny blocks = careful path + cut matches
             r = subprocess.run([exe, p, chunk], capture_output=True)
             assert r.returncode == 0 and b"IDENTICAL" in r.stdout, (name, chunk, r.stdout[-200:])
+        # the parallel decoder (snk_pgunzip.h): 64 KiB chunks = dozens of block-start searches / marker chunks per file
+        for threads, cb in (("4", "65536"), ("3", "300000")):
+            r = subprocess.run([exe, p, "1000000", "par", threads, cb], capture_output=True)
+            assert r.returncode == 0 and b"IDENTICAL" in r.stdout, (name, threads, cb, r.stdout[-200:])
 
 
 def test_damaged_streams_are_errors(exe, tmp_path):
@@ -65,3 +69,26 @@ def test_damaged_streams_are_errors(exe, tmp_path):
         open(p, "wb").write(blob)
         r = subprocess.run([exe, p, "65536"], capture_output=True)
         assert r.returncode == 2 and b"ERROR" in r.stdout, (name, r.stdout[-200:])
+        r = subprocess.run([exe, p, "65536", "par", "4", "65536"], capture_output=True)
+        assert r.returncode == 2 and b"ERROR" in r.stdout, (name, "par", r.stdout[-200:])
+
+
+def test_parallel_decoder_on_a_long_stream(exe, tmp_path):
+    """one 60 MB FASTQ stream (levels 1 / 6 / 9, and cut into three members): every chunk size, more chunks than threads,
+    member ends inside chunks; the output is what zlib produces, CRC-32 and ISIZE of every member hold"""
+    raw = _fastq_bytes(180000)
+    blobs = {"l1": gzip.compress(raw, 1), "l6": gzip.compress(raw, 6), "l9": gzip.compress(raw, 9),
+             "three": gzip.compress(raw[:7_000_000], 6) + gzip.compress(raw[7_000_000:7_000_100], 9) + gzip.compress(raw[7_000_100:], 2)}
+    for name, blob in blobs.items():
+        p = str(tmp_path / (name + ".gz"))
+        open(p, "wb").write(blob)
+        for threads, cb in (("8", "65536"), ("4", "1000000"), ("2", "4194304")):
+            r = subprocess.run([exe, p, "4194304", "par", threads, cb], capture_output=True)
+            assert r.returncode == 0 and b"IDENTICAL" in r.stdout, (name, threads, cb, r.stdout[-200:])
+    # a flipped bit in the middle of the long stream is an error (CRC at the latest), never silent garbage
+    bad = bytearray(blobs["l6"])
+    bad[len(bad) // 2] ^= 0x10
+    p = str(tmp_path / "bad.gz")
+    open(p, "wb").write(bytes(bad))
+    r = subprocess.run([exe, p, "4194304", "par", "4", "1000000"], capture_output=True)
+    assert r.returncode == 2 and b"ERROR" in r.stdout, r.stdout[-200:]

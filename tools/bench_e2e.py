@@ -1,0 +1,134 @@
+"""End to end, like for like: this repo's `SOAPnuke filter` and the compiled reference binary on the SAME
+FASTQ files in /dev/shm, whole-process wall clock, BASELINE configs[1] parameters (`-f/-r README adapters -J -l 10 -q 0.1`).
+
+    python tools/bench_e2e.py [pairs] [threads] [modes] [--keep]
+
+modes: comma list of plain,gz (input and output of the same kind; default both).  Prints one JSON object (also written to
+gpurun_out/e2e_<pairs>.json): Mreads/s of both tools per mode, byte-identity of the decompressed clean FASTQ, and the
+host configuration.  The reference is given `.gz` input in gz mode only; in plain mode with more than one merge cycle of
+reads it loses a patch -- its wall clock is still what it is, but its output is then not compared.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from soapnuke_amd import synth  # noqa: E402
+
+OURS = os.path.join(ROOT, "soapnuke_amd", "SOAPnuke")
+REF = os.path.join(ROOT, "oracle", "_ref", "SOAPnuke")
+
+
+def md5_of(path):
+    """md5 of the (decompressed) bytes"""
+    h = hashlib.md5()
+    if path.endswith(".gz"):
+        p = subprocess.Popen(["gzip", "-dc", path], stdout=subprocess.PIPE)
+        src = p.stdout
+    else:
+        p, src = None, open(path, "rb")
+    while True:
+        b = src.read(1 << 24)
+        if not b:
+            break
+        h.update(b)
+    if p:
+        p.wait()
+    return h.hexdigest()
+
+
+def make_inputs(tmp, n, modes):
+    d = synth.make_batch(min(n, 1_000_000), 150, paired=True)
+    f = [os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")]
+    u = d["n"]
+    t0 = time.time()
+    for k in range((n + u - 1) // u):
+        cnt = min(u, n - k * u)
+        for m in range(2):
+            part = f[m] + ".part"
+            synth.write_fastq(part, d["seq"][m][:cnt], d["qual"][m][:cnt], 150, m + 1, first_index=k * u)
+            with open(f[m], "ab") as out, open(part, "rb") as src:
+                while True:
+                    b = src.read(1 << 26)
+                    if not b:
+                        break
+                    out.write(b)
+            os.unlink(part)
+    t1 = time.time()
+    if "gz" in modes:      # ONE gzip member per file (what `gzip` makes of a FASTQ), both files at once
+        ps = [subprocess.Popen(["gzip", "-1", "-k", x]) for x in f]
+        for p in ps:
+            assert p.wait() == 0
+    return f, t1 - t0, time.time() - t1
+
+
+def run(exe, inputs, out_dir, ext, threads, env=None):
+    args = ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-l", "10", "-q", "0.1", "-T", str(threads)]
+    t0 = time.time()
+    r = subprocess.run([exe, "filter", "-1", inputs[0], "-2", inputs[1], "-C", "c1" + ext, "-D", "c2" + ext, "-o", out_dir] + args,
+                       capture_output=True, env=env)
+    return time.time() - t0, r
+
+
+def measure(tmp, n, T, modes):
+    res = {"pairs": n, "read_len": 150, "threads_T": T, "host_cores": os.cpu_count(),
+           "params": "-f/-r README adapters -J -l 10 -q 0.1", "where": "/dev/shm", "modes": {}}
+    if True:
+        f, t_gen, t_gz = make_inputs(tmp, n, modes)
+        res["generate_s"] = round(t_gen, 1)
+        res["gzip_inputs_s"] = round(t_gz, 1)
+        for mode in modes:
+            ext = ".fq.gz" if mode == "gz" else ".fq"
+            inputs = [x + ".gz" for x in f] if mode == "gz" else f
+            entry = {}
+            for name, exe in (("ours", OURS), ("reference", REF)):
+                if not os.path.exists(exe):
+                    continue
+                o = os.path.join(tmp, f"{name}_{mode}")
+                w, r = run(exe, inputs, o, ext, T)
+                entry[name] = {"wall_s": round(w, 2), "Mreads_per_s": round(2 * n / w / 1e6, 3), "rc": r.returncode}
+                if r.returncode != 0:
+                    entry[name]["stderr"] = r.stderr[-300:].decode(errors="replace")
+                print(f"{name:10s} {mode:5s} {n} pairs: {w:7.2f} s  {2 * n / w / 1e6:8.3f} Mreads/s  rc {r.returncode}", file=sys.stderr, flush=True)
+            if "ours" in entry and "reference" in entry and entry["ours"]["rc"] == 0 and entry["reference"]["rc"] == 0:
+                entry["speedup"] = round(entry["reference"]["wall_s"] / entry["ours"]["wall_s"], 2)
+                # the reference's plain-input runs drop a patch past one merge cycle (Q10): compare only what is comparable
+                comparable = mode == "gz" or n <= 6_000_000
+                if comparable:
+                    same = all(md5_of(os.path.join(tmp, f"ours_{mode}", c + ext)) == md5_of(os.path.join(tmp, f"reference_{mode}", c + ext))
+                               for c in ("c1", "c2"))
+                    entry["clean_fastq_identical"] = same
+                    rep = "Basic_Statistics_of_Sequencing_Quality.txt"
+                    entry["report_identical"] = open(os.path.join(tmp, f"ours_{mode}", rep), "rb").read() == \
+                        open(os.path.join(tmp, f"reference_{mode}", rep), "rb").read()
+            for name in ("ours", "reference"):
+                subprocess.call(["rm", "-rf", os.path.join(tmp, f"{name}_{mode}")])
+            res["modes"][mode] = entry
+    return res
+
+
+def main():
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(argv[0]) if len(argv) > 0 else 16_000_000
+    T = int(argv[1]) if len(argv) > 1 else 16
+    modes = (argv[2] if len(argv) > 2 else "plain,gz").split(",")
+    tmp = tempfile.mkdtemp(prefix="snke2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        res = measure(tmp, n, T, modes)
+    finally:
+        if "--keep" not in sys.argv:
+            subprocess.call(["rm", "-rf", tmp])
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, f"e2e_{n}.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,7 @@
 #include <unistd.h>
 #include <vector>
 #include "../../soapnuke_amd/host/snk_inflate.h"
+#include "../../soapnuke_amd/host/snk_pgunzip.h"
 static double now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 int main(int argc, char **argv) {
     const char *path = argv[1];
@@ -27,6 +28,25 @@ int main(int argc, char **argv) {
     int fd = open(path, O_RDONLY);
     struct stat st; fstat(fd, &st);
     const uint8_t *in = (const uint8_t *)mmap(NULL, st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (argc > 3 && !strcmp(argv[3], "par")) {           // ./inflate_test file.gz <out block> par <threads> <chunk bytes>
+        const int threads = argc > 4 ? atoi(argv[4]) : 4;
+        const size_t cb = argc > 5 ? (size_t)atol(argv[5]) : (size_t)4 << 20;
+        double a = now();
+        snk::ParallelGunzip pz(in, st.st_size, threads, cb);
+        std::vector<uint8_t> got, blk(chunk);
+        got.reserve(ref.size());
+        for (;;) {
+            const size_t n = pz.run(blk.data(), chunk);
+            got.insert(got.end(), blk.begin(), blk.begin() + n);
+            if (pz.error()) { printf("ERROR %s after %zu bytes\n", pz.error(), got.size()); return 2; }
+            if (n == 0 && pz.done()) break;
+        }
+        double b = now();
+        const bool same = got.size() == ref.size() && memcmp(got.data(), ref.data(), ref.size()) == 0;
+        printf("%s: %zu -> %zu bytes  %s  zlib %.3fs (%.0f MB/s)  parallel(%d) %.3fs (%.0f MB/s)\n", path, (size_t)st.st_size, ref.size(),
+               same ? "IDENTICAL" : "DIFFERENT", t1 - t0, ref.size() / (t1 - t0) / 1e6, threads, b - a, ref.size() / (b - a) / 1e6);
+        return same ? 0 : 1;
+    }
     snk::GzipInflate z;
     z.init(in, st.st_size);
     // output through a sliding buffer [HIST | chunk], as the reader does
