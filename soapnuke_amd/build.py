@@ -37,7 +37,7 @@ REPORT_LIB = os.path.join(HERE, "libsnk_report.so")
 def build_host(force=False, verbose=False):
     """The C++ host side: report writer library (plain g++) and the `SOAPnuke filter` CLI (links the
     C-ABI library with an $ORIGIN rpath)."""
-    srcs = [os.path.join(HOST, f) for f in ("snk_main.cpp", "snk_report.cpp", "snk_report.h", "snk_inflate.h", "snk_pgunzip.h")]
+    srcs = [os.path.join(HOST, f) for f in ("snk_main.cpp", "snk_report.cpp", "snk_report.h", "snk_inflate.h", "snk_pgunzip.h", "snk_deflate.h")]
     newest = max(os.path.getmtime(f) for f in srcs + [LIB])
     if force or not os.path.exists(REPORT_LIB) or os.path.getmtime(REPORT_LIB) < newest:
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", REPORT_LIB, "snk_report.cpp"]

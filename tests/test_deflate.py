@@ -1,0 +1,57 @@
+"""The CLI's own gzip encoder (soapnuke_amd/host/snk_deflate.h): whatever it writes must decompress -- with zlib and with
+this repo's decoder -- to exactly the input, for every kind of data and every slice size (one gzip member per slice, as
+the writer threads produce them).  Pure host code, no GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import snk_testlib as T
+from test_inflate import _fastq_bytes
+
+SRC = os.path.join(T.ROOT, "tools", "micro", "deflate_test.cpp")
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("defl") / "deflate_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", out, SRC, "-lz"])
+    return out
+
+
+def test_round_trip_all_kinds(exe, tmp_path):
+    raw = _fastq_bytes(40000)
+    rng = np.random.default_rng(4)
+    binned = bytearray(raw)
+    files = {
+        "fastq": raw,
+        "random": rng.integers(0, 256, 1_500_000, dtype=np.uint8).tobytes(),
+        "runs": b"A" * 700_000 + b"ACGT" * 100_000 + bytes(range(256)) * 300 + b"F" * 300_000,
+        "empty": b"",
+        "one": b"x",
+        "tiny": b"@r\nACGT\n+\nIIII\n",
+        "two_symbols": b"ab" * 5000,                       # a distance code with a single symbol
+        "skewed": bytes(rng.choice(256, 600_000, p=np.array([0.5 ** min(i + 1, 40) for i in range(256)]) / sum(0.5 ** min(i + 1, 40) for i in range(256))).astype(np.uint8)),  # code lengths past 15: the limiter
+        "zeros": bytes(2_000_000),
+    }
+    for name, blob in files.items():
+        p = str(tmp_path / name)
+        open(p, "wb").write(blob)
+        for slice_bytes in ("0", "1000003", "65536", "4099"):
+            if slice_bytes != "0" and len(blob) > 3_000_000 and slice_bytes == "4099":
+                continue
+            r = subprocess.run([exe, p] + ([slice_bytes] if slice_bytes != "0" else []), capture_output=True)
+            assert r.returncode == 0 and b"ROUNDTRIP_OK" in r.stdout, (name, slice_bytes, r.stdout[-300:])
+
+
+def test_ratio_is_in_zlib_low_level_territory(exe, tmp_path):
+    raw = _fastq_bytes(60000)
+    p = str(tmp_path / "fq")
+    open(p, "wb").write(raw)
+    r = subprocess.run([exe, p, "2000000"], capture_output=True)
+    assert r.returncode == 0, r.stdout[-300:]
+    txt = r.stdout.decode()
+    ours = int(txt.split("->")[1].split("bytes")[0])
+    zl = int(txt.split("zlib -2:")[1].split(")")[0])
+    assert ours < 1.03 * zl, (ours, zl)
