@@ -120,29 +120,24 @@ __device__ inline int has_contam_seq(const uint8_t *s, int len, const DevContam 
 // a dead window can never pass the hit test.
 struct GcWindow { int score, span; };
 
-__device__ inline int gc_next(const unsigned long long (&e)[4], int pos, int n, bool ones) {   // first cell >= pos that is a match (ones) / a mismatch, n if none
-    while (pos < n) {
-        const int w = pos >> 6;
-        unsigned long long x = ones ? e[w] : ~e[w];
-        x &= ~0ull << (pos & 63);
-        if (x) { const int p = (w << 6) + __ffsll((long long)x) - 1; return p < n ? p : n; }
-        pos = (w + 1) << 6;
-    }
-    return n;
-}
-
-// one lay of n cells: cell j compares a[j] with b[j].  early_stop: sections 1 and 2 (a dead window meeting a cell with
-// fewer than mml cells left abandons the lay); otherwise section 3 (a mismatch there abandons it, a match opens the
-// window first).  True = hit.
-__device__ inline bool gc_lay(GcWindow &st, const uint8_t *a, const uint8_t *b, int n, int mml, int tms, int lower, bool early_stop) {
-    if (n <= 0) return false;
-    unsigned long long e[4] = {0, 0, 0, 0};
-    for (int j = 0; j < n; ++j) e[j >> 6] |= (unsigned long long)(a[j] == b[j]) << (j & 63);
+// the event walk over one lay whose equality bits are given by word(w) (64 cells each)
+template <class WordFn>
+__device__ inline bool gc_walk(GcWindow &st, WordFn word, int n, int mml, int tms, int lower, bool early_stop) {
+    auto next = [&](int pos, bool ones) -> int {         // first cell >= pos that is a match (ones) / a mismatch, n if none
+        while (pos < n) {
+            const int w = pos >> 6;
+            unsigned long long x = ones ? word(w) : ~word(w);
+            x &= ~0ull << (pos & 63);
+            if (x) { const int p = (w << 6) + __ffsll((long long)x) - 1; return p < n ? p : n; }
+            pos = (w + 1) << 6;
+        }
+        return n;
+    };
     const int last_ok = n - mml;                 // cells j <= last_ok still have mml cells of the lay in front of them
     int pos = 0;
     while (pos < n) {
         if (st.score > tms) {                    // live window
-            const int z = gc_next(e, pos, n, false);
+            const int z = next(pos, false);
             const int run = z - pos;
             if (run > 0) {
                 const int need = max(max(lower - st.score, mml - st.span), 1);     // matches until the hit test passes
@@ -157,7 +152,7 @@ __device__ inline bool gc_lay(GcWindow &st, const uint8_t *a, const uint8_t *b, 
             if (st.score >= lower && st.span >= mml) return true;
             ++pos;
         } else {                                 // dead: nothing happens until the next match
-            const int o = gc_next(e, pos, n, true);
+            const int o = next(pos, true);
             if (o >= n) break;
             if (early_stop) {
                 if (o > last_ok) break;
@@ -172,6 +167,28 @@ __device__ inline bool gc_lay(GcWindow &st, const uint8_t *a, const uint8_t *b, 
         }
     }
     return false;
+}
+
+// one lay of n cells: cell j compares a[j] with b[j].  early_stop: sections 1 and 2 (a dead window meeting a cell with
+// fewer than mml cells left abandons the lay); otherwise section 3 (a mismatch there abandons it, a match opens the
+// window first).  True = hit.
+__device__ inline bool gc_lay(GcWindow &st, const uint8_t *a, const uint8_t *b, int n, int mml, int tms, int lower, bool early_stop) {
+    if (n <= 0) return false;
+    if (n <= 64) {                               // the usual case: one word, all in registers
+        unsigned lo = 0, hi = 0;
+        const int n0 = min(n, 32);
+        for (int j = 0; j < n0; ++j) lo |= (unsigned)(a[j] == b[j]) << j;
+        for (int j = 32; j < n; ++j) hi |= (unsigned)(a[j] == b[j]) << (j - 32);
+        const unsigned long long e = ((unsigned long long)hi << 32) | lo;
+        return gc_walk(st, [&](int) { return e; }, n, mml, tms, lower, early_stop);
+    }
+    unsigned long long e0 = 0, e1 = 0, e2 = 0, e3 = 0;       // contaminants of up to 255 characters
+    for (int j = 0; j < n; ++j) {
+        const unsigned long long bit = (unsigned long long)(a[j] == b[j]) << (j & 63);
+        const int w = j >> 6;
+        e0 |= w == 0 ? bit : 0ull; e1 |= w == 1 ? bit : 0ull; e2 |= w == 2 ? bit : 0ull; e3 |= w == 3 ? bit : 0ull;
+    }
+    return gc_walk(st, [&](int w) { return w == 0 ? e0 : (w == 1 ? e1 : (w == 2 ? e2 : e3)); }, n, mml, tms, lower, early_stop);
 }
 
 __device__ inline bool global_contam_hit(const uint8_t *ref, int rl, const uint8_t *gc, int cl, int mml, int mmn) {

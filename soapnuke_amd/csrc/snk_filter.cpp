@@ -231,6 +231,8 @@ struct snk_ctx {
     void *ts_stream[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ts_used[8] = {false, false, false, false, false, false, false, false};
     unsigned ts_next = 0;
+    unsigned char *d_cf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // contaminant verdicts, per stream slot
+    size_t cf_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool own_stats = false;
     // staging for the host-pointer entry point
     uint8_t *st_buf = nullptr;
@@ -453,6 +455,7 @@ void snk_destroy(snk_ctx *c) {
     if (c->d_ct) (void)hipFree(c->d_ct);
     if (c->d_gct) (void)hipFree(c->d_gct);
     if (c->d_tsw) (void)hipFree(c->d_tsw);
+    for (int k = 0; k < 8; ++k) if (c->d_cf[k]) (void)hipFree(c->d_cf[k]);
 
     if (c->st_buf) (void)hipFree(c->st_buf);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -559,16 +562,22 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         c->ts_used[slot] = true;
         c->ts_stream[slot] = stream;
         st.tsw = c->d_tsw + (size_t)slot * c->n_cu * 4 * SNK_TS_N;
-        unsigned char *d_cf = nullptr;
         if ((c->hp.n_ct[0] | c->hp.n_ct[1] | c->hp.n_gct) && c->hp.tile_ok && c->lcap <= 256) {
-            // contaminant screening: the sequential matchers run as their own pass, the tiled kernel
-            // consumes the verdicts (stream-ordered scratch)
-            HIP_OK(hipMallocAsync((void **)&d_cf, (size_t)b->n, s));
-            snk_launch_contam(c->d_params, D, d_cf, stream);
-            D.cf = d_cf;
+            // contaminant screening: the matchers run as their own pass, the tiled kernel consumes the verdicts.
+            // One verdict buffer per launching stream (like the trimming-position counters), grown on demand and kept.
+            if ((size_t)b->n > c->cf_cap[slot]) {
+                HIP_OK(hipStreamSynchronize(s));              // (nothing of this stream may still read the old buffer)
+                if (c->d_cf[slot]) (void)hipFree(c->d_cf[slot]);
+                c->d_cf[slot] = nullptr;
+                c->cf_cap[slot] = 0;
+                const size_t cap = ((size_t)b->n + 65535) & ~(size_t)65535;
+                HIP_OK(hipMalloc((void **)&c->d_cf[slot], cap));
+                c->cf_cap[slot] = cap;
+            }
+            snk_launch_contam(c->d_params, D, c->d_cf[slot], stream);
+            D.cf = c->d_cf[slot];
         }
         done = snk_launch_tiled(c->hp, c->ta, D, st, c->lcap, c->nq, c->n_cu, stream);
-        if (d_cf) HIP_OK(hipFreeAsync(d_cf, s));
         D.cf = nullptr;
         if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return SNK_E_UNSUPPORTED; }
     }

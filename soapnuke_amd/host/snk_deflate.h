@@ -21,6 +21,10 @@
 #include <string>
 #include <vector>
 
+#ifndef SNK_DEFLATE_MISS_SHIFT
+#define SNK_DEFLATE_MISS_SHIFT 4      // the scan strides by 1 + misses / 2^shift
+#endif
+
 namespace snk {
 
 class FastDeflate {
@@ -350,7 +354,7 @@ private:
             }
             // no match here: after 16 misses in a row the scan starts to stride (random-looking stretches -- bases,
             // unbinned qualities -- cost a fraction of a probe per byte; the next hit resets the stride)
-            i += 1 + (miss++ >> 4);
+            i += 1 + (miss++ >> SNK_DEFLATE_MISS_SHIFT);
             if (i - lit_from >= LIT_FLUSH) {
                 const size_t upto = std::min(i, safe);
                 literals(upto);

@@ -67,8 +67,16 @@ def make_inputs(tmp, n, modes):
     return f, t1 - t0, time.time() - t1
 
 
+C3 = False      # --c3: BASELINE configs[2] parameters (full trim + filter) instead of configs[1]'s
+
+
 def run(exe, inputs, out_dir, ext, threads, env=None):
     args = ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-l", "10", "-q", "0.1", "-T", str(threads)]
+    if C3:
+        cfg = os.path.join(os.path.dirname(inputs[0]), "c3.cfg")
+        with open(cfg, "w") as fh:
+            fh.write("trimBadTail=20,30\n")
+        args += ["-n", "0.01", "-m", "20", "-g", "10", "-X", "50", "-p", "0.8", "-c", cfg]
     t0 = time.time()
     r = subprocess.run([exe, "filter", "-1", inputs[0], "-2", inputs[1], "-C", "c1" + ext, "-D", "c2" + ext, "-o", out_dir] + args,
                        capture_output=True, env=env)
@@ -77,7 +85,8 @@ def run(exe, inputs, out_dir, ext, threads, env=None):
 
 def measure(tmp, n, T, modes):
     res = {"pairs": n, "read_len": 150, "threads_T": T, "host_cores": os.cpu_count(),
-           "params": "-f/-r README adapters -J -l 10 -q 0.1", "where": "/dev/shm", "modes": {}}
+           "params": "-f/-r README adapters -J -l 10 -q 0.1" + (" -n 0.01 -m 20 -g 10 -X 50 -p 0.8 + trimBadTail=20,30 (configs[2])" if C3 else ""),
+           "where": "/dev/shm", "modes": {}}
     if True:
         f, t_gen, t_gz = make_inputs(tmp, n, modes)
         res["generate_s"] = round(t_gen, 1)
@@ -113,6 +122,8 @@ def measure(tmp, n, T, modes):
 
 
 def main():
+    global C3
+    C3 = "--c3" in sys.argv
     argv = [a for a in sys.argv[1:] if not a.startswith("--")]
     n = int(argv[0]) if len(argv) > 0 else 16_000_000
     T = int(argv[1]) if len(argv) > 1 else 16
@@ -125,7 +136,7 @@ def main():
             subprocess.call(["rm", "-rf", tmp])
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, f"e2e_{n}.json"), "w") as fh:
+    with open(os.path.join(out, f"e2e_{n}{'_c3' if C3 else ''}.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res))
 

@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+CMD="python $ROOT/bench.py --steps 20 --warmup 4 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o tiled -- $CMD > "$OUT/bench_trace.log" 2>&1
 i=0
 for pmc in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_FLAT SQ_INSTS_BRANCH SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_SMEM" \
