@@ -60,6 +60,10 @@ using namespace snk;
 #ifndef SNK_ORDER
 #define SNK_ORDER 1
 #endif
+// wave priorities of phase 1 / hand-over / adapter search + pair level / phase 3, as a 4-digit number (tools/ab.sh experiments)
+#ifndef SNK_PRIO
+#define SNK_PRIO 3210
+#endif
 #if SNK_ORDER
 #define SNK_TILE_OF(w) ((long)blockIdx.x * Wc + (long)(w))
 #else
@@ -722,7 +726,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         // Wave priorities follow the phases (3 = phase 1 ... 0 = phase 3): the 16 waves of a CU are spread over all
         // phases, and the arbiter's default (oldest first) lets the ALU-dense phases of some waves starve the LDS
         // round trips of the waves in phase 1.  Phase 1 first, phase 3 last: 3.78 -> 3.36 ms.
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio((SNK_PRIO / 1000) % 10);
         if (cnt == 64) {
             if (fulllen) run_phase1(std::true_type{}, std::true_type{});
             else run_phase1(std::false_type{}, std::true_type{});
@@ -734,7 +738,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             if (nocts < 4) { bad0 = badv << (8 * (4 - nocts)); badv = 0; }
             else if (nocts > 4 && nocts < 8) badv <<= 8 * (8 - nocts);
         }
-        __builtin_amdgcn_s_setprio(2);            // hand-over, planes, fix-up
+        __builtin_amdgcn_s_setprio((SNK_PRIO / 100) % 10);            // hand-over, planes, fix-up
         // ------------------------------------------------------------ hand-over: lane = 4 positions -> lane = read
         ReadState R;
         rs_init(R, clen_v);
@@ -1014,7 +1018,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             }
             if (SNK_ABL != 9 && P.has_polyG) polyg = run_down<NW>(FG, R.len);     // src/read_filter.cpp:472-482
         }
-        __builtin_amdgcn_s_setprio(1);            // adapter search, trimming, pair level
+        __builtin_amdgcn_s_setprio((SNK_PRIO / 10) % 10);            // adapter search, trimming, pair level
         const bool good = lanev && !estat;
         int ada_pos = -1;
         const int nada = P.n_ada[m];
@@ -1108,7 +1112,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         const uint8_t *seq = B.seq[m], *qual = B.qual[m];
         u32 *remB = lds + (m * 2 + 1) * G.SET, *remQ = remB + G.WB;
         u64 *gbs = fcl + SNK_GS_N, *gqs = fcl + SNK_GS_N + (long)G.lcap * 5;
-        __builtin_amdgcn_s_setprio(0);            // phase 3
+        __builtin_amdgcn_s_setprio(SNK_PRIO % 10);            // phase 3
         const bool modl = live && (reason != SNK_KEEP || R.clen != R.len);
         u64 mod = __ballot(modl);
         if (SNK_ABL == 3 || !mod) continue;

@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <zlib.h>
+#include "snk_crc32.h"
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -44,7 +45,7 @@ public:
         bitcnt_ = 0;
         deflate_all(in, n);
         flush_bits();
-        const uint32_t crc = (uint32_t)crc32_z(0, in, n), isz = (uint32_t)n;
+        const uint32_t crc = snk::crc32_fast(0, in, n), isz = (uint32_t)n;
         for (int i = 0; i < 4; ++i) *op_++ = (uint8_t)(crc >> (8 * i));
         for (int i = 0; i < 4; ++i) *op_++ = (uint8_t)(isz >> (8 * i));
         out.resize(at + (size_t)(op_ - p));
@@ -250,23 +251,39 @@ private:
             else if (s == 18) put(cl_ext[i], 7);
             drain();
         }
-        // the symbols: a literal is at most 15 bits (three per drain), a match at most 15 + 5 + 15 + 13 = 48 bits
+        // the symbols: a match is at most 15 + 5 + 15 + 13 = 48 bits; literals go out K per drain, K * (longest literal
+        // code) + 7 <= 64: five at a time when no literal code is longer than 11 bits (FASTQ: the rule), else three
         uint32_t le[256];                                  // literal -> code | length << 16
-        for (int c = 0; c < 256; ++c) le[c] = (uint32_t)lc[c] | ((uint32_t)ll[c] << 16);
+        int maxlit = 0;
+        for (int c = 0; c < 256; ++c) { le[c] = (uint32_t)lc[c] | ((uint32_t)ll[c] << 16); maxlit = std::max<int>(maxlit, ll[c]); }
+        const bool five = maxlit <= 11;
         for (int i = 0; i < nsym; ++i) {
             const Sym s = syms_[i];
             if (s.dist == 0) {
                 const uint8_t *p = src, *const end = src + s.litlen;
                 drain();
-                while (end - p >= 3) {
-                    const uint32_t a = le[p[0]], b = le[p[1]], c = le[p[2]];
-                    put(a & 0xFFFF, (int)(a >> 16));
-                    put(b & 0xFFFF, (int)(b >> 16));
-                    put(c & 0xFFFF, (int)(c >> 16));
-                    drain();
-                    p += 3;
+                if (five) {
+                    while (end - p >= 5) {
+                        const uint32_t a = le[p[0]], b = le[p[1]], c = le[p[2]], d = le[p[3]], e = le[p[4]];
+                        put(a & 0xFFFF, (int)(a >> 16));
+                        put(b & 0xFFFF, (int)(b >> 16));
+                        put(c & 0xFFFF, (int)(c >> 16));
+                        put(d & 0xFFFF, (int)(d >> 16));
+                        put(e & 0xFFFF, (int)(e >> 16));
+                        drain();
+                        p += 5;
+                    }
+                } else {
+                    while (end - p >= 3) {
+                        const uint32_t a = le[p[0]], b = le[p[1]], c = le[p[2]];
+                        put(a & 0xFFFF, (int)(a >> 16));
+                        put(b & 0xFFFF, (int)(b >> 16));
+                        put(c & 0xFFFF, (int)(c >> 16));
+                        drain();
+                        p += 3;
+                    }
                 }
-                while (p < end) { const uint32_t a = le[*p++]; put(a & 0xFFFF, (int)(a >> 16)); }
+                while (p < end) { const uint32_t a = le[*p++]; put(a & 0xFFFF, (int)(a >> 16)); if (bitcnt_ > 40) drain(); }
                 drain();
                 src = end;
             } else {

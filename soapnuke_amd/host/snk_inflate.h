@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <zlib.h>
+#include "snk_crc32.h"
 #include <vector>
 
 namespace snk {
@@ -124,7 +125,7 @@ protected:
     void account(uint8_t *out) {
         const size_t n = (size_t)(out - acc_from_);
         if (n) {
-            if (verify_crc_) crc_ = (uint32_t)crc32(crc_, acc_from_, (uInt)n);
+            if (verify_crc_) crc_ = snk::crc32_fast(crc_, acc_from_, n);
             member_out_ += n;
             total_out_ += n;
         }

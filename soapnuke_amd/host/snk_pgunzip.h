@@ -411,13 +411,13 @@ private:
             if (z.error()) return;
             size_t from = 0;                                // pieces: cut at the member ends reported for this call
             for (const auto &e : z.member_ends()) {
-                crc = (uint32_t)crc32_z(crc, base + pos + from, e.out_off - from);
+                crc = snk::crc32_fast(crc, base + pos + from, e.out_off - from);
                 c.pieces.push_back(Piece{(uint64_t)(pos + e.out_off - piece_from), crc, true, e.crc, e.isize});
                 crc = 0;
                 piece_from = pos + e.out_off;
                 from = e.out_off;
             }
-            crc = (uint32_t)crc32_z(crc, base + pos + from, got - from);
+            crc = snk::crc32_fast(crc, base + pos + from, got - from);
             pos += got;
             if (z.stopped()) {
                 if (z.bitpos() == stop) break;
@@ -450,7 +450,7 @@ private:
             const uint16_t v = M[k];
             base[k] = v < 256 ? (uint8_t)v : w[v - 256];
         }
-        c.crc_front = (uint32_t)crc32_z(0, base, c.mlen);
+        c.crc_front = snk::crc32_fast(0, base, c.mlen);
         give(c.M);
         std::vector<uint8_t>().swap(c.win);
     }
@@ -618,11 +618,11 @@ private:
             if (sq_.error()) { fail(sq_.error()); return 0; }
             size_t from = 0;
             for (const auto &e : sq_.member_ends()) {
-                add_piece((uint32_t)crc32_z(0, p + from, e.out_off - from), e.out_off - from);
+                add_piece(snk::crc32_fast(0, p + from, e.out_off - from), e.out_off - from);
                 if (!end_member(e.crc, e.isize)) return 0;
                 from = e.out_off;
             }
-            add_piece((uint32_t)crc32_z(0, p + from, s_have_ - from), s_have_ - from);
+            add_piece(snk::crc32_fast(0, p + from, s_have_ - from), s_have_ - from);
             if (s_have_ == 0 && sq_.done()) { done_ = true; return 0; }
         }
         const size_t n = std::min(cap, s_have_ - s_off_);

@@ -55,3 +55,12 @@ def test_ratio_is_in_zlib_low_level_territory(exe, tmp_path):
     ours = int(txt.split("->")[1].split("bytes")[0])
     zl = int(txt.split("zlib -2:")[1].split(")")[0])
     assert ours < 1.03 * zl, (ours, zl)
+
+
+def test_crc32_matches_zlib(tmp_path):
+    """snk_crc32.h (PCLMULQDQ folding) is the same function as zlib's crc32_z: 20 000 random (offset, length, seed) cases
+    and a 64 MB buffer (tools/micro/crc_test.cpp)."""
+    exe = str(tmp_path / "crc_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(T.ROOT, "tools", "micro", "crc_test.cpp"), "-lz"])
+    r = subprocess.run([exe], capture_output=True)
+    assert r.returncode == 0 and b"CRC_OK" in r.stdout, r.stdout[-300:]
