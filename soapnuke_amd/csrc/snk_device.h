@@ -43,10 +43,24 @@ struct DevContam {
     int32_t sm1[SNK_DEV_MAX_ADA_LEN];  // segMatchTemp(r1) of the head loop (7 when segGrad == 0)
     int32_t sm3[SNK_DEV_MAX_ADA_LEN];  // segMatchTemp(r1) of the tail loop (no such guard there)
     uint8_t seq[SNK_DEV_MAX_ADA_LEN];
+    // ---- bit-parallel view (snk_contam.hip; contaminants of 1..64 upper-case ACGTN characters, adaEdge >= 1, budgets <= 3)
+    uint64_t cm[4], nm;     // cm[k] bit c = seq[c] == "ACGT"[k]; nm bit c = seq[c] == 'N'
+    int32_t bits_ok;        // the bit-parallel matcher covers this contaminant
+    int32_t scr;            // cells screened for some alignment: max over the alignments of max(segMatch threshold, 1) - 1, at most 63
+    int32_t bmax;           // largest mismatch budget of any alignment (>= 0)
+    int32_t pad_;
+    // monotone envelopes of the tail loop's per-r1 thresholds (r1 = overlap - adaEdge; the tail alignment with r1 starts at
+    // read offset len - adaEdge - r1): cell c is screened for the alignments with r1 >= rT[c], the budget is >= b for
+    // r1 >= rk[b] (nC: none)
+    int32_t rT[64], rk[4];
 };
 // One global contaminant (src/read_filter.cpp:927-1062): forward and reverse-complement strand.
 struct DevGContam {
     int32_t len, min_match_len, mm;
+    int32_t bits_ok;        // the sliding-count screen of snk_contam.hip covers it (4 <= min_match_len <= len <= 64, < 64, ACGTN)
+    int32_t g;              // (unused)
+    int32_t pad_;
+    uint64_t cm[2][4], nm[2];   // per strand, as DevContam::cm / nm
     uint8_t seq[2][SNK_DEV_MAX_ADA_LEN];
 };
 
@@ -119,7 +133,7 @@ int snk_launch_tiled(const DevParams &dp_host, const TileAdapters &ta, const Dev
                      const DevStats &st, int lcap, int nq, int n_cu, void *stream);
 void snk_launch_finalize(const DevStats &st, int lcap, int nq, void *stream);
 // contaminant verdicts of a batch (one work-item per pair) into cf[n], for the tiled kernel
-void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, void *stream);
+void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int lcap, void *stream);   // snk_contam.hip
 
 // rmdup pre-pass (snk_rmdup.hip); return 0 or a hipError_t
 int snk_launch_hash(const uint8_t *const seq[2], const uint16_t *const len[2], const int fixed_len[2], int pitch, long n,

@@ -97,6 +97,44 @@ bool build_contam(DevContam &C, const std::string &seq, int S, int adaMis, int a
         C.sm1[r1] = segGrad != 0 ? f2i_x86(7 + (float)r1 / segGrad) : 7;               // :529-533
         C.sm3[r1] = f2i_x86(7 + (float)r1 / segGrad);                                  // :580 (no guard)
     }
+    // bit-parallel view (snk_contam.hip): one mask per letter; the screen looks at the first `scr` cells of an alignment --
+    // a run of T matches cannot complete inside them when scr <= T - 1 for every alignment's T -- with the largest budget
+    C.bits_ok = (cl >= 1 && cl <= 64 && adaEdge >= 1 && adaMis >= 0 && adaMis <= 3) ? 1 : 0;
+    for (int c = 0; c < cl && C.bits_ok; ++c) {
+        const char *k = strchr("ACGT", seq[c]);
+        if (seq[c] == 'N') C.nm |= 1ull << c;
+        else if (k && *k) C.cm[k - "ACGT"] |= 1ull << c;
+        else C.bits_ok = 0;
+    }
+    // screen tables.  Tail alignment r1 may be screened over its first T(r1) - 1 cells against budget(r1); the kernel wants
+    // "cell c counts for r1 >= rT[c]" and "budget >= b for r1 >= rk[b]", so T goes through its suffix minimum (fewer cells:
+    // still a necessary condition) and the budget through its prefix maximum (looser: likewise)
+    const int nC = std::max(0, std::min(C.nC, SNK_DEV_MAX_ADA_LEN));
+    std::vector<long> tenv(nC + 1, 0x7fffffff);
+    std::vector<int> benv(nC + 1, 0);
+    for (int r1 = nC - 1; r1 >= 0; --r1) tenv[r1] = std::min<long>(tenv[r1 + 1], std::max(C.sm3[r1], 1));
+    int bmax = std::max(adaMis, 0), run = 0;
+    long tmax = std::max(S, 1);
+    for (int r1 = 0; r1 < nC; ++r1) {
+        run = std::max(run, std::max(C.mm[r1], 0));
+        benv[r1] = run;
+        bmax = std::max(bmax, run);
+        tmax = std::max(tmax, std::min<long>(tenv[r1], 64));
+        tmax = std::max<long>(tmax, std::min(std::max(C.sm1[r1], 1), 64));
+    }
+    for (int c = 0; c < 64; ++c) {
+        int r = nC;
+        for (int r1 = nC - 1; r1 >= 0; --r1) if (tenv[r1] - 1 > c) r = r1;       // tenv is nondecreasing: the smallest such r1
+        C.rT[c] = r;
+    }
+    for (int b = 0; b < 4; ++b) {
+        int r = nC;
+        for (int r1 = nC - 1; r1 >= 0; --r1) if (benv[r1] >= b) r = r1;
+        C.rk[b] = r;
+    }
+    if (bmax > 3) C.bits_ok = 0;
+    C.scr = (int)std::min<long>(tmax - 1, 63);
+    C.bmax = bmax;
     return true;
 }
 
@@ -160,6 +198,16 @@ std::string build_contams(const snk_params &P, std::vector<DevContam> &ct, int n
                 }
                 G.seq[1][k] = o;
             }
+            // sliding-count screen of snk_contam.hip
+            G.g = 0;
+            G.bits_ok = (G.min_match_len >= 4 && G.min_match_len <= cl && G.min_match_len <= 63 && cl <= 64) ? 1 : 0;
+            for (int d = 0; d < 2 && G.bits_ok; ++d)
+                for (int c = 0; c < cl; ++c) {
+                    const char *k = strchr("ACGT", (char)G.seq[d][c]);
+                    if (G.seq[d][c] == 'N') G.nm[d] |= 1ull << c;
+                    else if (k && *k) G.cm[d][k - "ACGT"] |= 1ull << c;
+                    else { G.bits_ok = 0; break; }
+                }
         }
         n_gct = (int)seqs.size();
     }
@@ -574,7 +622,7 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
                 HIP_OK(hipMalloc((void **)&c->d_cf[slot], cap));
                 c->cf_cap[slot] = cap;
             }
-            snk_launch_contam(c->d_params, D, c->d_cf[slot], stream);
+            snk_launch_contam(c->d_params, D, c->d_cf[slot], c->lcap, stream);
             D.cf = c->d_cf[slot];
         }
         done = snk_launch_tiled(c->hp, c->ta, D, st, c->lcap, c->nq, c->n_cu, stream);

@@ -146,45 +146,6 @@ snk_generic_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int n
     }
 }
 
-// Contaminant verdicts only (src/read_filter.cpp:189-248): the sequential matchers of the generic
-// kernel without its histogram work, so that the tiled kernel can consume the verdicts like the
-// duplicate flags.  One work-item per pair; the workgroup first copies its 256 rows (coalesced) and the
-// contaminant tables into LDS -- row stride an odd number of dwords, so the per-lane byte walks of the
-// matchers are free of bank conflicts -- instead of walking global memory one byte at a time.
-__global__ void __launch_bounds__(256) snk_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, int stride) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
-    const DevParams &P = *Pp;
-    const int pe = P.paired ? 1 : 0, tid = threadIdx.x;
-    uint8_t *rows = sm;
-    DevContam *lct = reinterpret_cast<DevContam *>(sm + (((size_t)256 * stride + 15) & ~(size_t)15));
-    DevGContam *lg = reinterpret_cast<DevGContam *>(lct + SNK_MAX_CONTAMS);
-    for (int k = tid; k < (int)(P.n_gct * sizeof(DevGContam) / 4); k += 256)
-        reinterpret_cast<uint32_t *>(lg)[k] = reinterpret_cast<const uint32_t *>(P.gct)[k];
-    const long nround = (B.n + 255) / 256 * 256;
-    for (long base = (long)blockIdx.x * 256; base < nround; base += (long)gridDim.x * 256) {
-        const long i = base + tid;
-        const int rows_here = (int)min((long)256, B.n - base);
-        int f = 0;
-        for (int m = 0; m <= pe; ++m) {
-            __syncthreads();
-            for (int k = tid; k < (int)(P.n_ct[m] * sizeof(DevContam) / 4); k += 256)
-                reinterpret_cast<uint32_t *>(lct)[k] = reinterpret_cast<const uint32_t *>(P.ct + m * SNK_MAX_CONTAMS)[k];
-            const uint8_t *src = B.seq[m] + base * (long)B.pitch;
-            const int dwr = B.pitch >> 2;                          // pitch is a multiple of 4 (C ABI)
-            for (int k = tid; k < rows_here * dwr; k += 256) {
-                const int r = k / dwr, c = k - r * dwr;
-                *reinterpret_cast<uint32_t *>(rows + (size_t)r * stride + 4 * c) = *reinterpret_cast<const uint32_t *>(src + (long)r * B.pitch + 4 * c);
-            }
-            __syncthreads();
-            if (i < B.n) {
-                const int len = min(B.len[m] ? (int)B.len[m][i] : B.fixed_len[m], P.lcap);
-                f |= contam_flags(lct, P.n_ct[m], lg, P.n_gct, rows + (size_t)tid * stride, len) << (2 * m);
-            }
-        }
-        if (i < B.n) cf[i] = (unsigned char)f;
-    }
-}
-
 // gs[] = column sums of the histograms (a/c/g/t/n, q20, q30, bases); reads_number
 // is accumulated by the kernels.  One workgroup per file block; idempotent.
 __global__ void __launch_bounds__(256) snk_finalize_kernel(DevStats st, int lcap, int nq) {
@@ -223,23 +184,6 @@ void snk_launch_generic(const DevParams *dp, const DevBatch &b, const DevStats &
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(snk_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        dp, b, st, lcap, nq);
-}
-
-void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, void *stream) {
-    if (b.n <= 0) return;
-    long blocks = (b.n + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    int sd = (b.pitch + 3) / 4;
-    if (!(sd & 1)) ++sd;                                            // odd dword stride
-    const int stride = sd * 4;
-    const size_t shmem = (((size_t)256 * stride + 15) & ~(size_t)15) + SNK_MAX_CONTAMS * (sizeof(DevContam) + sizeof(DevGContam));
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)snk_contam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(snk_contam_kernel, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, dp, b, cf, stride);
 }
 
 void snk_launch_finalize(const DevStats &st, int lcap, int nq, void *stream) {

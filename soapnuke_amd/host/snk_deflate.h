@@ -33,7 +33,8 @@ public:
     FastDeflate() : head_(1u << HASH_BITS, 0), syms_(BLOCK_SYMS + 64) { memset(lf_, 0, sizeof lf_); memset(df_, 0, sizeof df_); memset(h4_, 0, sizeof h4_); }
 
     // appends one complete gzip member holding in[0, n) to `out`
-    void gzip_member(const uint8_t *in, size_t n, std::string &out) {
+    // fastq: the text is FASTQ records (4 lines each) -- record-aware matching instead of the hash search, see deflate_fastq()
+    void gzip_member(const uint8_t *in, size_t n, std::string &out, bool fastq = false) {
         const size_t at = out.size();
         // worst case: literals only with 9-bit codes + block headers; stored-size bound with margin
         out.resize(at + n + n / 4 + (n / 65536 + 2) * 600 + 128);
@@ -43,7 +44,8 @@ public:
         op_ = p + 10;
         bitbuf_ = 0;
         bitcnt_ = 0;
-        deflate_all(in, n);
+        if (fastq && n > 0 && in[0] == '@') deflate_fastq(in, n);
+        else deflate_all(in, n);
         flush_bits();
         const uint32_t crc = snk::crc32_fast(0, in, n), isz = (uint32_t)n;
         for (int i = 0; i < 4; ++i) *op_++ = (uint8_t)(crc >> (8 * i));
@@ -300,6 +302,94 @@ private:
         drain();
         put(lc[256], ll[256]);
         drain();
+    }
+
+    // ---- FASTQ records: what repeats inside 32 KiB of FASTQ is the text of the name lines (and of '+' lines that repeat
+    // the name) -- the same characters at the same place one record earlier -- while bases and qualities are literals for
+    // any LZ77 that does not search far.  So: no hash table; the name and '+' lines are compared with the record before at
+    // the distance between the two line starts (runs of >= 4 equal bytes become matches), everything else goes out as
+    // literal runs.  Same block / Huffman machinery as deflate_all, about the same ratio on FASTQ, no search cost.  Text
+    // that is not FASTQ after all only compresses worse; the stream stays valid.
+    void deflate_fastq(const uint8_t *in, size_t n) {
+        const Tables &t = tab();
+        int nsym = 0;
+        size_t lit_from = 0, block_from = 0;
+        auto literals = [&](size_t upto) {
+            while (lit_from < upto) {
+                const size_t k = std::min<size_t>(upto - lit_from, 65535);
+                size_t j = lit_from;
+                const size_t e4 = lit_from + (k & ~(size_t)3);
+                for (; j < e4; j += 4) { h4_[0][in[j]]++; h4_[1][in[j + 1]]++; h4_[2][in[j + 2]]++; h4_[3][in[j + 3]]++; }
+                for (; j < lit_from + k; ++j) h4_[0][in[j]]++;
+                syms_[nsym++] = Sym{(uint16_t)k, 0};
+                lit_from += k;
+            }
+        };
+        auto maybe_block = [&](size_t pos) {
+            if (nsym >= BLOCK_SYMS - 64 || pos - block_from >= BLOCK_BYTES) {
+                literals(pos);
+                write_block(in + block_from, nsym, false);
+                nsym = 0;
+                block_from = pos;
+            }
+        };
+        // [at, at + len) against the same bytes `dist` earlier: matches for the runs of >= 4 equal bytes
+        auto same_place = [&](size_t at, size_t len, size_t dist) {
+            size_t k = 0;
+            while (k < len) {
+                const uint8_t *a = in + at + k, *b = a - dist;
+                const size_t maxl = len - k;
+                size_t l = 0;
+                while (l + 8 <= maxl) {
+                    const uint64_t x = load64(a + l) ^ load64(b + l);
+                    if (x) { l += (size_t)(__builtin_ctzll(x) >> 3); goto counted; }
+                    l += 8;
+                }
+                while (l < maxl && a[l] == b[l]) ++l;
+            counted:
+                if (l >= 4 && nsym < BLOCK_SYMS - 16) {    // (symbol buffer nearly full: the rest of the line stays literal)
+                    literals(at + k);
+                    size_t left = l;
+                    while (left) {                           // (a rest of 1..3 bytes would not be a legal match: take it from the piece before)
+                        size_t piece = std::min<size_t>(left, MAX_MATCH);
+                        if (left - piece > 0 && left - piece < 4) piece = left - 4;
+                        syms_[nsym++] = Sym{(uint16_t)piece, (uint16_t)dist};
+                        lf_[257 + t.len_code[piece]]++;
+                        df_[dist_sym((uint32_t)dist)]++;
+                        left -= piece;
+                    }
+                    k += l;
+                    lit_from = at + k;
+                } else {
+                    k += l + 1;                              // a short run and the byte that differs stay literals
+                }
+            }
+        };
+        size_t i = 0, prev_name = 0, prev_plus = 0;
+        bool have_prev = false;
+        while (i < n) {
+            const uint8_t *e1 = (const uint8_t *)memchr(in + i, '\n', n - i);
+            if (!e1) break;
+            const uint8_t *e2 = (const uint8_t *)memchr(e1 + 1, '\n', n - (size_t)(e1 + 1 - in));
+            if (!e2) break;
+            const uint8_t *e3 = (const uint8_t *)memchr(e2 + 1, '\n', n - (size_t)(e2 + 1 - in));
+            if (!e3) break;
+            const uint8_t *e4 = (const uint8_t *)memchr(e3 + 1, '\n', n - (size_t)(e3 + 1 - in));
+            if (!e4) break;
+            const size_t name = i, plus = (size_t)(e2 + 1 - in), next = (size_t)(e4 + 1 - in);
+            if (have_prev) {
+                if (name - prev_name <= WINDOW) same_place(name, (size_t)(e1 + 1 - in) - name, name - prev_name);
+                const size_t pl = (size_t)(e3 + 1 - in) - plus;
+                if (pl > 4 && plus - prev_plus <= WINDOW) same_place(plus, pl, plus - prev_plus);
+            }
+            prev_name = name;
+            prev_plus = plus;
+            have_prev = true;
+            i = next;
+            maybe_block(i);
+        }
+        literals(n);
+        write_block(in + block_from, nsym, true);
     }
 
     // ---- greedy LZ77 over the whole input, one block per BLOCK_SYMS symbols

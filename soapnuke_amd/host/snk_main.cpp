@@ -784,7 +784,7 @@ void gzip_member(const string &in, string &out) {
     static const bool use_zlib = getenv("SNK_ZLIB_OUT") != nullptr;
     if (!use_zlib) {
         thread_local snk::FastDeflate enc;
-        enc.gzip_member(reinterpret_cast<const uint8_t *>(in.data()), in.size(), out);
+        enc.gzip_member(reinterpret_cast<const uint8_t *>(in.data()), in.size(), out, true);     // (every text this CLI compresses is FASTQ records)
         return;
     }
     z_stream z;

@@ -45,6 +45,50 @@ def test_round_trip_all_kinds(exe, tmp_path):
             assert r.returncode == 0 and b"ROUNDTRIP_OK" in r.stdout, (name, slice_bytes, r.stdout[-300:])
 
 
+def test_fastq_mode_round_trips(exe, tmp_path):
+    """the record-aware front end (deflate_fastq: what the CLI uses): FASTQ of every shape, text that only looks like
+    FASTQ, names repeated on the '+' line, names longer than a match, a truncated last record, CRLF"""
+    rng = np.random.default_rng(9)
+    raw = _fastq_bytes(30000)
+
+    def recs(n, name, plus_name=False, L=100):
+        out = bytearray()
+        for i in range(n):
+            nm = name(i)
+            seq = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), L))
+            q = bytes(rng.integers(33, 74, L, dtype=np.uint8))
+            out += b"@" + nm + b"\n" + seq + b"\n+" + (nm if plus_name else b"") + b"\n" + q + b"\n"
+        return bytes(out)
+
+    files = {
+        "fastq": raw,
+        "plus_name": recs(20000, lambda i: b"SRR1234567.%d %d/1" % (i, i), plus_name=True),
+        "long_names": recs(3000, lambda i: b"x" * 700 + b"%d" % i + b"y" * 300, plus_name=True, L=30),
+        "changing_names": recs(20000, lambda i: bytes(rng.integers(48, 123, int(rng.integers(1, 40)), dtype=np.uint8)).replace(b"\n", b"_")),
+        "huge_name": b"@" + b"ab" * 300000 + b"\nACGT\n+\nIIII\n" + b"@" + b"ab" * 300000 + b"\nACGT\n+\nIIII\n",
+        "truncated": raw[:len(raw) - 77],
+        "crlf": raw[:400000].replace(b"\n", b"\r\n"),
+        "at_random": b"@" + rng.integers(0, 256, 1_000_000, dtype=np.uint8).tobytes(),
+        "at_newlines": b"@" + b"\n" * 500000,
+        "at_only": b"@",
+    }
+    for name, blob in files.items():
+        p = str(tmp_path / name)
+        open(p, "wb").write(blob)
+        for slice_bytes in ("0", "1000003"):
+            r = subprocess.run([exe, p] + ([slice_bytes] if slice_bytes != "0" else []), capture_output=True, env=dict(os.environ, FASTQ="1"))
+            assert r.returncode == 0 and b"ROUNDTRIP_OK" in r.stdout, (name, slice_bytes, r.stdout[-300:])
+    # ... and it is not worse than the hash search on FASTQ
+    sizes = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ)
+        if mode == "1":
+            env["FASTQ"] = "1"
+        r = subprocess.run([exe, str(tmp_path / "fastq")], capture_output=True, env=env)
+        sizes[mode] = int(r.stdout.decode().split("->")[1].split("bytes")[0])
+    assert sizes["1"] <= 1.01 * sizes["0"], sizes
+
+
 def test_ratio_is_in_zlib_low_level_territory(exe, tmp_path):
     raw = _fastq_bytes(60000)
     p = str(tmp_path / "fq")

@@ -58,6 +58,9 @@ run("C2 PE100", 100, True, PE_CASES["C2_adatrim_lowq"])
 run("C5 PE250 (C2 params)", 250, True, PE_CASES["C2_adatrim_lowq"], n=6_000_000)
 run("C2 + contam1/2 + global", 150, True, dict(PE_CASES["C2_adatrim_lowq"], contam1="ACGTTGCAAGGCTTAACCGGTTAGCATGCAAT", contam2="TTGGCCAAGGTTCCAAGGTTAACCGGTT",
                                                ct_match_r="0.5", global_contams="AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", g_mrs="0.4", g_mms="1"), n=5_000_000)
+run("C2 + contam1/2 only", 150, True, dict(PE_CASES["C2_adatrim_lowq"], contam1="ACGTTGCAAGGCTTAACCGGTTAGCATGCAAT", contam2="TTGGCCAAGGTTCCAAGGTTAACCGGTT",
+                                           ct_match_r="0.5"), n=5_000_000)
+run("C2 + global contam only", 150, True, dict(PE_CASES["C2_adatrim_lowq"], global_contams="AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", g_mrs="0.4", g_mms="1"), n=5_000_000)
 if only.startswith("sweep"):                    # which optional feature of C3 costs what
     only = ""
     base = dict(PE_CASES["C3_full"])

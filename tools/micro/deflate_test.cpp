@@ -19,7 +19,7 @@ int main(int argc, char **argv) {
     double t0 = now();
     for (size_t at = 0; at < raw.size() || at == 0; at += slice ? slice : 1) {
         const size_t n = std::min(slice ? slice : raw.size(), raw.size() - at);
-        enc.gzip_member(raw.data() + at, n, z);
+        enc.gzip_member(raw.data() + at, n, z, getenv("FASTQ") != nullptr);
         if (raw.empty()) break;
     }
     double t1 = now();
