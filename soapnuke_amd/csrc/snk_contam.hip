@@ -26,6 +26,9 @@
 
 using namespace snk;
 
+#ifndef SNK_CWAVES
+#define SNK_CWAVES 3         // waves per SIMD the register allocation aims at (168 VGPRs: 3 workgroups of 46 KB LDS per CU; 2 -> 3: 9.0 -> 7.65 ms)
+#endif
 #ifndef SNK_CABL
 #define SNK_CABL 0          // ablation builds (tools/ab_contam.sh): 1 no head section, 2 no middle/tail decisions, 3 no counting screen, 4 no planes
 #endif
@@ -460,13 +463,13 @@ __device__ bool gcontam_bits_nb(const DevGContam &G, int d, const u32 (&X)[4][NW
 // row stride an odd number of dwords, so the per-lane walks (plane building, the sequential matchers) are free of bank
 // conflicts.  NW = plane words (32 positions each); NW == 0: sequential matchers only (reads over 256 nt).
 template <int NW>
-__global__ void __launch_bounds__(256) snk_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, int stride) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SNK_CWAVES, SNK_CWAVES))) snk_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, int stride) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     const DevParams &P = *Pp;
     const int pe = P.paired ? 1 : 0, tid = threadIdx.x;
     uint8_t *rows = sm;
     DevContam *lct = reinterpret_cast<DevContam *>(sm + (((size_t)256 * stride + 15) & ~(size_t)15));
-    DevGContam *lg = reinterpret_cast<DevGContam *>(lct + SNK_MAX_CONTAMS);
+    DevGContam *lg = reinterpret_cast<DevGContam *>(lct + max(P.n_ct[0], P.n_ct[1]));       // (the launcher sizes the tables by these counts)
     const int n_gct = P.n_gct;
     for (int k = tid; k < (int)(n_gct * sizeof(DevGContam) / 4); k += 256)
         reinterpret_cast<uint32_t *>(lg)[k] = reinterpret_cast<const uint32_t *>(P.gct)[k];
@@ -528,13 +531,13 @@ __global__ void __launch_bounds__(256) snk_contam_kernel(const DevParams *Pp, De
 
 }  // namespace
 
-void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int lcap, void *stream) {
+void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int lcap, int n_ct, int n_gct, void *stream) {
     if (b.n <= 0) return;
     long blocks = (b.n + 255) / 256;
     int sd = (b.pitch + 3) / 4;
     if (!(sd & 1)) ++sd;                                            // odd dword stride
     const int stride = sd * 4;
-    const size_t shmem = (((size_t)256 * stride + 15) & ~(size_t)15) + SNK_MAX_CONTAMS * (sizeof(DevContam) + sizeof(DevGContam));
+    const size_t shmem = (((size_t)256 * stride + 15) & ~(size_t)15) + (size_t)n_ct * sizeof(DevContam) + (size_t)n_gct * sizeof(DevGContam);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)snk_contam_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -133,7 +133,7 @@ int snk_launch_tiled(const DevParams &dp_host, const TileAdapters &ta, const Dev
                      const DevStats &st, int lcap, int nq, int n_cu, void *stream);
 void snk_launch_finalize(const DevStats &st, int lcap, int nq, void *stream);
 // contaminant verdicts of a batch (one work-item per pair) into cf[n], for the tiled kernel
-void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int lcap, void *stream);   // snk_contam.hip
+void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int lcap, int n_ct, int n_gct, void *stream);   // snk_contam.hip
 
 // rmdup pre-pass (snk_rmdup.hip); return 0 or a hipError_t
 int snk_launch_hash(const uint8_t *const seq[2], const uint16_t *const len[2], const int fixed_len[2], int pitch, long n,

@@ -622,7 +622,7 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
                 HIP_OK(hipMalloc((void **)&c->d_cf[slot], cap));
                 c->cf_cap[slot] = cap;
             }
-            snk_launch_contam(c->d_params, D, c->d_cf[slot], c->lcap, stream);
+            snk_launch_contam(c->d_params, D, c->d_cf[slot], c->lcap, std::max(c->hp.n_ct[0], c->hp.n_ct[1]), c->hp.n_gct, stream);
             D.cf = c->d_cf[slot];
         }
         done = snk_launch_tiled(c->hp, c->ta, D, st, c->lcap, c->nq, c->n_cu, stream);

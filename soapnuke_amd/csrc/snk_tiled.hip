@@ -61,6 +61,9 @@ using namespace snk;
 #define SNK_ORDER 1
 #endif
 // wave priorities of phase 1 / hand-over / adapter search + pair level / phase 3, as a 4-digit number (tools/ab.sh experiments)
+#ifndef SNK_PAIR
+#define SNK_PAIR 0      // 1: two reads share the LDS ops of their short last quality strip (129..160 positions): 7 instead of 8 LDS ops per read, yet 4 % SLOWER (2.99 vs 2.87 ms, profiles/r02_pair_ab.txt) -- off
+#endif
 #ifndef SNK_PRIO
 #define SNK_PRIO 3210
 #endif
@@ -95,11 +98,11 @@ typedef __attribute__((address_space(3))) u32 *lds_u32_ptr;
 // asynchronous LDS reads of one read's row: its bases and qualities as dwords (lane l: positions 4l..4l+3, for the
 // bit collectors) and its qualities once more as one byte per lane and 64-position strip (lane = position, for the
 // per-position histogram); pair with lds_wait
-template <int S, int NS>
+template <int S, int E, int NS>                 // strips S .. E-1
 __device__ __forceinline__ void lds_read_qstrips(u32 (&q)[NS], u32 addrq) {
-    if constexpr (S < NS) {
+    if constexpr (S < E) {
         asm volatile("ds_read_u8 %0, %1 offset:%2" : "=&v"(q[S]) : "v"(addrq), "n"(64 * S));
-        lds_read_qstrips<S + 1>(q, addrq);
+        lds_read_qstrips<S + 1, E>(q, addrq);
     }
 }
 __device__ __forceinline__ void lds_read_b32(u32 &d, u32 addr) { asm volatile("ds_read_b32 %0, %1" : "=&v"(d) : "v"(addr)); }
@@ -434,6 +437,7 @@ __device__ int adapter_tile(const TileAdapter &A, const DevAdapter &AG, const u3
 
 struct TileGeom {
     int lcap, nq, Lh, lg, WB, WQ, SET;   // Lh = 1 << lg dwords per histogram bin row
+    int pairq;                           // 129..160 positions, staged path: the raw quality rows' slots of positions 160..191 count positions 128..159 too (PAIR, phase 1)
     // LDS staging of the read bytes (global_load_lds, 16 B/lane): per wave 2 buffers x
     // {bases, qualities} x cba bytes, a chunk = rb consecutive reads.  rb == 0: disabled.
     int rb, cba, stg_off, stg_wave;
@@ -535,9 +539,16 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         const int lenF = fixed ? len0 : G.lcap;
         constexpr bool nomask = false;
         const int l4 = lane4;                                                // byte offset of this lane's dword in a row
-        auto do_read = [&](auto FL, auto JC, const int r, u32 c4, const u32 q4, const u32 (&cq)[NS]) {
+        // PAIR (whole tiles of full-length reads with 129..160 positions, staged path): the third strip of a read has at most
+        // 32 live lanes, so ONE ds_read_u8 and ONE ds_add serve the third strips of reads r (even; lanes 0-31) and r + 1
+        // (lanes 32-63, which fetch the next row): 7 instead of 8 LDS ops per read.  The add is the ordinary one -- lanes
+        // 32-63 land in the slots of positions 160..191, which such a batch does not have; the flush books them under
+        // positions 128..159 (TileGeom::pairq).  pq: that strip as fetched with read r.
+        auto do_read = [&](auto FL, auto JC, auto PR, const int r, u32 c4, const u32 q4, const u32 (&cq)[NS], const u32 pq) {
             constexpr bool FULLLEN = decltype(FL)::value;
+            constexpr bool PAIR = decltype(PR)::value;
             constexpr int jq = decltype(JC)::v & 3;        // place of the read in its group of four
+            constexpr bool odd = decltype(JC)::v & 1;
             const int len_r = FULLLEN ? G.lcap : (fixed ? len0 : rl(clen_v, r));
             {   // ---- collectors (4 positions per lane)
                 u32 vm = padm;                             // bytes of this lane's dword inside the read
@@ -566,21 +577,26 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             // is counted from the collected planes once per tile (hand-over)
             static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                 constexpr int s = decltype(sc)::v;
-                const int pos = 64 * s + lane;
-                const u32 qb = cq[s];
-                u32 qc;
-                asm("v_med3_u32 %0, %1, %2, %3" : "=v"(qc) : "v"(qb), "v"(qlo_v), "s"(qhi));
-                u32 aQa = (qc << lgb) + laneQc;
-                if (!FULLLEN) aQa = pos < len_r ? aQa : dumB - 256u * (s >> 1);
-                if (SNK_ABL == 11) { asm volatile("" ::"v"(aQa)); }
-                else lds_add_u32<256 * (s >> 1)>(aQa, (s & 1) ? 0x10000u : 1u);
+                if constexpr (!(PAIR && odd && s == NS - 1)) {     // (PAIR: the even read's last strip holds both reads' bytes)
+                    const int pos = 64 * s + lane;
+                    const u32 qb = cq[s];
+                    u32 qc;
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(qc) : "v"(qb), "v"(qlo_v), "s"(qhi));
+                    u32 aQa = (qc << lgb) + laneQc;
+                    if (!FULLLEN) aQa = pos < len_r ? aQa : dumB - 256u * (s >> 1);
+                    if (SNK_ABL == 11) { asm volatile("" ::"v"(aQa)); }
+                    else lds_add_u32<256 * (s >> 1)>(aQa, (s & 1) ? 0x10000u : 1u);
+                }
             });
             int hm = FULL ? has_meanq : 0;        // (the mean-quality filter selects the FULL variant)
             asm volatile("" : "+s"(hm));          // a plain scalar compare + branch per read (hoisted, the flag turns into lane masks)
             if (FULL && hm != 0) {                // quality sum of the read (mean-quality filter only)
                 int qsum = 0;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) qsum += (64 * s + lane < len_r) ? (int)cq[s] - phred : 0;
+                for (int s = 0; s < NS; ++s) {
+                    if (PAIR && s == NS - 1) qsum += ((lane >= 32) == odd && 64 * s + (lane & 31) < len_r) ? (int)pq - phred : 0;
+                    else qsum += (64 * s + lane < len_r) ? (int)cq[s] - phred : 0;
+                }
                 v_sumq = wl(v_sumq, wave_sum(qsum), r);
             }
         };
@@ -604,6 +620,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         };
         auto run_phase1 = [&](auto FL, auto C64) {
             constexpr bool CNT64 = decltype(C64)::value;      // a whole tile: no per-read existence test
+            constexpr bool FULLLEN = decltype(FL)::value;
             const int nocts = CNT64 ? 8 : (cnt + 7) >> 3;
             if (STAGED) {
                 // bytes arrive in LDS by DMA (16 B/lane), the next chunk of rb reads in flight
@@ -639,28 +656,40 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 // DMA: when the row of the last read of chunk k has been ISSUED (two reads before it is used), the next
                 // row to fetch is row 0 of chunk k+1, whose DMA is waited for there; one step later that last row sits in
                 // registers, and the DMA of chunk k+2 goes into the buffer of chunk k.
+                constexpr bool PAIR = SNK_PAIR && NW == 5 && FULLLEN && CNT64;
                 constexpr int ROWOPS = 2 + NS;
                 constexpr int K = (SNK_ABL == 11 ? 0 : NS) + ROWOPS;
+                // PAIR: an even read's row fetch has all NS strips (the last one shared with the odd read behind it), an odd
+                // read's one less; likewise the histogram adds
+                constexpr int ROWE = 2 + NS, ROWO = 2 + NS - 1, ADDE = SNK_ABL == 11 ? 0 : NS, ADDO = SNK_ABL == 11 ? 0 : NS - 1;
                 const u32 stgA = lds0 + (u32)(G.stg_off + wave * G.stg_wave);
                 const u32 lc4 = (u32)l4, l1 = (u32)G.cba + (u32)lane, lq4 = (u32)G.cba + (u32)l4;
+                // the shared strip: lanes 0-31 positions 64*(NS-1).. of this row, lanes 32-63 the same positions of the next row
+                const u32 l2 = (u32)G.cba + (u32)(64 * (NS - 1)) + (u32)(lane & 31) + (lane >= 32 ? (u32)B.pitch : 0u);
                 issue(0);
                 if (nchunks > 1) issue(1);
                 if (SNK_ABL != 14) {
                     if (nchunks > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                auto lds_rd = [&](u32 &c4, u32 &q4, u32 (&q)[NS], const u32 row) {
+                auto lds_rd = [&](auto OD, u32 &c4, u32 &q4, u32 (&q)[NS], const u32 row) {
                     lds_read_b32(c4, row + lc4);
                     lds_read_b32(q4, row + lq4);
-                    lds_read_qstrips<0>(q, row + l1);
+                    const u32 a2 = row + l2;
+                    if constexpr (PAIR) {
+                        lds_read_qstrips<0, NS - 1>(q, row + l1);
+                        if constexpr (!decltype(OD)::value) asm volatile("ds_read_u8 %0, %1" : "=&v"(q[NS - 1]) : "v"(a2));
+                    } else {
+                        lds_read_qstrips<0, NS>(q, row + l1);
+                    }
                 };
                 u32 C4[4], Q4[4], QS[4][NS];                // register set of read r: r & 3
                 u32 row = stgA;                             // LDS address of the newest prefetched row (scalar)
                 const int rbm = rb - 1, lgrb = 31 - __builtin_clz((unsigned)rb);     // rb is a power of two >= 2 (launch())
-                lds_rd(C4[0], Q4[0], QS[0], row);
+                lds_rd(std::false_type{}, C4[0], Q4[0], QS[0], row);
                 row += (u32)B.pitch;                        // (row 1 is in chunk 0: rb >= 2)
-                lds_rd(C4[1], Q4[1], QS[1], row);
-                lds_wait<ROWOPS>(C4[0], Q4[0], QS[0]);
+                lds_rd(std::true_type{}, C4[1], Q4[1], QS[1], row);
+                lds_wait<PAIR ? ROWO : ROWOPS>(C4[0], Q4[0], QS[0]);
                 for (int o = 0; o < nocts; ++o) {           // reads 8o .. 8o+7
                     // which reads of this octet are the last of a chunk (rb is a power of two): one bit test per read
                     const u32 evm = rb == 2 ? 0xAAu : rb == 4 ? 0x88u : ((((8 * (o + 1)) & rbm) == 0) ? 0x80u : 0u);
@@ -677,9 +706,10 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                             } else {
                                 row += (u32)B.pitch;
                             }
-                            lds_rd(C4[(j + 2) & 3], Q4[(j + 2) & 3], QS[(j + 2) & 3], row);
-                            do_read(FL, IntC<j>{}, r, C4[j & 3], Q4[j & 3], QS[j & 3]);
-                            lds_wait<K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
+                            lds_rd(std::integral_constant<bool, (j & 1) != 0>{}, C4[(j + 2) & 3], Q4[(j + 2) & 3], QS[(j + 2) & 3], row);
+                            do_read(FL, IntC<j>{}, std::integral_constant<bool, PAIR>{}, r, C4[j & 3], Q4[j & 3], QS[j & 3], QS[j & 2][NS - 1]);
+                            // behind the row of read r+1: the row of read r+2 and the adds of read r (same parity)
+                            lds_wait<PAIR ? ((j & 1) ? ROWO + ADDO : ROWE + ADDE) : K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
                             if (closes && k + 2 < nchunks) issue(k + 2);     // every row of chunk k sits in registers now
                         } else skip_read();
                         if (j == 3) park4(2 * o);
@@ -715,7 +745,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
 #pragma unroll
                             for (int s = 0; s < NS; ++s) cq[s] = nqb[s];
                             if (r + 1 < cnt) load(t0 + r + 1);
-                            do_read(FL, IntC<j>{}, r, c4, q4, cq);
+                            do_read(FL, IntC<j>{}, std::false_type{}, r, c4, q4, cq, 0u);
                         } else skip_read();
                         if (j == 3) park4(2 * o);
                         if (j == 7) { park4(2 * o + 1); park8(o); }
@@ -1247,9 +1277,12 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
                         if (w < G.WB) { bin = w >> G.lg; pm = w - (bin << G.lg); off = SNK_GS_N + (long)(bin ^ ((bin >> 1) & (bin < 4))); }
                         else { const int ww = w - G.WB; bin = ww >> G.lg; pm = ww - (bin << G.lg); off = SNK_GS_N + (long)G.lcap * 5 + bin; }
                         const long stride = w < G.WB ? 5 : G.nq;
-                        const u32 alo = a & 0xFFFFu, blo = b & 0xFFFFu, ahi = a >> 16, bhi = b >> 16;
                         // slots of positions >= lcap hold the spill-over of lanes past the read end: dropped
-                        const int plo = 128 * (pm >> 6) + (pm & 63), phi = plo + 64;
+                        // (quality rows of 129..160-position batches: phase 1 counts the third strip of the odd reads in the slots of
+                        // positions 160..191 -- PAIR -- which such a batch does not have)
+                        const bool pq = G.pairq && (w >= G.WB || bin == 5) && pm >= 96;   // raw set only: the removed set's slots there hold spill-over
+                        const u32 alo = a & 0xFFFFu, blo = pq ? 0u : (b & 0xFFFFu), ahi = pq ? 0u : (a >> 16), bhi = pq ? 0u : (b >> 16);
+                        const int plo = 128 * (pm >> 6) + (pm & 63) - (pq ? 32 : 0), phi = plo + 64;
                         const bool lo_ok = plo < G.lcap, hi_ok = phi < G.lcap;
                         if ((w >= G.WB && bin == G.nq) || (w < G.WB && bin == 5)) {
                             if ((alo && lo_ok) || (ahi && hi_ok)) ovf = 1;       // quality outside [0,nq): overflow / underflow row
@@ -1385,6 +1418,7 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
     const long GW = wgs * W;
     const int iters = (int)((tiles + GW - 1) / GW);
     const int flush_every = 65535 / (W * 64);
+    G.pairq = (SNK_PAIR && NW == 5 && G.rb) ? 1 : 0;
     if (G.rb) go<NW, FULL, true>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
     else go<NW, FULL, false>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
     return 1;
@@ -1405,6 +1439,7 @@ int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch
     G.SET = G.WB + G.WQ;
     if (((size_t)2 * 2 * G.SET + SNK_LDS_TAIL) * sizeof(u32) > 160 * 1024) return 0;
     G.rb = G.cba = G.stg_off = G.stg_wave = G.scr_off = G.scr_wave = 0;
+    G.pairq = 0;
     const bool full = hp.need_n || hp.has_polyG || hp.polyX_num != -1 || hp.has_lq || hp.has_meanq;
     const int nw = (lcap + 31) / 32;        // dwords per bit plane
 #define SNK_GO(NW_)                                                                    \

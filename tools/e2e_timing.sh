@@ -14,9 +14,14 @@ for HT in "$@"; do
   for mode in plain gz; do
     if [ $mode = gz ]; then I1=$TMP/r1.fq.gz; I2=$TMP/r2.fq.gz; E=.fq.gz; else I1=$TMP/r1.fq; I2=$TMP/r2.fq; E=.fq; fi
     echo "== host threads $HT, $mode"
-    s=$(date +%s.%N)
-    SNK_TIMING=1 SNK_HOST_THREADS=$HT $ROOT/soapnuke_amd/SOAPnuke filter -1 $I1 -2 $I2 -C c1$E -D c2$E -o $TMP/out $A 2>&1 | grep -E "timing|Error" 
-    e=$(date +%s.%N); echo "wall $(echo "$e - $s" | bc -l 2>/dev/null || python -c "print($e-$s)")"
+    SNK_TIMING=1 SNK_HOST_THREADS=$HT python - $ROOT/soapnuke_amd/SOAPnuke filter -1 $I1 -2 $I2 -C c1$E -D c2$E -o $TMP/out $A <<'PY' 2>&1 | grep -E "timing|Error|wall"
+import resource, subprocess, sys, time
+t0 = time.time()
+subprocess.call(sys.argv[1:])
+w = time.time() - t0
+u = resource.getrusage(resource.RUSAGE_CHILDREN)
+print("wall %.2f s  user %.1f s  sys %.1f s  (%.1f CPUs busy)" % (w, u.ru_utime, u.ru_stime, (u.ru_utime + u.ru_stime) / w))
+PY
     rm -rf $TMP/out
   done
 done
