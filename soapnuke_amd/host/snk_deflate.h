@@ -1,16 +1,20 @@
 // snk_deflate.h -- a fast gzip (RFC 1952 / 1951) ENCODER for the clean-FASTQ writer threads.
 //
 // The reference compresses its output with zlib level 2 (gzsetparams(..., 2, Z_DEFAULT_STRATEGY), src/peprocess.cpp:1809)
-// at ~100 MB/s per thread; with .gz output that is more than half of this CLI's host CPU time, on a host
+// at ~100 MB/s per thread; with .gz output that is a large part of this CLI's host CPU time, on a host
 // whose core count is the budget.  Compressed BYTES are not part of the parity contract ("zlib ... affects only
-// compressed bytes"): any valid gzip stream of the same text is equivalent.  This encoder is the usual speed-first
-// design -- greedy LZ77 with a single-probe hash table of 4-byte sequences (32 KiB window, matches of 4..258 bytes
-// extended 8 bytes at a time), one dynamic-Huffman block per ~128 KiB of symbols with exact symbol counts, length-limited
-// codes by the Kraft-sum repair heuristic, a 64-bit bit writer -- and lands at the compression ratio of zlib's low levels
-// on FASTQ at several times their speed.  Every member carries its CRC-32 (zlib's crc32_z) and ISIZE.
+// compressed bytes"): any valid gzip stream of the same text is equivalent.  Two front ends feed one dynamic-Huffman back
+// end (one block per ~512 KiB of input with exact symbol counts, length-limited codes, a 64-bit bit writer that emits five
+// literals per drain, CRC-32 by PCLMULQDQ folding -- snk_crc32.h -- and ISIZE per member):
+//   deflate_fastq()  the text is FASTQ records.  No search at all: the name and '+' lines are compared with the record
+//                    before at the same place (runs of >= 4 equal bytes become matches), bases and qualities go out as
+//                    literal runs.  ~4 x the speed of the hash search and a few per cent smaller on FASTQ.
+//   deflate_all()    anything else: greedy LZ77 with a single-probe hash table of 4-byte sequences (32 KiB window, matches
+//                    of 4..258 bytes extended 8 bytes at a time, striding over stretches without matches); the ratio of
+//                    zlib's low levels at about twice their speed.
 //
-// tests/test_deflate.py: output decompressed by zlib and by snk_inflate.h equals the input for FASTQ, runs, random
-// bytes, empty input, sizes around every block boundary.
+// tests/test_deflate.py: output decompressed by zlib and by snk_inflate.h equals the input for FASTQ of every shape, text
+// that only looks like FASTQ, runs, random bytes, empty input, sizes around every block boundary, both front ends.
 #ifndef SNK_DEFLATE_H
 #define SNK_DEFLATE_H
 #include <stddef.h>
