@@ -246,6 +246,52 @@ __device__ __forceinline__ void trim_finish(const DevParams &P, int mate, ReadSt
     }
 }
 
+// A1 stat_read() and A3 fastq_trim() of one read, sequential (the generic kernel; the per-lane fallback of the long-read kernel)
+__device__ inline void stat_read_dev(const DevParams &P, int mate, const uint8_t *s, const uint8_t *q,
+                              int len, ReadState &r, int &err) {
+    rs_init(r, len);
+    err = SNK_OK;
+    int ada_pos = -1;
+    for (int i = 0; i < P.n_ada[mate]; ++i) {               // :175-188
+        ada_pos = adapter_pos_seq(s, len, P.ada[mate * SNK_MAX_ADAPTERS + i]);
+        if (ada_pos >= 0) break;
+    }
+    if (ada_pos >= 0) { r.inc_ada = 1; r.adacut = len - ada_pos; }
+    if (len == 0) { err = SNK_E_EMPTY_SEQ; return; }      // :250
+    int last = 'Q', run = 0, maxrun = 1;
+    for (int i = 0; i < len; ++i) {                          // :258-308
+        const int c = s[i];
+        if (c == last) { if (++run > maxrun) maxrun = run; } else run = 1;
+        last = c;
+        const int u = c & 0xDF;                              // fold case
+        if (u == 'A') ++r.n_a;
+        else if (u == 'N') ++r.n_n;
+        else if (!(u == 'C' || u == 'G' || u == 'T')) { err = SNK_E_BAD_BASE; return; }
+        const int bq = (int)q[i] - P.phred;
+        r.sumq += bq;
+        r.lowq += (bq <= P.low_qual);
+    }
+    r.polyx = (P.polyX_num != -1 && maxrun >= P.polyX_num) ? 1 : 0;
+}
+
+__device__ inline void fastq_trim_dev(const DevParams &P, int mate, const uint8_t *s, const uint8_t *q,
+                               ReadState &r) {
+    if (!P.trim_on) return;                                  // src/read_filter.cpp:354
+    const int len = r.len;
+    int hix = 0, tix = 0, g = 0;
+    if (P.has_lq) {                                          // :390-429
+        for (int i = 0; i < P.lq_head_len; ++i) {
+            if (rdc(q, len, i) - P.phred < P.lq_head_q) ++hix; else break;
+        }
+        for (int i = 0; i < P.lq_tail_len; ++i) {
+            if (rdc(q, len, len - i - 1) - P.phred < P.lq_tail_q) ++tix; else break;
+        }
+    }
+    if (P.has_polyG)                                         // :472-482
+        for (int i = len - 1; i >= 0; --i) { if ((s[i] & 0xDF) == 'G') ++g; else break; }
+    trim_finish(P, mate, r, hix, tix, g);
+}
+
 __device__ __forceinline__ int pe_dis(bool a, bool b) { return (a ? 1 : 0) + (b ? 2 : 0); }
 
 // A6: the cascade (src/sequence.cpp:198-387 PE, :76-178 SE); returns the reason and

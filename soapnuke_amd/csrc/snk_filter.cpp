@@ -627,6 +627,8 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         }
         done = snk_launch_tiled(c->hp, c->ta, D, st, c->lcap, c->nq, c->n_cu, stream);
         D.cf = nullptr;
+        // reads of 257..1024 positions: the block-wise bit-sliced path (snk_long.hip); it writes the stats block directly
+        if (!done) done = snk_launch_long(c->d_params, c->hp, c->ta, D, DevStats{c->d_sum, c->d_max, c->d_err, c->d_tsw}, c->lcap, c->nq, c->n_cu, stream);
         if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return SNK_E_UNSUPPORTED; }
     }
     if (!done) snk_launch_generic(c->d_params, D, st, c->lcap, c->nq, stream);

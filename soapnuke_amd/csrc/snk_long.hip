@@ -1,0 +1,361 @@
+// snk_long.hip -- the fast path for reads of 257..1024 positions (reference limit READ_MAX_LEN 1000,
+// src/global_variable.h:9).  The wave-tiled kernel keeps a read's bit planes in registers and its histograms in LDS, both
+// sized for <= 256 positions; long reads take two kernels instead:
+//
+//   snk_long_decide_kernel   lane = read (one work-item per pair).  Every lane streams its own row with 16-byte loads
+//       (64 rows per wave-load: the row pitch is the stride, a 128-byte line serves eight loads of its lane) and does
+//       A1 stat_read (src/read_filter.cpp:80-313) byte-parallel on the dwords: case-folded A / N counts, the low-quality
+//       count, the quality sum (v_sad_u8), the poly-X run.  The adapter search (A2, :707-790) is the bit-sliced one of the
+//       tiled kernel (snk_adapter_bits.cuh) on BLOCKS of the read: planes of 320 positions (10 words) serve the 256
+//       candidate offsets of a block plus the 64 positions an adapter can reach past them; a block in the middle of a read
+//       has phase B offsets only, phase A belongs to the first block, phase C to the last one, which ends with the read.
+//       Trimming (A3), the discard cascade (A6), the reason counters and the trimming-position counters follow as in the
+//       generic kernel.  A read with anything but upper-case ACGTN, or shorter than 64, takes the sequential functions of
+//       snk_common.cuh in its lane.
+//   snk_long_hist_kernel     lane = position.  A workgroup owns 128 positions of one mate for a slice of the batch: raw and
+//       clean per-position base / quality histograms (A8, src/peprocess.cpp:1182-1201 and the clean twin) in LDS (u32, 47 KB),
+//       one coalesced 64-byte load and two LDS adds per strip; clean counts come from the records of the first kernel (the
+//       kept reads, at the shifted positions).  Flushed once per workgroup.
+#include <hip/hip_runtime.h>
+#include "snk_common.cuh"
+#include "snk_adapter_bits.cuh"
+
+using namespace snk;
+
+namespace {
+
+constexpr int LNW = 10;            // plane words of a block: 256 candidate offsets + 64 positions behind them
+constexpr int LBLK = 256;          // candidate offsets per block
+constexpr int LVLEN = 32 * LNW - 1;   // characters a non-final block shows to the adapter search
+
+__device__ __forceinline__ u32 zero_bytes(u32 x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); }   // 0x80 per zero byte
+__device__ __forceinline__ u32 pack4(u32 z) { return ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu; }           // bits 7,15,23,31 -> 0..3
+// 0x80 in the bytes k of a dword at position pos with pos + k < len
+__device__ __forceinline__ u32 valid80(int len, int pos) {
+    const int d = len - pos;
+    return d >= 4 ? 0x80808080u : (d <= 0 ? 0u : (0x80808080u >> (8 * (4 - d))));
+}
+
+struct Scan { int n_a, n_n, lowq, sumq, maxrun; bool weird; };
+
+// A1 counts of one read (src/read_filter.cpp:258-308), byte-parallel over its row; weird = something outside "ACGTN"
+__device__ __forceinline__ Scan scan_read(const DevParams &P, const uint8_t *s, const uint8_t *q, int len) {
+    Scan r = {0, 0, 0, 0, 1, false};
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(s), *q4 = reinterpret_cast<const uint4 *>(q);
+    const u32 KL = ((u32)min(max(P.phred + P.low_qual, 0), 127) * 0x01010101u) | 0x80808080u;
+    const bool px = P.polyX_num != -1, lq_any = P.phred + P.low_qual >= 0;
+    u32 qsum = 0;
+    int last = 'Q', run = 0;
+    for (int pos = 0; pos < len; pos += 16) {
+        const uint4 sv = s4[pos >> 4], qv = q4[pos >> 4];
+        const u32 sd[4] = {sv.x, sv.y, sv.z, sv.w}, qd[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32 v = sd[k], w = qd[k], ok = valid80(len, pos + 4 * k);
+            const u32 f = v & 0xDFDFDFDFu;
+            r.n_a += __popc(zero_bytes(f ^ 0x41414141u) & ok);
+            r.n_n += __popc(zero_bytes(f ^ 0x4E4E4E4Eu) & ok);
+            const u32 t = v & 0x06060606u;
+            const u32 ex = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);        // the letter of each code
+            const u32 good = zero_bytes(ex ^ v) | zero_bytes(v ^ 0x4E4E4E4Eu);
+            r.weird |= (~good & ok) != 0;
+            // quality - phred <= low_qual  <=>  K - quality >= 0 (bytes below 128; others are range errors of the histogram pass)
+            r.lowq += lq_any ? __popc((KL - (w & 0x7F7F7F7Fu)) & ~w & ok) : 0;
+            const u32 bm = (ok >> 7) * 0xFFu;                                          // 0xFF in the valid bytes
+            qsum = __builtin_amdgcn_sad_u8(w & bm, 0u, qsum);
+            if (px) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (pos + 4 * k + b < len) {
+                        const int c = (int)((v >> (8 * b)) & 0xFFu);
+                        if (c == last) { if (++run > r.maxrun) r.maxrun = run; } else run = 1;
+                        last = c;
+                    }
+                }
+            }
+        }
+    }
+    r.sumq = (int)qsum - P.phred * len;
+    return r;
+}
+
+// planes of the block [p0, p0 + 320) of a read: X[k] bit j = read[p0 + j] == "ACGT"[k], XN likewise for 'N'; ones from vlen on
+__device__ __forceinline__ void block_planes(const uint8_t *s, int p0, int vlen, int pitch, u32 (&X)[4][LNW], u32 (&XN)[LNW]) {
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(s + p0);          // p0 is a multiple of 256
+#pragma unroll
+    for (int w = 0; w < LNW; ++w) {
+        u32 e = 0, c1 = 0, c2 = 0, nn = 0;
+        if (32 * w < vlen) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 sv = {0, 0, 0, 0};
+                if (p0 + 32 * w + 16 * h + 16 <= pitch) sv = s4[2 * w + h];          // (the last word of the last block may reach past the row)
+                const u32 sd[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int d = 4 * h + k;
+                    const u32 v = sd[k];
+                    const u32 t = v & 0x06060606u;
+                    const u32 ex = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);
+                    e |= pack4(zero_bytes(ex ^ v)) << (4 * d);
+                    nn |= pack4(zero_bytes(v ^ 0x4E4E4E4Eu)) << (4 * d);
+                    c1 |= pack4((v << 6) & 0x80808080u) << (4 * d);
+                    c2 |= pack4((v << 5) & 0x80808080u) << (4 * d);
+                }
+            }
+        }
+        const u32 in = lowmask32(vlen - 32 * w);
+        e &= in;
+        X[0][w] = (e & ~c1 & ~c2) | ~in;
+        X[1][w] = (e & c1 & ~c2) | ~in;
+        X[2][w] = (e & c1 & c2) | ~in;
+        X[3][w] = (e & ~c1 & c2) | ~in;
+        XN[w] = (nn & in) | ~in;
+    }
+}
+
+__device__ __forceinline__ u64 wave_max64(u64 v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const u64 x = __shfl_xor(v, o, 64);
+        v = x > v ? x : v;
+    }
+    return v;
+}
+
+__device__ void count_reason_long(unsigned long long *fs, bool pe, int reason, int v) {
+    if (reason == SNK_R_DUP) { atomicAdd(&fs[SNK_FS_DUP], 1ull); return; }
+    if (reason == SNK_R_TILE) { atomicAdd(&fs[SNK_FS_TILE], 1ull); return; }
+    if (reason == SNK_R_FOV) { atomicAdd(&fs[SNK_FS_FOV], 1ull); return; }
+    const int f = reason_family(reason);
+    if (f < 0) return;
+    atomicAdd(&fs[f], 1ull);
+    if (pe) {
+        if (v & 1) atomicAdd(&fs[f + 1], 1ull);
+        if (v & 2) atomicAdd(&fs[f + 2], 1ull);
+        if (v == 3) atomicAdd(&fs[f + 3], 1ull);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, DevStats st, int lcap, int nq) {
+    const DevParams &P = *Pp;
+    const long fb = file_block(lcap, nq);
+    const long ts_off = SNK_GS_N + (long)lcap * 5 + (long)lcap * nq;
+    const int pe = P.paired ? 1 : 0;
+    const long nround = (B.n + 255) / 256 * 256;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nround; i += (long)gridDim.x * blockDim.x) {
+        const bool exists = i < B.n;
+        ReadState r[2];
+        int cf[2] = {0, 0};
+        const uint8_t *s[2] = {nullptr, nullptr}, *q[2] = {nullptr, nullptr};
+        const unsigned long long gidx = B.first_index + (unsigned long long)i;
+        bool bad = !exists;
+        for (int m = 0; m <= pe; ++m) {
+            int len = 0;
+            if (exists) {
+                len = B.len[m] ? (int)B.len[m][i] : B.fixed_len[m];
+                s[m] = B.seq[m] + i * (long)B.pitch;
+                q[m] = B.qual[m] + i * (long)B.pitch;
+                if (len > lcap && !bad) { report_err(st, gidx, m, SNK_E_TOO_LONG); bad = true; }
+            }
+            const bool live = exists && !bad;
+            rs_init(r[m], len);
+            if (live && (P.n_ct[m] | P.n_gct)) cf[m] = contam_flags(P.ct + m * SNK_MAX_CONTAMS, P.n_ct[m], P.gct, P.n_gct, s[m], len);
+            Scan sc = {0, 0, 0, 0, 1, true};
+            if (live && len >= 64) sc = scan_read(P, s[m], q[m], len);
+            const bool fast = live && !sc.weird;
+            int e = SNK_OK;
+            if (live && !fast) {                                   // anything unusual: the sequential restatement, in this lane
+                stat_read_dev(P, m, s[m], q[m], len, r[m], e);
+                if (e) { report_err(st, gidx, m, e); bad = true; }
+            }
+            if (fast) {
+                r[m].n_a = sc.n_a;
+                r[m].n_n = sc.n_n;
+                r[m].lowq = sc.lowq;
+                r[m].sumq = sc.sumq;
+                r[m].polyx = (P.polyX_num != -1 && sc.maxrun >= P.polyX_num) ? 1 : 0;
+            }
+            // ---- adapter search over the blocks of the read (uniform control flow: every lane walks along, `todo` decides)
+            const int n_ada = P.n_ada[m];
+            if (n_ada > 0 && __any(fast)) {
+                int res[SNK_TILE_MAX_ADA];
+#pragma unroll
+                for (int a = 0; a < SNK_TILE_MAX_ADA; ++a) res[a] = -1;
+                for (int p0 = 0; __any(fast && p0 < len); p0 += LBLK) {
+                    const int rem = len - p0;
+                    const bool here = fast && rem > 0, final = rem <= LVLEN;
+                    const int vlen = here ? (final ? rem : LVLEN) : 0;
+                    u32 X[4][LNW], XN[LNW];
+                    block_planes(here ? s[m] : B.seq[m], here ? p0 : 0, vlen, B.pitch, X, XN);
+                    bool earlier = false;                            // an adapter in front of this one already has its hit
+                    for (int a = 0; a < n_ada; ++a) {
+                        int cur = -1;
+#pragma unroll
+                        for (int k = 0; k < SNK_TILE_MAX_ADA; ++k) cur = (k == a) ? res[k] : cur;
+                        const bool todo = here && cur < 0 && !earlier;
+                        if (__any(todo)) {
+                            const int rel = adapter_tile<LNW, true>(TA.a[m][a], P.ada[m * SNK_MAX_ADAPTERS + a], X, XN, vlen, todo, s[m] + p0,
+                                                                    p0 == 0, final);
+                            if (todo && rel >= 0) {
+#pragma unroll
+                                for (int k = 0; k < SNK_TILE_MAX_ADA; ++k) res[k] = (k == a) ? p0 + rel : res[k];
+                                cur = p0 + rel;
+                            }
+                        }
+                        earlier |= cur >= 0;
+                    }
+                    // a lane is through once it has seen its final block
+                    if (here && final) len = min(len, p0);           // (local copy: ends this lane's walk)
+                }
+                len = r[m].len;
+                if (fast) {
+                    int ada_pos = -1;
+#pragma unroll
+                    for (int a = SNK_TILE_MAX_ADA - 1; a >= 0; --a) ada_pos = (a < n_ada && res[a] >= 0) ? res[a] : ada_pos;
+                    if (ada_pos >= 0) { r[m].inc_ada = 1; r[m].adacut = len - ada_pos; }
+                }
+            }
+        }
+        const bool ok = exists && !bad;
+        if (ok)
+            for (int m = 0; m <= pe; ++m) fastq_trim_dev(P, m, s[m], q[m], r[m]);
+        int v = 0, reason = 255;
+        if (ok) {
+            reason = discard_reason(P, r[0], r[pe], B.dup ? B.dup[i] : 0, v, cf[0], cf[pe]);
+            count_reason_long(st.sum, pe, reason, v);
+        }
+        if (exists) {                                                // (a pair that raised an error gets a record no later pass uses)
+            store_rec(B.out[0], i, r[0], reason, v);
+            if (pe) store_rec(B.out[1], i, r[1], reason, v);
+        }
+        const unsigned long long key = (gidx + 1) << 16;
+        for (int m = 0; m <= pe; ++m) {
+            if (ok) {
+                unsigned long long *file = st.sum + SNK_FS_N + m * fb;
+                int hh = -1, lh = -1, ht = -1, lt = -1, ad = -1;
+                if (P.copy_back) { hh = r[m].hd_h; lh = r[m].lq_h; ht = r[m].hd_t; lt = r[m].lq_t; ad = r[m].adacut; }
+                ts_update(file + ts_off, hh, lh, ht, lt, ad, (pe && m == 1) ? r[m].len : 0, !pe);
+            }
+            // reads_number and the "last read" word of the raw / clean files: one atomic per wave
+            const unsigned long long nraw = __popcll(__ballot(ok)), ncl = __popcll(__ballot(ok && reason == SNK_KEEP));
+            const u64 kraw = wave_max64(ok ? (key | (u64)r[m].len) : 0ull);
+            const u64 kcl = wave_max64((ok && reason == SNK_KEEP) ? (key | (u64)r[m].clen) : 0ull);
+            if ((threadIdx.x & 63) == 0) {
+                if (nraw) { atomicAdd(&st.sum[SNK_FS_N + m * fb + SNK_GS_READS], nraw); atomicMax(&st.maxb[m], kraw); }
+                if (ncl) { atomicAdd(&st.sum[SNK_FS_N + (2 + m) * fb + SNK_GS_READS], ncl); atomicMax(&st.maxb[2 + m], kcl); }
+            }
+            if (ok && reason == SNK_KEEP) {
+                unsigned long long *file = st.sum + SNK_FS_N + (2 + m) * fb;
+                ts_update(file + ts_off, r[m].hd_h, r[m].lq_h, r[m].hd_t, r[m].lq_t, r[m].adacut,
+                          (pe && m == 1) ? r[m].clen : r[m].len, !pe);
+            }
+        }
+    }
+}
+
+// ---- per-position histograms.  blockIdx.x = (mate, position block of 128, slice of the batch)
+constexpr int HPB = 128;
+
+__global__ void __launch_bounds__(256)
+snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int nq, int nblk, int slices) {
+    extern __shared__ u32 h[];                       // raw[(5 + nq)][128] | clean[(5 + nq)][128]
+    const DevParams &P = *Pp;
+    const int rows = 5 + nq, words = rows * HPB;
+    u32 *hraw = h, *hcl = h + words;
+    int id = blockIdx.x;
+    const int slice = id % slices; id /= slices;
+    const int pb = id % nblk, m = id / nblk;
+    for (int k = threadIdx.x; k < 2 * words; k += blockDim.x) h[k] = 0;
+    __syncthreads();
+    const long per = (B.n + slices - 1) / slices;
+    const long r0 = (long)slice * per, r1 = min(B.n, r0 + per);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int base = pb * HPB, phred = P.phred;
+    const uint8_t *seq = B.seq[m], *qual = B.qual[m];
+    const snk_read_result *rec = B.out[m];
+    const long fb = file_block(lcap, nq);
+    auto add = [&](u32 *hh, int slot, int c, int qc, bool on, bool &err) {
+        if (on) {
+            const int u = c & 0xDF;
+            const int b = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
+            atomicAdd(&hh[b * HPB + slot], 1u);
+            const int bq = qc - phred;
+            if (bq < 0 || bq >= nq) err = true;
+            else atomicAdd(&hh[(5 + bq) * HPB + slot], 1u);
+        }
+    };
+    for (long rr = r0 + wave; rr < r1; rr += 8) {                    // two reads per trip: their loads go out together
+        bool e0 = false, e1 = false, ec = false;
+        const long ra = rr, rb = rr + 4;
+        const bool hb = rb < r1;
+        int la = B.len[m] ? (int)B.len[m][ra] : B.fixed_len[m], lb = hb ? (B.len[m] ? (int)B.len[m][rb] : B.fixed_len[m]) : 0;
+        if (la > lcap) la = 0;                                        // (reported by the first kernel)
+        if (lb > lcap) lb = 0;
+        const snk_read_result xa = rec[ra], xb = rec[hb ? rb : ra];
+        const int sa = xa.clean_start, ca = xa.reason == SNK_KEEP ? (int)xa.clean_len : 0;
+        const int sb = xb.clean_start, cb = (hb && xb.reason == SNK_KEEP) ? (int)xb.clean_len : 0;
+        const uint8_t *pa = seq + ra * (long)B.pitch, *qa = qual + ra * (long)B.pitch;
+        const uint8_t *pbp = seq + (hb ? rb : ra) * (long)B.pitch, *qbp = qual + (hb ? rb : ra) * (long)B.pitch;
+        int c[8], qc[8];
+        bool on[8];
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const int pos = base + 64 * sidx + lane;
+            on[0 + sidx] = pos < la;          on[2 + sidx] = pos < ca;
+            on[4 + sidx] = pos < lb;          on[6 + sidx] = pos < cb;
+            c[0 + sidx] = on[0 + sidx] ? pa[pos] : 0;          qc[0 + sidx] = on[0 + sidx] ? qa[pos] : 0;
+            c[2 + sidx] = on[2 + sidx] ? pa[sa + pos] : 0;     qc[2 + sidx] = on[2 + sidx] ? qa[sa + pos] : 0;
+            c[4 + sidx] = on[4 + sidx] ? pbp[pos] : 0;         qc[4 + sidx] = on[4 + sidx] ? qbp[pos] : 0;
+            c[6 + sidx] = on[6 + sidx] ? pbp[sb + pos] : 0;    qc[6 + sidx] = on[6 + sidx] ? qbp[sb + pos] : 0;
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const int slot = 64 * sidx + lane;
+            add(hraw, slot, c[0 + sidx], qc[0 + sidx], on[0 + sidx], e0);
+            add(hcl, slot, c[2 + sidx], qc[2 + sidx], on[2 + sidx], ec);
+            add(hraw, slot, c[4 + sidx], qc[4 + sidx], on[4 + sidx], e1);
+            add(hcl, slot, c[6 + sidx], qc[6 + sidx], on[6 + sidx], ec);
+        }
+        // a quality outside [0, nq) of the RAW pass is the reference's heap corruption (src/peprocess.cpp:1196): first one reported
+        if (__any(e0) && lane == 0) report_err(st, B.first_index + (u64)ra, m, SNK_E_QUAL_RANGE);
+        if (__any(e1) && lane == 0) report_err(st, B.first_index + (u64)rb, m, SNK_E_QUAL_RANGE);
+    }
+    __syncthreads();
+    unsigned long long *fraw = st.sum + SNK_FS_N + m * fb + SNK_GS_N, *fcl = st.sum + SNK_FS_N + (2 + m) * fb + SNK_GS_N;
+    for (int k = threadIdx.x; k < words; k += blockDim.x) {
+        const int row = k / HPB, p = base + (k - row * HPB);
+        if (p >= lcap) continue;
+        const long off = row < 5 ? (long)p * 5 + row : (long)lcap * 5 + (long)p * nq + (row - 5);
+        const u32 a = hraw[k], b = hcl[k];
+        if (a) atomicAdd(&fraw[off], (unsigned long long)a);
+        if (b) atomicAdd(&fcl[off], (unsigned long long)b);
+    }
+}
+
+}  // namespace
+
+// returns 0 when this path cannot take the batch (the caller falls back to the generic kernel)
+int snk_launch_long(const DevParams *dp, const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, int lcap, int nq,
+                    int n_cu, void *stream) {
+    if (!hp.tile_ok || lcap <= 256 || lcap > 1024 || b.n <= 0) return 0;
+    if (b.pitch % 16 != 0 || b.pitch < ((lcap + 15) & ~15)) return 0;
+    if ((((uintptr_t)b.seq[0] | (uintptr_t)b.qual[0] | (uintptr_t)b.seq[1] | (uintptr_t)b.qual[1]) % 16) != 0) return 0;
+    long wgs = (b.n + 255) / 256;
+    if (wgs > (long)n_cu * 8) wgs = (long)n_cu * 8;
+    hipLaunchKernelGGL(snk_long_decide_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, dp, ta, b, st, lcap, nq);
+    const int nblk = (lcap + HPB - 1) / HPB, mates = hp.paired ? 2 : 1;
+    const size_t shmem = (size_t)2 * (5 + nq) * HPB * sizeof(u32);
+    int slices = (int)((long)n_cu * 3 / (nblk * mates));
+    if (slices < 1) slices = 1;
+    while (slices > 1 && b.n / slices < 512) --slices;              // a flush per workgroup wants some reads behind it
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)snk_long_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(snk_long_hist_kernel, dim3((unsigned)(mates * nblk * slices)), dim3(256), shmem, (hipStream_t)stream, dp, b, st, lcap, nq,
+                       nblk, slices);
+    return 1;
+}

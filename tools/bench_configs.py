@@ -14,7 +14,7 @@ from soapnuke_amd.filter import FilterContext  # noqa: E402
 
 
 def run(name, L, paired, kw, n=10_000_000, var_len=False):
-    uniq = 1_000_000 if L <= 150 else 500_000
+    uniq = 1_000_000 if L <= 150 else (500_000 if L <= 256 else 200_000)
     d = synth.make_batch(uniq, L, paired=paired, var_len=var_len)
     ctx = FilterContext(abi.default_params(paired=paired, max_read_len=L, **kw), device=0)
     dev = ctx.upload(d)
@@ -56,6 +56,10 @@ run("defaults (no adapter)", 150, True, PE_CASES["defaults"])
 run("C2 SE150", 150, False, se(PE_CASES["C2_adatrim_lowq"]))
 run("C2 PE100", 100, True, PE_CASES["C2_adatrim_lowq"])
 run("C5 PE250 (C2 params)", 250, True, PE_CASES["C2_adatrim_lowq"], n=6_000_000)
+run("long C2 PE500", 500, True, PE_CASES["C2_adatrim_lowq"], n=2_000_000)
+run("long C2 PE1000", 1000, True, PE_CASES["C2_adatrim_lowq"], n=1_000_000)
+run("long C3 PE1000", 1000, True, PE_CASES["C3_full"], n=1_000_000)
+run("long defaults PE1000", 1000, True, PE_CASES["defaults"], n=1_000_000)
 run("C2 + contam1/2 + global", 150, True, dict(PE_CASES["C2_adatrim_lowq"], contam1="ACGTTGCAAGGCTTAACCGGTTAGCATGCAAT", contam2="TTGGCCAAGGTTCCAAGGTTAACCGGTT",
                                                ct_match_r="0.5", global_contams="AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", g_mrs="0.4", g_mms="1"), n=5_000_000)
 run("C2 + contam1/2 only", 150, True, dict(PE_CASES["C2_adatrim_lowq"], contam1="ACGTTGCAAGGCTTAACCGGTTAGCATGCAAT", contam2="TTGGCCAAGGTTCCAAGGTTAACCGGTT",
