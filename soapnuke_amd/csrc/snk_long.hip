@@ -46,30 +46,43 @@ __device__ __forceinline__ Scan scan_read(const DevParams &P, const uint8_t *s, 
     const bool px = P.polyX_num != -1, lq_any = P.phred + P.low_qual >= 0;
     u32 qsum = 0;
     int last = 'Q', run = 0;
-    for (int pos = 0; pos < len; pos += 16) {
-        const uint4 sv = s4[pos >> 4], qv = q4[pos >> 4];
-        const u32 sd[4] = {sv.x, sv.y, sv.z, sv.w}, qd[4] = {qv.x, qv.y, qv.z, qv.w};
+    // 128 bytes per array and trip, all loads first: a lane's eight 16-byte loads share one 128-byte line, which must
+    // not be evicted between them (64 lanes x 2 arrays x 128 B per wave is most of the CU's L1)
+    for (int pos0 = 0; pos0 < len; pos0 += 128) {
+        uint4 svv[8], qvv[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const u32 v = sd[k], w = qd[k], ok = valid80(len, pos + 4 * k);
-            const u32 f = v & 0xDFDFDFDFu;
-            r.n_a += __popc(zero_bytes(f ^ 0x41414141u) & ok);
-            r.n_n += __popc(zero_bytes(f ^ 0x4E4E4E4Eu) & ok);
-            const u32 t = v & 0x06060606u;
-            const u32 ex = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);        // the letter of each code
-            const u32 good = zero_bytes(ex ^ v) | zero_bytes(v ^ 0x4E4E4E4Eu);
-            r.weird |= (~good & ok) != 0;
-            // quality - phred <= low_qual  <=>  K - quality >= 0 (bytes below 128; others are range errors of the histogram pass)
-            r.lowq += lq_any ? __popc((KL - (w & 0x7F7F7F7Fu)) & ~w & ok) : 0;
-            const u32 bm = (ok >> 7) * 0xFFu;                                          // 0xFF in the valid bytes
-            qsum = __builtin_amdgcn_sad_u8(w & bm, 0u, qsum);
-            if (px) {
+        for (int g = 0; g < 8; ++g) {
+            const bool in = pos0 + 16 * g < len;
+            svv[g] = in ? s4[(pos0 >> 4) + g] : uint4{0, 0, 0, 0};
+            qvv[g] = in ? q4[(pos0 >> 4) + g] : uint4{0, 0, 0, 0};
+        }
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (pos + 4 * k + b < len) {
-                        const int c = (int)((v >> (8 * b)) & 0xFFu);
-                        if (c == last) { if (++run > r.maxrun) r.maxrun = run; } else run = 1;
-                        last = c;
+        for (int g = 0; g < 8; ++g) {
+            const int pos = pos0 + 16 * g;
+            const uint4 sv = svv[g], qv = qvv[g];
+            const u32 sd[4] = {sv.x, sv.y, sv.z, sv.w}, qd[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32 v = sd[k], w = qd[k], ok = valid80(len, pos + 4 * k);
+                const u32 f = v & 0xDFDFDFDFu;
+                r.n_a += __popc(zero_bytes(f ^ 0x41414141u) & ok);
+                r.n_n += __popc(zero_bytes(f ^ 0x4E4E4E4Eu) & ok);
+                const u32 t = v & 0x06060606u;
+                const u32 ex = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);        // the letter of each code
+                const u32 good = zero_bytes(ex ^ v) | zero_bytes(v ^ 0x4E4E4E4Eu);
+                r.weird |= (~good & ok) != 0;
+                // quality - phred <= low_qual  <=>  K - quality >= 0 (bytes below 128; others are range errors of the histogram pass)
+                r.lowq += lq_any ? __popc((KL - (w & 0x7F7F7F7Fu)) & ~w & ok) : 0;
+                const u32 bm = (ok >> 7) * 0xFFu;                                          // 0xFF in the valid bytes
+                qsum = __builtin_amdgcn_sad_u8(w & bm, 0u, qsum);
+                if (px) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (pos + 4 * k + b < len) {
+                            const int c = (int)((v >> (8 * b)) & 0xFFu);
+                            if (c == last) { if (++run > r.maxrun) r.maxrun = run; } else run = 1;
+                            last = c;
+                        }
                     }
                 }
             }
@@ -258,11 +271,28 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
 // ---- per-position histograms.  blockIdx.x = (mate, position block of 128, slice of the batch)
 constexpr int HPB = 128;
 
+// LDS word of (row, slot); row 5 + nq is a bin nobody reads: lanes past a read's end and out-of-range qualities add there,
+// so the adds need no branches
+__device__ __forceinline__ void hist_add(u32 *hh, int slot, int trash, int nq, int phred, u32 c, u32 qc, bool on, bool &err) {
+    const u32 u = c & 0xDFu, t = (u >> 1) & 3u;                     // A 0, C 1, T 2, G 3
+    const u32 ex = (0x47544341u >> (8 * t)) & 0xFFu;                // the letter of that code
+    int b = u == ex ? (int)(t ^ (t >> 1)) : 4;                      // A C G T -> 0 1 2 3, anything else (N) 4
+    const int bq = (int)qc - phred;
+    const bool qok = (unsigned)bq < (unsigned)nq;
+    err |= on && !qok;
+    b = on ? b : trash;
+    const int qrow = (on && qok) ? 5 + bq : trash;
+    atomicAdd(&hh[b * HPB + slot], 1u);
+    atomicAdd(&hh[qrow * HPB + slot], 1u);
+}
+
+// Every lane takes FOUR positions of a read as one dword load (lanes 0-31: the 128 positions of one read, lanes 32-63: of
+// the next one) -- 256 bytes per load instruction instead of 64, which is what the kernel lives on: it is bound by the bytes
+// in flight.  Position 4j + k sits in column 32k + j of a bin row, so the 32 lanes of a half hit 32 different banks.
 __global__ void __launch_bounds__(256)
 snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int nq, int nblk, int slices) {
-    extern __shared__ u32 h[];                       // raw[(5 + nq)][128] | clean[(5 + nq)][128]
-    const DevParams &P = *Pp;
-    const int rows = 5 + nq, words = rows * HPB;
+    extern __shared__ u32 h[];                       // raw[(5 + nq + 1)][128] | clean[(5 + nq + 1)][128]
+    const int rows = 5 + nq, words = (rows + 1) * HPB;
     u32 *hraw = h, *hcl = h + words;
     int id = blockIdx.x;
     const int slice = id % slices; id /= slices;
@@ -272,60 +302,64 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
     const long per = (B.n + slices - 1) / slices;
     const long r0 = (long)slice * per, r1 = min(B.n, r0 + per);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int base = pb * HPB, phred = P.phred;
+    const int half = lane >> 5, j = lane & 31;
+    const int base = pb * HPB, phred = __builtin_amdgcn_readfirstlane(Pp->phred);
     const uint8_t *seq = B.seq[m], *qual = B.qual[m];
     const snk_read_result *rec = B.out[m];
+    const uint16_t *lens = B.len[m];
+    const int fixed = B.fixed_len[m], pitch = B.pitch;
     const long fb = file_block(lcap, nq);
-    auto add = [&](u32 *hh, int slot, int c, int qc, bool on, bool &err) {
-        if (on) {
-            const int u = c & 0xDF;
-            const int b = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
-            atomicAdd(&hh[b * HPB + slot], 1u);
-            const int bq = qc - phred;
-            if (bq < 0 || bq >= nq) err = true;
-            else atomicAdd(&hh[(5 + bq) * HPB + slot], 1u);
-        }
-    };
-    for (long rr = r0 + wave; rr < r1; rr += 8) {                    // two reads per trip: their loads go out together
-        bool e0 = false, e1 = false, ec = false;
-        const long ra = rr, rb = rr + 4;
-        const bool hb = rb < r1;
-        int la = B.len[m] ? (int)B.len[m][ra] : B.fixed_len[m], lb = hb ? (B.len[m] ? (int)B.len[m][rb] : B.fixed_len[m]) : 0;
-        if (la > lcap) la = 0;                                        // (reported by the first kernel)
-        if (lb > lcap) lb = 0;
-        const snk_read_result xa = rec[ra], xb = rec[hb ? rb : ra];
-        const int sa = xa.clean_start, ca = xa.reason == SNK_KEEP ? (int)xa.clean_len : 0;
-        const int sb = xb.clean_start, cb = (hb && xb.reason == SNK_KEEP) ? (int)xb.clean_len : 0;
-        const uint8_t *pa = seq + ra * (long)B.pitch, *qa = qual + ra * (long)B.pitch;
-        const uint8_t *pbp = seq + (hb ? rb : ra) * (long)B.pitch, *qbp = qual + (hb ? rb : ra) * (long)B.pitch;
-        int c[8], qc[8];
-        bool on[8];
+    constexpr int U = 4;                                            // pairs of reads per trip: their loads go out together
+    for (long rr = r0 + wave * 2 * U; rr < r1; rr += 4 * 2 * U) {
+        u32 cw[U], qw[U], ccw[U], cqw[U];
+        int nv[U], nc[U];
 #pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
-            const int pos = base + 64 * sidx + lane;
-            on[0 + sidx] = pos < la;          on[2 + sidx] = pos < ca;
-            on[4 + sidx] = pos < lb;          on[6 + sidx] = pos < cb;
-            c[0 + sidx] = on[0 + sidx] ? pa[pos] : 0;          qc[0 + sidx] = on[0 + sidx] ? qa[pos] : 0;
-            c[2 + sidx] = on[2 + sidx] ? pa[sa + pos] : 0;     qc[2 + sidx] = on[2 + sidx] ? qa[sa + pos] : 0;
-            c[4 + sidx] = on[4 + sidx] ? pbp[pos] : 0;         qc[4 + sidx] = on[4 + sidx] ? qbp[pos] : 0;
-            c[6 + sidx] = on[6 + sidx] ? pbp[sb + pos] : 0;    qc[6 + sidx] = on[6 + sidx] ? qbp[sb + pos] : 0;
+        for (int k = 0; k < U; ++k) {
+            const long rk = rr + 2 * k + half;
+            const bool have = rk < r1;
+            const long r = have ? rk : r1 - 1;
+            int l = lens ? (int)lens[r] : fixed;
+            if (l > lcap || !have) l = 0;                           // (too long: reported by the first kernel)
+            const snk_read_result x = rec[r];
+            const int start = x.clean_start, cl = (have && x.reason == SNK_KEEP) ? (int)x.clean_len : 0;
+            nv[k] = max(min(l - base - 4 * j, 4), 0);               // positions of this lane's dword the read has
+            nc[k] = max(min(cl - base - 4 * j, 4), 0);
+            const uint8_t *ps = seq + r * (long)pitch, *pq = qual + r * (long)pitch;
+            const int off = base + 4 * j;
+            cw[k] = nv[k] ? *reinterpret_cast<const u32 *>(ps + off) : 0u;
+            qw[k] = nv[k] ? *reinterpret_cast<const u32 *>(pq + off) : 0u;
+            ccw[k] = cw[k];
+            cqw[k] = qw[k];
+            if (start != 0 && nc[k]) {                              // head-trimmed: the clean read sits at shifted positions
+                const int so = start + off, al = so & ~3, sh = 8 * (so & 3);
+                const u32 s0 = *reinterpret_cast<const u32 *>(ps + al), q0 = *reinterpret_cast<const u32 *>(pq + al);
+                const u32 s1 = (sh && al + 8 <= pitch) ? *reinterpret_cast<const u32 *>(ps + al + 4) : 0u;
+                const u32 q1 = (sh && al + 8 <= pitch) ? *reinterpret_cast<const u32 *>(pq + al + 4) : 0u;
+                ccw[k] = __builtin_amdgcn_alignbit(s1, s0, sh);
+                cqw[k] = __builtin_amdgcn_alignbit(q1, q0, sh);
+            }
         }
 #pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
-            const int slot = 64 * sidx + lane;
-            add(hraw, slot, c[0 + sidx], qc[0 + sidx], on[0 + sidx], e0);
-            add(hcl, slot, c[2 + sidx], qc[2 + sidx], on[2 + sidx], ec);
-            add(hraw, slot, c[4 + sidx], qc[4 + sidx], on[4 + sidx], e1);
-            add(hcl, slot, c[6 + sidx], qc[6 + sidx], on[6 + sidx], ec);
+        for (int k = 0; k < U; ++k) {
+            bool e = false, ec = false;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int col = 32 * b + j;
+                hist_add(hraw, col, rows, nq, phred, (cw[k] >> (8 * b)) & 0xFFu, (qw[k] >> (8 * b)) & 0xFFu, b < nv[k], e);
+                hist_add(hcl, col, rows, nq, phred, (ccw[k] >> (8 * b)) & 0xFFu, (cqw[k] >> (8 * b)) & 0xFFu, b < nc[k], ec);
+            }
+            // a quality outside [0, nq) of the RAW pass is the reference's heap corruption (src/peprocess.cpp:1196): first one reported
+            const unsigned long long em = __ballot(e);
+            if (em && lane == 0) {
+                if (em & 0xFFFFFFFFull) report_err(st, B.first_index + (u64)(rr + 2 * k), m, SNK_E_QUAL_RANGE);
+                if (em >> 32) report_err(st, B.first_index + (u64)(rr + 2 * k + 1), m, SNK_E_QUAL_RANGE);
+            }
         }
-        // a quality outside [0, nq) of the RAW pass is the reference's heap corruption (src/peprocess.cpp:1196): first one reported
-        if (__any(e0) && lane == 0) report_err(st, B.first_index + (u64)ra, m, SNK_E_QUAL_RANGE);
-        if (__any(e1) && lane == 0) report_err(st, B.first_index + (u64)rb, m, SNK_E_QUAL_RANGE);
     }
     __syncthreads();
     unsigned long long *fraw = st.sum + SNK_FS_N + m * fb + SNK_GS_N, *fcl = st.sum + SNK_FS_N + (2 + m) * fb + SNK_GS_N;
-    for (int k = threadIdx.x; k < words; k += blockDim.x) {
-        const int row = k / HPB, p = base + (k - row * HPB);
+    for (int k = threadIdx.x; k < rows * HPB; k += blockDim.x) {
+        const int row = k / HPB, col = k - row * HPB, p = base + 4 * (col & 31) + (col >> 5);
         if (p >= lcap) continue;
         const long off = row < 5 ? (long)p * 5 + row : (long)lcap * 5 + (long)p * nq + (row - 5);
         const u32 a = hraw[k], b = hcl[k];
@@ -346,7 +380,7 @@ int snk_launch_long(const DevParams *dp, const DevParams &hp, const TileAdapters
     if (wgs > (long)n_cu * 8) wgs = (long)n_cu * 8;
     hipLaunchKernelGGL(snk_long_decide_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, dp, ta, b, st, lcap, nq);
     const int nblk = (lcap + HPB - 1) / HPB, mates = hp.paired ? 2 : 1;
-    const size_t shmem = (size_t)2 * (5 + nq) * HPB * sizeof(u32);
+    const size_t shmem = (size_t)2 * (5 + nq + 1) * HPB * sizeof(u32);
     int slices = (int)((long)n_cu * 3 / (nblk * mates));
     if (slices < 1) slices = 1;
     while (slices > 1 && b.n / slices < 512) --slices;              // a flush per workgroup wants some reads behind it

@@ -323,7 +323,7 @@ def test_pitch_not_multiple_of_16(name, pitch, var_len):
 
 @pytest.mark.parametrize("L", [51, 64, 65, 96, 97, 128, 129, 255, 256, 257, 1000])
 def test_capacity_boundaries(L):
-    """read-length capacities around the plane-word / strip / tiled-kernel limits (tiled up to 256, generic beyond)"""
+    """read-length capacities around the plane-word / strip / tiled-kernel limits (tiled up to 256, the long-read path beyond)"""
     n = 6000 if L <= 257 else 1500
     d = synth.make_batch(n, L, paired=True, var_len=True, seed=50 + L)
     p = abi.default_params(paired=True, max_read_len=L, **PE_CASES["C3_full"])

@@ -25,12 +25,13 @@ def run(name, L, paired, kw, n=10_000_000, var_len=False):
     dev["n"] = uniq * reps
     b = ctx.make_batch(dev)
     rec = ctx.alloc_records(dev["n"])
-    ctx.filter_batch(b, rec)
+    kern = int(os.environ.get("SNK_BENCH_KERNEL", "0"))          # 1: force the generic kernel
+    ctx.filter_batch(b, rec, kernel=kern)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        ctx.filter_batch(b, rec)
+        ctx.filter_batch(b, rec, kernel=kern)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
