@@ -48,6 +48,27 @@ def test_cli_matches_reference_binary(case, tmp_path):
         assert _cat(os.path.join(ours, c)) == _cat(os.path.join(ref, c)), c
 
 
+@pytest.mark.parametrize("L,paired", [(600, True), (900, False)])      # (the reference binary itself rejects 1000-character lines)
+def test_cli_long_reads(L, paired, tmp_path):
+    """reads of 257..1000 positions end to end: the long-read kernels (snk_long.hip) behind the CLI, reports (600 / 1000 rows
+    per position table) and clean FASTQ byte-identical to the reference binary"""
+    kw = dict(adapters1=[synth.ADAPTER1], ada_trim=1, low_qual=10, low_qual_ratio=0.1, n_ratio=0.01)
+    cli, cfg = ["-f", synth.ADAPTER1, "-J", "-l", "10", "-q", "0.1", "-n", "0.01"], []
+    if paired:
+        kw.update(adapters2=[synth.ADAPTER2], trim_bad_tail=(20, 30))
+        cli += ["-r", synth.ADAPTER2]
+        cfg = ["trimBadTail=20,30"]
+    case = ("long%d" % L, paired, L, 6000, 2, 300, dict(seed=70 + L // 100), kw, cli, cfg)
+    d, p = R.case_inputs(case)
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ours = _run_ours(case, work, gz=False)
+    for f in (R.REPORT_FILES_PE if paired else R.REPORT_FILES_SE):
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in (["c1.fq", "c2.fq"] if paired else ["c1.fq"]):
+        assert _cat(os.path.join(ours, c)) == _cat(os.path.join(ref, c)), c
+
+
 def test_cli_gz_in_gz_out(tmp_path):
     case = R.REPORT_CASES[0]
     d, p = R.case_inputs(case)
