@@ -22,6 +22,9 @@
 //      sequential decoding from that point on: the result is always what zlib would produce, or an error.
 #ifndef SNK_PGUNZIP_H
 #define SNK_PGUNZIP_H
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
@@ -446,7 +449,25 @@ private:
         uint8_t *base = c.buf.data() + HIST;
         const uint16_t *M = c.M.data();
         const uint8_t *w = c.win.data();
-        for (size_t k = 0; k < c.mlen; ++k) {
+        size_t k = 0;
+#if defined(__SSE2__)
+        // sixteen symbols at a time: most groups hold no marker (in FASTQ the markers live in the read names) and are just
+        // narrowed; a group with one takes the scalar look-ups
+        for (; k + 16 <= c.mlen; k += 16) {
+            const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(M + k));
+            const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(M + k + 8));
+            const __m128i hi = _mm_srli_epi16(_mm_or_si128(a, b), 8);
+            if (_mm_movemask_epi8(_mm_cmpeq_epi16(hi, _mm_setzero_si128())) == 0xFFFF) {
+                _mm_storeu_si128(reinterpret_cast<__m128i *>(base + k), _mm_packus_epi16(a, b));
+            } else {
+                for (size_t t = k; t < k + 16; ++t) {
+                    const uint16_t v = M[t];
+                    base[t] = v < 256 ? (uint8_t)v : w[v - 256];
+                }
+            }
+        }
+#endif
+        for (; k < c.mlen; ++k) {
             const uint16_t v = M[k];
             base[k] = v < 256 ? (uint8_t)v : w[v - 256];
         }
