@@ -98,6 +98,20 @@ def test_long_reads_several_adapters_and_budgets():
     assert_same(p, run_hip_device(p, d, 2), T.run_oracle(p, d), True)
 
 
+def test_long_reads_contaminants_and_duplicates():
+    """contaminant verdicts (sequential matchers inside the decide kernel beyond 256 positions) and duplicate / tile flags"""
+    from cases import CONTAM_CASES, plant_contams
+    L, n = 400, 2500
+    kw = dict(CONTAM_CASES["both_discard"])
+    d = synth.make_batch(n, L, paired=True, var_len=True, seed=123)
+    plant_contams(d, kw)
+    p = abi.default_params(paired=True, max_read_len=L, rmdup=1, **kw)
+    rng = np.random.default_rng(3)
+    dup = (rng.random(n) < 0.1).astype(np.uint8) | ((rng.random(n) < 0.03).astype(np.uint8) << 1)
+    want = T.run_oracle(p, d, dup=dup)
+    assert_same(p, run_hip_device(p, d, 2, dup=dup, chunks=2), want, True)
+
+
 def test_long_reads_quality_range_error():
     """a quality below the offset is the reference's heap corruption (src/peprocess.cpp:1196): reported with the read's index"""
     L, n = 600, 1000
