@@ -218,8 +218,11 @@ int snk_stats_clear(snk_ctx *ctx, void *hip_stream);
 /* Run the hot path on one device-resident patch: per-read records into
  * out[m] (device, n*16 bytes each; out[1] ignored for SE), stats accumulated
  * into the bound block.  Asynchronous on `hip_stream` (hipStream_t, NULL =
- * default stream).  kernel: 0 = auto, 1 = generic (any read length),
- * 2 = wave-tiled fast path.                                                  */
+ * default stream).  kernel: 0 = auto, 1 = generic decisions (any read length,
+ * any adapter) + the LDS histogram kernel, 2 = fast paths only (wave-tiled
+ * up to 256 positions, block-wise beyond; error if neither takes the
+ * configuration), 3 = the generic kernel alone (the anchor: one global
+ * atomic per base and quality).                                              */
 int snk_filter_batch_device(snk_ctx *ctx, const snk_batch *batch,
                             snk_read_result *d_out1, snk_read_result *d_out2,
                             void *hip_stream, int kernel);

@@ -126,8 +126,11 @@ struct DevStats {
 
 #define SNK_ERR_NONE 0xFFFFFFFFFFFFFFFFull
 
+// own_hist: 1 = the kernel adds its per-position histograms itself (the anchor), 0 = snk_launch_hist() follows
 void snk_launch_generic(const DevParams *dp, const DevBatch &b, const DevStats &st, int lcap,
-                        int nq, void *stream);
+                        int nq, int own_hist, void *stream);
+// per-position raw / clean histograms from the records of a decision kernel (snk_long.hip); returns 0 when it cannot run
+int snk_launch_hist(const DevParams *dp, int paired, const DevBatch &b, const DevStats &st, int lcap, int nq, int n_cu, void *stream);
 // returns 0 when the tiled kernel cannot run this configuration
 int snk_launch_tiled(const DevParams &dp_host, const TileAdapters &ta, const DevBatch &b,
                      const DevStats &st, int lcap, int nq, int n_cu, void *stream);

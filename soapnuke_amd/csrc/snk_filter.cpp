@@ -599,6 +599,7 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         HIP_OK(hipEventRecord(ev.first, s));
     }
     int done = 0;
+    if (kernel < 0 || kernel > 3) { set_err("snk_filter_batch_device: kernel must be 0..3"); return SNK_E_PARAM; }
     if (kernel == 0 || kernel == 2) {
         int slot = -1;
         for (int k = 0; k < 8 && slot < 0; ++k) if (c->ts_used[k] && c->ts_stream[k] == stream) slot = k;
@@ -631,7 +632,19 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         if (!done) done = snk_launch_long(c->d_params, c->hp, c->ta, D, DevStats{c->d_sum, c->d_max, c->d_err, c->d_tsw}, c->lcap, c->nq, c->n_cu, stream);
         if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return SNK_E_UNSUPPORTED; }
     }
-    if (!done) snk_launch_generic(c->d_params, D, st, c->lcap, c->nq, stream);
+    if (!done) {
+        // the generic kernel decides; the per-position histograms come from the LDS histogram kernel behind it (kernel == 3:
+        // the generic kernel's own global atomics -- the anchor -- as whenever that kernel cannot take the batch)
+        const DevStats gst{c->d_sum, c->d_max, c->d_err, c->d_tsw};
+        const size_t hist_lds = (size_t)2 * (5 + c->nq + 1) * 128 * sizeof(uint32_t);
+        const bool split = kernel != 3 && hist_lds <= 150 * 1024 && (b->pitch & 3) == 0 &&
+                           ((((uintptr_t)D.seq[0] | (uintptr_t)D.qual[0] | (uintptr_t)D.seq[1] | (uintptr_t)D.qual[1]) & 3) == 0);
+        snk_launch_generic(c->d_params, D, st, c->lcap, c->nq, split ? 0 : 1, stream);
+        if (split && !snk_launch_hist(c->d_params, c->p.paired ? 1 : 0, D, gst, c->lcap, c->nq, c->n_cu, stream)) {
+            set_err("snk_filter_batch_device: histogram kernel refused the batch");
+            return SNK_E_UNSUPPORTED;
+        }
+    }
     if (c->timing) { HIP_OK(hipEventRecord(ev.second, s)); c->ev_pending.push_back(ev); }
     HIP_OK(hipGetLastError());
     return SNK_OK;

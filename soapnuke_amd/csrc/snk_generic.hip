@@ -33,11 +33,14 @@ __device__ void count_reason(unsigned long long *fs, bool pe, int reason, int v)
     }
 }
 
+// own_hist == 0: the per-position histograms (and the quality-range check that comes with them) are left to
+// snk_long_hist_kernel, which runs behind this kernel on the records it wrote -- one global atomic per base and quality was
+// nine tenths of this kernel's time
 __device__ int hist_read(const DevParams &P, unsigned long long *file, int lcap, int nq,
-                         const uint8_t *s, const uint8_t *q, int start, int n) {
+                         const uint8_t *s, const uint8_t *q, int start, int n, int own_hist) {
     unsigned long long *bs = file + SNK_GS_N, *qs = file + SNK_GS_N + (long)lcap * 5;
     int rc = SNK_OK;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < (own_hist ? n : 0); ++i) {
         const int u = s[start + i] & 0xDF;
         const int b = u == 'A' ? 0 : u == 'C' ? 1 : u == 'G' ? 2 : u == 'T' ? 3 : 4;
         atomicAdd(&bs[i * 5 + b], 1ull);
@@ -50,7 +53,7 @@ __device__ int hist_read(const DevParams &P, unsigned long long *file, int lcap,
 }
 
 __global__ void __launch_bounds__(256)
-snk_generic_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int nq) {
+snk_generic_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int nq, int own_hist) {
     const DevParams &P = *Pp;
     const long fb = file_block(lcap, nq);
     const long ts_off = SNK_GS_N + (long)lcap * 5 + (long)lcap * nq;
@@ -71,7 +74,13 @@ snk_generic_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int n
             stat_read_dev(P, m, s[m], q[m], len, r[m], e);
             if (e) { report_err(st, gidx, m, e); bad = true; break; }
         }
-        if (bad) continue;
+        if (bad) {                                           // (a record no later pass uses)
+            ReadState z;
+            rs_init(z, 0);
+            store_rec(B.out[0], i, z, 255, 0);
+            if (pe) store_rec(B.out[1], i, z, 255, 0);
+            continue;
+        }
         for (int m = 0; m <= pe; ++m) fastq_trim_dev(P, m, s[m], q[m], r[m]);
         int v = 0;
         const int reason = discard_reason(P, r[0], r[pe], B.dup ? B.dup[i] : 0, v, cf[0], cf[pe]);
@@ -85,7 +94,7 @@ snk_generic_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int n
             int hh = -1, lh = -1, ht = -1, lt = -1, ad = -1;
             if (P.copy_back) { hh = r[m].hd_h; lh = r[m].lq_h; ht = r[m].hd_t; lt = r[m].lq_t; ad = r[m].adacut; }
             ts_update(file + ts_off, hh, lh, ht, lt, ad, (pe && m == 1) ? r[m].len : 0, !pe);
-            const int rc = hist_read(P, file, lcap, nq, s[m], q[m], 0, r[m].len);
+            const int rc = hist_read(P, file, lcap, nq, s[m], q[m], 0, r[m].len, own_hist);
             if (rc) report_err(st, gidx, m, rc);
             atomicMax(&st.maxb[m], key | (unsigned long long)r[m].len);
         }
@@ -94,7 +103,7 @@ snk_generic_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int n
                 unsigned long long *file = st.sum + SNK_FS_N + (2 + m) * fb;
                 ts_update(file + ts_off, r[m].hd_h, r[m].lq_h, r[m].hd_t, r[m].lq_t, r[m].adacut,
                           (pe && m == 1) ? r[m].clen : r[m].len, !pe);
-                hist_read(P, file, lcap, nq, s[m], q[m], r[m].start, r[m].clen);
+                hist_read(P, file, lcap, nq, s[m], q[m], r[m].start, r[m].clen, own_hist);
                 atomicMax(&st.maxb[2 + m], key | (unsigned long long)r[m].clen);
             }
         }
@@ -133,12 +142,12 @@ __global__ void __launch_bounds__(256) snk_finalize_kernel(DevStats st, int lcap
 }  // namespace
 
 void snk_launch_generic(const DevParams *dp, const DevBatch &b, const DevStats &st, int lcap,
-                        int nq, void *stream) {
+                        int nq, int own_hist, void *stream) {
     if (b.n <= 0) return;
     long blocks = (b.n + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(snk_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       dp, b, st, lcap, nq);
+                       dp, b, st, lcap, nq, own_hist);
 }
 
 void snk_launch_finalize(const DevStats &st, int lcap, int nq, void *stream) {

@@ -321,7 +321,9 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
             int l = lens ? (int)lens[r] : fixed;
             if (l > lcap || !have) l = 0;                           // (too long: reported by the first kernel)
             const snk_read_result x = rec[r];
-            const int start = x.clean_start, cl = (have && x.reason == SNK_KEEP) ? (int)x.clean_len : 0;
+            const int start = x.clean_start;
+            int cl = (have && x.reason == SNK_KEEP) ? (int)x.clean_len : 0;
+            if (start + cl > l) cl = 0;                             // (never for a record of the decision kernels)
             nv[k] = max(min(l - base - 4 * j, 4), 0);               // positions of this lane's dword the read has
             nc[k] = max(min(cl - base - 4 * j, 4), 0);
             const uint8_t *ps = seq + r * (long)pitch, *pq = qual + r * (long)pitch;
@@ -379,14 +381,22 @@ int snk_launch_long(const DevParams *dp, const DevParams &hp, const TileAdapters
     long wgs = (b.n + 255) / 256;
     if (wgs > (long)n_cu * 8) wgs = (long)n_cu * 8;
     hipLaunchKernelGGL(snk_long_decide_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, dp, ta, b, st, lcap, nq);
-    const int nblk = (lcap + HPB - 1) / HPB, mates = hp.paired ? 2 : 1;
+    return snk_launch_hist(dp, hp.paired, b, st, lcap, nq, n_cu, stream);
+}
+
+// the histogram kernel on its own: behind the long-read decide kernel, and behind the generic kernel (any capacity)
+int snk_launch_hist(const DevParams *dp, int paired, const DevBatch &b, const DevStats &st, int lcap, int nq, int n_cu, void *stream) {
+    if (b.n <= 0 || lcap <= 0 || (b.pitch & 3)) return 0;
+    if ((((uintptr_t)b.seq[0] | (uintptr_t)b.qual[0] | (uintptr_t)b.seq[1] | (uintptr_t)b.qual[1]) & 3) != 0) return 0;
+    const int nblk = (lcap + HPB - 1) / HPB, mates = paired ? 2 : 1;
     const size_t shmem = (size_t)2 * (5 + nq + 1) * HPB * sizeof(u32);
+    if (shmem > 150 * 1024) return 0;
     int slices = (int)((long)n_cu * 3 / (nblk * mates));
     if (slices < 1) slices = 1;
     while (slices > 1 && b.n / slices < 512) --slices;              // a flush per workgroup wants some reads behind it
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)snk_long_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute((const void *)snk_long_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     hipLaunchKernelGGL(snk_long_hist_kernel, dim3((unsigned)(mates * nblk * slices)), dim3(256), shmem, (hipStream_t)stream, dp, b, st, lcap, nq,

@@ -321,6 +321,17 @@ def test_pitch_not_multiple_of_16(name, pitch, var_len):
         assert_same(p, got, o, True)
 
 
+@pytest.mark.parametrize("name", ["C3_full", "hard_lq_trim", "defaults"])
+def test_generic_anchor(name):
+    """kernel = 3: the generic kernel alone, histograms by its own global atomics (kernel = 1 leaves them to the LDS histogram
+    kernel behind it); both against the oracle"""
+    d = synth.make_batch(8000, 150, paired=True, var_len=True, seed=23)
+    p = abi.default_params(paired=True, max_read_len=150, **PE_CASES[name])
+    want = T.run_oracle(p, d)
+    assert_same(p, run_hip_device(p, d, 3), want, True)
+    assert_same(p, run_hip_device(p, d, 1, chunks=3), want, True)
+
+
 @pytest.mark.parametrize("L", [51, 64, 65, 96, 97, 128, 129, 255, 256, 257, 1000])
 def test_capacity_boundaries(L):
     """read-length capacities around the plane-word / strip / tiled-kernel limits (tiled up to 256, the long-read path beyond)"""
