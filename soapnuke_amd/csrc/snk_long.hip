@@ -275,8 +275,10 @@ constexpr int HPB = 128;
 // so the adds need no branches
 __device__ __forceinline__ void hist_add(u32 *hh, int slot, int trash, int nq, int phred, u32 c, u32 qc, bool on, bool &err) {
     const u32 u = c & 0xDFu, t = (u >> 1) & 3u;                     // A 0, C 1, T 2, G 3
-    const u32 ex = (0x47544341u >> (8 * t)) & 0xFFu;                // the letter of that code
-    int b = u == ex ? (int)(t ^ (t >> 1)) : 4;                      // A C G T -> 0 1 2 3, anything else (N) 4
+    const u32 sel = t | 0x0C0C0C00u;                                // v_perm: byte t of the constant into byte 0, zeros above
+    const u32 ex = __builtin_amdgcn_perm(0u, 0x47544341u, sel);     // the letter of that code ("ACTG")
+    const u32 bt = __builtin_amdgcn_perm(0u, 0x02030100u, sel);     // its row: A C G T -> 0 1 2 3
+    int b = u == ex ? (int)bt : 4;                                  // anything else (N): 4
     const int bq = (int)qc - phred;
     const bool qok = (unsigned)bq < (unsigned)nq;
     err |= on && !qok;
