@@ -36,10 +36,14 @@ BYTES_PER_PAIR = 2 * (2 * L + 16)      # bases + qualities read onc
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def bench_params_kwargs():
+    from soapnuke_amd import synth
+    return dict(adapters1=[synth.ADAPTER1], adapters2=[synth.ADAPTER2], ada_trim=1, low_qual=10, low_qual_ratio=0.1)
+
+
 def bench_params():
-    from soapnuke_amd import abi, synth
-    return abi.default_params(paired=True, max_read_len=L, adapters1=[synth.ADAPTER1],
-                              adapters2=[synth.ADAPTER2], ada_trim=1, low_qual=10, low_qual_ratio=0.1)
+    from soapnuke_amd import abi
+    return abi.default_params(paired=True, max_read_len=L, **bench_params_kwargs())
 
 
 def cpu_baseline(data, n_sample):
@@ -102,6 +106,51 @@ def end_to_end(n_pairs, threads=16):
         return bench_e2e.measure(tmp, n_pairs, threads, ["plain", "gz"])
     finally:
         subprocess.call(["rm", "-rf", tmp])
+
+
+def other_workloads():
+    """Kernel time of the widened rows (SURVEY 8f / VERDICT r1 #7, #8), device-resident like the headline: contaminant
+    screening in front of the tiled kernel, reads of 1000 positions (snk_long.hip), and the fallback for configurations
+    the fast paths refuse (generic decisions + LDS histogram kernel).  Informational; parity for each in tests/."""
+    import torch
+    from soapnuke_amd import abi, synth
+    from soapnuke_amd.filter import FilterContext
+    c2 = bench_params_kwargs()
+    rows = [
+        ("contaminants (contam1/2 32/28 nt + one 33-nt global), PE150, 5 M pairs", 150, 5_000_000, 0,
+         dict(c2, contam1="ACGTTGCAAGGCTTAACCGGTTAGCATGCAAT", contam2="TTGGCCAAGGTTCCAAGGTTAACCGGTT", ct_match_r="0.5",
+              global_contams="AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", g_mrs="0.4", g_mms="1")),
+        ("long reads, PE1000, 1 M pairs", 1000, 1_000_000, 0, c2),
+        ("fallback (kernel=1: generic decisions + LDS histograms), PE150, 2 M pairs", 150, 2_000_000, 1, c2),
+    ]
+    out = []
+    for name, L, n, kern, kw in rows:
+        uniq = 500_000 if L <= 150 else 100_000
+        d = synth.make_batch(uniq, L, paired=True)
+        ctx = FilterContext(abi.default_params(paired=True, max_read_len=L, **kw), device=0)
+        dev = ctx.upload(d)
+        reps = n // uniq
+        dev["seq"] = [x.repeat(reps, 1) for x in dev["seq"]]
+        dev["qual"] = [x.repeat(reps, 1) for x in dev["qual"]]
+        dev["n"] = uniq * reps
+        b = ctx.make_batch(dev)
+        rec = ctx.alloc_records(dev["n"])
+        ctx.filter_batch(b, rec, kernel=kern)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            ctx.filter_batch(b, rec, kernel=kern)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        _, _, err = ctx.fetch()
+        out.append({"workload": name, "ms": round(ms, 3), "Mreads_per_s": round(2 * dev["n"] / ms / 1e3, 1),
+                    "algorithmic_GBps": round(2 * dev["n"] * (2 * L + 16) / ms / 1e6, 1), "error": int(err[0])})
+        ctx.close()
+        del dev, rec
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -249,6 +298,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(data, min(n_unique, 1_000_000))
             if e2e is not None:
                 out["end_to_end"] = e2e
+            try:
+                out["other_workloads"] = other_workloads()
+            except Exception as ex:
+                out["other_workloads"] = {"error": repr(ex)[:200]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
