@@ -12,10 +12,11 @@
 //       Trimming (A3), the discard cascade (A6), the reason counters and the trimming-position counters follow as in the
 //       generic kernel.  A read with anything but upper-case ACGTN, or shorter than 64, takes the sequential functions of
 //       snk_common.cuh in its lane.
-//   snk_long_hist_kernel     lane = position.  A workgroup owns 128 positions of one mate for a slice of the batch: raw and
-//       clean per-position base / quality histograms (A8, src/peprocess.cpp:1182-1201 and the clean twin) in LDS (u32, 47 KB),
-//       one coalesced 64-byte load and two LDS adds per strip; clean counts come from the records of the first kernel (the
-//       kept reads, at the shifted positions).  Flushed once per workgroup.
+//   snk_long_hist_kernel     lane = four positions.  A workgroup owns 128 positions of one mate for a slice of the batch:
+//       raw and clean per-position base / quality histograms (A8, src/peprocess.cpp:1182-1201 and the clean twin) in LDS
+//       (u32, 49 KB); one dword load per lane covers the 128 positions of two reads, clean counts come from the records of
+//       the decision kernel (the kept reads, at the shifted positions), the adds are branch-free.  Flushed once per
+//       workgroup.  It also runs behind the generic kernel (any capacity), which then only decides.
 #include <hip/hip_runtime.h>
 #include "snk_common.cuh"
 #include "snk_adapter_bits.cuh"
