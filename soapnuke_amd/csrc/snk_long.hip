@@ -3,15 +3,15 @@
 // sized for <= 256 positions; long reads take two kernels instead:
 //
 //   snk_long_decide_kernel   lane = read (one work-item per pair).  Every lane streams its own row with 16-byte loads
-//       (64 rows per wave-load: the row pitch is the stride, a 128-byte line serves eight loads of its lane) and does
-//       A1 stat_read (src/read_filter.cpp:80-313) byte-parallel on the dwords: case-folded A / N counts, the low-quality
-//       count, the quality sum (v_sad_u8), the poly-X run.  The adapter search (A2, :707-790) is the bit-sliced one of the
-//       tiled kernel (snk_adapter_bits.cuh) on BLOCKS of the read: planes of 320 positions (10 words) serve the 256
-//       candidate offsets of a block plus the 64 positions an adapter can reach past them; a block in the middle of a read
-//       has phase B offsets only, phase A belongs to the first block, phase C to the last one, which ends with the read.
-//       Trimming (A3), the discard cascade (A6), the reason counters and the trimming-position counters follow as in the
-//       generic kernel.  A read with anything but upper-case ACGTN, or shorter than 64, takes the sequential functions of
-//       snk_common.cuh in its lane.
+//       (64 rows per wave-load: the row pitch is the stride).  The adapter search (A2, src/read_filter.cpp:707-790) is the
+//       bit-sliced one of the tiled kernel (snk_adapter_bits.cuh) on BLOCKS of the read: planes of 320 positions (10
+//       words) serve the 256 candidate offsets of a block plus the 64 positions an adapter can reach past them; a block in
+//       the middle of a read has phase B offsets only, phase A belongs to the first block, phase C to the last one, which
+//       ends with the read.  A1 stat_read (:80-313) comes out of the same planes -- the A / N counts are popcounts, a
+//       position that is neither ACGT nor N sends the read to the sequential functions of snk_common.cuh in its lane
+//       (lower case, other letters; also reads shorter than 64) -- plus one byte-parallel pass over the qualities
+//       (low-quality count, sum by v_sad_u8) and, when poly-X is asked for, one over the characters.  Trimming (A3), the
+//       discard cascade (A6), the reason counters and the trimming-position counters follow as in the generic kernel.
 //   snk_long_hist_kernel     lane = four positions.  A workgroup owns 128 positions of one mate for a slice of the batch:
 //       raw and clean per-position base / quality histograms (A8, src/peprocess.cpp:1182-1201 and the clean twin) in LDS
 //       (u32, 49 KB); one dword load per lane covers the 128 positions of two reads, clean counts come from the records of
@@ -22,6 +22,10 @@
 #include "snk_adapter_bits.cuh"
 
 using namespace snk;
+
+#ifndef SNK_LABL
+#define SNK_LABL 0          // ablation builds: 1 no scan, 2 no adapter blocks, 3 no trimming / cascade / records, 4 histogram kernel not launched
+#endif
 
 namespace {
 
@@ -37,72 +41,62 @@ __device__ __forceinline__ u32 valid80(int len, int pos) {
     return d >= 4 ? 0x80808080u : (d <= 0 ? 0u : (0x80808080u >> (8 * (4 - d))));
 }
 
-struct Scan { int n_a, n_n, lowq, sumq, maxrun; bool weird; };
+// the rows are global memory: said explicitly, or the loads through pointers that passed a select / an array become FLAT loads
+typedef u32 v4u32 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v4u32 *gl_uint4_p;
 
-// A1 counts of one read (src/read_filter.cpp:258-308), byte-parallel over its row; weird = something outside "ACGTN"
-__device__ __forceinline__ Scan scan_read(const DevParams &P, const uint8_t *s, const uint8_t *q, int len) {
-    Scan r = {0, 0, 0, 0, 1, false};
-    const uint4 *s4 = reinterpret_cast<const uint4 *>(s), *q4 = reinterpret_cast<const uint4 *>(q);
+// the quality half of A1 alone: low-quality count and quality sum of one read
+__device__ __forceinline__ void scan_quals(const DevParams &P, const uint8_t *q, int len, int &lowq, int &sumq) {
+    const gl_uint4_p q4 = (gl_uint4_p)q;
     const u32 KL = ((u32)min(max(P.phred + P.low_qual, 0), 127) * 0x01010101u) | 0x80808080u;
-    const bool px = P.polyX_num != -1, lq_any = P.phred + P.low_qual >= 0;
+    const bool lq_any = P.phred + P.low_qual >= 0;
     u32 qsum = 0;
-    int last = 'Q', run = 0;
-    // 128 bytes per array and trip, all loads first: a lane's eight 16-byte loads share one 128-byte line, which must
-    // not be evicted between them (64 lanes x 2 arrays x 128 B per wave is most of the CU's L1)
+    int lq = 0;
     for (int pos0 = 0; pos0 < len; pos0 += 128) {
-        uint4 svv[8], qvv[8];
+        v4u32 qvv[8];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const bool in = pos0 + 16 * g < len;
-            svv[g] = in ? s4[(pos0 >> 4) + g] : uint4{0, 0, 0, 0};
-            qvv[g] = in ? q4[(pos0 >> 4) + g] : uint4{0, 0, 0, 0};
-        }
+        for (int g = 0; g < 8; ++g) qvv[g] = pos0 + 16 * g < len ? q4[(pos0 >> 4) + g] : v4u32{0, 0, 0, 0};
+        if (pos0 + 128 <= len) {                                     // whole trip inside the read: no masks
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int pos = pos0 + 16 * g;
-            const uint4 sv = svv[g], qv = qvv[g];
-            const u32 sd[4] = {sv.x, sv.y, sv.z, sv.w}, qd[4] = {qv.x, qv.y, qv.z, qv.w};
+            for (int g = 0; g < 8; ++g) {
+                const u32 qd[4] = {qvv[g].x, qvv[g].y, qvv[g].z, qvv[g].w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const u32 v = sd[k], w = qd[k], ok = valid80(len, pos + 4 * k);
-                const u32 f = v & 0xDFDFDFDFu;
-                r.n_a += __popc(zero_bytes(f ^ 0x41414141u) & ok);
-                r.n_n += __popc(zero_bytes(f ^ 0x4E4E4E4Eu) & ok);
-                const u32 t = v & 0x06060606u;
-                const u32 ex = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);        // the letter of each code
-                const u32 good = zero_bytes(ex ^ v) | zero_bytes(v ^ 0x4E4E4E4Eu);
-                r.weird |= (~good & ok) != 0;
-                // quality - phred <= low_qual  <=>  K - quality >= 0 (bytes below 128; others are range errors of the histogram pass)
-                r.lowq += lq_any ? __popc((KL - (w & 0x7F7F7F7Fu)) & ~w & ok) : 0;
-                const u32 bm = (ok >> 7) * 0xFFu;                                          // 0xFF in the valid bytes
-                qsum = __builtin_amdgcn_sad_u8(w & bm, 0u, qsum);
-                if (px) {
+                for (int k = 0; k < 4; ++k) {
+                    lq += __popc((KL - (qd[k] & 0x7F7F7F7Fu)) & ~qd[k] & 0x80808080u);
+                    qsum = __builtin_amdgcn_sad_u8(qd[k], 0u, qsum);
+                }
+            }
+        } else {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        if (pos + 4 * k + b < len) {
-                            const int c = (int)((v >> (8 * b)) & 0xFFu);
-                            if (c == last) { if (++run > r.maxrun) r.maxrun = run; } else run = 1;
-                            last = c;
-                        }
-                    }
+            for (int g = 0; g < 8; ++g) {
+                const u32 qd[4] = {qvv[g].x, qvv[g].y, qvv[g].z, qvv[g].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32 ok = valid80(len, pos0 + 16 * g + 4 * k);
+                    lq += __popc((KL - (qd[k] & 0x7F7F7F7Fu)) & ~qd[k] & ok);
+                    qsum = __builtin_amdgcn_sad_u8(qd[k] & ((ok >> 7) * 0xFFu), 0u, qsum);
                 }
             }
         }
     }
-    r.sumq = (int)qsum - P.phred * len;
-    return r;
+    lowq = lq_any ? lq : 0;
+    sumq = (int)qsum - P.phred * len;
 }
 
 // planes of the block [p0, p0 + 320) of a read: X[k] bit j = read[p0 + j] == "ACGT"[k], XN likewise for 'N'; ones from vlen on
-__device__ __forceinline__ void block_planes(const uint8_t *s, int p0, int vlen, int pitch, u32 (&X)[4][LNW], u32 (&XN)[LNW]) {
-    const uint4 *s4 = reinterpret_cast<const uint4 *>(s + p0);          // p0 is a multiple of 256
+// Also the A1 base counts of a read of upper-case ACGTN only (src/read_filter.cpp:258-308), which are popcounts of its planes:
+// cntA / cntN += the 'A' / 'N' of the block's own positions (256, or all of a final block), other |= positions that are neither
+// ACGT nor N (lower case included: such a read takes the sequential path, where case is folded).
+__device__ __forceinline__ void block_planes(const uint8_t *s, int p0, int vlen, int pitch, bool final, u32 (&X)[4][LNW], u32 (&XN)[LNW],
+                                             int &cntA, int &cntN, u32 &other) {
+    const gl_uint4_p s4 = (gl_uint4_p)(s + p0);                         // p0 is a multiple of 256
 #pragma unroll
     for (int w = 0; w < LNW; ++w) {
         u32 e = 0, c1 = 0, c2 = 0, nn = 0;
         if (32 * w < vlen) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                uint4 sv = {0, 0, 0, 0};
+                v4u32 sv = {0, 0, 0, 0};
                 if (p0 + 32 * w + 16 * h + 16 <= pitch) sv = s4[2 * w + h];          // (the last word of the last block may reach past the row)
                 const u32 sd[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
@@ -120,6 +114,11 @@ __device__ __forceinline__ void block_planes(const uint8_t *s, int p0, int vlen,
         }
         const u32 in = lowmask32(vlen - 32 * w);
         e &= in;
+        if (w < 8 || final) {
+            cntA += __popc(e & ~c1 & ~c2);
+            cntN += __popc(nn & in);
+            other |= in & ~(e | nn);
+        }
         X[0][w] = (e & ~c1 & ~c2) | ~in;
         X[1][w] = (e & c1 & ~c2) | ~in;
         X[2][w] = (e & c1 & c2) | ~in;
@@ -165,7 +164,9 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
         const uint8_t *s[2] = {nullptr, nullptr}, *q[2] = {nullptr, nullptr};
         const unsigned long long gidx = B.first_index + (unsigned long long)i;
         bool bad = !exists;
-        for (int m = 0; m <= pe; ++m) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (m > pe) continue;                                   // (two unrolled copies: r[], s[], q[] indexed by constants stay in registers, the rows keep their global address space)
             int len = 0;
             if (exists) {
                 len = B.len[m] ? (int)B.len[m][i] : B.fixed_len[m];
@@ -176,33 +177,22 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
             const bool live = exists && !bad;
             rs_init(r[m], len);
             if (live && (P.n_ct[m] | P.n_gct)) cf[m] = contam_flags(P.ct + m * SNK_MAX_CONTAMS, P.n_ct[m], P.gct, P.n_gct, s[m], len);
-            Scan sc = {0, 0, 0, 0, 1, true};
-            if (live && len >= 64) sc = scan_read(P, s[m], q[m], len);
-            const bool fast = live && !sc.weird;
-            int e = SNK_OK;
-            if (live && !fast) {                                   // anything unusual: the sequential restatement, in this lane
-                stat_read_dev(P, m, s[m], q[m], len, r[m], e);
-                if (e) { report_err(st, gidx, m, e); bad = true; }
-            }
-            if (fast) {
-                r[m].n_a = sc.n_a;
-                r[m].n_n = sc.n_n;
-                r[m].lowq = sc.lowq;
-                r[m].sumq = sc.sumq;
-                r[m].polyx = (P.polyX_num != -1 && sc.maxrun >= P.polyX_num) ? 1 : 0;
-            }
-            // ---- adapter search over the blocks of the read (uniform control flow: every lane walks along, `todo` decides)
+            // ---- the read in blocks of 256 positions (uniform control flow: every lane walks along): its planes give the base
+            // counts and the adapter search; the qualities are a pass of their own; the poly-X run, when asked for, too
+            const bool longish = live && len >= 64;                  // (shorter: the sequential functions)
             const int n_ada = P.n_ada[m];
-            if (n_ada > 0 && __any(fast)) {
-                int res[SNK_TILE_MAX_ADA];
+            int res[SNK_TILE_MAX_ADA], cntA = 0, cntN = 0;
+            u32 other = 0;
 #pragma unroll
-                for (int a = 0; a < SNK_TILE_MAX_ADA; ++a) res[a] = -1;
-                for (int p0 = 0; __any(fast && p0 < len); p0 += LBLK) {
-                    const int rem = len - p0;
-                    const bool here = fast && rem > 0, final = rem <= LVLEN;
-                    const int vlen = here ? (final ? rem : LVLEN) : 0;
-                    u32 X[4][LNW], XN[LNW];
-                    block_planes(here ? s[m] : B.seq[m], here ? p0 : 0, vlen, B.pitch, X, XN);
+            for (int a = 0; a < SNK_TILE_MAX_ADA; ++a) res[a] = -1;
+            bool through = false;                                    // this lane has seen its final block
+            for (int p0 = 0; __any(longish && !through); p0 += LBLK) {
+                const int rem = len - p0;
+                const bool here = longish && !through, final = rem <= LVLEN;
+                const int vlen = here ? (final ? rem : LVLEN) : 0;
+                u32 X[4][LNW], XN[LNW];
+                block_planes(here ? s[m] : B.seq[m], here ? p0 : 0, vlen, B.pitch, final, X, XN, cntA, cntN, other);
+                if (SNK_LABL != 2 && n_ada > 0) {
                     bool earlier = false;                            // an adapter in front of this one already has its hit
                     for (int a = 0; a < n_ada; ++a) {
                         int cur = -1;
@@ -220,24 +210,51 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
                         }
                         earlier |= cur >= 0;
                     }
-                    // a lane is through once it has seen its final block
-                    if (here && final) len = min(len, p0);           // (local copy: ends this lane's walk)
                 }
-                len = r[m].len;
-                if (fast) {
-                    int ada_pos = -1;
+                through |= here && final;
+            }
+            const bool fast = longish && other == 0;
+            int e = SNK_OK;
+            if (live && !fast) {                                   // anything unusual: the sequential restatement, in this lane
+                stat_read_dev(P, m, s[m], q[m], len, r[m], e);
+                if (e) { report_err(st, gidx, m, e); bad = true; }
+            }
+            if (fast) {
+                r[m].n_a = cntA;
+                r[m].n_n = cntN;
+                scan_quals(P, q[m], len, r[m].lowq, r[m].sumq);
+                if (P.polyX_num != -1) {                            // contig_base (:262-268): one character at a time
+                    int last = 'Q', run = 0, maxrun = 1;
+                    const gl_uint4_p s4 = (gl_uint4_p)s[m];
+                    for (int pos = 0; pos < len; pos += 16) {
+                        const v4u32 sv = s4[pos >> 4];
+                        const u32 sd[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
-                    for (int a = SNK_TILE_MAX_ADA - 1; a >= 0; --a) ada_pos = (a < n_ada && res[a] >= 0) ? res[a] : ada_pos;
-                    if (ada_pos >= 0) { r[m].inc_ada = 1; r[m].adacut = len - ada_pos; }
+                        for (int k = 0; k < 16; ++k) {
+                            if (pos + k < len) {
+                                const int c = (int)((sd[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                                if (c == last) { if (++run > maxrun) maxrun = run; } else run = 1;
+                                last = c;
+                            }
+                        }
+                    }
+                    r[m].polyx = maxrun >= P.polyX_num ? 1 : 0;
                 }
+                int ada_pos = -1;
+#pragma unroll
+                for (int a = SNK_TILE_MAX_ADA - 1; a >= 0; --a) ada_pos = (a < n_ada && res[a] >= 0) ? res[a] : ada_pos;
+                if (ada_pos >= 0) { r[m].inc_ada = 1; r[m].adacut = len - ada_pos; }
             }
         }
-        const bool ok = exists && !bad;
-        if (ok)
-            for (int m = 0; m <= pe; ++m) fastq_trim_dev(P, m, s[m], q[m], r[m]);
+        const bool ok = exists && !bad && SNK_LABL != 3;
+        if (ok) {
+            fastq_trim_dev(P, 0, s[0], q[0], r[0]);
+            if (pe) fastq_trim_dev(P, 1, s[1], q[1], r[1]);
+        }
         int v = 0, reason = 255;
         if (ok) {
-            reason = discard_reason(P, r[0], r[pe], B.dup ? B.dup[i] : 0, v, cf[0], cf[pe]);
+            reason = pe ? discard_reason(P, r[0], r[1], B.dup ? B.dup[i] : 0, v, cf[0], cf[1])
+                        : discard_reason(P, r[0], r[0], B.dup ? B.dup[i] : 0, v, cf[0], cf[0]);
             count_reason_long(st.sum, pe, reason, v);
         }
         if (exists) {                                                // (a pair that raised an error gets a record no later pass uses)
@@ -245,7 +262,9 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
             if (pe) store_rec(B.out[1], i, r[1], reason, v);
         }
         const unsigned long long key = (gidx + 1) << 16;
-        for (int m = 0; m <= pe; ++m) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if (m > pe) continue;
             if (ok) {
                 unsigned long long *file = st.sum + SNK_FS_N + m * fb;
                 int hh = -1, lh = -1, ht = -1, lt = -1, ad = -1;
@@ -384,6 +403,7 @@ int snk_launch_long(const DevParams *dp, const DevParams &hp, const TileAdapters
     long wgs = (b.n + 255) / 256;
     if (wgs > (long)n_cu * 8) wgs = (long)n_cu * 8;
     hipLaunchKernelGGL(snk_long_decide_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, dp, ta, b, st, lcap, nq);
+    if (SNK_LABL == 4) return 1;
     return snk_launch_hist(dp, hp.paired, b, st, lcap, nq, n_cu, stream);
 }
 
