@@ -23,9 +23,6 @@
 
 using namespace snk;
 
-#ifndef SNK_LABL
-#define SNK_LABL 0          // ablation builds: 1 no scan, 2 no adapter blocks, 3 no trimming / cascade / records, 4 histogram kernel not launched
-#endif
 
 namespace {
 
@@ -192,7 +189,7 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
                 const int vlen = here ? (final ? rem : LVLEN) : 0;
                 u32 X[4][LNW], XN[LNW];
                 block_planes(here ? s[m] : B.seq[m], here ? p0 : 0, vlen, B.pitch, final, X, XN, cntA, cntN, other);
-                if (SNK_LABL != 2 && n_ada > 0) {
+                if (n_ada > 0) {
                     bool earlier = false;                            // an adapter in front of this one already has its hit
                     for (int a = 0; a < n_ada; ++a) {
                         int cur = -1;
@@ -246,7 +243,7 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
                 if (ada_pos >= 0) { r[m].inc_ada = 1; r[m].adacut = len - ada_pos; }
             }
         }
-        const bool ok = exists && !bad && SNK_LABL != 3;
+        const bool ok = exists && !bad;
         if (ok) {
             fastq_trim_dev(P, 0, s[0], q[0], r[0]);
             if (pe) fastq_trim_dev(P, 1, s[1], q[1], r[1]);
@@ -403,7 +400,6 @@ int snk_launch_long(const DevParams *dp, const DevParams &hp, const TileAdapters
     long wgs = (b.n + 255) / 256;
     if (wgs > (long)n_cu * 8) wgs = (long)n_cu * 8;
     hipLaunchKernelGGL(snk_long_decide_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, dp, ta, b, st, lcap, nq);
-    if (SNK_LABL == 4) return 1;
     return snk_launch_hist(dp, hp.paired, b, st, lcap, nq, n_cu, stream);
 }
 
