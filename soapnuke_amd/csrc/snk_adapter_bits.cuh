@@ -136,7 +136,7 @@ __device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C
 
 // Bit-sliced screening of the candidates p = 0 .. len-edge of phases B and C over the first S-1 adapter
 // characters with NC unary mismatch-counter planes (4: budgets up to 3, the tiled kernel's limit).
-// NC = largest budget + 1 counter planes (4: budgets up to 3, the tiled kernel's limit).
+// NC = largest budget + 1 counter planes, at most 4: offsets whose own budget is 4 or more are not screened out by the count.
 template <int NW, bool FULL, int NC>
 __device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&NX)[4][NW], const u32 (&NXN)[NW], int len, bool done,
                                               u32 (&aliveB)[NW], u32 (&aliveC)[NW]) {
@@ -181,7 +181,7 @@ __device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&
         }
     }
     // budgets as thermometer planes T_k = [budget >= k]; reject = mis count > budget
-    const int rk1 = A.rk[1], rk2 = A.rk[2], rk3 = A.rk[3];
+    const int rk1 = A.rk[1], rk2 = A.rk[2], rk3 = A.rk[3], rk4 = A.rk[0];     // (rk[0]: budgets >= 4, nC when there is none)
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const u32 valid = lowmask32(len - edge + 1 - 32 * j);
@@ -196,7 +196,14 @@ __device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&
             const u32 t3 = lowmask32(len - edge - rk3 + 1 - 32 * j) & (mis >= 3 ? 0xFFFFFFFFu : ~bm);
             rej |= C[NC >= 4 ? 2 : 0][j] & ~t3;
         }
-        rej |= C[NC - 1][j];                                                 // more mismatches than any budget of this adapter
+        if (NC >= 4) {
+            // four or more mismatches: out, except where the budget itself is 4 or more -- the counters stop at four, those
+            // offsets all go to the exact decision
+            const u32 t4 = lowmask32(len - edge - rk4 + 1 - 32 * j) & (mis >= 4 ? 0xFFFFFFFFu : ~bm);
+            rej |= C[NC >= 4 ? 3 : 0][j] & ~t4;
+        } else {
+            rej |= C[NC - 1][j];                                             // more mismatches than any budget of this adapter
+        }
         const u32 alive = done ? 0u : (valid & ~rej);
         aliveB[j] = alive & bm;
         aliveC[j] = alive & ~bm;
@@ -279,7 +286,7 @@ __device__ int adapter_tile(const TileAdapter &A, const DevAdapter &AG, const u3
                 clear_bit(aliveC, p);
                 n = len - p;                                         // compared length, edge <= n < al
                 res = p;
-                if (n < S) { skip_eval = true; skip_ok = !A.negC; }  // no run possible: survived <=> mis <= budget
+                if (n < S && A.maxb <= 3) { skip_eval = true; skip_ok = !A.negC; }  // no run possible: survived <=> mis <= budget (exact counters)
                 else budget = AG.budgetC[n - edge];
             } else {
                 have = false;

@@ -25,7 +25,7 @@ struct DevAdapter {
     uint8_t  code[SNK_DEV_MAX_ADA_LEN]; // 0..3 = ACGT, 4 = can never match a valid read base
     int32_t  tile_ok;       // 1 when the tiled kernel can handle this adapter
     int32_t  maxBudget;     // max over all phases of max(budget,0)
-    int32_t  rk[4];         // rk[k] = smallest phase-C r1 with budgetC[r1] >= k (nC if none), k = 1..3
+    int32_t  rk[4];         // rk[k] = smallest phase-C r1 with budgetC[r1] >= k (nC if none), k = 1..3; rk[0]: k = 4
     int32_t  negC;          // phase-C budgets are INT_MIN (misGrad == 0): only a run of S accepts
     uint64_t nmask;         // bit c = adapter[c] == 'N' (matches a read 'N' exactly)
 };

@@ -237,14 +237,14 @@ void build_adapter(DevAdapter &A, const char *seq, int mis, float mr, int edge) 
     }
     A.maxBudget = maxb;
     A.negC = (misGrad == 0.0f) ? 1 : 0;
-    for (int k = 1; k <= 3; ++k) {
-        A.rk[k] = A.nC > 0 ? A.nC : 0;
+    for (int k = 1; k <= 4; ++k) {                        // rk[0] holds k = 4
+        A.rk[k & 3] = A.nC > 0 ? A.nC : 0;
         for (int r1 = 0; r1 < A.nC && r1 < SNK_DEV_MAX_ADA_LEN; ++r1)
-            if (A.budgetC[r1] >= k) { A.rk[k] = r1; break; }
+            if (A.budgetC[r1] >= k) { A.rk[k & 3] = r1; break; }
     }
     // bit-parallel view for the tiled kernel: code 0..3 = ACGT, 4 = matches no valid read base,
     // 5 = 'N'.  Lower-case adapter characters would need case-exact planes: generic kernel only.
-    A.tile_ok = (al >= 6 && al <= 64 && edge >= 1 && edge <= al && mis >= 0 && maxb <= 3) ? 1 : 0;
+    A.tile_ok = (al >= 6 && al <= 64 && edge >= 1 && edge <= al && mis >= 0) ? 1 : 0;      // (any budget: beyond 3 the screen lets the offset through)
     for (int c = 0; c < al; ++c) {
         int k = 4;
         switch (seq[c]) { case 'A': k = 0; break; case 'C': k = 1; break; case 'G': k = 2; break; case 'T': k = 3; break; case 'N': k = 5; break; default: break; }

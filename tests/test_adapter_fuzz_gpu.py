@@ -104,3 +104,18 @@ def test_phase_a_dimers_reach_the_tiled_kernel():
     assert len(phase_a) > 100
     # adapter at read position 0 (adacut_pos = length - 0): nothing is left of mate 1
     assert all(want["rec"][0]["adacut_pos"][r] == 150 and got["rec"][0]["adacut_pos"][r] == 150 for r in phase_a)
+
+
+@pytest.mark.parametrize("mis", [(4, 5), (6, 4), (9, 3)])
+def test_adapter_budgets_above_three(mis):
+    """adaMis 4..9: the unary counters of the screen stop at four mismatches, offsets whose own budget is four or more all
+    go to the exact decision -- the tiled kernel takes them (kernel = 2), whatever the budget"""
+    rng = np.random.default_rng(sum(mis))
+    ada = [[random_adapter(rng, 24, 64) for _ in range(2)] for _ in range(2)]
+    d = synth.make_batch(READS, 150, paired=True, var_len=True, seed=4242 + mis[0], adapters=(ada[0][0], ada[1][0]))
+    for m in range(2):
+        plant(rng, d["seq"][m], d["len"][m], 150, ada[m], 0.3)
+    p = abi.default_params(paired=True, max_read_len=150, adapters1=ada[0], adapters2=ada[1], ada_trim=1, ada_mis=mis,
+                           ada_mr=(0.5, 0.7), ada_edge=(6, 3), low_qual=10, low_qual_ratio=0.3, min_read_length=30)
+    want = T.run_oracle(p, d)
+    assert_same(p, run_hip_device(p, d, 2, chunks=2), want, True)
