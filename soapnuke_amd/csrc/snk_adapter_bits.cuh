@@ -135,7 +135,7 @@ __device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C
 }
 
 // Bit-sliced screening of the candidates p = 0 .. len-edge of phases B and C over the first S-1 adapter
-// characters with NC unary mismatch-counter planes (4: budgets up to 3, the tiled kernel's limit).
+// characters with NC unary mismatch-counter planes.
 // NC = largest budget + 1 counter planes, at most 4: offsets whose own budget is 4 or more are not screened out by the count.
 template <int NW, bool FULL, int NC>
 __device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&NX)[4][NW], const u32 (&NXN)[NW], int len, bool done,

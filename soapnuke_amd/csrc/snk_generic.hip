@@ -1,9 +1,13 @@
 // snk_generic.hip -- "generic" gfx950 kernel of the SOAPnuke-filter hot path:
 // one work-item per read pair, any read length up to 1000, any adapter length up
 // to 255, any parameter combination.  It is the correctness anchor and the
-// fallback for shapes the wave-tiled kernel (snk_tiled.hip) does not cover
-// (reads > 256 nt, adapters > 64 nt); it is NOT the fast path: its loads are
-// strided by the batch pitch and its histograms are global atomics.
+// fallback for what the fast paths (snk_tiled.hip up to 256 positions, snk_long.hip
+// beyond) do not cover: adapters over 64 nt or in lower case, more than four per
+// mate, rows that are not 16-byte aligned beyond 256 positions.  Its loads are
+// strided by the batch pitch.  As a fallback it only decides (records, reason and
+// trimming-position counters) and leaves the per-position histograms to the LDS
+// histogram kernel of snk_long.hip; with own_hist it adds them itself, one global
+// atomic per base and quality (the anchor, kernel = 3).
 //
 // Semantics follow the reference row by row:
 //   A1 stat_read      src/read_filter.cpp:80-313
