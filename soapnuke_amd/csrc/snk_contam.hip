@@ -19,8 +19,8 @@
 //               contaminant; the offsets with such a stretch are decided exactly by the window walk (gc_walk) on the 64
 //               equality bits of their lay.
 //
-// What the bit paths do not cover (contaminants over 64 characters or with anything but ACGTN, budgets over 3 / 4,
-// reads shorter than the contaminant, reads over 256 nt) goes to the sequential matchers of snk_common.cuh, per lane.
+// What the bit paths do not cover (contaminants over 64 characters or with anything but ACGTN, reads shorter than the
+// contaminant, reads over 256 nt) goes to the sequential matchers of snk_common.cuh, per lane.
 #include <hip/hip_runtime.h>
 #include "snk_common.cuh"
 
@@ -141,7 +141,7 @@ __device__ __forceinline__ void count_steps(const u32 (&Pl)[NW], u64 m64, u32 (&
 // Exact outcome of one hasContam() alignment (src/read_filter.cpp:536-547 and its two siblings): m = cells whose
 // characters are equal, n = cells where the read has 'N' and the contaminant has not, over ncells cells.  Hit <=> a run
 // of T matches completes before the (B+1)-th mismatch, or the alignment ends with at most B mismatches.
-template <int NC>                      // NC - 1 = the largest budget there is
+template <int NC>                      // NC - 1 = the largest budget there is (0: no bound known)
 __device__ __forceinline__ bool contam_accept(u64 m, u64 n, int ncells, int T, int B) {
     const u64 cells = lowmask64(ncells);
     u64 mis = ~m & ~n & cells;
@@ -150,8 +150,9 @@ __device__ __forceinline__ bool contam_accept(u64 m, u64 n, int ncells, int T, i
     const int iters = max(B, 0) + 1;     // B < 0 (INT_MIN thresholds): the first mismatch ends it, and no mismatch is no hit either
     u64 seen = 0;                        // cells up to and including the previous mismatch
     bool hit = false, open = true;
+    const int trips = NC > 0 ? NC : iters;           // NC == 0: budgets beyond the counter planes, as many trips as it takes
 #pragma unroll
-    for (int it = 0; it < NC; ++it) {
+    for (int it = 0; it < trips; ++it) {
         if (open && it < iters) {
             const int z = mis ? __ffsll((long long)mis) - 1 : ncells;
             const u64 upto = lowmask64(z);
@@ -170,7 +171,7 @@ __device__ __forceinline__ bool contam_accept(u64 m, u64 n, int ncells, int T, i
 // its first S - 1 cells against adaMis, one hanging off the read end with r1 = k - edge over its first T(r1) - 1 cells
 // against its budget(r1) -- through their monotone envelopes (rT, rk: DevContam), so that "cell c counts for this
 // offset" and "this offset's budget is at least b" are prefix masks over the offsets.
-template <int NW, int NC>
+template <int NW, int NC, bool BIG = false>      // BIG: budgets of 4 and more exist -- NC == 4 planes count to four, such offsets are never screened out
 __device__ bool has_contam_bits(const DevContam &C, const DevContam &L, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active) {
     const int cl = C.len, edge = C.edge, nC = C.nC;
     const u64 cm0 = C.cm[0], cm1 = C.cm[1], cm2 = C.cm[2], cm3 = C.cm[3], nm = C.nm;
@@ -193,7 +194,7 @@ __device__ bool has_contam_bits(const DevContam &C, const DevContam &L, const u3
                 cand &= cand - 1;
                 const int sh = cl - k;
                 const u64 m = (x0 & (cm0 >> sh)) | (x1 & (cm1 >> sh)) | (x2 & (cm2 >> sh)) | (x3 & (cm3 >> sh)) | (xn & (nm >> sh));
-                if (contam_accept<NC>(m, xn & ~(nm >> sh), k, L.sm1[k - edge], L.mm[k - edge])) { hit = true; cand = 0; }
+                if (contam_accept<BIG ? 0 : NC>(m, xn & ~(nm >> sh), k, L.sm1[k - edge], L.mm[k - edge])) { hit = true; cand = 0; }
             }
         }
     }
@@ -252,6 +253,7 @@ __device__ bool has_contam_bits(const DevContam &C, const DevContam &L, const u3
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             u32 rej = Cn[NC - 1][j];
+            if (BIG) rej &= ~((mis >= NC ? mid[j] : 0u) | (lowmask32(tb - C.rk[0] - 32 * j) & ~mid[j]));   // budget >= 4 here (rk[0]: that envelope)
 #pragma unroll
             for (int b = 1; b < NC; ++b) {
                 const u32 tbp = (mis >= b ? mid[j] : 0u) | (lowmask32(tb - C.rk[b] - 32 * j) & ~mid[j]);
@@ -271,7 +273,7 @@ __device__ bool has_contam_bits(const DevContam &C, const DevContam &L, const u3
             const int B = mid ? C.mis : L.mm[r1], T = mid ? C.S : L.sm3[r1];
             const u64 n = window64(XN, p);
             const u64 m = (window64(X[0], p) & cm0) | (window64(X[1], p) & cm1) | (window64(X[2], p) & cm2) | (window64(X[3], p) & cm3) | (n & nm);
-            if (contam_accept<NC>(m, n & ~nm, ncells, T, B)) {
+            if (contam_accept<BIG ? 0 : NC>(m, n & ~nm, ncells, T, B)) {
                 hit = true;
 #pragma unroll
                 for (int j = 0; j < NW; ++j) alive[j] = 0;
@@ -287,7 +289,8 @@ __device__ bool has_contam_bits_nc(const DevContam &C, const DevContam &L, const
     if (b <= 0) return has_contam_bits<NW, 1>(C, L, X, XN, len, active);
     if (b == 1) return has_contam_bits<NW, 2>(C, L, X, XN, len, active);
     if (b == 2) return has_contam_bits<NW, 3>(C, L, X, XN, len, active);
-    return has_contam_bits<NW, 4>(C, L, X, XN, len, active);
+    if (b == 3) return has_contam_bits<NW, 4>(C, L, X, XN, len, active);
+    return has_contam_bits<NW, 4, true>(C, L, X, XN, len, active);
 }
 
 // x = ~(plane >> c) for a uniform c in [0, 64): the offsets whose cell at contaminant position c is NOT that letter;

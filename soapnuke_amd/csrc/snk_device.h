@@ -43,7 +43,7 @@ struct DevContam {
     int32_t sm1[SNK_DEV_MAX_ADA_LEN];  // segMatchTemp(r1) of the head loop (7 when segGrad == 0)
     int32_t sm3[SNK_DEV_MAX_ADA_LEN];  // segMatchTemp(r1) of the tail loop (no such guard there)
     uint8_t seq[SNK_DEV_MAX_ADA_LEN];
-    // ---- bit-parallel view (snk_contam.hip; contaminants of 1..64 upper-case ACGTN characters, adaEdge >= 1, budgets <= 3)
+    // ---- bit-parallel view (snk_contam.hip; contaminants of 1..64 upper-case ACGTN characters, adaEdge >= 1)
     uint64_t cm[4], nm;     // cm[k] bit c = seq[c] == "ACGT"[k]; nm bit c = seq[c] == 'N'
     int32_t bits_ok;        // the bit-parallel matcher covers this contaminant
     int32_t scr;            // cells screened for some alignment: max over the alignments of max(segMatch threshold, 1) - 1, at most 63
@@ -51,7 +51,7 @@ struct DevContam {
     int32_t pad_;
     // monotone envelopes of the tail loop's per-r1 thresholds (r1 = overlap - adaEdge; the tail alignment with r1 starts at
     // read offset len - adaEdge - r1): cell c is screened for the alignments with r1 >= rT[c], the budget is >= b for
-    // r1 >= rk[b] (nC: none)
+    // r1 >= rk[b] (nC: none), b = 1..3; rk[0]: b = 4
     int32_t rT[64], rk[4];
 };
 // One global contaminant (src/read_filter.cpp:927-1062): forward and reverse-complement strand.

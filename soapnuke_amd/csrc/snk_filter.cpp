@@ -99,7 +99,7 @@ bool build_contam(DevContam &C, const std::string &seq, int S, int adaMis, int a
     }
     // bit-parallel view (snk_contam.hip): one mask per letter; the screen looks at the first `scr` cells of an alignment --
     // a run of T matches cannot complete inside them when scr <= T - 1 for every alignment's T -- with the largest budget
-    C.bits_ok = (cl >= 1 && cl <= 64 && adaEdge >= 1 && adaMis >= 0 && adaMis <= 3) ? 1 : 0;
+    C.bits_ok = (cl >= 1 && cl <= 64 && adaEdge >= 1 && adaMis >= 0) ? 1 : 0;
     for (int c = 0; c < cl && C.bits_ok; ++c) {
         const char *k = strchr("ACGT", seq[c]);
         if (seq[c] == 'N') C.nm |= 1ull << c;
@@ -127,12 +127,11 @@ bool build_contam(DevContam &C, const std::string &seq, int S, int adaMis, int a
         for (int r1 = nC - 1; r1 >= 0; --r1) if (tenv[r1] - 1 > c) r = r1;       // tenv is nondecreasing: the smallest such r1
         C.rT[c] = r;
     }
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 1; b <= 4; ++b) {                        // rk[0] holds b = 4
         int r = nC;
         for (int r1 = nC - 1; r1 >= 0; --r1) if (benv[r1] >= b) r = r1;
-        C.rk[b] = r;
+        C.rk[b & 3] = r;
     }
-    if (bmax > 3) C.bits_ok = 0;
     C.scr = (int)std::min<long>(tmax - 1, 63);
     C.bmax = bmax;
     return true;

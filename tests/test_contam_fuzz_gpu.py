@@ -5,7 +5,7 @@ functions by tests/test_oracle_vs_ref.py), through the whole filter: bit-exact r
 
 Contexts: contaminants of 8..64 nt (plus some the bit paths must hand to the sequential matchers: over 64 nt, lower
 case), with 'N', low-complexity ones (long carried windows across the lays of global_contam_pos), ctMatchR 0.2..1,
-adaMis 0..4, adaEdge 1..12, global contaminants with match ratios 0.3..1 and 0..4 mismatches; reads of 150 / 250 /
+adaMis 0..7, adaEdge 1..12, global contaminants with match ratios 0.3..1 and 0..4 mismatches; reads of 150 / 250 /
 variable length (also shorter than the contaminant), random, low-complexity and with planted whole / head- / tail-
 truncated / mutated / N-sprinkled copies."""
 import numpy as np
@@ -89,7 +89,9 @@ def context(i):
               ada_mis=(int(rng.integers(0, 4)), int(rng.integers(0, 4))),
               ada_edge=(int(rng.integers(1, 13)), int(rng.integers(1, 13))))
     if i % 11 == 10:
-        kw["ada_mis"] = (4, 1)                              # budget over 3: sequential matchers for mate 1
+        kw["ada_mis"] = (4, 1)                              # budgets over 3: the counters stop at four, such offsets are all decided exactly
+    if i % 11 == 9:
+        kw["ada_mis"] = (7, 5)
     cts = []
     kind = i % 3                                            # 0: contam lists, 1: global only, 2: both
     if kind != 1:
