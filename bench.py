@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=PAIRS_TOTAL, help="pairs per GPU per step")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 tiled")
+    ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 2, 3], help="0 auto, 1 generic decisions + LDS histograms, 2 fast paths only, 3 generic alone (anchor)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-side legs (cpu_baseline, end_to_end)")
     ap.add_argument("--e2e-pairs", type=int, default=4_000_000, help="pairs of the end_to_end leg (0: only the cpu_baseline sample)")
     args = ap.parse_args()
@@ -275,7 +275,7 @@ def main():
             "data": f"synthetic PE150 (seed {synth.SEED}+rank): {n_unique} unique pairs x{reps} distinct HBM copies per GPU",
             "config": {"workload": "BASELINE configs[1]: PE 10Mx150bp, adapter-trim + lowQual (-f/-r README adapters, -J -l 10 -q 0.1)",
                        "pairs_per_gpu_per_step": n, "read_len": L, "Mpairs_per_s": round(value / 2, 3),
-                       "kernel": {0: "auto", 1: "generic", 2: "tiled"}[args.kernel],
+                       "kernel": {0: "auto", 1: "generic+hist", 2: "tiled", 3: "generic"}[args.kernel],
                        "parallelism": f"shard{world}" if world > 1 else "single",
                        "clean_pairs_per_step_per_gpu": kept // (args.steps * world)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
