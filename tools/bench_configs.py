@@ -63,6 +63,8 @@ run("long C3 PE1000", 1000, True, PE_CASES["C3_full"], n=1_000_000)
 run("long defaults PE1000", 1000, True, PE_CASES["defaults"], n=1_000_000)
 run("C2 + contam1/2 + global", 150, True, dict(PE_CASES["C2_adatrim_lowq"], contam1="ACGTTGCAAGGCTTAACCGGTTAGCATGCAAT", contam2="TTGGCCAAGGTTCCAAGGTTAACCGGTT",
                                                ct_match_r="0.5", global_contams="AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", g_mrs="0.4", g_mms="1"), n=5_000_000)
+run("C5 PE250 + contam1/2 + global", 250, True, dict(PE_CASES["C2_adatrim_lowq"], contam1="ACGTTGCAAGGCTTAACCGGTTAGCATGCAAT", contam2="TTGGCCAAGGTTCCAAGGTTAACCGGTT",
+                                                     ct_match_r="0.5", global_contams="AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", g_mrs="0.4", g_mms="1"), n=3_000_000)
 run("C2 + contam1/2 only", 150, True, dict(PE_CASES["C2_adatrim_lowq"], contam1="ACGTTGCAAGGCTTAACCGGTTAGCATGCAAT", contam2="TTGGCCAAGGTTCCAAGGTTAACCGGTT",
                                            ct_match_r="0.5"), n=5_000_000)
 run("C2 + global contam only", 150, True, dict(PE_CASES["C2_adatrim_lowq"], global_contams="AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", g_mrs="0.4", g_mms="1"), n=5_000_000)
