@@ -36,14 +36,26 @@ BYTES_PER_PAIR = 2 * (2 * L + 16)      # bases + qualities read onc
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def bench_params_kwargs():
+WORKLOADS = {
+    # name: (description, extra parameters on top of configs[1]'s, variable read lengths)
+    "c2": ("BASELINE configs[1]: PE 10Mx150bp, adapter-trim + lowQual (-f/-r README adapters, -J -l 10 -q 0.1)", {}, False),
+    "c3": ("BASELINE configs[2] parameters on 10M pairs: configs[1] + -n 0.01 -m 20 -g 10 -X 50 -p 0.8 + trimBadTail=20,30 (full trim+filter)",
+           dict(n_ratio=0.01, mean_quality=20, polyG_tail=10, polyX_num=50, highA_ratio=0.8, trim_bad_tail=(20, 30)), False),
+    "c2var": ("configs[1] parameters, variable read lengths 75..150", {}, True),
+    "c3var": ("configs[2] parameters, variable read lengths 75..150",
+              dict(n_ratio=0.01, mean_quality=20, polyG_tail=10, polyX_num=50, highA_ratio=0.8, trim_bad_tail=(20, 30)), True),
+}
+
+
+def bench_params_kwargs(workload="c2"):
     from soapnuke_amd import synth
-    return dict(adapters1=[synth.ADAPTER1], adapters2=[synth.ADAPTER2], ada_trim=1, low_qual=10, low_qual_ratio=0.1)
+    return dict(dict(adapters1=[synth.ADAPTER1], adapters2=[synth.ADAPTER2], ada_trim=1, low_qual=10, low_qual_ratio=0.1),
+                **WORKLOADS[workload][1])
 
 
-def bench_params():
+def bench_params(workload="c2"):
     from soapnuke_amd import abi
-    return abi.default_params(paired=True, max_read_len=L, **bench_params_kwargs())
+    return abi.default_params(paired=True, max_read_len=L, **bench_params_kwargs(workload))
 
 
 def cpu_baseline(data, n_sample):
@@ -161,6 +173,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=PAIRS_TOTAL, help="pairs per GPU per step")
     ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 2, 3], help="0 auto, 1 generic decisions + LDS histograms, 2 fast paths only, 3 generic alone (anchor)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-side legs (cpu_baseline, end_to_end)")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="c2 = the headline (BASELINE configs[1]); the others are profiling workloads")
     ap.add_argument("--e2e-pairs", type=int, default=4_000_000, help="pairs of the end_to_end leg (0: only the cpu_baseline sample)")
     args = ap.parse_args()
 
@@ -198,12 +211,14 @@ def main():
     n_unique = min(PAIRS_UNIQUE, args.pairs)
     reps = max(1, args.pairs // n_unique)
     n = n_unique * reps
-    data = synth.make_batch(n_unique, L, paired=True, seed=synth.SEED + rank)
-    ctx = FilterContext(bench_params(), device=local_rank)
+    var_len = WORKLOADS[args.workload][2]
+    data = synth.make_batch(n_unique, L, paired=True, seed=synth.SEED + rank, var_len=var_len)
+    ctx = FilterContext(bench_params(args.workload), device=local_rank)
     dev = ctx.upload(data)
     if reps > 1:   # distinct HBM copies: no cache reuse between replicas (6.4 GB >> 256 MB L3)
         dev["seq"] = [x.repeat(reps, 1) for x in dev["seq"]]
         dev["qual"] = [x.repeat(reps, 1) for x in dev["qual"]]
+        dev["len"] = [None if x is None else x.repeat(reps) for x in dev["len"]]
         dev["n"] = n
     rec = ctx.alloc_records(n)
     batch = ctx.make_batch(dev, first_index=rank * n)
@@ -253,14 +268,17 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = 2.0 * n * world * args.steps / elapsed / 1e6
         k_ms = float(np.mean(kernel_ms))
-        achieved = BYTES_PER_PAIR * n / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        bytes_launch = BYTES_PER_PAIR * n
+        if var_len:      # SURVEY 8(d)'s per-read figure on the real lengths: 2 * len + 16
+            bytes_launch = reps * int(sum(2 * int(x.astype(np.int64).sum()) + 16 * len(x) for x in data["len"]))
+        achieved = bytes_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # HBM bytes per launch from the PMC passes of this same command (tools/profile.sh; bench.py
         # cannot run rocprofv3 around itself): only quoted when the workload is the profiled one
         traffic, extra = None, {}
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
                 tj = json.load(fh)
-            if n == 10_000_000 and L == 150 and args.kernel in (0, 2):
+            if n == 10_000_000 and L == 150 and args.kernel in (0, 2) and args.workload == "c2":
                 traffic = int(tj["hbm_bytes_per_launch"])
                 extra = {"traffic_source": tj["source"], "valu_insts_per_read": tj["valu_insts_per_read"],
                          "valu_issue_frac": tj["valu_issue_frac"], "salu_insts_per_read": tj.get("salu_insts_per_read")}
@@ -273,16 +291,16 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": f"synthetic PE150 (seed {synth.SEED}+rank): {n_unique} unique pairs x{reps} distinct HBM copies per GPU",
-            "config": {"workload": "BASELINE configs[1]: PE 10Mx150bp, adapter-trim + lowQual (-f/-r README adapters, -J -l 10 -q 0.1)",
+            "config": {"workload": WORKLOADS[args.workload][0],
                        "pairs_per_gpu_per_step": n, "read_len": L, "Mpairs_per_s": round(value / 2, 3),
                        "kernel": {0: "auto", 1: "generic+hist", 2: "tiled", 3: "generic"}[args.kernel],
                        "parallelism": f"shard{world}" if world > 1 else "single",
                        "clean_pairs_per_step_per_gpu": kept // (args.steps * world)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel_ms": round(k_ms, 4), "bytes_per_launch": BYTES_PER_PAIR * n, **extra},
+                         "kernel_ms": round(k_ms, 4), "bytes_per_launch": bytes_launch, **extra},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             e2e = None
             if args.e2e_pairs > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "SOAPnuke")):
                 try:

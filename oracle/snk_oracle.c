@@ -447,6 +447,11 @@ static void fastq_trim(const snk_params *P, int mate, const uint8_t *seq,
     }
     if (lqt_flag) {                                                /* :390-429 */
         int head_ix = 0, tail_ix = 0;
+        /* Quirk Q11: neither loop checks the read length (:411-426).  With a limit above the
+         * length and every base below the threshold the reference indexes qual_seq[size] ('\0', defined), then
+         * past it / before qual_seq[0] (heap bytes: undefined).  Here everything outside [0,len) reads as 0,
+         * i.e. the run goes on to the limit whenever 0 - phred < threshold.  Generators keep limits <= the
+         * shortest read where the compiled reference is the judge. */
         for (int ix = 0; ix < P->lq_head_len; ix++) {
             int bq = rd(qual, len, ix) - P->quality_phred;
             if (bq < P->lq_head_qual) head_ix++;

@@ -48,7 +48,8 @@ using namespace snk;
 // 2 = phases 1+2, 3 = no phase 3, 4 = no adapter search, 5 = no trimming-position counters, 6 = no exact
 // decision of adapter candidates, 7 = no adapter screening, 8 / 9 / 10 = no polyX / no low-quality-end + polyG /
 // no trim_finish (FULL variant), 11 = no LDS histogram adds, 12 = no DMA, 14 = DMA never waited for, 15 = 12-like
-// phase 1 with an L2-resident source (see SNK_L2SRC).  The shipped library is built with 0.
+// phase 1 with an L2-resident source (see SNK_L2SRC), 16 = no per-read quality sum (FULL), 17 = no low-quality-end collectors (FULL).
+// The shipped library is built with 0.  SNK_ONLY_NW=5 compiles the 129..160-position instances only (ablation builds).
 #ifndef SNK_ABL
 #define SNK_ABL 0
 #endif
@@ -229,7 +230,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         v16u PQA = PC, PTT = PC;           // [0,8): aQ, [8,16): aA ; [0,8): aT
         u32 aC = 0, aQ = 0, aA = 0, aT = 0, badv = 0, bad0 = 0;
         const bool has_px = FULL && __builtin_amdgcn_readfirstlane(P.polyX_num) != -1;
-        const bool has_lq = FULL && __builtin_amdgcn_readfirstlane(P.has_lq) != 0;
+        const bool has_lq = FULL && SNK_ABL != 17 && __builtin_amdgcn_readfirstlane(P.has_lq) != 0;
         const int has_meanq = __builtin_amdgcn_readfirstlane(P.has_meanq);
         const int len0 = rl(clen_v, 0);
         const bool fixed = __all(!lanev || clen_v == len0);
@@ -312,7 +313,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             });
             int hm = FULL ? has_meanq : 0;        // (the mean-quality filter selects the FULL variant)
             asm volatile("" : "+s"(hm));          // a plain scalar compare + branch per read (hoisted, the flag turns into lane masks)
-            if (FULL && hm != 0) {                // quality sum of the read (mean-quality filter only)
+            if (FULL && hm != 0 && SNK_ABL != 16) {                // quality sum of the read (mean-quality filter only)
                 int qsum = 0;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -1167,11 +1168,16 @@ int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch
 #define SNK_GO(NW_)                                                                    \
     return full ? launch<NW_, true>(hp, ta, b, st, G, n_cu, stream)                    \
                 : launch<NW_, false>(hp, ta, b, st, G, n_cu, stream);
+#ifdef SNK_ONLY_NW
+    if (nw != SNK_ONLY_NW) return 0;
+    SNK_GO(SNK_ONLY_NW)
+#else
     if (nw <= 2) { SNK_GO(2) }
     else if (nw <= 4) { SNK_GO(4) }
     else if (nw <= 5) { SNK_GO(5) }
     else if (nw <= 6) { SNK_GO(6) }
     else { SNK_GO(8) }
+#endif
 #undef SNK_GO
 }
 

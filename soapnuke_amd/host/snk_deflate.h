@@ -65,6 +65,12 @@ private:
     struct Sym { uint16_t litlen, dist; };               // dist == 0: a run of `litlen` literal bytes (taken from the input); else a match of that length
     std::vector<uint32_t> head_;                         // hash -> position + 1 of its newest occurrence (0: none)
     std::vector<Sym> syms_;
+    // one run of equal bytes in a very long name / '+' line appends its literal run symbols plus l / 258 match pieces behind a
+    // single capacity check: the buffer grows instead of trusting the slack (heap write past BLOCK_SYMS + 64)
+    inline void push_sym(int &nsym, const Sym &v) {
+        if ((size_t)nsym >= syms_.size()) syms_.resize(syms_.size() * 2);
+        syms_[(size_t)nsym++] = v;
+    }
     uint8_t *op_ = nullptr;
     uint64_t bitbuf_ = 0;
     int bitcnt_ = 0;
@@ -325,7 +331,7 @@ private:
                 const size_t e4 = lit_from + (k & ~(size_t)3);
                 for (; j < e4; j += 4) { h4_[0][in[j]]++; h4_[1][in[j + 1]]++; h4_[2][in[j + 2]]++; h4_[3][in[j + 3]]++; }
                 for (; j < lit_from + k; ++j) h4_[0][in[j]]++;
-                syms_[nsym++] = Sym{(uint16_t)k, 0};
+                push_sym(nsym, Sym{(uint16_t)k, 0});
                 lit_from += k;
             }
         };
@@ -357,7 +363,7 @@ private:
                     while (left) {                           // (a rest of 1..3 bytes would not be a legal match: take it from the piece before)
                         size_t piece = std::min<size_t>(left, MAX_MATCH);
                         if (left - piece > 0 && left - piece < 4) piece = left - 4;
-                        syms_[nsym++] = Sym{(uint16_t)piece, (uint16_t)dist};
+                        push_sym(nsym, Sym{(uint16_t)piece, (uint16_t)dist});
                         lf_[257 + t.len_code[piece]]++;
                         df_[dist_sym((uint32_t)dist)]++;
                         left -= piece;
@@ -421,7 +427,7 @@ private:
                     for (; j < e4; j += 4) { h4_[0][in[j]]++; h4_[1][in[j + 1]]++; h4_[2][in[j + 2]]++; h4_[3][in[j + 3]]++; }
                     for (; j < lit_from + k; ++j) h4_[0][in[j]]++;
                 }
-                syms_[nsym++] = Sym{(uint16_t)k, 0};
+                push_sym(nsym, Sym{(uint16_t)k, 0});
                 lit_from += k;
             }
         };
@@ -451,7 +457,7 @@ private:
                 if (l > maxl) l = maxl;
                 literals(i);
                 const uint32_t dist = (uint32_t)(i + 1 - cand);
-                syms_[nsym++] = Sym{(uint16_t)l, (uint16_t)dist};
+                push_sym(nsym, Sym{(uint16_t)l, (uint16_t)dist});
                 lf_[257 + t.len_code[l]]++;
                 df_[dist_sym(dist)]++;
                 // keep the table warm inside the match (every other position: cheap, and FASTQ repeats are long)

@@ -264,6 +264,7 @@ private:
     std::condition_variable cv_;
     bool quit_ = false;
     size_t next_task_ = 0, consumed_ = 0;                  // chunk indices: next to decode / all below are released
+    size_t chain_need_ = 0;                                // the chain thread waits for this chunk (or an earlier one)
     std::vector<size_t> resolve_q_;                        // chunks waiting for their markers to be replaced (FIFO by position)
     size_t resolve_head_ = 0;
     // the chain: chunk indices in stream order, as far as the chain thread got
@@ -342,7 +343,14 @@ private:
             bool resolve = false;
             {
                 std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [&] { return quit_ || resolve_head_ < resolve_q_.size() || (next_task_ < nchunks_ && next_task_ < consumed_ + lookahead_); });
+                // decode tasks: inside the consumer's window, or wanted by the chain thread (it may have to walk past any number
+                // of chunks without a matching block start -- single-block members, long stored runs -- before the consumer
+                // gets anything to release: ADVICE r2, deadlock); none once the chain has ended or fallen back
+                cv_.wait(l, [&] {
+                    return quit_ || resolve_head_ < resolve_q_.size() ||
+                           (!chain_end_ && !chain_fallback_ && next_task_ < nchunks_ &&
+                            (next_task_ < consumed_ + lookahead_ || next_task_ <= chain_need_));
+                });
                 if (quit_) return;
                 if (resolve_head_ < resolve_q_.size()) { i = resolve_q_[resolve_head_++]; resolve = true; }
                 else i = next_task_++;
@@ -358,12 +366,22 @@ private:
             cv_.notify_all();
         }
     }
-    // the first found block start behind chunk j-1 at or past `bit`
-    uint64_t next_stop(size_t &j, uint64_t bit) {
-        for (; j < nchunks_; ++j) {
+    // the first found block start behind chunk j-1 at or past `bit`; the search gives up (gave_up = true) after SEARCH_AHEAD
+    // chunks without one: a stream without non-final dynamic blocks (many small single-block members, stored data) has no
+    // starts at all, and one thread walking find_block over the whole file is slower than decoding it
+    enum { SEARCH_AHEAD = 6 };
+    uint64_t next_stop(size_t &j, uint64_t bit, bool &gave_up) {
+        gave_up = false;
+        const size_t lim = std::min(nchunks_, j + (size_t)SEARCH_AHEAD);
+        for (; j < lim; ++j) {
+            {
+                std::lock_guard<std::mutex> l(m_);
+                if (quit_ || chain_fallback_) { gave_up = true; return ~0ull; }
+            }
             const uint64_t s = ensure_search(j);
             if (s != ~0ull && s >= bit) return s;
         }
+        gave_up = j < nchunks_;
         return ~0ull;
     }
     void decode_chunk(size_t i) {
@@ -375,7 +393,9 @@ private:
         z.init(in_, n_);
         z.set_verify_crc(false);
         size_t j = i + 1;
-        uint64_t stop = next_stop(j, s0 + 1);
+        bool gave_up = false;
+        uint64_t stop = next_stop(j, s0 + 1, gave_up);
+        if (gave_up) return;                                // no block start near: the chain breaks here, the consumer decodes sequentially
         bool byte_mode = i == 0;                            // chunk 0 starts at the gzip header: nothing unknown
         if (i > 0) {
             z.start_at_block(s0);
@@ -389,7 +409,8 @@ private:
             if (w == MarkerInflate::STOP) {
                 if (z.bitpos() == stop) { finish(c, z, 0, false); return; }
                 ++j;                                        // ran past it: that start was a false positive
-                stop = next_stop(j, z.bitpos());
+                stop = next_stop(j, z.bitpos(), gave_up);
+                if (gave_up) return;
                 continue;
             }
             byte_mode = true;                               // MEMBER_END: nothing reaches back across it
@@ -425,7 +446,8 @@ private:
             if (z.stopped()) {
                 if (z.bitpos() == stop) break;
                 ++j;
-                stop = next_stop(j, z.bitpos());
+                stop = next_stop(j, z.bitpos(), gave_up);
+                if (gave_up) return;
                 continue;
             }
             if (z.done()) { stop = ~0ull; break; }
@@ -479,6 +501,7 @@ private:
     // ---------------------------------------------------------------- chain thread
     void wait_done(size_t j) {
         std::unique_lock<std::mutex> l(m_);
+        if (j > chain_need_) { chain_need_ = j; cv_.notify_all(); }      // the workers' window follows the chain
         cv_.wait(l, [&] { return quit_ || chunks_[j].done.load(std::memory_order_acquire) != 0; });
     }
     void drop(size_t j) {                                   // a chunk that is not part of the stream (no start / false start)

@@ -76,3 +76,61 @@ def plant_contams(d, kw, seed=4):
 
 def contam_kwargs(kw, paired):
     return {k: v for k, v in kw.items() if paired or k not in ("contam2", "adapters2")}
+
+
+# ---- random parameter contexts (VERDICT r2 task 1): oracle vs compiled reference, HIP vs oracle
+
+def rebase_quality(d, phred=33, qmax=41, seed=7):
+    """moves the qualities of a synth batch (Phred-33, values 2..41) to another offset / value range: values above
+    `qmax` are cut, and when `qmax` > 41 a tenth of the positions is redrawn uniformly from 0..qmax"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    L = d["L"]
+    for m in range(len(d["qual"])):
+        q = d["qual"][m][:, :L].astype(np.int16) - 33
+        if qmax > 41:
+            q = np.where(rng.random(q.shape) < 0.1, rng.integers(0, qmax + 1, q.shape), q)
+        q = np.clip(q, 0, qmax)
+        d["qual"][m][:, :L] = (q + phred).astype(np.uint8)
+        if d["len"][m] is not None:                      # keep the garbage past the read ends
+            beyond = np.arange(L)[None, :] >= d["len"][m][:, None].astype(np.int32)
+            d["qual"][m][:, :L][beyond] = 0xEE
+    return d
+
+
+def random_context(rng, L, paired, min_len):
+    """one random parameter set the reference defines (no UB zone): trimBadHead/Tail limits stay <= the shortest read
+    (quirk Q11: beyond it src/read_filter.cpp:411-426 reads outside the quality string), qualities stay inside
+    [0, maxBaseQuality] (Q4), adapters are not longer than the shortest read (Q6)"""
+    import numpy as np
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    kw = {}
+    nada = int(rng.integers(0, 4))
+    if nada:
+        for k in ("adapters1", "adapters2")[:2 if paired else 1]:
+            kw[k] = [bytes(B[rng.integers(0, 4, int(rng.integers(8, min(60, min_len - 2))))]).decode() for _ in range(nada)]
+        kw["ada_trim"] = int(rng.integers(0, 2))
+        kw["ada_mis"] = (int(rng.integers(0, 5)), int(rng.integers(0, 5)))
+        kw["ada_mr"] = (float(rng.choice([0.2, 0.4, 0.5, 0.7, 1.0])), float(rng.choice([0.3, 0.5, 0.8])))
+        kw["ada_edge"] = (int(rng.integers(1, 8)), int(rng.integers(1, 8)))      # <= the shortest adapter
+    kw["low_qual"] = int(rng.integers(0, 30))
+    kw["low_qual_ratio"] = float(rng.choice([-1, 0.05, 0.1, 0.3, 0.5, 0.9]))
+    kw["n_ratio"] = float(rng.choice([-1, 0.0, 0.01, 0.05, 0.2]))
+    if rng.random() < 0.5:
+        kw["mean_quality"] = int(rng.integers(5, 38))
+    if rng.random() < 0.4:
+        kw["polyG_tail"] = float(rng.choice([5, 10, 20.5, 40]))
+    if rng.random() < 0.4:
+        kw["polyX_num"] = int(rng.integers(3, 60))
+    if rng.random() < 0.4:
+        kw["highA_ratio"] = float(rng.choice([0.2, 0.3, 0.5, 0.8]))
+    kw["min_read_length"] = int(rng.choice([-1, 0, 30, 60, L - 10]))
+    if rng.random() < 0.3:
+        kw["max_read_length"] = int(rng.integers(L // 2, L + 5))
+    if rng.random() < 0.4:
+        kw["hard_trim"] = [int(x) for x in rng.integers(0, L + 20 if rng.random() < 0.2 else 12, 4 if paired else 2)]
+    if rng.random() < 0.4:
+        kw["trim_bad_head"] = (int(rng.integers(3, 35)), int(rng.integers(1, min_len + 1)))
+    if rng.random() < 0.5:
+        kw["trim_bad_tail"] = (int(rng.integers(3, 35)), int(rng.integers(1, min_len + 1)))
+    return kw

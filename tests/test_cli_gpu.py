@@ -512,3 +512,33 @@ def test_cli_quality_system_sanity(paired, shift, qualsys, expect, tmp_path):
     else:
         assert a.returncode == 0 and b.returncode == 0
         assert msg not in a.stderr and msg not in b.stderr
+
+
+# ---- round 3: Phred-64 input, non-default maxBaseQuality (VERDICT r2 task 1 i)
+
+@pytest.mark.parametrize("paired,cfg,qmax", [(True, ["qualSys=1"], 41), (True, ["qualSys=1", "outQualSys=1"], 41),
+                                             (False, ["qualSys=1", "maxBaseQuality=44"], 43), (True, ["maxBaseQuality=40"], 39),
+                                             (True, ["maxBaseQuality=50", "outQualSys=1"], 49)])
+def test_cli_phred64_and_max_base_quality(paired, cfg, qmax, tmp_path):
+    """`qualSys=1` on Phred-64 files (+- `outQualSys=1`) and `maxBaseQuality` != 42: HIP kernels behind the CLI, every report
+    file and the clean FASTQ (qualities re-based by the writer, src/peprocess.cpp:3398-3405) against the reference binary.
+    (SE takes an even maxBaseQuality: seProcess's column scan reads position_qual[i][maxBaseQuality], one word past the row
+    -- src/seprocess.cpp:275 vs global_variable.cpp:43 -- which for odd values is the next heap chunk's size field: quirk Q12)"""
+    from cases import rebase_quality
+    phred = 64 if "qualSys=1" in cfg else 33
+    mbq = [int(c.split("=")[1]) for c in cfg if c.startswith("maxBaseQuality")]
+    kw = dict(adapters1=[synth.ADAPTER1], ada_trim=1, low_qual=10, low_qual_ratio=0.1, n_ratio=0.01, mean_quality=20,
+              trim_bad_tail=(20, 30), quality_phred=phred, max_base_quality=mbq[0] if mbq else 42)
+    cli = ["-f", synth.ADAPTER1, "-J", "-l", "10", "-q", "0.1", "-n", "0.01", "-m", "20"]
+    if paired:
+        kw.update(adapters2=[synth.ADAPTER2])
+        cli += ["-r", synth.ADAPTER2]
+    else:
+        kw.pop("trim_bad_tail")                        # (SE: the reference's option check wants one field, Appendix A)
+    case = ("phred", paired, 150, 30000, 3, 200, dict(seed=81), kw, cli, cfg + (["trimBadTail=20,30"] if paired else []))
+    d, p = R.case_inputs(case)
+    rebase_quality(d, phred, qmax, seed=qmax)
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ours = _run_ours(case, work, gz=False)
+    _compare_dirs(ours, ref, paired)

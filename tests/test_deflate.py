@@ -108,3 +108,31 @@ def test_crc32_matches_zlib(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(T.ROOT, "tools", "micro", "crc_test.cpp"), "-lz"])
     r = subprocess.run([exe], capture_output=True)
     assert r.returncode == 0 and b"CRC_OK" in r.stdout, r.stdout[-300:]
+
+
+def test_symbol_buffer_growth_under_asan(tmp_path):
+    """one name line can append far more symbols than the slack behind BLOCK_SYMS (its literal runs plus one match
+    piece per 258 equal bytes, for every equal run of the line, behind a capacity check per run).  12-byte records fill the
+    symbol buffer to just below the block limit; the name line behind them repeats itself at distance 12 -- a few short
+    equal runs, then one of 32 000 bytes.  Built with AddressSanitizer (the round-2 header writes past the buffer here:
+    heap-buffer-overflow at ntiny = 32728), must round-trip."""
+    exe = str(tmp_path / "deflate_asan")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address", "-std=c++17", "-o", exe, SRC, "-lz"])
+
+    def giant(nshort, nlong):
+        c = bytearray(b"@BCDEFGHIJKL")
+        for _ in range(nshort):
+            for _ in range(8):
+                c.append(c[len(c) - 12])
+            c.append((c[len(c) - 12] + 1 - 65) % 26 + 65)         # differs
+        for _ in range(nlong):
+            c.append(c[len(c) - 12])
+        return bytes(c)
+
+    for ntiny in (32728, 32731, 32735):
+        for nshort in (20, 28):
+            blob = b"@aaaa\nA\n+\nI\n" * ntiny + giant(nshort, 32000) + b"\nACGT\n+\nIIII\n"
+            p = str(tmp_path / "blob")
+            open(p, "wb").write(blob)
+            r = subprocess.run([exe, p], capture_output=True, env=dict(os.environ, FASTQ="1", ASAN_OPTIONS="detect_leaks=0"))
+            assert r.returncode == 0 and b"ROUNDTRIP_OK" in r.stdout, (ntiny, nshort, r.stdout[-200:], r.stderr[-600:])

@@ -92,3 +92,24 @@ def test_parallel_decoder_on_a_long_stream(exe, tmp_path):
     open(p, "wb").write(bytes(bad))
     r = subprocess.run([exe, p, "4194304", "par", "4", "1000000"], capture_output=True)
     assert r.returncode == 2 and b"ERROR" in r.stdout, r.stdout[-200:]
+
+
+def test_parallel_decoder_between_members_without_block_starts(exe, tmp_path):
+    """a long stretch of single-final-block members (what libdeflate's bgzip writes: nothing the block-start search
+    accepts) between two ordinary streams.  The round-2 scheduler dead-locked here -- the chain thread waited for a chunk no
+    worker was allowed to take -- and one thread searched the whole stretch for block starts.  Small thread counts, default and
+    small chunk sizes; zlib's bytes, within seconds."""
+    raw = _fastq_bytes(60000)
+    mid = b"".join(gzip.compress(raw[k:k + 6000], 6) for k in range(0, 9_000_000, 6000))       # ~ 1500 one-block members
+    stored = zlib.compressobj(0, zlib.DEFLATED, 31)
+    blobs = {
+        "members": gzip.compress(raw[:4_000_000], 6) + mid + gzip.compress(raw[4_000_000:9_000_000], 6),
+        "stored_run": gzip.compress(raw[:3_000_000], 6) + stored.compress(raw[:6_000_000]) + stored.flush() + gzip.compress(raw[:3_000_000], 1),
+        "members_only": mid,
+    }
+    for name, blob in blobs.items():
+        p = str(tmp_path / (name + ".gz"))
+        open(p, "wb").write(blob)
+        for threads, cb in (("2", "2097152"), ("6", "2097152"), ("2", "65536"), ("3", "131072")):
+            r = subprocess.run([exe, p, "4194304", "par", threads, cb], capture_output=True, timeout=120)
+            assert r.returncode == 0 and b"IDENTICAL" in r.stdout, (name, threads, cb, r.stdout[-200:])

@@ -144,3 +144,39 @@ def test_contam_matchers_fuzz():
         assert a == b, ("global_contam_pos", cl, rl, gmr, mm, mode)
         hits += b >= 0
     assert hits > 1000
+
+
+# ---- random parameter contexts, Phred-64 and non-default maxBaseQuality (VERDICT r2 task 1 iii)
+
+def _fuzz_case(i):
+    from cases import random_context, rebase_quality
+    rng = np.random.default_rng([77, i])
+    paired = bool(i % 3)
+    L = int(rng.choice([100, 150, 250]))
+    var_len = bool(rng.integers(0, 2))
+    kw = random_context(rng, L, paired, L // 2 if var_len else L)
+    phred = 64 if i % 4 == 1 else 33
+    mbq = int(rng.choice([40, 42, 45, 50])) if i % 2 else 42
+    ad = (kw.get("adapters1", [synth.ADAPTER1])[0], kw.get("adapters2", [synth.ADAPTER2])[0])
+    n = 1500
+    d = synth.make_batch(n, L, paired=paired, var_len=var_len, seed=1000 + i, adapters=ad,
+                         dimer_frac=0.05 if i % 5 == 0 else 0.0)
+    if var_len:   # the generator's shortest read follows the adapter length: cut the trimBad limits to what it really made (Q11)
+        shortest = min(int(x.min()) for x in d["len"] if x is not None)
+        for k in ("trim_bad_head", "trim_bad_tail"):
+            if k in kw:
+                kw[k] = (kw[k][0], min(kw[k][1], shortest))
+    rebase_quality(d, phred, mbq - 1, seed=i)          # Q4: the reference's rows are 0..maxBaseQuality-1
+    # (the shim has no writer: the reference re-bases the qualities to outQualSys in output_fastqs before its clean
+    # statistics, src/peprocess.cpp:3398-3405,1099 -- equal offsets here, the CLI tests cover outQualSys)
+    p = abi.default_params(paired=paired, max_read_len=L, quality_phred=phred, output_quality_phred=phred, max_base_quality=mbq,
+                           **(kw if paired else se_kwargs({k: v for k, v in kw.items() if k != "adapters2"})))
+    return p, d, paired
+
+
+@pytest.mark.parametrize("i", range(48))
+def test_random_parameter_contexts(i):
+    """records, every counter and the max block, oracle vs the compiled reference, over random parameter sets inside the
+    zone the reference defines (trimBadHead/Tail limits <= the shortest read)"""
+    p, d, paired = _fuzz_case(i)
+    _compare(p, d, paired)
