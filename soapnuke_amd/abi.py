@@ -178,7 +178,17 @@ EXPORTS = [
     "snk_rmdup_hash_device", "snk_rmdup_bucket_count_device", "snk_rmdup_mark_device", "snk_rmdup_prime",
     # include/snk_selftest.h
     "snk_selftest_bit_transpose",
+    # include/snk_fastq.h
+    "snk_fastq_tmp_bytes", "snk_fastq_parse_device", "snk_fastq_format_device",
 ]
+
+
+class FastqFormat(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("space_num", C.c_int32), ("qual_delta", C.c_int32), ("id_suffix_times", C.c_int32),
+                ("id_suffix", C.c_char * 4), ("base_from", C.c_uint8), ("base_to", C.c_uint8), ("pad_", C.c_uint8 * 2)]
+
+
+FQ_STATUS_N, FQ_F_LEN_MISMATCH, FQ_F_TOO_LONG, FQ_F_TRUNCATED = 4, 1, 2, 4
 
 
 def load_library(path=None):
@@ -213,4 +223,8 @@ def load_library(path=None):
     lib.snk_rmdup_prime.argtypes = [C.c_uint64]
     lib.snk_rmdup_prime.restype = C.c_uint32
     lib.snk_selftest_bit_transpose.argtypes = [i32, vp, i32, vp, vp]
+    lib.snk_fastq_tmp_bytes.argtypes = [C.c_uint64, C.c_int64]
+    lib.snk_fastq_tmp_bytes.restype = C.c_size_t
+    lib.snk_fastq_parse_device.argtypes = [vp, C.c_uint64, C.c_int64, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.snk_fastq_format_device.argtypes = [vp, vp, vp, vp, C.c_int64, C.POINTER(FastqFormat), vp, vp, vp, C.c_size_t, vp]
     return lib

@@ -256,6 +256,8 @@ void build_adapter(DevAdapter &A, const char *seq, int mis, float mr, int edge) 
 
 }  // namespace
 
+void snk_set_error(const char *msg) { g_err = msg ? msg : ""; }      // snk_fastq.hip
+
 struct snk_ctx {
     snk_params p;
     std::vector<std::string> ada_store[2];

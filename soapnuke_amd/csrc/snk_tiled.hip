@@ -37,6 +37,7 @@
 // practice by the latency of the few KB per wave that the LDS budget lets the DMA keep in
 // flight.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 #include "snk_common.cuh"
@@ -227,10 +228,15 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         // read's end are forced to 'A' first, so they raise no flag and count as code 00 (subtracted at the hand-over).
         v16u PC = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         // (16-element vectors: the compiler parks into them with s_set_gpr_idx; 8-element ones get a v_cndmask chain)
-        v16u PQA = PC, PTT = PC;           // [0,8): aQ, [8,16): aA ; [0,8): aT
+        v16u PQA = PC;                     // [0,8): aQ, [8,16): aA
+        v8u PTT = {0, 0, 0, 0, 0, 0, 0, 0}; // aT
         u32 aC = 0, aQ = 0, aA = 0, aT = 0, badv = 0, bad0 = 0;
+        u32 aS = 0;                        // FULL, mean-quality filter: byte sums of this lane's four qualities, reads 2k (low half) and 2k+1
         const bool has_px = FULL && __builtin_amdgcn_readfirstlane(P.polyX_num) != -1;
         const bool has_lq = FULL && SNK_ABL != 17 && __builtin_amdgcn_readfirstlane(P.has_lq) != 0;
+        // a side of the low-quality-end trim whose limit is 0 cuts nothing: its plane is not collected (BASELINE configs[2] has trimBadTail only)
+        const bool has_lqh = has_lq && __builtin_amdgcn_readfirstlane(P.lq_head_len) > 0;
+        const bool has_lqt = has_lq && __builtin_amdgcn_readfirstlane(P.lq_tail_len) > 0;
         const int has_meanq = __builtin_amdgcn_readfirstlane(P.has_meanq);
         const int len0 = rl(clen_v, 0);
         const bool fixed = __all(!lanev || clen_v == len0);
@@ -267,6 +273,17 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         // (lanes 32-63, which fetch the next row): 7 instead of 8 LDS ops per read.  The add is the ordinary one -- lanes
         // 32-63 land in the slots of positions 160..191, which such a batch does not have; the flush books them under
         // positions 128..159 (TileGeom::pairq).  pq: that strip as fetched with read r.
+        // after an odd read: the two packed quality sums cross the wave and land in the lanes of their reads
+        auto sum_flush = [&](const int r) {
+            int hm = FULL ? has_meanq : 0;
+            asm volatile("" : "+s"(hm));
+            if (FULL && hm != 0 && SNK_ABL != 16) {
+                const u32 tot = (u32)wave_sum((int)aS);
+                v_sumq = wl(v_sumq, (int)(tot & 0xFFFFu), r - 1);
+                v_sumq = wl(v_sumq, (int)(tot >> 16), r);
+                aS = 0;
+            }
+        };
         auto do_read = [&](auto FL, auto JC, auto PR, const int r, u32 c4, const u32 q4, const u32 (&cq)[NS], const u32 pq) {
             constexpr bool FULLLEN = decltype(FL)::value;
             constexpr bool PAIR = decltype(PR)::value;
@@ -290,9 +307,17 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 badv = carry_out;                                              // badv = 2 * badv + (some byte is not the letter of its code)
                 aQ = (aQ >> 1) | ((q4 + KQ) & 0x80808080u);                   // v_add, v_lshrrev, v_and_or
                 if (FULL) {
-                    if (has_lq) {
-                        aA = (aA >> 1) | ((q4 + KA) & 0x80808080u);
-                        aT = (aT >> 1) | ((q4 + KT) & 0x80808080u);
+                    if (has_lqh) aA = (aA >> 1) | ((q4 + KA) & 0x80808080u);
+                    if (has_lqt) aT = (aT >> 1) | ((q4 + KT) & 0x80808080u);
+                    int hm = has_meanq;                // (the mean-quality filter selects the FULL variant)
+                    asm volatile("" : "+s"(hm));       // a plain scalar compare + branch per read (hoisted, the flag turns into lane masks)
+                    if (hm != 0 && SNK_ABL != 16) {
+                        // quality sum of the read (src/read_filter.cpp:299-308): v_sad_u8 adds this lane's four bytes, two reads share
+                        // a dword (a read's characters sum to at most 256 * 255 < 2^16), one wave reduction per two reads; the Phred
+                        // offset comes off per read in phase 2
+                        const u32 qm = q4 & vm;
+                        if (!odd) aS = __builtin_amdgcn_sad_u8(qm, 0u, 0u);
+                        else aS = __builtin_amdgcn_sad_hi_u8(qm, 0u, aS);
                     }
                 }
             }
@@ -311,22 +336,15 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     else lds_add_u32<256 * (s >> 1)>(aQa, (s & 1) ? 0x10000u : 1u);
                 }
             });
-            int hm = FULL ? has_meanq : 0;        // (the mean-quality filter selects the FULL variant)
-            asm volatile("" : "+s"(hm));          // a plain scalar compare + branch per read (hoisted, the flag turns into lane masks)
-            if (FULL && hm != 0 && SNK_ABL != 16) {                // quality sum of the read (mean-quality filter only)
-                int qsum = 0;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    if (PAIR && s == NS - 1) qsum += ((lane >= 32) == odd && 64 * s + (lane & 31) < len_r) ? (int)pq - phred : 0;
-                    else qsum += (64 * s + lane < len_r) ? (int)cq[s] - phred : 0;
-                }
-                v_sumq = wl(v_sumq, wave_sum(qsum), r);
-            }
+            if (FULL && odd) sum_flush(r);
         };
         // a read that does not exist (last tile of a batch): keep the collectors aligned
-        auto skip_read = [&]() {
+        auto skip_read = [&](auto JC, const int r) {
             aQ >>= 1; badv <<= 1;
-            if (FULL) { aA >>= 1; aT >>= 1; }
+            if (FULL) {
+                aA >>= 1; aT >>= 1;
+                if (decltype(JC)::v & 1) sum_flush(r);          // (read r - 1 may exist)
+            }
         };
         // parks after reads 8o+3 and 8o+7 (uniform o); read 32 starts the second flag word
         auto park4 = [&](const int slot) {
@@ -434,7 +452,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                             // behind the row of read r+1: the row of read r+2 and the adds of read r (same parity)
                             lds_wait<PAIR ? ((j & 1) ? ROWO + ADDO : ROWE + ADDE) : K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
                             if (closes && k + 2 < nchunks) issue(k + 2);     // every row of chunk k sits in registers now
-                        } else skip_read();
+                        } else skip_read(IntC<j>{}, r);
                         if (j == 3) park4(2 * o);
                         if (j == 7) { park4(2 * o + 1); park8(o); }
                     });
@@ -469,7 +487,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                             for (int s = 0; s < NS; ++s) cq[s] = nqb[s];
                             if (r + 1 < cnt) load(t0 + r + 1);
                             do_read(FL, IntC<j>{}, std::false_type{}, r, c4, q4, cq, 0u);
-                        } else skip_read();
+                        } else skip_read(IntC<j>{}, r);
                         if (j == 3) park4(2 * o);
                         if (j == 7) { park4(2 * o + 1); park8(o); }
                     });
@@ -640,11 +658,15 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                         EQ[j] = ~(LP[j] ^ lp) & ~(HP[j] ^ hp) & (j ? 0xFFFFFFFFu : 0xFFFFFFFEu);
                     }
                 }
-                if (has_lq) {
+                if (has_lqh) {
                     cross1(PA, LQH);
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) LQH[j] = ~LQH[j];                          // collected: quality >= threshold
+                }
+                if (has_lqt) {
                     cross1(PT, LQT);
 #pragma unroll
-                    for (int j = 0; j < NW; ++j) { LQH[j] = ~LQH[j]; LQT[j] = ~LQT[j]; }   // collected: quality >= threshold
+                    for (int j = 0; j < NW; ++j) LQT[j] = ~LQT[j];
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the scratch may be the next mate's DMA target
@@ -739,7 +761,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             R.n_a = na + v_adja;
             R.n_n = v_nn;
             R.lowq = nlowq;
-            R.sumq = v_sumq;
+            R.sumq = has_meanq ? v_sumq - phred * R.len : 0;      // (phase 1 summed the characters)
         }
         int hix = 0, tix = 0, polyg = 0;
         if (FULL) {
@@ -957,8 +979,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
     }
 }
 
-template <int NW, bool FULL, bool STAGED>
-__global__ void __launch_bounds__(1024)
+template <int NW, bool FULL, bool STAGED, int MAXW = 16>
+__global__ void __launch_bounds__(MAXW * 64)
 snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, const DevStats st, const TileGeom G, const int iters,
                  const int flush_every) {
     // parameters travel by value in the kernarg segment: the compiler keeps them in SGPRs instead
@@ -1082,11 +1104,11 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
     }
 }
 
-template <int NW, bool FULL, bool STAGED>
+template <int NW, bool FULL, bool STAGED, int MAXW = 16>
 void go(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, const TileGeom &G, int iters,
         int flush_every, unsigned wgs, int threads, size_t shmem, void *stream) {
     static bool attr_done = false;
-    auto kern = snk_tiled_kernel<NW, FULL, STAGED>;
+    auto kern = snk_tiled_kernel<NW, FULL, STAGED, MAXW>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
@@ -1110,6 +1132,8 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
     const bool can_stage = (b.pitch % 16 == 0) && b.pitch <= 1024 &&
                            (((uintptr_t)b.seq[0] | (uintptr_t)b.qual[0] | (uintptr_t)b.seq[1] | (uintptr_t)b.qual[1]) % 16 == 0);
     int W = 16;
+    // (12 waves of up to 168 VGPRs -- no spills in the FULL variant, 47 with 16 waves -- are slower: C3 4.11 vs 3.84 ms, C2 3.26 vs 2.89)
+    constexpr int MAXW = 16;
     G.rb = 0; G.cba = 0; G.stg_off = (int)hist; G.stg_wave = 0;
     constexpr int SCR = 2048;          // hand-over scratch per wave: 8 rows of 256 B
     if (can_stage) {
@@ -1142,8 +1166,8 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
     const int iters = (int)((tiles + GW - 1) / GW);
     const int flush_every = 65535 / (W * 64);
     G.pairq = (SNK_PAIR && NW == 5 && G.rb) ? 1 : 0;
-    if (G.rb) go<NW, FULL, true>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
-    else go<NW, FULL, false>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
+    if (G.rb) go<NW, FULL, true, MAXW>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
+    else go<NW, FULL, false, MAXW>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
     return 1;
 }
 
