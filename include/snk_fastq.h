@@ -71,7 +71,8 @@ typedef struct snk_fastq_format {
  * with clean_start / clean_len from d_rec[i] (this mate's records), appended in input order.
  *   d_out_off[n + 1]  offset of record i's text in d_out (records that are not kept have length 0); d_out_off[n] =
  *                     total bytes
- * d_out must hold the text's upper bound: n_bytes of the input + n * id_suffix_times * strlen(id_suffix). */
+ * d_out must hold the text's upper bound: n_bytes of the input + n * id_suffix_times * strlen(id_suffix) + 1 (the newline a
+ * last line without terminator did not have). */
 int snk_fastq_format_device(const uint8_t *d_text, const uint32_t *d_line, const snk_read_result *d_keep,
                             const snk_read_result *d_rec, int64_t n, const snk_fastq_format *fmt, uint8_t *d_out,
                             uint32_t *d_out_off, void *d_tmp, size_t tmp_bytes, void *stream);

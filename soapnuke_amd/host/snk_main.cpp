@@ -45,6 +45,8 @@
 #include "snk_deflate.h"
 #include "snk_report.h"
 #include "../../include/snk_rmdup.h"
+#include "../../include/snk_fastq.h"
+#include <immintrin.h>
 
 using std::cerr;
 using std::cout;
@@ -550,8 +552,9 @@ struct RawChunk {
         if (!own) { fprintf(stderr, "Error:out of memory\n"); exit(1); }
         own_cap = n;
     }
-    std::vector<uint32_t> ls, le;                      // line start / end (end excludes the line terminator)
+    std::vector<uint32_t> ls, le;                      // line start / end (end excludes the line terminator); empty in count mode
     int n = 0;
+    size_t nbytes = 0;                                 // text of the n records: base[0, nbytes)
     const char *line(int k, int &len) const { len = (int)(le[k] - ls[k]); return base + ls[k]; }
     // chunks are recycled: a fresh 100 MB buffer per batch means 100 MB of page faults per batch (and one mmap lock
     // for all threads of the process)
@@ -566,7 +569,7 @@ struct RawChunk {
     }
     static void put(RawChunk *c) {
         if (!c) return;
-        c->ls.clear(); c->le.clear(); c->n = 0; c->base = nullptr;
+        c->ls.clear(); c->le.clear(); c->n = 0; c->base = nullptr; c->nbytes = 0;
         std::lock_guard<std::mutex> l(pool_mutex());
         if (pool().size() < 16) pool().push_back(c); else delete c;
     }
@@ -593,6 +596,187 @@ void parallel_newlines(const char *p, size_t n, int workers, std::vector<uint32_
     for (auto &v : part) tot += v.size();
     pos.reserve(tot);
     for (auto &v : part) pos.insert(pos.end(), v.begin(), v.end());
+}
+
+// ---- count mode (the device parses the text, SURVEY 8f N2 / include/snk_fastq.h): the readers only have to cut the stream
+// behind every `batch` records, i.e. behind 4 * batch line ends -- newlines are counted (SIMD compare + popcount), not indexed
+__attribute__((target("avx2"))) size_t count_nl_avx2(const char *p, size_t n) {
+    const __m256i nl = _mm256_set1_epi8('\n');
+    size_t c = 0, i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const unsigned a = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i)), nl));
+        const unsigned b = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i + 32)), nl));
+        const unsigned d = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i + 64)), nl));
+        const unsigned e = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i + 96)), nl));
+        c += (size_t)__builtin_popcountll((unsigned long long)a | ((unsigned long long)b << 32)) + (size_t)__builtin_popcountll((unsigned long long)d | ((unsigned long long)e << 32));
+    }
+    for (; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
+size_t count_nl(const char *p, size_t n) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return count_nl_avx2(p, n);
+    size_t c = 0;
+    const __m128i nl = _mm_set1_epi8('\n');
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) c += (size_t)__builtin_popcount((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i)), nl)));
+    for (; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
+// offset just behind the k-th '\n' (k >= 1) of p[0, n); n when there are fewer
+size_t after_kth_nl(const char *p, size_t n, size_t k) {
+    const char *a = p, *e = p + n;
+    while (k && a < e && (a = (const char *)memchr(a, '\n', (size_t)(e - a)))) { ++a; --k; }
+    return (k || !a) ? n : (size_t)(a - p);
+}
+struct NlPiece { size_t begin, end, count; };           // offsets relative to the chunk's data
+// newline counts of p[from, to) in pieces of 1 MB, appended to `pieces`; returns their sum
+size_t count_pieces(const char *p, size_t from, size_t to, int workers, std::vector<NlPiece> &pieces) {
+    const size_t step = (size_t)1 << 20, at = pieces.size();
+    for (size_t a = from; a < to; a += step) pieces.push_back(NlPiece{a, std::min(to, a + step), 0});
+    const int k = (int)(pieces.size() - at);
+    parallel_for(workers, k, [&](int, int lo, int hi) {
+        for (int w = lo; w < hi; ++w) { NlPiece &q = pieces[at + (size_t)w]; q.count = count_nl(p + q.begin, q.end - q.begin); }
+    });
+    size_t tot = 0;
+    for (size_t w = at; w < pieces.size(); ++w) tot += pieces[w].count;
+    return tot;
+}
+// offset behind the `want`-th newline, given the piece counts (their sum is >= want)
+size_t locate_nl(const char *p, const std::vector<NlPiece> &pieces, size_t want) {
+    size_t cum = 0;
+    for (const NlPiece &q : pieces) {
+        if (cum + q.count >= want) return q.begin + after_kth_nl(p + q.begin, q.end - q.begin, want - cum);
+        cum += q.count;
+    }
+    return pieces.empty() ? 0 : pieces.back().end;
+}
+// line index of a count-mode chunk, built on the host when somebody needs it (the first batch: read lengths and the
+// quality-system check)
+void index_chunk(RawChunk *c, int space_num, int workers) {
+    if (!c->ls.empty() || c->n == 0) return;
+    std::vector<uint32_t> nlpos;
+    parallel_newlines(c->base, c->nbytes, workers, nlpos);
+    c->ls.reserve((size_t)c->n * 4);
+    c->le.reserve((size_t)c->n * 4);
+    size_t start = 0;
+    for (uint32_t nl : nlpos) {
+        const size_t e_incl = (size_t)nl + 1;
+        c->ls.push_back((uint32_t)start);
+        c->le.push_back((uint32_t)(e_incl > start + (size_t)space_num ? e_incl - (size_t)space_num : start));
+        start = e_incl;
+    }
+    if (start < c->nbytes) { c->ls.push_back((uint32_t)start); c->le.push_back((uint32_t)c->nbytes); }    // last line without '\n'
+    if (c->ls.size() != (size_t)c->n * 4) die("truncated fastq record");
+}
+
+void reader_gz_count(const string path, int batch, int workers, Channel<RawChunk *> *out) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) die("cannot open file," + path);
+    struct stat st;
+    fstat(fd, &st);
+    const uint8_t *zin = (const uint8_t *)mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (zin == MAP_FAILED) die("cannot map file," + path);
+    madvise((void *)zin, (size_t)st.st_size, MADV_SEQUENTIAL);
+    size_t pg_chunk = (size_t)2 << 20;
+    if (const char *e = getenv("SNK_GZ_CHUNK")) { const long v = atol(e); if (v >= 65536) pg_chunk = (size_t)v; }
+    snk::ParallelGunzip z(zin, (size_t)st.st_size, workers, pg_chunk);
+    const size_t H = snk::GzipInflate::HIST, block = (size_t)1 << 24;
+    RawChunk *cur = RawChunk::get();
+    const size_t cap0 = H + (size_t)batch * 400 + 2 * block;
+    cur->reserve(cap0);
+    memset(cur->own, 0, H);
+    size_t fill = 0, counted = 0, nl_total = 0;
+    const size_t want = (size_t)batch * 4;
+    std::vector<NlPiece> pieces;
+    bool eof = false;
+    for (;;) {
+        char *data = cur->own + H;
+        if (counted < fill && nl_total < want) {
+            Tick t_(1);
+            nl_total += count_pieces(data, counted, fill, workers, pieces);
+            counted = fill;
+        }
+        if (nl_total >= want) {                          // a full batch: hand it over, keep the unread tail + window
+            const size_t end_off = locate_nl(data, pieces, want);
+            RawChunk *next = RawChunk::get();
+            next->reserve(std::max(cur->own_cap, cap0));
+            const size_t left = fill - end_off;
+            memcpy(next->own, data + end_off - H, H + left);
+            cur->n = batch;
+            cur->base = data;
+            cur->nbytes = end_off;
+            { Tick t_(2); out->push(cur); }
+            cur = next;
+            fill = left;
+            counted = 0;
+            nl_total = 0;
+            pieces.clear();
+            continue;
+        }
+        if (eof) {
+            const size_t lines = nl_total + ((fill > 0 && data[fill - 1] != '\n') ? 1 : 0);
+            if (lines % 4) die("truncated fastq record");
+            cur->n = (int)(lines / 4);
+            cur->base = data;
+            cur->nbytes = fill;
+            if (cur->n) out->push(cur); else RawChunk::put(cur);
+            break;
+        }
+        if (H + fill + block > cur->own_cap) { cur->reserve(cur->own_cap * 2); data = cur->own + H; }
+        size_t got;
+        { Tick t_(0); got = z.run((uint8_t *)data + fill, block); }
+        if (z.error()) die(string("read error in input fastq (") + z.error() + ")," + path);
+        if (got == 0 && z.done()) eof = true;
+        fill += got;
+        if (fill > 0xF0000000ull) die("batch larger than 4 GB: lower the batch size");
+    }
+    munmap((void *)zin, (size_t)st.st_size);
+    close(fd);
+    out->close();
+}
+
+void reader_plain_count(const string path, int batch, int workers, Channel<RawChunk *> *out) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) die("cannot open file," + path);
+    struct stat st;
+    fstat(fd, &st);
+    const size_t size = (size_t)st.st_size;
+    const char *base = (const char *)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (base == MAP_FAILED) die("cannot map file," + path);
+    madvise((void *)base, size, MADV_SEQUENTIAL);
+    const size_t want = (size_t)batch * 4;
+    size_t pos = 0;
+    double per_line = 100.0;
+    std::vector<NlPiece> pieces;
+    while (pos < size) {
+        pieces.clear();
+        const char *p = base + pos;
+        size_t win = 0, total = 0;                        // window [pos, pos + win) counted so far
+        while (total < want && pos + win < size) {
+            const size_t need = want - total;
+            const size_t ext = std::min(size - pos, win + (size_t)(per_line * 1.02 * (double)need) + 65536);
+            if (ext > 0xF0000000ull) die("batch larger than 4 GB: lower the batch size");
+            { Tick t_(1); total += count_pieces(p, win, ext, workers, pieces); }
+            win = ext;
+            if (total) per_line = (double)win / (double)total;
+        }
+        RawChunk *c = RawChunk::get();
+        c->base = p;
+        if (total >= want) {
+            c->nbytes = locate_nl(p, pieces, want);
+            c->n = batch;
+        } else {                                         // end of file (the last line may lack its '\n')
+            const size_t lines = total + ((win > 0 && p[win - 1] != '\n') ? 1 : 0);
+            if (lines % 4) die("truncated fastq record");
+            c->nbytes = win;
+            c->n = (int)(lines / 4);
+        }
+        pos += c->nbytes;
+        if (c->n) { Tick t_(2); out->push(c); } else { RawChunk::put(c); break; }
+    }
+    out->close();                                        // the mapping stays until exit: chunks point into it
+    close(fd);
 }
 
 void reader_gz(const string path, int batch, int space_num, int workers, Channel<RawChunk *> *out) {
@@ -755,11 +939,11 @@ bool is_gzip_file(const string &path) {
     return n == 2 && m[0] == 0x1f && m[1] == 0x8b;
 }
 
-void reader_main(const string path, int batch, int space_num, int workers, Channel<RawChunk *> *out) {
+void reader_main(const string path, int batch, int space_num, int workers, bool index, Channel<RawChunk *> *out) {
     struct stat st;
     if (stat(path.c_str(), &st) != 0 || st.st_size == 0) die("cannot open file or empty file," + path);
-    if (is_gzip_file(path)) reader_gz(path, batch, space_num, workers, out);
-    else reader_plain(path, batch, space_num, workers, out);
+    if (is_gzip_file(path)) { if (index) reader_gz(path, batch, space_num, workers, out); else reader_gz_count(path, batch, workers, out); }
+    else { if (index) reader_plain(path, batch, space_num, workers, out); else reader_plain_count(path, batch, workers, out); }
 }
 
 int first_line_space_num(const string &path) {          // src/peprocess.cpp:2066-2077
@@ -780,13 +964,14 @@ int first_line_space_num(const string &path) {          // src/peprocess.cpp:206
 // one gzip member of `in`, appended to `out`.  The reference writes level-2 zlib streams (src/peprocess.cpp:1809); the
 // compressed bytes are not part of the contract, so the members come from this repo's own encoder (snk_deflate.h: the
 // same ratio on FASTQ at about twice the speed), or from zlib level 2 with SNK_ZLIB_OUT=1.
-void gzip_member(const string &in, string &out) {
+void gzip_member(const char *in_p, size_t in_n, string &out) {
     static const bool use_zlib = getenv("SNK_ZLIB_OUT") != nullptr;
     if (!use_zlib) {
         thread_local snk::FastDeflate enc;
-        enc.gzip_member(reinterpret_cast<const uint8_t *>(in.data()), in.size(), out, true);     // (every text this CLI compresses is FASTQ records)
+        enc.gzip_member(reinterpret_cast<const uint8_t *>(in_p), in_n, out, true);     // (every text this CLI compresses is FASTQ records)
         return;
     }
+    const string in(in_p, in_n);
     z_stream z;
     memset(&z, 0, sizeof z);
     if (deflateInit2(&z, 2, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("deflateInit2 failed");
@@ -801,6 +986,7 @@ void gzip_member(const string &in, string &out) {
     out.resize(at + (bound - z.avail_out));
     deflateEnd(&z);
 }
+void gzip_member(const string &in, string &out) { gzip_member(in.data(), in.size(), out); }
 
 struct OutFile {                                        // clean / dup output: bytes are produced by the workers
     int fd = -1;
@@ -923,6 +1109,14 @@ struct Slot {                                           // one batch in flight
     RawChunk *raw[2] = {nullptr, nullptr};
     int n = 0, dev = 0, lcap = 0;                        // records; index into the device list; capacity it was packed with
     uint64_t first = 0;
+    // device-text mode (include/snk_fastq.h): the batch's raw text travels, the device parses and formats.  h_text doubles
+    // as the landing buffer of the clean text (the upload is long done by then, and the clean text is never larger)
+    uint8_t *h_text[2] = {nullptr, nullptr}, *d_text[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
+    uint32_t *d_line[2] = {nullptr, nullptr}, *d_outoff[2] = {nullptr, nullptr}, *h_outoff[2] = {nullptr, nullptr};
+    uint32_t *d_status[2] = {nullptr, nullptr}, *h_status[2] = {nullptr, nullptr};
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0, nbytes[2] = {0, 0};
+    hipEvent_t parsed = nullptr;
 };
 
 // One-shot sanity check of the quality system on the first patch of fq1 (stat_pe_fqs / stat_se_fqs run it once,
@@ -1042,13 +1236,19 @@ int main(int argc, char **argv) {
         bc_to = b[1];
     }
 
+    // Device-text mode (include/snk_fastq.h): the raw text of a batch is uploaded as it is, the device builds the
+    // line index, fills the SoA planes and, behind the filter kernels, gathers the clean text; the host only reads, counts
+    // newlines, (de)compresses and writes.  The output variants that need per-record work on the names or several outputs
+    // per read keep the host formatter (same bytes either way; SNK_HOST_TEXT=1 forces it).
+    const bool dev_text = !getenv("SNK_HOST_TEXT") && !o.streaming && !o.p.rmdup && o.trim_fq[0].empty() && o.clean_out_split == 0 &&
+                          !(o.total_reads > 0) && o.out_file_type != "fasta" && !o.index_remove && o.tile.empty() && o.fov.empty();
     // ---- readers
     std::unique_ptr<Channel<RawChunk *>> chan[2];          // one per input file, re-made for every pass over the input
     std::vector<std::thread> readers;
     auto start_readers = [&] {
         for (int m = 0; m < mates; ++m) {
             chan[m].reset(new Channel<RawChunk *>(2));
-            readers.emplace_back(reader_main, inputs[m], B, space_num, std::max(1, WK / mates), chan[m].get());
+            readers.emplace_back(reader_main, inputs[m], B, space_num, std::max(1, WK / mates), !dev_text, chan[m].get());
         }
     };
     auto join_readers = [&] { for (auto &t : readers) t.join(); readers.clear(); };
@@ -1064,6 +1264,7 @@ int main(int argc, char **argv) {
     start_readers();
     RawChunk *first[2];
     if (!next_chunks(first)) die("no data");
+    if (dev_text) for (int m = 0; m < mates; ++m) index_chunk(first[m], space_num, WK);      // read lengths + quality-system check of the first batch
     auto longest = [&](RawChunk *const c[2]) {
         int mx = 1;
         for (int m = 0; m < mates; ++m)
@@ -1075,7 +1276,7 @@ int main(int argc, char **argv) {
     // one context + one set of batch slots per device; one accumulator per virtual reference thread
     //  and device.  A run is a sequence of epochs of constant capacity (normally one).
     const int G = (int)o.devices.size();
-    const int NSLOT = 3;
+    const int NSLOT = dev_text ? 4 : 3;                   // (device-text mode: the main thread holds one staged batch back until its parse verdict is in)
     const int64_t vblock = snk_vthread_block(T, o.patch_size);
     struct Dev {
         int id = 0;
@@ -1090,6 +1291,7 @@ int main(int argc, char **argv) {
     int64_t nsum = 0;
     int pitch = 0;
     size_t plane = 0;
+    size_t text_cap = 0;                                  // device-text mode: bytes of one mate's text per batch the slots can take
     struct Epoch { int lcap; std::vector<std::vector<uint64_t>> sums, maxs; };
     std::vector<Epoch> epochs;
 
@@ -1116,11 +1318,23 @@ int main(int argc, char **argv) {
             for (Slot &sl : d.slots) {
                 sl.dev = (int)(&d - devs.data());
                 for (int m = 0; m < mates; ++m) {
-                    HIPCHK(hipHostMalloc(&sl.h_seq[m], plane)); HIPCHK(hipHostMalloc(&sl.h_qual[m], plane));
-                    HIPCHK(hipHostMalloc(&sl.h_len[m], (size_t)B * 2)); HIPCHK(hipHostMalloc(&sl.h_rec[m], (size_t)B * sizeof(snk_read_result)));
                     HIPCHK(hipMalloc(&sl.d_seq[m], plane)); HIPCHK(hipMalloc(&sl.d_qual[m], plane));
                     HIPCHK(hipMalloc(&sl.d_len[m], (size_t)B * 2)); HIPCHK(hipMalloc(&sl.d_rec[m], (size_t)B * sizeof(snk_read_result)));
+                    if (dev_text) {
+                        HIPCHK(hipHostMalloc(&sl.h_text[m], text_cap + 64)); HIPCHK(hipMalloc(&sl.d_text[m], text_cap + 64)); HIPCHK(hipMalloc(&sl.d_out[m], text_cap + 64));
+                        HIPCHK(hipMalloc(&sl.d_line[m], ((size_t)B * 4 + 1) * 4)); HIPCHK(hipMalloc(&sl.d_outoff[m], ((size_t)B + 1) * 4));
+                        HIPCHK(hipHostMalloc(&sl.h_outoff[m], ((size_t)B + 1) * 4));
+                        HIPCHK(hipMalloc(&sl.d_status[m], SNK_FQ_STATUS_N * 4)); HIPCHK(hipHostMalloc(&sl.h_status[m], SNK_FQ_STATUS_N * 4));
+                        continue;
+                    }
+                    HIPCHK(hipHostMalloc(&sl.h_seq[m], plane)); HIPCHK(hipHostMalloc(&sl.h_qual[m], plane));
+                    HIPCHK(hipHostMalloc(&sl.h_len[m], (size_t)B * 2)); HIPCHK(hipHostMalloc(&sl.h_rec[m], (size_t)B * sizeof(snk_read_result)));
                     memset(sl.h_seq[m], 0, plane); memset(sl.h_qual[m], 0, plane);
+                }
+                if (dev_text) {
+                    sl.tmp_bytes = snk_fastq_tmp_bytes(text_cap, B);
+                    HIPCHK(hipMalloc(&sl.d_tmp, sl.tmp_bytes));
+                    HIPCHK(hipEventCreateWithFlags(&sl.parsed, hipEventDisableTiming));
                 }
                 HIPCHK(hipHostMalloc(&sl.h_flags, (size_t)B)); HIPCHK(hipMalloc(&sl.d_flags, (size_t)B));
                 HIPCHK(hipHostMalloc(&sl.h_err, sizeof(uint64_t)));
@@ -1136,9 +1350,15 @@ int main(int argc, char **argv) {
             HIPCHK(hipDeviceSynchronize());
             for (Slot &sl : d.slots) {
                 for (int m = 0; m < mates; ++m) {
-                    HIPCHK(hipHostFree(sl.h_seq[m])); HIPCHK(hipHostFree(sl.h_qual[m])); HIPCHK(hipHostFree(sl.h_len[m])); HIPCHK(hipHostFree(sl.h_rec[m]));
                     HIPCHK(hipFree(sl.d_seq[m])); HIPCHK(hipFree(sl.d_qual[m])); HIPCHK(hipFree(sl.d_len[m])); HIPCHK(hipFree(sl.d_rec[m]));
+                    if (dev_text) {
+                        HIPCHK(hipHostFree(sl.h_text[m])); HIPCHK(hipFree(sl.d_text[m])); HIPCHK(hipFree(sl.d_out[m])); HIPCHK(hipFree(sl.d_line[m]));
+                        HIPCHK(hipFree(sl.d_outoff[m])); HIPCHK(hipHostFree(sl.h_outoff[m])); HIPCHK(hipFree(sl.d_status[m])); HIPCHK(hipHostFree(sl.h_status[m]));
+                        continue;
+                    }
+                    HIPCHK(hipHostFree(sl.h_seq[m])); HIPCHK(hipHostFree(sl.h_qual[m])); HIPCHK(hipHostFree(sl.h_len[m])); HIPCHK(hipHostFree(sl.h_rec[m]));
                 }
+                if (dev_text) { HIPCHK(hipFree(sl.d_tmp)); HIPCHK(hipEventDestroy(sl.parsed)); }
                 HIPCHK(hipHostFree(sl.h_flags)); HIPCHK(hipFree(sl.d_flags)); HIPCHK(hipHostFree(sl.h_err));
                 HIPCHK(hipStreamDestroy(sl.stream));
                 HIPCHK(hipEventDestroy(sl.done));
@@ -1184,6 +1404,13 @@ int main(int argc, char **argv) {
         }
         epochs.push_back(std::move(e));
     };
+    auto text_cap_for = [&](RawChunk *const c[2]) {      // room for a batch of this kind of records, with some slack for longer names
+        size_t mx = 0;
+        for (int m = 0; m < mates; ++m) mx = std::max(mx, c[m]->n ? c[m]->nbytes / (size_t)c[m]->n : 0);
+        const int recs = c[0]->n < B ? c[0]->n : B;         // a short first batch is the whole input
+        return (size_t)((double)(mx + 8) * 1.15 * (double)recs) + ((size_t)4 << 20);
+    };
+    if (dev_text) text_cap = text_cap_for(first);
     setup(o.streaming ? std::max(longest(first), 256) : longest(first));   // -j: the first batch is one small patch, a poor sample of the read lengths
 
     // records -> pinned planes (parallel over records); false: a read is longer than the capacity
@@ -1327,7 +1554,57 @@ int main(int argc, char **argv) {
     const int dq = o.p.output_quality_phred - o.p.quality_phred;
     const bool fasta = o.out_file_type == "fasta";
     uint64_t ndup_written = 0;
-    std::thread writer([&] {
+    // device-text mode: the clean text of a batch arrives whole (h_text, record offsets in h_outoff); plain output is written
+    // as it is, .gz output is cut at record boundaries into one gzip member per worker
+    auto writer_dev = [&] {
+        Slot *sp;
+        std::vector<string> zbuf[2];
+        for (;;) {
+            { Tick t_(7); if (!to_write.pop(sp)) break; }
+            Slot &s = *sp;
+            { Tick t_(8); HIPCHK(hipEventSynchronize(s.done)); }
+            if (*s.h_err != SNK_ERR_WORD_NONE) {
+                snk_error err;
+                snk_error_decode(*s.h_err, &err);
+                report_device_error(err);
+            }
+            const int n = s.n;
+            if (o.out_gz) {
+                const long long t_fmt0 = g_clk.on ? StageClock::now() : 0;
+                for (int m = 0; m < mates; ++m) { zbuf[m].resize(WK); for (int w = 0; w < WK; ++w) zbuf[m][w].clear(); }
+                parallel_for(WK, mates * WK, [&](int, int lo, int hi) {
+                    for (int k = lo; k < hi; ++k) {
+                        const int m = k / WK, w = k % WK;
+                        const uint32_t a = s.h_outoff[m][(size_t)((long)n * w / WK)], b = s.h_outoff[m][(size_t)((long)n * (w + 1) / WK)];
+                        if (b > a) gzip_member((const char *)s.h_text[m] + a, (size_t)(b - a), zbuf[m][w]);
+                    }
+                });
+                if (g_clk.on) g_clk.ns[9] += StageClock::now() - t_fmt0;
+                Tick t_write_(10);
+                for (int m = 0; m < mates; ++m) wr[m].write_parts(zbuf[m]);
+            } else {
+                Tick t_write_(10);
+                // both files at once, a few writers each (page allocation of one file does not scale past a few threads)
+                struct Piece { int fd; const char *p; size_t n; off_t at; };
+                std::vector<Piece> pieces;
+                for (int m = 0; m < mates; ++m) {
+                    const size_t tot = s.h_outoff[m][n];
+                    const int np = tot < ((size_t)8 << 20) ? 1 : 6;
+                    for (int k = 0; k < np; ++k) {
+                        const size_t a = tot * (size_t)k / (size_t)np, b = tot * (size_t)(k + 1) / (size_t)np;
+                        if (b > a) pieces.push_back(Piece{wr[m].fd, (const char *)s.h_text[m] + a, b - a, wr[m].pos + (off_t)a});
+                    }
+                    wr[m].pos += (off_t)tot;
+                }
+                parallel_for((int)pieces.size(), (int)pieces.size(), [&](int, int lo, int hi) {
+                    for (int k = lo; k < hi; ++k) OutFile::put_at(pieces[(size_t)k].fd, pieces[(size_t)k].p, pieces[(size_t)k].n, pieces[(size_t)k].at);
+                });
+            }
+            log << local_time() << " processed_reads:\t" << s.first + (uint64_t)n << endl;
+            devs[(size_t)s.dev].free_slots->push(sp);
+        }
+    };
+    std::thread writer = dev_text ? std::thread(writer_dev) : std::thread([&] {
         Slot *sp;
         std::vector<string> text[2], zbuf[2], ttext[2], tzbuf[2];
         std::vector<std::vector<uint32_t>> recoff[2];          // cut_mode: start of every kept record in text[m][w]
@@ -1497,7 +1774,159 @@ int main(int argc, char **argv) {
     uint64_t total = 0, batch_no = 0;
     RawChunk *c[2] = {first[0], first[1]};
     bool have = true;
-    while (have) {
+    if (dev_text) {
+        snk_fastq_format fmt[2];
+        for (int m = 0; m < 2; ++m) {
+            memset(&fmt[m], 0, sizeof fmt[m]);
+            fmt[m].struct_size = (int32_t)sizeof(snk_fastq_format);
+            fmt[m].space_num = space_num;
+            fmt[m].qual_delta = dq;
+            fmt[m].id_suffix_times = (o.pe_info && mates == 2) ? 1 : 0;
+            fmt[m].id_suffix[0] = '/'; fmt[m].id_suffix[1] = m == 0 ? '1' : '2';
+            fmt[m].base_from = (uint8_t)bc_from; fmt[m].base_to = (uint8_t)bc_to;
+        }
+        // raw text -> pinned -> device; line index + SoA planes by the device (asynchronous; s.parsed marks the end)
+        auto stage = [&](Slot &s, RawChunk *const ch[2]) {
+            s.n = ch[0]->n;
+            s.lcap = lcap;
+            {
+                Tick t_(5);
+                const size_t step = (size_t)4 << 20;
+                struct Cp { uint8_t *d; const char *p; size_t n; };
+                std::vector<Cp> cps;
+                for (int m = 0; m < mates; ++m) {
+                    s.nbytes[m] = ch[m]->nbytes;
+                    for (size_t a = 0; a < ch[m]->nbytes; a += step) cps.push_back(Cp{s.h_text[m] + a, ch[m]->base + a, std::min(step, ch[m]->nbytes - a)});
+                }
+                parallel_for(WK, (int)cps.size(), [&](int, int lo, int hi) { for (int k = lo; k < hi; ++k) memcpy(cps[(size_t)k].d, cps[(size_t)k].p, cps[(size_t)k].n); });
+            }
+            for (int m = 0; m < mates; ++m) {
+                HIPCHK(hipMemcpyAsync(s.d_text[m], s.h_text[m], s.nbytes[m], hipMemcpyHostToDevice, s.stream));
+                if (snk_fastq_parse_device(s.d_text[m], s.nbytes[m], s.n, space_num, pitch, lcap, s.d_seq[m], s.d_qual[m], s.d_len[m], s.d_line[m],
+                                           s.d_status[m], s.d_tmp, s.tmp_bytes, s.stream) != SNK_OK) die(snk_last_error());
+                HIPCHK(hipMemcpyAsync(s.h_status[m], s.d_status[m], SNK_FQ_STATUS_N * 4, hipMemcpyDeviceToHost, s.stream));
+            }
+            HIPCHK(hipEventRecord(s.parsed, s.stream));
+        };
+        // parse verdicts, then filter kernels, clean text, copies back; 0 = submitted, else the length of a read longer than the capacity
+        auto submit = [&](Slot &s) -> int {
+            Dev &dv = devs[(size_t)s.dev];
+            HIPCHK(hipSetDevice(dv.id));
+            { Tick t_(6); HIPCHK(hipEventSynchronize(s.parsed)); }
+            int too_long = 0;
+            for (int m = 0; m < mates; ++m) {
+                const uint32_t fl = s.h_status[m][SNK_FQ_ST_FLAGS];
+                if (fl & SNK_FQ_F_TRUNCATED) die("truncated fastq record");
+                if (fl & SNK_FQ_F_TOO_LONG) too_long = std::max<int>(too_long, (int)s.h_status[m][SNK_FQ_ST_MAXLEN]);
+                else if (fl & SNK_FQ_F_LEN_MISMATCH) die("sequence and quality lengths differ");
+            }
+            if (too_long) return too_long;
+            const int n = s.n;
+            for (int lo = 0; lo < n;) {                      // split at virtual-thread block boundaries (appendix C)
+                const uint64_t g = s.first + (uint64_t)lo;
+                const int vt = (int)((g / (uint64_t)vblock) % (uint64_t)T);
+                const uint64_t next = (g / (uint64_t)vblock + 1) * (uint64_t)vblock;
+                const int hi = (int)std::min<uint64_t>((uint64_t)n, next - s.first);
+                snk_batch b;
+                memset(&b, 0, sizeof b);
+                b.n = hi - lo;
+                b.pitch = pitch;
+                for (int m = 0; m < mates; ++m) {
+                    b.seq[m] = s.d_seq[m] + (size_t)lo * pitch;
+                    b.qual[m] = s.d_qual[m] + (size_t)lo * pitch;
+                    b.len[m] = s.d_len[m] + lo;
+                }
+                b.first_index = g;
+                if (snk_bind_stats(dv.ctx, dv.d_sum[(size_t)vt], dv.d_max[(size_t)vt]) != SNK_OK) die(snk_last_error());
+                if (snk_filter_batch_device(dv.ctx, &b, s.d_rec[0] + lo, mates == 2 ? s.d_rec[1] + lo : nullptr, s.stream, 0) != SNK_OK)
+                    die(snk_last_error());
+                lo = hi;
+            }
+            for (int m = 0; m < mates; ++m) {
+                if (snk_fastq_format_device(s.d_text[m], s.d_line[m], s.d_rec[0], s.d_rec[m], n, &fmt[m], s.d_out[m], s.d_outoff[m], s.d_tmp, s.tmp_bytes,
+                                            s.stream) != SNK_OK) die(snk_last_error());
+                HIPCHK(hipMemcpyAsync(s.h_outoff[m], s.d_outoff[m], ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, s.stream));
+                // the clean text is at most the input text (+ the pe_info suffixes): that much is copied, its real size is h_outoff[n]
+                const size_t bound = std::min(text_cap + 64, s.nbytes[m] + (size_t)n * 2 * (size_t)fmt[m].id_suffix_times + 1);   // (+ 1: the newline a ragged last line did not have)
+                HIPCHK(hipMemcpyAsync(s.h_text[m], s.d_out[m], bound, hipMemcpyDeviceToHost, s.stream));
+            }
+            if (snk_error_peek_async(dv.ctx, s.h_err, s.stream) != SNK_OK) die(snk_last_error());
+            HIPCHK(hipEventRecord(s.done, s.stream));
+            to_write.push(&s);
+            return 0;
+        };
+        struct Held { Slot *sp = nullptr; RawChunk *raw[2] = {nullptr, nullptr}; uint64_t first = 0; };
+        Held pend;                                            // staged, its parse verdict not looked at yet
+        auto drain_all = [&] { for (Dev &d : devs) { Slot *t_[8]; for (int k = 0; k < NSLOT; ++k) d.free_slots->pop(t_[k]); for (int k = 0; k < NSLOT; ++k) d.free_slots->push(t_[k]); } };
+        auto take_slot = [&](uint64_t no) -> Slot * {
+            Dev &dv = devs[(size_t)(no % (uint64_t)G)];
+            HIPCHK(hipSetDevice(dv.id));
+            Slot *sp;
+            { Tick t_(4); dv.free_slots->pop(sp); }
+            return sp;
+        };
+        // a batch whose text does not fit the slots, or a read longer than the capacity: everything in flight is finished, the
+        // epoch closed (capacity), buffers rebuilt, and the held batches run again
+        auto rebuild = [&](int new_lcap, size_t new_text_cap, std::vector<Held> &again) {
+            for (Held &h : again) if (h.sp) { devs[(size_t)h.sp->dev].free_slots->push(h.sp); h.sp = nullptr; }
+            drain_all();
+            collect_epoch();                                  // (teardown drops the accumulators: whatever was counted so far becomes an epoch)
+            teardown();
+            text_cap = std::max(text_cap, new_text_cap);
+            setup(std::max<int>(lcap, new_lcap));
+        };
+        auto run_sync = [&](Held &h, uint64_t no) {           // stage + submit one held batch, growing the capacity as often as it takes
+            for (;;) {
+                Slot *sp = take_slot(no);
+                sp->first = h.first;
+                stage(*sp, h.raw);
+                const int tl = submit(*sp);
+                if (!tl) break;
+                std::vector<Held> one(1);
+                one[0].sp = sp;
+                rebuild(tl, 0, one);
+            }
+            for (int m = 0; m < mates; ++m) RawChunk::put(h.raw[m]);
+            h = Held();
+        };
+        auto finish_pending = [&](Held *staged_behind, uint64_t no_pend) {
+            if (!pend.sp) return;
+            const int tl = submit(*pend.sp);
+            if (!tl) { for (int m = 0; m < mates; ++m) RawChunk::put(pend.raw[m]); pend = Held(); return; }
+            std::vector<Held> again;
+            again.push_back(pend);
+            if (staged_behind && staged_behind->sp) again.push_back(*staged_behind);
+            rebuild(tl, 0, again);
+            pend.sp = nullptr;
+            run_sync(pend, no_pend);
+            if (staged_behind && staged_behind->sp) { staged_behind->sp = nullptr; run_sync(*staged_behind, no_pend + 1); }
+        };
+        while (have) {
+            size_t need = 0;
+            for (int m = 0; m < mates; ++m) need = std::max(need, c[m]->nbytes + (size_t)c[m]->n * 2 + 64);
+            if (need > text_cap) {                            // longer names than the first batch had: larger text buffers
+                finish_pending(nullptr, batch_no - 1);
+                std::vector<Held> none;
+                rebuild(0, need + need / 8, none);
+            }
+            const uint64_t no = batch_no++;
+            Held cur;
+            cur.sp = take_slot(no);
+            cur.raw[0] = c[0]; cur.raw[1] = c[1];
+            cur.first = total;
+            cur.sp->first = total;
+            stage(*cur.sp, cur.raw);
+            total += (uint64_t)c[0]->n;
+            if (pend.sp) {
+                finish_pending(&cur, no - 1);
+                if (!cur.sp && !cur.raw[0]) { { Tick t_(3); have = next_chunks(c); } continue; }     // it ran again behind the rebuilt capacity
+            }
+            pend = cur;
+            { Tick t_(3); have = next_chunks(c); }
+        }
+        finish_pending(nullptr, batch_no - 1);
+    }
+    while (have && !dev_text) {
         Dev &dv = devs[(size_t)(batch_no++ % (uint64_t)G)];   // batches go round the devices; the writer keeps input order
         HIPCHK(hipSetDevice(dv.id));
         Slot *sp;

@@ -542,3 +542,58 @@ def test_cli_phred64_and_max_base_quality(paired, cfg, qmax, tmp_path):
     ref = R.run_reference_cli(case, d, work, gz_input=True)
     ours = _run_ours(case, work, gz=False)
     _compare_dirs(ours, ref, paired)
+
+
+# ---- round 3: device-side FASTQ ingest / egress (include/snk_fastq.h) behind the CLI
+
+@pytest.mark.parametrize("paired,gz,ragged", [(True, False, False), (False, True, False), (True, True, False), (True, False, True), (False, True, True)])
+def test_cli_device_text_growing_names_and_ragged_end(paired, gz, ragged, tmp_path):
+    """device-text mode on awkward text: read names that get much longer after the first batch (the slots' text buffers
+    grow), read lengths that grow (capacity regrowth through the same path) -- against the reference binary, and the host
+    formatter (SNK_HOST_TEXT=1) must write the very same bytes.  ragged: no newline behind the last line; the reference then
+    drops the last quality character of the file with the line terminator it did not find (quality shorter than the
+    sequence: it indexes past the string), both readers here keep it -- compared with each other only."""
+    rng = np.random.default_rng(19)
+    lens = np.concatenate([rng.integers(50, 91, 3000), rng.integers(50, 141, 3000), rng.integers(80, 201, 3000)])
+    n = len(lens)
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    work = str(tmp_path)
+    for m in range(2 if paired else 1):
+        with open(os.path.join(work, f"r{m + 1}.fq"), "wb") as f:
+            for i, l in enumerate(lens):
+                name = b"@SNK:%d:%d" % (i % 9, i) + (b":" + b"x" * (i // 40) if i >= 4000 else b"") + b"/%d" % (m + 1)
+                q = bytes((33 + np.clip(rng.normal(34, 6, l), 2, 41)).astype(np.uint8))
+                rec = name + b"\n" + bytes(B[rng.integers(0, 4, l)]) + b"\n+\n" + q + b"\n"
+                f.write(rec[:-1] if (ragged and i == n - 1) else rec)
+        subprocess.check_call(["gzip", "-1", "-f", "-k", os.path.join(work, f"r{m + 1}.fq")])
+    open(os.path.join(work, "cfg"), "w").write("patch=250\n" + ("pe_info\n" if paired else "") + "outQualSys=1\n")
+    ext = ".gz" if gz else ""
+    tail = ["-C", "c1.fq" + ext] + (["-D", "c2.fq" + ext] if paired else []) + ["-T", "2", "-l", "10", "-q", "0.3", "-c", os.path.join(work, "cfg")]
+    ins = lambda e: ["-1", os.path.join(work, "r1.fq" + e)] + (["-2", os.path.join(work, "r2.fq" + e)] if paired else [])   # noqa: E731
+    r = subprocess.run([T.REF_BIN, "filter"] + ins(".gz") + ["-o", os.path.join(work, "ref")] + tail, capture_output=True)
+    assert r.returncode == 0, r.stderr[-300:]
+    for out, extra in (("ours", {}), ("host", {"SNK_HOST_TEXT": "1"})):
+        env = dict(os.environ, SNK_BATCH_PAIRS="1024", **extra)
+        r = subprocess.run([CLI, "filter"] + ins(ext) + ["-o", os.path.join(work, out)] + tail, capture_output=True, env=env)
+        assert r.returncode == 0, (out, r.stdout[-300:], r.stderr[-500:])
+        other = "ours" if ragged else "ref"
+        if out == other:
+            continue
+        for f in (R.REPORT_FILES_PE if paired else R.REPORT_FILES_SE):
+            assert filecmp.cmp(os.path.join(work, out, f), os.path.join(work, other, f), shallow=False), (out, f)
+        for c in (["c1.fq", "c2.fq"] if paired else ["c1.fq"]):
+            assert _cat(os.path.join(work, out, c + ext)) == _cat(os.path.join(work, other, c + ext)), (out, c)
+
+
+def test_cli_device_text_input_errors(tmp_path):
+    """malformed input in device-text mode: the same messages as the host reader's"""
+    work = str(tmp_path)
+    good = b"".join(b"@r%d\nACGTACGTACGTACGTACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n" % i for i in range(3000))
+    cases = {"mismatch": good.replace(b"@r1500\nACGT", b"@r1500\nACGTAC", 1), "truncated": good[:len(good) - 40] }
+    for name, blob in cases.items():
+        open(os.path.join(work, name + ".fq"), "wb").write(blob)
+        for extra in ({}, {"SNK_HOST_TEXT": "1"}):
+            r = subprocess.run([CLI, "filter", "-1", os.path.join(work, name + ".fq"), "-C", "c.fq", "-o", os.path.join(work, "o_" + name)],
+                               capture_output=True, env=dict(os.environ, SNK_BATCH_PAIRS="512", **extra))
+            assert r.returncode == 1, (name, extra, r.stderr[-200:])
+            assert (b"lengths differ" in r.stderr) if name == "mismatch" else (b"truncated" in r.stderr), (name, extra, r.stderr[-200:])
