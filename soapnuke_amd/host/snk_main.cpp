@@ -80,7 +80,9 @@ struct Options {
 
 [[noreturn]] void die(const string &msg) {          // the reference's convention: message, exit(1)
     cerr << "Error:" << msg << endl;
-    exit(1);
+    cout.flush();
+    fflush(stdout);
+    _exit(1);                                        // (no exit handlers: other threads may be inside the HIP runtime)
 }
 
 bool ends_with_gz(const string &s) { return s.size() >= 3 && s.rfind(".gz") == s.size() - 3; }
@@ -1208,6 +1210,8 @@ bool rccl_allreduce_blocks(const std::vector<int> &devices, const std::function<
 }  // namespace
 
 int main(int argc, char **argv) {
+    const long long t_main0 = StageClock::now();
+    auto since_start = [&](const char *what) { if (g_clk.on) fprintf(stderr, "[timing] t+%.3f s  %s\n", (double)(StageClock::now() - t_main0) * 1e-9, what); };
     if (argc < 2) { usage(); return 1; }
     Options o;
     parse_args(argc, argv, o);
@@ -1264,6 +1268,7 @@ int main(int argc, char **argv) {
     start_readers();
     RawChunk *first[2];
     if (!next_chunks(first)) die("no data");
+    since_start("first batch read");
     if (dev_text) for (int m = 0; m < mates; ++m) index_chunk(first[m], space_num, WK);      // read lengths + quality-system check of the first batch
     auto longest = [&](RawChunk *const c[2]) {
         int mx = 1;
@@ -1295,6 +1300,7 @@ int main(int argc, char **argv) {
     struct Epoch { int lcap; std::vector<std::vector<uint64_t>> sums, maxs; };
     std::vector<Epoch> epochs;
 
+    std::vector<std::thread> slot_makers;
     auto setup = [&](int maxlen) {
         if (maxlen > SNK_READ_MAX_LEN) die("read longer than 1000 bases");
         o.p.max_read_len = maxlen;
@@ -1315,8 +1321,12 @@ int main(int argc, char **argv) {
             }
             d.slots.assign(NSLOT, Slot());
             d.free_slots.reset(new Channel<Slot *>(NSLOT + 1));
-            for (Slot &sl : d.slots) {
-                sl.dev = (int)(&d - devs.data());
+            // the first slot now, the others behind the scenes while the first batches run (pinning a few hundred MB per slot
+            // is most of the start-up time of a short run)
+            auto alloc_slot = [&, dp = &d](Slot &sl) {
+                Dev &d = *dp;
+                HIPCHK(hipSetDevice(d.id));
+                sl.dev = (int)(dp - devs.data());
                 for (int m = 0; m < mates; ++m) {
                     HIPCHK(hipMalloc(&sl.d_seq[m], plane)); HIPCHK(hipMalloc(&sl.d_qual[m], plane));
                     HIPCHK(hipMalloc(&sl.d_len[m], (size_t)B * 2)); HIPCHK(hipMalloc(&sl.d_rec[m], (size_t)B * sizeof(snk_read_result)));
@@ -1341,10 +1351,14 @@ int main(int argc, char **argv) {
                 HIPCHK(hipStreamCreate(&sl.stream));
                 HIPCHK(hipEventCreate(&sl.done));
                 d.free_slots->push(&sl);
-            }
+            };
+            alloc_slot(d.slots[0]);
+            slot_makers.emplace_back([&, dp = &d, alloc_slot] { for (int k = 1; k < NSLOT; ++k) alloc_slot(dp->slots[(size_t)k]); });
         }
     };
     auto teardown = [&] {
+        for (auto &t : slot_makers) t.join();
+        slot_makers.clear();
         for (Dev &d : devs) {
             HIPCHK(hipSetDevice(d.id));
             HIPCHK(hipDeviceSynchronize());
@@ -1411,7 +1425,9 @@ int main(int argc, char **argv) {
         return (size_t)((double)(mx + 8) * 1.15 * (double)recs) + ((size_t)4 << 20);
     };
     if (dev_text) text_cap = text_cap_for(first);
+    since_start("first batch indexed");
     setup(o.streaming ? std::max(longest(first), 256) : longest(first));   // -j: the first batch is one small patch, a poor sample of the read lengths
+    since_start("contexts and slots ready");
 
     // records -> pinned planes (parallel over records); false: a read is longer than the capacity
     auto pack = [&](Slot &s, bool with_qual) -> bool {
@@ -1519,6 +1535,8 @@ int main(int argc, char **argv) {
             dupw[m].resize(T);
             for (int t = 0; t < T; ++t) dupw[m][t].open(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz", true);
         }
+        for (auto &t : slot_makers) t.join();
+        slot_makers.clear();
         for (Dev &d : devs) for (Slot &sl : d.slots) for (int m = 0; m < mates; ++m) memset(sl.h_seq[m], 0, plane);
         for (Dev &d : devs) for (Slot &sl : d.slots) { sl.raw[0] = sl.raw[1] = nullptr; }
         // second pass over the input
@@ -2015,8 +2033,10 @@ int main(int argc, char **argv) {
         total += (uint64_t)n;
         { Tick t_(3); have = next_chunks(c); }
     }
+    since_start("last batch submitted");
     to_write.close();
     writer.join();
+    since_start("writer done");
     join_readers();
     for (int m = 0; m < mates; ++m) wr[m].close();
     if (trim_out) for (int m = 0; m < mates; ++m) trimw[m].close();
@@ -2057,9 +2077,18 @@ int main(int argc, char **argv) {
     if (o.total_reads > 0 && !o.total_head) extract_every_kth(o, mates, clean_total);
     char ebuf[512];
     o.p.max_read_len = lfin;
-    if (snk_write_reports(&o.p, T, sp.data(), mp.data(), o.out_dir.c_str(), ebuf, sizeof ebuf) != 0) { cerr << ebuf << endl; return 1; }
+    if (snk_write_reports(&o.p, T, sp.data(), mp.data(), o.out_dir.c_str(), ebuf, sizeof ebuf) != 0) { cerr << ebuf << endl; cout.flush(); fflush(stdout); _exit(1); }
     log << local_time() << "\tAnalysis accomplished!" << endl;
+    since_start("reports written");
     g_clk.report();
-    teardown();
-    return 0;
+    // everything is on disk: the process image goes away as a whole (unpinning and freeing a GB buffer by buffer, then the
+    // runtime's own exit handlers, is a tenth of a second of a short run)
+    for (auto &t : slot_makers) t.join();
+    log.flush();
+    log.close();
+    cout.flush();
+    cerr.flush();
+    fflush(stdout);
+    fflush(stderr);
+    _exit(0);
 }
