@@ -1179,18 +1179,20 @@ void widen_add(const uint64_t *src, int ls, uint64_t *dst, int ld, int nq) {
 bool rccl_allreduce_blocks(const std::vector<int> &devices, const std::function<snk_ctx *(int, int)> &ctx_of, int T) {
     const int G = (int)devices.size();
     for (int a = 0; a < G; ++a) for (int b = a + 1; b < G; ++b) if (devices[(size_t)a] == devices[(size_t)b]) return false;
+    // any failure in here is a warning: the caller holds host copies of every block and adds them up itself
+    auto give_up = [](const string &why) { cerr << "Warning:stats all-reduce over RCCL unavailable (" << why << "), merging on the host" << endl; return false; };
     void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) die(string("cannot load RCCL: ") + dlerror());
+    if (!h) return give_up(string("cannot load RCCL: ") + dlerror());
     typedef int (*init_all_fn)(void **, int, const int *);
     typedef int (*comm_fn)(void *);
     typedef int (*void_fn)(void);
     init_all_fn init_all = (init_all_fn)dlsym(h, "ncclCommInitAll");
     comm_fn destroy = (comm_fn)dlsym(h, "ncclCommDestroy");
     void_fn gstart = (void_fn)dlsym(h, "ncclGroupStart"), gend = (void_fn)dlsym(h, "ncclGroupEnd");
-    if (!init_all || !destroy || !gstart || !gend) die("RCCL symbols missing");
+    if (!init_all || !destroy || !gstart || !gend) return give_up("RCCL symbols missing");
     std::vector<void *> comms((size_t)G, nullptr);
-    if (init_all(comms.data(), G, devices.data()) != 0) die("ncclCommInitAll failed");
+    if (init_all(comms.data(), G, devices.data()) != 0) return give_up("ncclCommInitAll failed");
     std::vector<std::thread> th;
     std::atomic<int> failed(0);
     for (int g = 0; g < G; ++g)
@@ -1203,7 +1205,7 @@ bool rccl_allreduce_blocks(const std::vector<int> &devices, const std::function<
         });
     for (auto &t : th) t.join();
     for (void *c : comms) destroy(c);
-    if (failed) die(string("stats all-reduce failed: ") + snk_last_error());
+    if (failed) return give_up(string("all-reduce failed: ") + snk_last_error());
     return true;
 }
 
@@ -1281,6 +1283,9 @@ int main(int argc, char **argv) {
     // one context + one set of batch slots per device; one accumulator per virtual reference thread
     //  and device.  A run is a sequence of epochs of constant capacity (normally one).
     const int G = (int)o.devices.size();
+    // -j prints every patch's cumulative per-thread statistics from the accumulators of the device that ran it: with
+    // several devices each holds only its share of a thread's patches
+    if (o.streaming && G > 1) die("-j/--streaming runs on one device: give --devices a single id");
     const int NSLOT = dev_text ? 4 : 3;                   // (device-text mode: the main thread holds one staged batch back until its parse verdict is in)
     const int64_t vblock = snk_vthread_block(T, o.patch_size);
     struct Dev {
@@ -1393,28 +1398,40 @@ int main(int argc, char **argv) {
     // a sum/max all-reduce over RCCL, issued by one host thread per GPU), then travel to the host
     auto collect_epoch = [&] {
         for (Dev &d : devs) { HIPCHK(hipSetDevice(d.id)); HIPCHK(hipDeviceSynchronize()); }
-        bool reduced = false;
-        if (G > 1) reduced = rccl_allreduce_blocks(o.devices, [&](int g, int t) {
-            Dev &d = devs[(size_t)g];
-            if (snk_bind_stats(d.ctx, d.d_sum[(size_t)t], d.d_max[(size_t)t]) != SNK_OK) die(snk_last_error());
-            return d.ctx;
-        }, T);
         Epoch e;
         e.lcap = lcap;
         e.sums.assign((size_t)T, std::vector<uint64_t>((size_t)nsum, 0));
         e.maxs.assign((size_t)T, std::vector<uint64_t>(SNK_MAX_N, 0));
         std::vector<uint64_t> ts((size_t)nsum), tm(SNK_MAX_N);
-        for (int g = 0; g < (reduced ? 1 : G); ++g) {       // not reduced (the same device listed twice): summed here
-            Dev &d = devs[(size_t)g];
+        auto fetch_block = [&](Dev &d, int t) {
+            snk_error err;
             HIPCHK(hipSetDevice(d.id));
+            if (snk_bind_stats(d.ctx, d.d_sum[(size_t)t], d.d_max[(size_t)t]) != SNK_OK) die(snk_last_error());
+            if (snk_stats_fetch(d.ctx, ts.data(), tm.data(), &err, nullptr) != SNK_OK) die(snk_last_error());
+            report_device_error(err);
+        };
+        // every device's blocks come to the host first and are added up here: the RCCL all-reduce below is then checked
+        // against this sum, and a failure of the collective costs a warning, not the run
+        for (int g = 0; g < G; ++g)
             for (int t = 0; t < T; ++t) {
-                snk_error err;
-                if (snk_bind_stats(d.ctx, d.d_sum[(size_t)t], d.d_max[(size_t)t]) != SNK_OK) die(snk_last_error());
-                if (snk_stats_fetch(d.ctx, ts.data(), tm.data(), &err, nullptr) != SNK_OK) die(snk_last_error());
-                report_device_error(err);
+                fetch_block(devs[(size_t)g], t);
                 for (int64_t k = 0; k < nsum; ++k) e.sums[(size_t)t][(size_t)k] += ts[(size_t)k];
                 for (int k = 0; k < SNK_MAX_N; ++k) e.maxs[(size_t)t][(size_t)k] = std::max(e.maxs[(size_t)t][(size_t)k], tm[(size_t)k]);
             }
+        if (G > 1 && rccl_allreduce_blocks(o.devices, [&](int g, int t) {
+                Dev &d = devs[(size_t)g];
+                if (snk_bind_stats(d.ctx, d.d_sum[(size_t)t], d.d_max[(size_t)t]) != SNK_OK) die(snk_last_error());
+                return d.ctx;
+            }, T)) {
+            // the path's one collective: after it every device holds the merged blocks
+            bool same = true;
+            for (int t = 0; t < T && same; ++t) {
+                fetch_block(devs[0], t);
+                same = memcmp(ts.data(), e.sums[(size_t)t].data(), (size_t)nsum * sizeof(uint64_t)) == 0 &&
+                       memcmp(tm.data(), e.maxs[(size_t)t].data(), SNK_MAX_N * sizeof(uint64_t)) == 0;
+            }
+            if (!same) cerr << "Warning:the RCCL all-reduce of the statistics disagrees with the host-side sum; using the host-side sum" << endl;
+            else log << local_time() << "\tstatistics merged over RCCL (" << G << " devices)" << endl;
         }
         epochs.push_back(std::move(e));
     };
@@ -2027,6 +2044,11 @@ int main(int argc, char **argv) {
             snk_error err;
             if (snk_bind_stats(dv.ctx, dv.d_sum[(size_t)vt], dv.d_max[(size_t)vt]) != SNK_OK) die(snk_last_error());
             if (snk_stats_fetch(dv.ctx, s.snap_sum.data(), s.snap_max.data(), &err, nullptr) != SNK_OK) die(snk_last_error());
+            // the thread's counts of earlier epochs (before a capacity regrowth the accumulators were closed and zeroed)
+            for (const Epoch &e : epochs) {
+                widen_add(e.sums[(size_t)vt].data(), e.lcap, s.snap_sum.data(), lcap, nq);
+                for (int k = 0; k < SNK_MAX_N; ++k) s.snap_max[(size_t)k] = std::max(s.snap_max[(size_t)k], e.maxs[(size_t)vt][(size_t)k]);
+            }
         }
         HIPCHK(hipEventRecord(s.done, s.stream));
         to_write.push(sp);

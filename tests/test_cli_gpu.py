@@ -597,3 +597,30 @@ def test_cli_device_text_input_errors(tmp_path):
                                capture_output=True, env=dict(os.environ, SNK_BATCH_PAIRS="512", **extra))
             assert r.returncode == 1, (name, extra, r.stderr[-200:])
             assert (b"lengths differ" in r.stderr) if name == "mismatch" else (b"truncated" in r.stderr), (name, extra, r.stderr[-200:])
+
+
+def test_cli_streaming_across_a_capacity_regrowth_and_devices(tmp_path):
+    """-j prints cumulative per-thread statistics; after a capacity regrowth (a read longer than the 256 positions -j
+    starts with) the counts of the closed epoch must still be in them -- stdout byte-identical to the reference with one
+    thread.  And -j with more than one device is refused (each device would only know its own patches)."""
+    rng = np.random.default_rng(29)
+    lens = np.concatenate([rng.integers(60, 101, 1500), rng.integers(200, 301, 1500)])
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    work = str(tmp_path)
+    seqs = [bytes(B[rng.integers(0, 4, l)]) for l in lens]
+    quals = [bytes((33 + np.clip(rng.normal(34, 6, l), 2, 41)).astype(np.uint8)) for l in lens]
+    _write_fastq(os.path.join(work, "r1.fq"), seqs, quals, 1)
+    open(os.path.join(work, "cfg"), "w").write("patch=300\n")
+    tail = ["-C", "c1.fq.gz", "-T", "1", "-l", "10", "-q", "0.3", "-j", "-c", os.path.join(work, "cfg")]
+    inp = ["-1", os.path.join(work, "r1.fq.gz")]
+    ref = subprocess.run([T.REF_BIN, "filter"] + inp + ["-o", os.path.join(work, "ref")] + tail, capture_output=True, timeout=120)
+    ours = subprocess.run([CLI, "filter"] + inp + ["-o", os.path.join(work, "ours")] + tail, capture_output=True)
+    assert ref.returncode == 0 and ours.returncode == 0, (ref.stderr[-200:], ours.stderr[-300:])
+    if ours.stdout != ref.stdout:
+        a, b = ours.stdout.split(b"\n"), ref.stdout.split(b"\n")
+        bad = next((i for i in range(min(len(a), len(b))) if a[i] != b[i]), min(len(a), len(b)))
+        raise AssertionError((len(a), len(b), bad, a[bad][:200] if bad < len(a) else None, b[bad][:200] if bad < len(b) else None))
+    for f in R.REPORT_FILES_SE:
+        assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
+    r = subprocess.run([CLI, "filter"] + inp + ["-o", os.path.join(work, "two"), "--devices", "0,0"] + tail, capture_output=True)
+    assert r.returncode == 1 and b"-j/--streaming runs on one device" in r.stderr, r.stderr[-200:]

@@ -143,3 +143,28 @@ def test_two_ranks_two_gpus_rccl(tmp_path, rmdup):
 
 def test_two_ranks_two_gpus_rccl_c_abi(tmp_path):
     _run(tmp_path, "nccl", False, c_abi=True)
+
+
+def test_bench_launcher_path_under_nccl_at_world_one():
+    """VERDICT r2 task 7 (i): `bench.py` through its own torch.distributed.run re-exec -- launcher command line, port
+    handling, `device_id=`, the `nccl` process group, the stats all-reduce inside the timed region, the max-over-ranks
+    all-reduce and the JSON emission -- at world size 1, which is all a one-GPU box can offer.  Same branch as
+    `--gpus N` without a launcher (SNK_BENCH_FORCE_LAUNCHER=1 only removes the `N > 1` test)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, SNK_BENCH_FORCE_LAUNCHER="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "200000",
+                        "--no-cpu-baseline"], capture_output=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    line = [x for x in r.stdout.decode().splitlines() if x.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+    # the same workload without the launcher counts the same clean pairs
+    r2 = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "200000",
+                         "--no-cpu-baseline"], capture_output=True, env={k: v for k, v in env.items() if k != "SNK_BENCH_FORCE_LAUNCHER"}, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-800:]
+    out2 = json.loads([x for x in r2.stdout.decode().splitlines() if x.startswith("{")][-1])
+    assert out["config"]["clean_pairs_per_step_per_gpu"] == out2["config"]["clean_pairs_per_step_per_gpu"]
