@@ -31,7 +31,9 @@ extern "C" {
 
 /* reference limits: READ_MAX_LEN src/global_variable.h:9 */
 #define SNK_READ_MAX_LEN 1000
-#define SNK_MAX_ADAPTERS 16   /* per mate; reference takes a list, src/read_filter.cpp:177-184 */
+#define SNK_MAX_ADAPTERS 16   /* per mate in snk_params.adapters[]; longer lists travel through snk_params.adapter_list
+                                 (the reference takes a list file of any length, src/process_argv.cpp:242-304,
+                                 loop at src/read_filter.cpp:175-188) */
 #define SNK_MAX_ADAPTER_LEN 255
 
 /* ------------------------------------------------------------------ params
@@ -80,7 +82,15 @@ typedef struct snk_params {
     const char *ct_match_r;       /* gp.ctMatchR ("0.2"; a list when contam is a list) */
     const char *global_contams;   /* gp.global_contams */
     const char *g_mrs, *g_mms;    /* gp.g_mrs, gp.g_mms (one value per global contaminant) */
+    /* adapter lists of any length: when adapter_list[m] is non-NULL, mate m's n_adapters[m] adapters are
+     * adapter_list[m][0 .. n_adapters[m]) and adapters[m][] is ignored (n_adapters[m] may exceed SNK_MAX_ADAPTERS) */
+    const char *const *adapter_list[2];
 } snk_params;
+
+/* adapter i of mate m, whichever of the two forms carries it */
+static inline const char *snk_adapter_at(const snk_params *p, int m, int i) {
+    return p->adapter_list[m] ? p->adapter_list[m][i] : (i < SNK_MAX_ADAPTERS ? p->adapters[m][i] : (const char *)0);
+}
 
 /* fill with the reference defaults (src/global_parameter.h:20-83) */
 void snk_params_default(snk_params *p);

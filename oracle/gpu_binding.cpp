@@ -87,13 +87,16 @@ void fill_params(ParamHolder &H, const C_global_parameter &gp, int max_len) {
     }
     P.ada_mis[0] = gp.adaMis;   P.ada_mr[0] = gp.adaMR;   P.ada_edge[0] = gp.adaEdge;
     P.ada_mis[1] = gp.adaMis2;  P.ada_mr[1] = gp.adaMR2;  P.ada_edge[1] = gp.adaEdge2;
-    if (gp.ada1s.size() > SNK_MAX_ADAPTERS || gp.ada2s.size() > SNK_MAX_ADAPTERS) die("too many adapters for the GPU path");
     H.keep.clear();
     H.keep.reserve(gp.ada1s.size() + gp.ada2s.size() + 8);
     P.n_adapters[0] = (int)gp.ada1s.size();
     P.n_adapters[1] = (int)gp.ada2s.size();
-    for (size_t i = 0; i < gp.ada1s.size(); ++i) { H.keep.push_back(gp.ada1s[i]); P.adapters[0][i] = H.keep.back().c_str(); }
-    for (size_t i = 0; i < gp.ada2s.size(); ++i) { H.keep.push_back(gp.ada2s[i]); P.adapters[1][i] = H.keep.back().c_str(); }
+    // lists of any length go through snk_params.adapter_list
+    static std::vector<const char *> ptrs[2];
+    ptrs[0].clear(); ptrs[1].clear();
+    for (size_t i = 0; i < gp.ada1s.size(); ++i) { H.keep.push_back(gp.ada1s[i]); ptrs[0].push_back(H.keep.back().c_str()); }
+    for (size_t i = 0; i < gp.ada2s.size(); ++i) { H.keep.push_back(gp.ada2s[i]); ptrs[1].push_back(H.keep.back().c_str()); }
+    for (int m = 0; m < 2; ++m) P.adapter_list[m] = ptrs[m].empty() ? nullptr : ptrs[m].data();
     auto str = [&](const std::string &s) -> const char * {
         if (s.empty()) return nullptr;
         H.keep.push_back(s);

@@ -59,8 +59,8 @@ static C_global_parameter make_gp(const snk_params *P) {
     }
     gp.adaMis = P->ada_mis[0];  gp.adaMR = P->ada_mr[0];  gp.adaEdge = P->ada_edge[0];
     gp.adaMis2 = P->ada_mis[1]; gp.adaMR2 = P->ada_mr[1]; gp.adaEdge2 = P->ada_edge[1];
-    for (int i = 0; i < P->n_adapters[0]; i++) gp.ada1s.push_back(P->adapters[0][i]);
-    for (int i = 0; i < P->n_adapters[1]; i++) gp.ada2s.push_back(P->adapters[1][i]);
+    for (int i = 0; i < P->n_adapters[0]; i++) gp.ada1s.push_back(snk_adapter_at(P, 0, i));
+    for (int i = 0; i < P->n_adapters[1]; i++) gp.ada2s.push_back(snk_adapter_at(P, 1, i));
     if (P->contam[0]) gp.contam1_seq = P->contam[0];
     if (P->contam[1]) gp.contam2_seq = P->contam[1];
     if (P->ct_match_r && *P->ct_match_r) gp.ctMatchR = P->ct_match_r;

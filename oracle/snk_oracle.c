@@ -379,7 +379,7 @@ static int stat_read(const snk_params *P, int mate, const uint8_t *seq,
     r->hd_h = r->lq_h = r->hd_t = r->lq_t = r->adacut = -1;        /* C_fastq_init */
     int ada_pos = -1;                                              /* :175-188 */
     for (int i = 0; i < P->n_adapters[mate]; i++) {
-        const char *ad = P->adapters[mate][i];
+        const char *ad = snk_adapter_at(P, mate, i);
         ada_pos = snk_oracle_adapter_pos(seq, len, ad, (int)strlen(ad),
                                          P->ada_mis[mate], P->ada_mr[mate],
                                          P->ada_edge[mate]);

@@ -46,6 +46,7 @@ class Params(C.Structure):
         ("rmdup", C.c_int32), ("max_read_len", C.c_int32),
         ("contam", C.c_char_p * 2), ("ct_match_r", C.c_char_p),
         ("global_contams", C.c_char_p), ("g_mrs", C.c_char_p), ("g_mms", C.c_char_p),
+        ("adapter_list", C.POINTER(C.c_char_p) * 2),
     ]
 
 
@@ -131,10 +132,15 @@ def default_params(paired=True, max_read_len=150, **kw):
         if k in ("adapters1", "adapters2"):
             m = 0 if k == "adapters1" else 1
             p.n_adapters[m] = len(v)
-            for i, a in enumerate(v):
-                b = a.encode() if isinstance(a, str) else bytes(a)
-                keep.append(b)
-                p.adapters[m][i] = b
+            bs = [a.encode() if isinstance(a, str) else bytes(a) for a in v]
+            keep += bs
+            if len(v) > SNK_MAX_ADAPTERS:                     # longer lists: snk_params.adapter_list
+                arr = (C.c_char_p * len(v))(*bs)
+                keep.append(arr)
+                p.adapter_list[m] = C.cast(arr, C.POINTER(C.c_char_p))
+            else:
+                for i, b in enumerate(bs):
+                    p.adapters[m][i] = b
         elif k == "hard_trim":
             p.has_hard_trim = 1
             for i, x in enumerate(v):

@@ -12,6 +12,9 @@
 namespace snk {
 namespace {
 
+// a TileAdapter read through the constant address space (uniform address: scalar loads, hoisted like kernel arguments)
+typedef __attribute__((address_space(4))) TileAdapter CTileAdapter;
+
 __device__ __forceinline__ u32 lowmask32(int n) { return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u)); }
 __device__ __forceinline__ u64 lowmask64(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); }
 
@@ -137,8 +140,8 @@ __device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C
 // Bit-sliced screening of the candidates p = 0 .. len-edge of phases B and C over the first S-1 adapter
 // characters with NC unary mismatch-counter planes.
 // NC = largest budget + 1 counter planes, at most 4: offsets whose own budget is 4 or more are not screened out by the count.
-template <int NW, bool FULL, int NC>
-__device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&NX)[4][NW], const u32 (&NXN)[NW], int len, bool done,
+template <int NW, bool FULL, int NC, class AD>
+__device__ __forceinline__ void screen_planes(const AD &A, const u32 (&NX)[4][NW], const u32 (&NXN)[NW], int len, bool done,
                                               u32 (&aliveB)[NW], u32 (&aliveC)[NW]) {
     const int al = A.len, S = max(A.S, 1), edge = A.edge, mis = A.mis;
     u32 C[NC][NW], BY[NW];
@@ -214,13 +217,14 @@ __device__ __forceinline__ void screen_planes(const TileAdapter &A, const u32 (&
 // X[k] bit p = read[p] == "ACGT"[k] (exact), ones beyond the read; XN likewise for 'N'.
 // doA / doC (per lane): the planes start at the read's first character / end at its last one.  A block in the middle of
 // a long read (snk_long.hip) has neither: only the offsets of phase B exist there.
-template <int NW, bool FULL>
-__device__ int adapter_tile(const TileAdapter &A, const DevAdapter &AG, const u32 (&X)[4][NW], const u32 (&XN)[NW],
-                            int len, bool todo, const uint8_t *sptr, bool doA = true, bool doC = true) {
+template <int NW, bool FULL, class AD>
+__device__ int adapter_tile(const AD &A, const DevAdapter &AG, const u32 (&X)[4][NW], const u32 (&XN)[NW],
+                            int len, bool todo, const uint8_t *sptr, bool doA = true, bool doC = true, bool seq_lane = false) {
     const int al = A.len, S = max(A.S, 1), edge = A.edge, mis = A.mis;
     int result = -1;
     bool done = !todo;
-    if (!done && len < al) {           // shorter than the adapter: negative offsets, rare -> sequential
+    // seq_lane: a read with characters the planes do not hold against an adapter with lower-case characters
+    if (!done && (len < al || seq_lane)) {           // shorter than the adapter: negative offsets, rare -> sequential
         result = adapter_pos_seq(sptr, len, AG);
         done = true;
     }

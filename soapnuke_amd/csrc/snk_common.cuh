@@ -253,7 +253,7 @@ __device__ inline void stat_read_dev(const DevParams &P, int mate, const uint8_t
     err = SNK_OK;
     int ada_pos = -1;
     for (int i = 0; i < P.n_ada[mate]; ++i) {               // :175-188
-        ada_pos = adapter_pos_seq(s, len, P.ada[mate * SNK_MAX_ADAPTERS + i]);
+        ada_pos = adapter_pos_seq(s, len, P.ada[mate * P.ada_stride + i]);
         if (ada_pos >= 0) break;
     }
     if (ada_pos >= 0) { r.inc_ada = 1; r.adacut = len - ada_pos; }

@@ -28,6 +28,9 @@ struct DevAdapter {
     int32_t  rk[4];         // rk[k] = smallest phase-C r1 with budgetC[r1] >= k (nC if none), k = 1..3; rk[0]: k = 4
     int32_t  negC;          // phase-C budgets are INT_MIN (misGrad == 0): only a run of S accepts
     uint64_t nmask;         // bit c = adapter[c] == 'N' (matches a read 'N' exactly)
+    int32_t  has_lower;     // lower-case characters: they match lower-case read characters only (src/read_filter.cpp:728 compares bytes), which the
+                            // letter planes do not hold -- a read with anything but upper-case ACGT takes the sequential matcher for this adapter
+    int32_t  pad_;
 };
 
 // One hasContam() contaminant (src/read_filter.cpp:507-603): the per-r1 thresholds of its head and
@@ -75,6 +78,7 @@ struct TileAdapter {
     int32_t budgetA[6];
     int32_t rk[4];
     int32_t maxb;               // DevAdapter::maxBudget over phases B and C (the screen needs maxb + 1 counter planes)
+    int32_t has_lower;          // DevAdapter::has_lower
 };
 struct TileAdapters { TileAdapter a[2][SNK_TILE_MAX_ADA]; };
 
@@ -89,13 +93,16 @@ struct DevParams {
     int32_t polyG_thr;                 // min n with (float)n >= polyG_tail  (:456)
     int32_t lcap;                      // positions per histogram row block
     int32_t n_ada[2];
+    int32_t ada_stride;                // adapters of mate m: ada[m * ada_stride + i], tile_ada likewise
     int32_t tile_ok;                   // every adapter can run in the wave-tiled kernel
     int32_t need_n;                    // some adapter contains 'N' (needs the N plane)
     // per-length integer thresholds replacing the fp32 ratio compares:
     //   discard iff count >= thr_x[len]            (n_ratio, highA, low-quality ratio)
     //   discard iff sumq  <  thr_meanq[len]        (mean quality)
     const int32_t *thr_n, *thr_a, *thr_lowq, *thr_meanq;
-    const DevAdapter *ada;             // [2][SNK_MAX_ADAPTERS]
+    const DevAdapter *ada;             // [2][ada_stride]
+    const TileAdapter *tile_ada;       // [2][ada_stride]: the compact descriptors of all adapters (the first SNK_TILE_MAX_ADA of a
+                                       // mate also travel in the kernel arguments)
     // contaminant screening (generic kernel only; tile_ok is 0 when any is configured)
     int32_t n_ct[2], n_gct, contam_discard;
     const DevContam *ct;               // [2][SNK_MAX_CONTAMS]

@@ -241,8 +241,9 @@ void build_adapter(DevAdapter &A, const char *seq, int mis, float mr, int edge) 
         for (int r1 = 0; r1 < A.nC && r1 < SNK_DEV_MAX_ADA_LEN; ++r1)
             if (A.budgetC[r1] >= k) { A.rk[k & 3] = r1; break; }
     }
-    // bit-parallel view for the tiled kernel: code 0..3 = ACGT, 4 = matches no valid read base,
-    // 5 = 'N'.  Lower-case adapter characters would need case-exact planes: generic kernel only.
+    // bit-parallel view for the tiled kernel: code 0..3 = ACGT, 4 = matches no upper-case ACGT read base,
+    // 5 = 'N'.  A lower-case adapter character (code 4) can only match a lower-case read character: reads that
+    // hold anything but upper-case ACGT take the sequential matcher for such an adapter (has_lower).
     A.tile_ok = (al >= 6 && al <= 64 && edge >= 1 && edge <= al && mis >= 0) ? 1 : 0;      // (any budget: beyond 3 the screen lets the offset through)
     for (int c = 0; c < al; ++c) {
         int k = 4;
@@ -250,7 +251,7 @@ void build_adapter(DevAdapter &A, const char *seq, int mis, float mr, int edge) 
         A.code[c] = (uint8_t)k;
         if (k < 4 && c < 64) A.cmask[k] |= 1ull << c;
         if (k == 5 && c < 64) A.nmask |= 1ull << c;
-        if (seq[c] == 'a' || seq[c] == 'c' || seq[c] == 'g' || seq[c] == 't' || seq[c] == 'n') A.tile_ok = 0;
+        if (seq[c] == 'a' || seq[c] == 'c' || seq[c] == 'g' || seq[c] == 't' || seq[c] == 'n') A.has_lower = 1;
     }
 }
 
@@ -261,6 +262,8 @@ void snk_set_error(const char *msg) { g_err = msg ? msg : ""; }      // snk_fast
 struct snk_ctx {
     snk_params p;
     std::vector<std::string> ada_store[2];
+    std::vector<const char *> ada_ptrs[2];        // snk_params.adapter_list of the context's own copy
+    TileAdapter *d_tile_ada = nullptr;
     int device = 0;
     int n_cu = 256;
     int lcap = 0, nq = 0;
@@ -330,10 +333,12 @@ static int build_ctx(snk_ctx *c) {
     c->sum_u64 = snk_stats_u64(c->lcap, c->nq);
 
     // ---- adapters
-    std::vector<DevAdapter> ada(2 * SNK_MAX_ADAPTERS);
+    const int stride = std::max(1, std::max(P.n_adapters[0], P.n_adapters[1]));
+    std::vector<DevAdapter> ada((size_t)2 * stride);
+    for (auto &a : ada) memset(&a, 0, sizeof(a));
     for (int m = 0; m < 2; ++m)
         for (int i = 0; i < P.n_adapters[m]; ++i)
-            build_adapter(ada[m * SNK_MAX_ADAPTERS + i], c->ada_store[m][i].c_str(), P.ada_mis[m],
+            build_adapter(ada[(size_t)m * stride + i], c->ada_store[m][i].c_str(), P.ada_mis[m],
                           P.ada_mr[m], P.ada_edge[m]);
     HIP_OK(hipMalloc(&c->d_ada, ada.size() * sizeof(DevAdapter)));
     HIP_OK(hipMemcpy(c->d_ada, ada.data(), ada.size() * sizeof(DevAdapter), hipMemcpyHostToDevice));
@@ -400,6 +405,7 @@ static int build_ctx(snk_ctx *c) {
     D.lcap = c->lcap;
     D.n_ada[0] = P.n_adapters[0];
     D.n_ada[1] = P.n_adapters[1];
+    D.ada_stride = stride;
     D.tile_ok = 1;
     D.need_n = 0;
     D.n_ct[0] = n_ct[0]; D.n_ct[1] = n_ct[1]; D.n_gct = n_gct;
@@ -407,13 +413,16 @@ static int build_ctx(snk_ctx *c) {
     D.ct = c->d_ct;
     D.gct = c->d_gct;
     memset(&c->ta, 0, sizeof(c->ta));
+    std::vector<TileAdapter> tile_ada((size_t)2 * stride);
+    for (auto &t : tile_ada) memset(&t, 0, sizeof(t));
     for (int m = 0; m < 2; ++m)
         for (int i = 0; i < P.n_adapters[m]; ++i) {
-            const DevAdapter &A = ada[m * SNK_MAX_ADAPTERS + i];
-            if (!A.tile_ok || i >= SNK_TILE_MAX_ADA) D.tile_ok = 0;
+            const DevAdapter &A = ada[(size_t)m * stride + i];
+            if (!A.tile_ok) D.tile_ok = 0;
             if (A.nmask) D.need_n = 1;
-            if (i < SNK_TILE_MAX_ADA) {
-                TileAdapter &T = c->ta.a[m][i];
+            {
+                TileAdapter &T = tile_ada[(size_t)m * stride + i];
+                T.has_lower = A.has_lower;
                 for (int k = 0; k < 4; ++k) T.cmask[k] = A.cmask[k];
                 T.nmask = A.nmask;
                 for (int ci = 0; ci < 64 && ci < A.len; ++ci) T.code4[ci >> 4] |= (uint64_t)(A.code[ci] & 15) << (4 * (ci & 15));
@@ -422,8 +431,12 @@ static int build_ctx(snk_ctx *c) {
                 for (int r1 = 0; r1 < A.nC && r1 < SNK_DEV_MAX_ADA_LEN; ++r1) if (A.budgetC[r1] > T.maxb) T.maxb = A.budgetC[r1];
                 for (int k = 0; k < 6; ++k) T.budgetA[k] = A.budgetA[k];
                 for (int k = 0; k < 4; ++k) T.rk[k] = A.rk[k];
+                if (i < SNK_TILE_MAX_ADA) c->ta.a[m][i] = T;
             }
         }
+    HIP_OK(hipMalloc(&c->d_tile_ada, tile_ada.size() * sizeof(TileAdapter)));
+    HIP_OK(hipMemcpy(c->d_tile_ada, tile_ada.data(), tile_ada.size() * sizeof(TileAdapter), hipMemcpyHostToDevice));
+    D.tile_ada = c->d_tile_ada;
     D.thr_n = c->d_tables;
     D.thr_a = c->d_tables + L1;
     D.thr_lowq = c->d_tables + 2 * L1;
@@ -460,8 +473,8 @@ snk_ctx *snk_create(const snk_params *params, int device) {
         return nullptr;
     }
     for (int m = 0; m < 2; ++m) {
-        if (params->n_adapters[m] < 0 || params->n_adapters[m] > SNK_MAX_ADAPTERS) {
-            set_err("snk_create: too many adapters");
+        if (params->n_adapters[m] < 0 || (params->n_adapters[m] > SNK_MAX_ADAPTERS && !params->adapter_list[m]) || params->n_adapters[m] > 65536) {
+            set_err("snk_create: more than SNK_MAX_ADAPTERS adapters need snk_params.adapter_list");
             return nullptr;
         }
         if (params->n_adapters[m] && params->ada_mis[m] + 1 == 0) {
@@ -469,7 +482,7 @@ snk_ctx *snk_create(const snk_params *params, int device) {
             return nullptr;
         }
         for (int i = 0; i < params->n_adapters[m]; ++i) {
-            const char *a = params->adapters[m][i];
+            const char *a = snk_adapter_at(params, m, i);
             if (!a || strlen(a) >= SNK_DEV_MAX_ADA_LEN) {
                 set_err("snk_create: adapter missing or longer than 255");
                 return nullptr;
@@ -481,11 +494,15 @@ snk_ctx *snk_create(const snk_params *params, int device) {
     c->device = device;
     for (int m = 0; m < 2; ++m)
         for (int i = 0; i < params->n_adapters[m]; ++i) {
-            c->ada_store[m].push_back(params->adapters[m][i]);
+            c->ada_store[m].push_back(snk_adapter_at(params, m, i));
         }
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
         for (int i = 0; i < SNK_MAX_ADAPTERS; ++i)
             c->p.adapters[m][i] = i < params->n_adapters[m] ? c->ada_store[m][i].c_str() : nullptr;
+        c->ada_ptrs[m].clear();
+        for (auto &a : c->ada_store[m]) c->ada_ptrs[m].push_back(a.c_str());
+        c->p.adapter_list[m] = c->ada_ptrs[m].empty() ? nullptr : c->ada_ptrs[m].data();
+    }
     if (build_ctx(c) != SNK_OK) { std::string keep = g_err; snk_destroy(c); g_err = keep; return nullptr; }
     return c;
 }
@@ -495,6 +512,7 @@ void snk_destroy(snk_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->d_ada) (void)hipFree(c->d_ada);
+    if (c->d_tile_ada) (void)hipFree(c->d_tile_ada);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->own_stats) {
         if (c->d_sum) (void)hipFree(c->d_sum);

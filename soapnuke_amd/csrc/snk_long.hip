@@ -178,10 +178,9 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
             // counts and the adapter search; the qualities are a pass of their own; the poly-X run, when asked for, too
             const bool longish = live && len >= 64;                  // (shorter: the sequential functions)
             const int n_ada = P.n_ada[m];
-            int res[SNK_TILE_MAX_ADA], cntA = 0, cntN = 0;
+            int cntA = 0, cntN = 0;
+            int best_a = 0x7fffffff, best_pos = -1;                  // the adapter earliest in the list with a hit so far, and where
             u32 other = 0;
-#pragma unroll
-            for (int a = 0; a < SNK_TILE_MAX_ADA; ++a) res[a] = -1;
             bool through = false;                                    // this lane has seen its final block
             for (int p0 = 0; __any(longish && !through); p0 += LBLK) {
                 const int rem = len - p0;
@@ -190,22 +189,15 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
                 u32 X[4][LNW], XN[LNW];
                 block_planes(here ? s[m] : B.seq[m], here ? p0 : 0, vlen, B.pitch, final, X, XN, cntA, cntN, other);
                 if (n_ada > 0) {
-                    bool earlier = false;                            // an adapter in front of this one already has its hit
+                    // the first adapter of the list with a hit decides, whatever block its hit is in (src/read_filter.cpp:175-188):
+                    // only adapters in front of the best one so far are still searched
                     for (int a = 0; a < n_ada; ++a) {
-                        int cur = -1;
-#pragma unroll
-                        for (int k = 0; k < SNK_TILE_MAX_ADA; ++k) cur = (k == a) ? res[k] : cur;
-                        const bool todo = here && cur < 0 && !earlier;
+                        const bool todo = here && a < best_a;
                         if (__any(todo)) {
-                            const int rel = adapter_tile<LNW, true>(TA.a[m][a], P.ada[m * SNK_MAX_ADAPTERS + a], X, XN, vlen, todo, s[m] + p0,
-                                                                    p0 == 0, final);
-                            if (todo && rel >= 0) {
-#pragma unroll
-                                for (int k = 0; k < SNK_TILE_MAX_ADA; ++k) res[k] = (k == a) ? p0 + rel : res[k];
-                                cur = p0 + rel;
-                            }
+                            const CTileAdapter &Acur = ((const CTileAdapter *)(uintptr_t)P.tile_ada)[m * P.ada_stride + a];
+                            const int rel = adapter_tile<LNW, true>(Acur, P.ada[m * P.ada_stride + a], X, XN, vlen, todo, s[m] + p0, p0 == 0, final);
+                            if (todo && rel >= 0) { best_a = a; best_pos = p0 + rel; }
                         }
-                        earlier |= cur >= 0;
                     }
                 }
                 through |= here && final;
@@ -237,9 +229,7 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
                     }
                     r[m].polyx = maxrun >= P.polyX_num ? 1 : 0;
                 }
-                int ada_pos = -1;
-#pragma unroll
-                for (int a = SNK_TILE_MAX_ADA - 1; a >= 0; --a) ada_pos = (a < n_ada && res[a] >= 0) ? res[a] : ada_pos;
+                const int ada_pos = best_pos;
                 if (ada_pos >= 0) { r[m].inc_ada = 1; r[m].adacut = len - ada_pos; }
             }
         }

@@ -800,8 +800,11 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         for (int i = 0; i < (SNK_ABL == 4 ? 0 : nada); ++i) {      // src/read_filter.cpp:175-188
             const bool todo = good && ada_pos < 0;
             if (!__any(todo)) break;
-            const int pp = adapter_tile<NW, FULL>(TA.a[m][i], P.ada[m * SNK_MAX_ADAPTERS + i], X, XN, R.len, todo,
-                                            seq + (t0 + lane) * (long)B.pitch);
+            // the compact descriptors of the whole list sit in a device array read through the constant address space: scalar
+            // loads, invariant for the compiler, like the kernel arguments the first four used to travel in
+            const CTileAdapter &Acur = ((const CTileAdapter *)(uintptr_t)P.tile_ada)[m * P.ada_stride + i];
+            const int pp = adapter_tile<NW, FULL>(Acur, P.ada[m * P.ada_stride + i], X, XN, R.len, todo,
+                                            seq + (t0 + lane) * (long)B.pitch, true, true, Acur.has_lower != 0 && badread);
             if (todo && pp >= 0) ada_pos = pp;
         }
         if (ada_pos >= 0) { R.inc_ada = 1; R.adacut = R.len - ada_pos; }

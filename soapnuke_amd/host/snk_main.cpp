@@ -58,6 +58,7 @@ namespace {
 struct Options {
     string fq1, fq2, clean1, clean2, out_dir, log = "log";
     std::vector<string> ada1, ada2;
+    std::vector<const char *> ada_ptr[2];                             // snk_params.adapter_list (lists of any length)
     snk_params p;
     string trim, trim_bad_head, trim_bad_tail, out_file_type = "fastq";
     int threads = 6, patch_size = 0, batch_pairs = 1 << 18;
@@ -310,11 +311,12 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
         if (h.size() == 2) { o.p.lq_head_qual = atoi(h[0].c_str()); o.p.lq_head_len = atoi(h[1].c_str()); }
         if (t.size() == 2) { o.p.lq_tail_qual = atoi(t[0].c_str()); o.p.lq_tail_len = atoi(t[1].c_str()); }
     }
-    if (o.ada1.size() > SNK_MAX_ADAPTERS || o.ada2.size() > SNK_MAX_ADAPTERS) die("too many adapters");
+    // adapter lists of any length (a list file, src/process_argv.cpp:242-304): snk_params.adapter_list
     o.p.n_adapters[0] = (int)o.ada1.size();
     o.p.n_adapters[1] = (int)o.ada2.size();
-    for (size_t i = 0; i < o.ada1.size(); ++i) o.p.adapters[0][i] = o.ada1[i].c_str();
-    for (size_t i = 0; i < o.ada2.size(); ++i) o.p.adapters[1][i] = o.ada2[i].c_str();
+    for (const string &a : o.ada1) o.ada_ptr[0].push_back(a.c_str());
+    for (const string &a : o.ada2) o.ada_ptr[1].push_back(a.c_str());
+    for (int m = 0; m < 2; ++m) o.p.adapter_list[m] = o.ada_ptr[m].empty() ? nullptr : o.ada_ptr[m].data();
     if (!o.fov.empty() && o.seq_type != "0") { cerr << "Warning:Zebra-500 data(--fov), --seqType is 0" << endl; exit(1); }   // src/read_filter.cpp:137-140
     o.p.contam[0] = o.contam[0].empty() ? nullptr : o.contam[0].c_str();
     o.p.contam[1] = o.contam[1].empty() ? nullptr : o.contam[1].c_str();

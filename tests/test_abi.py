@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
                   if h.endswith(".h"))                     # every public header: snk_filter.h, snk_rmdup.h
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)      # drop comments
     declared = set(re.findall(r"\b(snk_[a-z_]+)\s*\(", hdr)) - {"snk_file_block_u64", "snk_stats_u64",
-                                                               "snk_file_off", "snk_bs_off", "snk_qs_off", "snk_ts_off"}
+                                                               "snk_file_off", "snk_bs_off", "snk_qs_off", "snk_ts_off", "snk_adapter_at"}
     assert declared == set(abi.EXPORTS), declared ^ set(abi.EXPORTS)
     for s in declared:
         assert hasattr(lib, s), s
@@ -26,14 +26,15 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "snk_filter.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "snk_filter.h"\n#include "snk_fastq.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(snk_params),sizeof(snk_batch),sizeof(snk_read_result),sizeof(snk_error),'
-                   'offsetof(snk_params,adapters),offsetof(snk_batch,first_index));return 0;}\n')
+                   'offsetof(snk_params,adapters),offsetof(snk_batch,first_index));'
+                   'printf("%zu %zu\\n",offsetof(snk_params,adapter_list),sizeof(snk_fastq_format));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(T.ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(abi.Params), C.sizeof(abi.Batch), C.sizeof(abi.ReadResult), C.sizeof(abi.Error),
-            abi.Params.adapters.offset, abi.Batch.first_index.offset]
+            abi.Params.adapters.offset, abi.Batch.first_index.offset, abi.Params.adapter_list.offset, C.sizeof(abi.FastqFormat)]
     assert got == want
     assert C.sizeof(abi.ReadResult) == 16 and abi.record_dtype().itemsize == 16
 
@@ -56,7 +57,7 @@ def test_default_params_match_reference_defaults():
     lib.snk_params_default(C.byref(p))
     q = abi.default_params()
     for name, _ in abi.Params._fields_:
-        if name in ("adapters",):
+        if name in ("adapters", "adapter_list"):
             continue
         a, b = getattr(p, name), getattr(q, name)
         if hasattr(a, "__len__"):

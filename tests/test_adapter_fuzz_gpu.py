@@ -119,3 +119,48 @@ def test_adapter_budgets_above_three(mis):
                            ada_mr=(0.5, 0.7), ada_edge=(6, 3), low_qual=10, low_qual_ratio=0.3, min_read_length=30)
     want = T.run_oracle(p, d)
     assert_same(p, run_hip_device(p, d, 2, chunks=2), want, True)
+
+
+# ---- round 3: adapter lists longer than four, lower-case adapters, lists longer than SNK_MAX_ADAPTERS
+
+def _lower_some(rng, a):
+    b = bytearray(a.encode())
+    for k in rng.integers(0, len(b), int(rng.integers(1, 4))):
+        b[int(k)] |= 0x20
+    return b.decode()
+
+
+@pytest.mark.parametrize("i", range(16))
+def test_long_adapter_lists_and_lower_case_on_the_fast_paths(i):
+    """1..12 adapters per mate (i % 4 == 3: 20..40, through snk_params.adapter_list), a quarter of them with lower-case
+    characters, reads with lower-case stretches that such adapters can match: kernel = 2 must take the configuration
+    (tiled kernel up to 256 positions, the long-read path beyond), first adapter of the list with a hit wins."""
+    rng = np.random.default_rng(8100 + i)
+    paired = i % 3 != 2
+    L = [150, 100, 250, 400][i % 4] if i % 5 else 150
+    na = [int(rng.integers(20, 41)) if i % 4 == 3 else int(rng.integers(5, 13)) for _ in range(2)]
+    ada = [[random_adapter(rng, 8, min(64, L // 2 - 8)) for _ in range(na[m])] for m in range(2)]
+    for m in range(2):
+        for k in range(len(ada[m])):
+            if rng.random() < 0.25:
+                ada[m][k] = _lower_some(rng, ada[m][k])
+    kw = dict(adapters1=ada[0], ada_trim=int(rng.integers(0, 2)), ada_mis=(int(rng.integers(0, 4)), int(rng.integers(0, 4))),
+              ada_mr=(float(rng.choice([0.3, 0.5, 0.7])), float(rng.choice([0.3, 0.5, 0.7]))),
+              ada_edge=(int(rng.integers(1, 8)), int(rng.integers(1, 8))), low_qual=10, low_qual_ratio=0.3)
+    if paired:
+        kw["adapters2"] = ada[1]
+    n = 12000 if L <= 256 else 4000
+    d = synth.make_batch(n, L, paired=paired, var_len=bool(i % 2), seed=9100 + i, adapters=(ada[0][0].upper(), ada[1][0].upper()))
+    for m in range(2 if paired else 1):
+        plant(rng, d["seq"][m], d["len"][m], L, ada[m], 0.3)
+        rows = rng.choice(n, n // 10, replace=False)                       # reads with lower-case stretches (and the planted lower-case adapters)
+        blk = d["seq"][m][rows, :L]
+        d["seq"][m][rows, :L] = np.where((rng.random(blk.shape) < 0.2) & (blk >= 65) & (blk <= 90), blk | 0x20, blk)
+        if d["len"][m] is not None:
+            beyond = np.arange(L)[None, :] >= d["len"][m][:, None].astype(np.int32)
+            d["seq"][m][:, :L][beyond] = 0xEE
+    p = abi.default_params(paired=paired, max_read_len=L, **kw)
+    want = T.run_oracle(p, d)
+    assert int((want["rec"][0]["adacut_pos"] >= 0).sum()) > 50
+    assert_same(p, run_hip_device(p, d, 2, chunks=2), want, paired)
+    assert_same(p, run_hip_device(p, d, 1), want, paired)

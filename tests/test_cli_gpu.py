@@ -624,3 +624,28 @@ def test_cli_streaming_across_a_capacity_regrowth_and_devices(tmp_path):
         assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
     r = subprocess.run([CLI, "filter"] + inp + ["-o", os.path.join(work, "two"), "--devices", "0,0"] + tail, capture_output=True)
     assert r.returncode == 1 and b"-j/--streaming runs on one device" in r.stderr, r.stderr[-200:]
+
+
+def test_cli_adapter_list_files_of_any_length(tmp_path):
+    """-f / -r given as list files (src/process_argv.cpp:242-304) with more adapters than fit snk_params.adapters[]: the
+    lists travel through snk_params.adapter_list to the tiled kernel; reports and clean FASTQ against the reference binary"""
+    rng = np.random.default_rng(77)
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    lists = [[bytes(B[rng.integers(0, 4, int(rng.integers(12, 50)))]).decode() for _ in range(k)] for k in (23, 37)]
+    lists[0][5] = synth.ADAPTER1
+    lists[1][30] = synth.ADAPTER2
+    n, L = 20000, 150
+    d = synth.make_batch(n, L, paired=True, seed=123)
+    for m in range(2):                                         # some reads carry adapters from the middle of the lists
+        rows = rng.choice(n, 3000, replace=False)
+        for r in rows:
+            a = np.frombuffer(lists[m][int(rng.integers(0, len(lists[m])))].encode(), dtype=np.uint8)
+            p = int(rng.integers(20, L - len(a)))
+            d["seq"][m][r, p:p + len(a)] = a
+    work = str(tmp_path)
+    for m in range(2):
+        open(os.path.join(work, f"ada{m + 1}.list"), "w").write("\n".join(lists[m]) + "\n")
+    case = ("adalist", True, L, n, 3, 250, {}, {}, ["-f", os.path.join(work, "ada1.list"), "-r", os.path.join(work, "ada2.list"), "-J", "-l", "10", "-q", "0.2"], [])
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ours = _run_ours(case, work, gz=False)
+    _compare_dirs(ours, ref, True)
