@@ -191,9 +191,38 @@ __device__ inline bool gc_lay(GcWindow &st, const uint8_t *a, const uint8_t *b, 
     return gc_walk(st, [&](int w) { return w == 0 ? e0 : (w == 1 ? e1 : (w == 2 ? e2 : e3)); }, n, mml, tms, lower, early_stop);
 }
 
+// The same lay cell by cell, with nothing assumed about the parameters: for settings outside the event walk's range (more
+// than 4 mismatches, or a match length not above the mismatch number) a window that is "dead" can still pass the hit
+// test, which is evaluated behind every cell that does not abandon the lay (src/read_filter.cpp:973-1060).
+__device__ inline bool gc_lay_cells(GcWindow &st, const uint8_t *a, const uint8_t *b, int n, int mml, int tms, int lower, bool early_stop) {
+    for (int j = 0; j < n; ++j) {
+        const bool eq = a[j] == b[j], live = st.score > tms, room = n - j >= mml;
+        if (live) { st.score += eq ? 1 : -200; st.span += 1; }
+        else if (eq) {
+            if (early_stop && !room) break;
+            st.score = 1;
+            st.span = 1;
+            if (!early_stop && !room) break;
+        } else if (!room) break;
+        if (st.score >= lower && st.span >= mml) return true;
+    }
+    return false;
+}
+
 __device__ inline bool global_contam_hit(const uint8_t *ref, int rl, const uint8_t *gc, int cl, int mml, int mmn) {
     const int tms = -200 * mmn, lower = (mml - mmn) + tms;
     GcWindow st = {-1000, 0};
+    if (!(mmn >= 0 && mmn <= 4 && mml > mmn)) {                            // outside the event walk's range: cell by cell
+        for (int i = cl - mml; i >= 0; --i)
+            if (gc_lay_cells(st, ref, gc + i, min(cl - i, rl), mml, tms, lower, true)) return true;
+        st = GcWindow{-1000, 0};
+        for (int i = 0; i <= rl - cl; ++i)
+            if (gc_lay_cells(st, ref + i, gc, cl, mml, tms, lower, true)) return true;
+        st = GcWindow{-1000, 0};
+        for (int i = cl > rl ? cl - rl : 0; i <= cl - mml; ++i)
+            if (gc_lay_cells(st, ref + rl - (cl - i), gc, cl - i, mml, tms, lower, false)) return true;
+        return false;
+    }
     for (int i = cl - mml; i >= 0; --i)                                    // contaminant hanging off the front, less and less
         if (gc_lay(st, ref, gc + i, min(cl - i, rl), mml, tms, lower, true)) return true;
     st = GcWindow{-1000, 0};

@@ -180,9 +180,11 @@ std::string build_contams(const snk_params &P, std::vector<DevContam> &ct, int n
             G.len = cl;
             G.min_match_len = (int)((float)cl * (float)atof(mrs[i].c_str()));           // :969
             G.mm = atoi(mms[i].c_str());
-            // the window walk of the kernels (snk_common.cuh) covers the sensible range; outside it the reference's score
-            // arithmetic degenerates (a window that is "dead" can pass the hit test)
-            if (G.mm < 0 || G.mm > 4 || G.min_match_len <= G.mm) return "global contaminant: mismatch number must be 0..4 and smaller than the match length";
+            // the event walk and the bit-parallel screen of the kernels cover 0 <= mismatches <= 4 < ... < match length; outside
+            // it the reference's score arithmetic degenerates (a window that is "dead" can pass the hit test) and the kernels
+            // walk the lays cell by cell (gc_lay_cells, snk_common.cuh)
+            const bool in_range = G.mm >= 0 && G.mm <= 4 && G.min_match_len > G.mm;
+            if (G.min_match_len < 0 || G.min_match_len > cl) return "global contaminant: match ratio must be in [0, 1]";
             memcpy(G.seq[0], seqs[i].data(), cl);
             for (int k = 0; k < cl; ++k) {                           // reversecomplementary(), :1068-1090
                 const int ch = toupper((unsigned char)seqs[i][cl - 1 - k]);
@@ -199,7 +201,7 @@ std::string build_contams(const snk_params &P, std::vector<DevContam> &ct, int n
             }
             // sliding-count screen of snk_contam.hip
             G.g = 0;
-            G.bits_ok = (G.min_match_len >= 4 && G.min_match_len <= cl && G.min_match_len <= 63 && cl <= 64) ? 1 : 0;
+            G.bits_ok = (in_range && G.min_match_len >= 4 && G.min_match_len <= cl && G.min_match_len <= 63 && cl <= 64) ? 1 : 0;
             for (int d = 0; d < 2 && G.bits_ok; ++d)
                 for (int c = 0; c < cl; ++c) {
                     const char *k = strchr("ACGT", (char)G.seq[d][c]);

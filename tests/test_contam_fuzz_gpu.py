@@ -149,3 +149,29 @@ def test_contam_fuzz(i):
     assert_same(p, got, want, paired)
     if not kw.get("contam_trim"):                           # ... and the screen did see contaminated reads
         assert int(want["sum"][abi.FS_CONTAM]) + int(want["sum"][abi.FS_GCONTAM]) > 0
+
+
+@pytest.mark.parametrize("i", range(10))
+def test_global_contaminants_outside_the_event_walk_range(i):
+    """glob_cotm_mM above 4, or a match length not above the mismatch number -- settings the reference accepts
+    and whose score arithmetic lets "dead" windows pass the hit test: the kernels walk the lays cell by cell there
+    (gc_lay_cells); HIP vs oracle on both kernels, and the oracle's matcher itself is pinned on the compiled reference for
+    the same settings by tests/test_oracle_vs_ref.py::test_contam_matchers_fuzz."""
+    rng = np.random.default_rng(6600 + i)
+    L, paired = (150, True) if i % 2 == 0 else (100, False)
+    gs, mrs, mms = [], [], []
+    for _ in range(int(rng.integers(1, 3))):
+        g = random_contam(rng, 10, 48)
+        mr = float(rng.choice([0.1, 0.2, 0.3, 0.5]))
+        mml = int(np.float32(len(g)) * np.float32(mr))
+        mm = int(rng.integers(5, 9)) if rng.random() < 0.5 else int(rng.integers(mml, mml + 3))
+        gs.append(g), mrs.append(str(mr)), mms.append(str(mm))
+    kw = dict(global_contams=",".join(gs), g_mrs=",".join(mrs), g_mms=",".join(mms))
+    d = synth.make_batch(6000, L, paired=paired, var_len=bool(i % 3), seed=6700 + i)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    for m in range(2 if paired else 1):
+        plant(rng, d["seq"][m], d["len"][m], L, gs + [g.encode().translate(comp)[::-1].decode() for g in gs], 0.3)
+    p = abi.default_params(paired=paired, max_read_len=L, **kw)
+    want = T.run_oracle(p, d)
+    for kernel in (2, 1):
+        assert_same(p, run_hip_device(p, d, kernel, chunks=2), want, paired)

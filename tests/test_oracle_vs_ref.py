@@ -138,7 +138,9 @@ def test_contam_matchers_fuzz():
         a = o.snk_oracle_has_contam(bytes(read), rl, contam, cl, thr, mis, edge)
         b = r.snkref_has_contam(bytes(read), rl, contam, cl, mr, mis, edge)
         assert a == b, ("hasContam", cl, rl, mr, mis, edge, mode)
-        gmr, mm = float(np.float32(rng.choice([0.3, 0.5, 0.7, 0.2]))), int(rng.integers(0, 3))
+        # (it % 3 == 2: settings outside the kernels' event walk -- more than 4 mismatches, or a match length not above the
+        # mismatch number -- where the reference lets dead windows pass its hit test)
+        gmr, mm = float(np.float32(rng.choice([0.3, 0.5, 0.7, 0.2, 0.1]))), int(rng.integers(0, 3) if it % 3 != 2 else rng.integers(3, 9))
         a = o.snk_oracle_global_contam_pos(bytes(read), rl, contam, cl, gmr, mm)
         b = r.snkref_global_contam_pos(bytes(read), rl, contam, cl, gmr, mm)
         assert a == b, ("global_contam_pos", cl, rl, gmr, mm, mode)
