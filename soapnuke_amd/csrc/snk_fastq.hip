@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const u32 *in, u64 n, c
 // out[0 .. n] = exclusive scan of in[0 .. n); tmp: n / 1024 + 2 words; in == out is allowed
 void launch_scan(const u32 *in, u64 n, u32 *out, u32 *tmp, hipStream_t s) {
     const u32 nb = (u32)((n + SCAN_BLK - 1) / SCAN_BLK);
-    if (n == 0) { hipMemsetAsync(out, 0, sizeof(u32), s); return; }
+    if (n == 0) { (void)hipMemsetAsync(out, 0, sizeof(u32), s); return; }
     hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(256), 0, s, in, n, tmp);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, s, tmp, nb);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, s, in, n, (const u32 *)tmp, out);
@@ -318,7 +318,7 @@ int snk_fastq_format_device(const uint8_t *d_text, const uint32_t *d_line, const
     F.bc_from = fmt->base_from;
     F.bc_to = fmt->base_to;
     hipStream_t s = (hipStream_t)stream;
-    if (n == 0) { hipMemsetAsync(d_out_off, 0, sizeof(u32), s); return SNK_OK; }
+    if (n == 0) { (void)hipMemsetAsync(d_out_off, 0, sizeof(u32), s); return SNK_OK; }
     hipLaunchKernelGGL(fq_outlen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const u32 *)d_line, d_keep, d_rec, (long)n, F, d_out_off);
     launch_scan(d_out_off, (u64)n, d_out_off, (u32 *)d_tmp, s);
     const long waves = n < 256 * 4 * 8 ? (long)((n + 3) / 4 * 4) : 256L * 4 * 8;

@@ -455,6 +455,15 @@ static int build_ctx(snk_ctx *c) {
     HIP_OK(hipMemset(c->d_sum, 0, c->sum_u64 * sizeof(uint64_t)));
     HIP_OK(hipMemset(c->d_max, 0, SNK_MAX_N * sizeof(uint64_t)));
     HIP_OK(hipMemset(c->d_err, 0xFF, sizeof(uint64_t)));
+    if ((n_ct[0] | n_ct[1] | n_gct) && D.tile_ok) {
+        // contaminant verdicts of the tiled path: one buffer per launching stream slot, sized for a usual batch up front so
+        // that the launch path does not allocate (it still grows a slot on demand for larger batches)
+        for (int k = 0; k < 2; ++k) {
+            const size_t cap = (size_t)1 << 20;
+            HIP_OK(hipMalloc((void **)&c->d_cf[k], cap));
+            c->cf_cap[k] = cap;
+        }
+    }
     HIP_OK(hipMalloc(&c->d_tsw, (size_t)8 * c->n_cu * 4 * SNK_TS_N * sizeof(unsigned)));
     HIP_OK(hipMemset(c->d_tsw, 0, (size_t)8 * c->n_cu * 4 * SNK_TS_N * sizeof(unsigned)));
 
@@ -613,6 +622,7 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
     D.out[1] = d_out2;
     DevStats st{c->d_sum, c->d_max, c->d_err, c->d_tsw};
     hipStream_t s = (hipStream_t)stream;
+    if (kernel < 0 || kernel > 3) { set_err("snk_filter_batch_device: kernel must be 0..3"); return SNK_E_PARAM; }     // (before a timing event pair is taken)
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (c->timing) {
         if (!c->ev_free.empty()) { ev = c->ev_free.back(); c->ev_free.pop_back(); }
@@ -620,7 +630,8 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         HIP_OK(hipEventRecord(ev.first, s));
     }
     int done = 0;
-    if (kernel < 0 || kernel > 3) { set_err("snk_filter_batch_device: kernel must be 0..3"); return SNK_E_PARAM; }
+    // every exit below this line hands the timing event pair back
+    auto fail = [&](int rc) { if (c->timing && ev.first) c->ev_free.push_back(ev); return rc; };
     if (kernel == 0 || kernel == 2) {
         int slot = -1;
         for (int k = 0; k < 8 && slot < 0; ++k) if (c->ts_used[k] && c->ts_stream[k] == stream) slot = k;
@@ -651,7 +662,7 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         D.cf = nullptr;
         // reads of 257..1024 positions: the block-wise bit-sliced path (snk_long.hip); it writes the stats block directly
         if (!done) done = snk_launch_long(c->d_params, c->hp, c->ta, D, DevStats{c->d_sum, c->d_max, c->d_err, c->d_tsw}, c->lcap, c->nq, c->n_cu, stream);
-        if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return SNK_E_UNSUPPORTED; }
+        if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return fail(SNK_E_UNSUPPORTED); }
     }
     if (!done) {
         // the generic kernel decides; the per-position histograms come from the LDS histogram kernel behind it (kernel == 3:
@@ -663,7 +674,7 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         snk_launch_generic(c->d_params, D, st, c->lcap, c->nq, split ? 0 : 1, stream);
         if (split && !snk_launch_hist(c->d_params, c->p.paired ? 1 : 0, D, gst, c->lcap, c->nq, c->n_cu, stream)) {
             set_err("snk_filter_batch_device: histogram kernel refused the batch");
-            return SNK_E_UNSUPPORTED;
+            return fail(SNK_E_UNSUPPORTED);
         }
     }
     if (c->timing) { HIP_OK(hipEventRecord(ev.second, s)); c->ev_pending.push_back(ev); }
@@ -850,6 +861,6 @@ int snk_selftest_bit_transpose(int device, const uint32_t *in, int n_matrices, u
     if (snk_launch_bittr_selftest(d_in, n_matrices, d_out, d_lo) != 0) { set_err("bit transpose self-test: launch failed"); return SNK_E_HIP; }
     HIP_OK(hipMemcpy(out, d_out, nb, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(out_lo, d_lo, nb / 2, hipMemcpyDeviceToHost));
-    hipFree(d_in); hipFree(d_out); hipFree(d_lo);
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_lo);
     return SNK_OK;
 }

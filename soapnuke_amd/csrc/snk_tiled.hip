@@ -2,19 +2,18 @@
 //
 // One wavefront owns a tile of 64 read pairs and walks it in three phases and a hand-over:
 //
-//  phase 1  lane = read POSITION.  The tile's read bytes arrive in LDS by DMA
-//           (global_load_lds, 16 B/lane, next chunk in flight); per read the wave reads
-//           its 64-position strips one read ahead, adds the raw per-position quality
-//           histogram into LDS (lane l owns positions l, l+64, ... so the adds of one
-//           instruction never collide), and shifts one bit per read into four collector
-//           registers per strip: bits 1 and 2 of the character (its 2-bit code), "is exactly
-//           A/C/G/T" and "quality <= lowQual" (v_alignbit on bit 0 or on the sign of a
-//           difference).  LDS reads / adds / waits are hand-placed asm.
-//  hand-over  After 64 reads every lane holds, per strip and plane, 64 bits over the reads of
-//           the tile.  Their popcounts ARE the raw base histogram of the lane's position
-//           (one LDS add per letter, strip and tile), and one 64 x 64 bit-matrix transpose
-//           per strip and plane (snk_bittr.cuh: v_permlane32/16_swap + DPP) turns them into
-//           the per-read bit planes of phase 2.
+//  phase 1  The tile's read bytes arrive in LDS by DMA (global_load_lds, 16 B/lane, next chunk in flight).  Per read
+//           the wave reads its row twice: as dwords -- lane l holds bases and qualities 4l..4l+3, and every predicate is
+//           evaluated on the four bytes at once and shifted into packed collectors (2-bit character codes, "quality above
+//           lowQual", in the FULL variant "quality >= the low-quality-end thresholds" and the byte sums of the mean-quality
+//           filter by v_sad_u8; a per-READ flag "some character is not the letter of its code" travels through the carry)
+//           -- and as bytes, lane = position, one 64-position strip per instruction, for the raw per-position quality
+//           histogram in LDS (lane l owns positions l, l+64, ...: the adds of one instruction never collide).  The
+//           collectors are parked every 4 / 8 reads.  LDS reads / adds / waits are hand-placed asm, two reads ahead.
+//  hand-over  The parked dwords hold, per byte, the bits of 8 (codes: 4) reads at one position.  Byte transposes + wide
+//           LDS writes/reads give every lane = position its 64 read bits per plane; their popcounts ARE the raw base
+//           histogram of the position (one LDS add per letter, strip and tile), and 64 x 64 bit-matrix transposes
+//           (snk_bittr.cuh: v_permlane32/16_swap + DPP) turn them into the per-read bit planes of phase 2.
 //  phase 2  lane = READ.  Each lane now holds its read as bit planes (one bit per
 //           position).  Adapter search (src/read_filter.cpp:707-790) runs bit-sliced over
 //           all candidate offsets at once: for the first S-1 adapter characters (S =
