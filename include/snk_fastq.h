@@ -77,6 +77,17 @@ int snk_fastq_format_device(const uint8_t *d_text, const uint32_t *d_line, const
                             const snk_read_result *d_rec, int64_t n, const snk_fastq_format *fmt, uint8_t *d_out,
                             uint32_t *d_out_off, void *d_tmp, size_t tmp_bytes, void *stream);
 
+/* gzip members of a clean text, made on the device (the reference compresses its clean files with zlib level 2, one gzip
+ * member per thread part: src/peprocess.cpp:1809, 2386; the compressed bytes are not part of the contract, the text is).
+ * d_text / d_off[n + 1]: the text and record offsets snk_fastq_format_device() wrote (any text cut into records will do).
+ * Every `records_per_member` records (a power of two, at most 1024) become one gzip member -- one dynamic-Huffman deflate block
+ * whose code is built from the symbol counts of the whole call, CRC-32 and ISIZE in the trailer -- and the members are
+ * concatenated in d_gz[0, d_info[0]).  d_info (uint32_t[4]): [0] total bytes, [1] members, [2] non-zero when gz_cap was too
+ * small (nothing usable was written: compress on the host).  d_gz: 4-byte aligned, gz_cap < 2^32; it is zeroed by the call. */
+size_t snk_fastq_deflate_tmp_bytes(int64_t max_records, int32_t records_per_member);
+int snk_fastq_deflate_device(const uint8_t *d_text, const uint32_t *d_off, int64_t n, int32_t records_per_member, uint8_t *d_gz,
+                             uint64_t gz_cap, uint32_t *d_info, void *d_tmp, size_t tmp_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

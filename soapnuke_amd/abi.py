@@ -186,6 +186,7 @@ EXPORTS = [
     "snk_selftest_bit_transpose",
     # include/snk_fastq.h
     "snk_fastq_tmp_bytes", "snk_fastq_parse_device", "snk_fastq_format_device",
+    "snk_fastq_deflate_tmp_bytes", "snk_fastq_deflate_device",
 ]
 
 
@@ -233,4 +234,7 @@ def load_library(path=None):
     lib.snk_fastq_tmp_bytes.restype = C.c_size_t
     lib.snk_fastq_parse_device.argtypes = [vp, C.c_uint64, C.c_int64, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.snk_fastq_format_device.argtypes = [vp, vp, vp, vp, C.c_int64, C.POINTER(FastqFormat), vp, vp, vp, C.c_size_t, vp]
+    lib.snk_fastq_deflate_tmp_bytes.argtypes = [C.c_int64, i32]
+    lib.snk_fastq_deflate_tmp_bytes.restype = C.c_size_t
+    lib.snk_fastq_deflate_device.argtypes = [vp, vp, C.c_int64, i32, vp, C.c_uint64, vp, vp, C.c_size_t, vp]
     return lib

@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsnk_filter.so")
-SOURCES = ["snk_filter.cpp", "snk_generic.hip", "snk_tiled.hip", "snk_rmdup.hip", "snk_contam.hip", "snk_long.hip", "snk_fastq.hip"]
+SOURCES = ["snk_filter.cpp", "snk_generic.hip", "snk_tiled.hip", "snk_rmdup.hip", "snk_contam.hip", "snk_long.hip", "snk_fastq.hip", "snk_gzip.hip"]
 HEADERS = ["snk_device.h", "snk_common.cuh", "snk_bittr.cuh", "snk_adapter_bits.cuh", os.path.join("..", "..", "include", "snk_filter.h"),
            os.path.join("..", "..", "include", "snk_rmdup.h"), os.path.join("..", "..", "include", "snk_selftest.h"), os.path.join("..", "..", "include", "snk_fastq.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

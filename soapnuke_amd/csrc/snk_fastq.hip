@@ -261,6 +261,11 @@ inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
+// the scan, for snk_gzip.hip
+void snk_fq_launch_scan(const unsigned *in, unsigned long long n, unsigned *out, unsigned *tmp, void *stream) {
+    launch_scan(in, n, out, tmp, (hipStream_t)stream);
+}
+
 extern "C" {
 
 size_t snk_fastq_tmp_bytes(uint64_t max_bytes, int64_t max_records) {

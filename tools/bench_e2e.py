@@ -68,6 +68,7 @@ def make_inputs(tmp, n, modes):
 
 
 C3 = False      # --c3: BASELINE configs[2] parameters (full trim + filter) instead of configs[1]'s
+EXTRA_CFG = []  # more config-file lines (tools/bench_e2e_big.py: rmdup)
 
 
 REPORTS = ["Statistics_of_Filtered_Reads.txt", "Basic_Statistics_of_Sequencing_Quality.txt"] + [
@@ -77,11 +78,11 @@ REPORTS = ["Statistics_of_Filtered_Reads.txt", "Basic_Statistics_of_Sequencing_Q
 
 def run(exe, inputs, out_dir, ext, threads, env=None):
     args = ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-l", "10", "-q", "0.1", "-T", str(threads)]
-    if C3:
+    if C3 or EXTRA_CFG:
         cfg = os.path.join(os.path.dirname(inputs[0]), "c3.cfg")
         with open(cfg, "w") as fh:
-            fh.write("trimBadTail=20,30\n")
-        args += ["-n", "0.01", "-m", "20", "-g", "10", "-X", "50", "-p", "0.8", "-c", cfg]
+            fh.write("".join(x + "\n" for x in (["trimBadTail=20,30"] if C3 else []) + list(EXTRA_CFG)))
+        args += (["-n", "0.01", "-m", "20", "-g", "10", "-X", "50", "-p", "0.8"] if C3 else []) + ["-c", cfg]
     t0 = time.time()
     r = subprocess.run([exe, "filter", "-1", inputs[0], "-2", inputs[1], "-C", "c1" + ext, "-D", "c2" + ext, "-o", out_dir] + args,
                        capture_output=True, env=env)

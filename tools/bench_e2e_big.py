@@ -2,7 +2,10 @@
 (VERDICT r2 task 1 ii): `.gz -> .gz`, full trim + filter parameters, this repo's CLI and the compiled reference binary on
 the same files in /dev/shm, ALL ten report files and the md5 of the decompressed clean FASTQ compared.
 
-    python tools/bench_e2e_big.py [pairs=256000000] [threads=16]
+    python tools/bench_e2e_big.py [pairs=256000000] [threads=16] [--len 250] [--rmdup] [--dup 0.05]
+
+--len 250 --rmdup: BASELINE configs[4]'s shape (PE250, configs[1] parameters + config key `rmdup`; --dup: fraction of pairs that
+repeat an earlier pair of the same million), where the dupReads.<thread>.<mate>.gz side files are compared as well.
 
 Inputs are written as multi-member gzip (one member per million pairs, compressed by a pool of `gzip -1` processes: a
 single `gzip` stream of 85 GB takes 15 minutes on its own); nothing plain is kept.  Prints one JSON object, also written
@@ -38,15 +41,31 @@ def md5_gz(path):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256_000_000
-    T = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    opt = sys.argv[1:]
+    L = int(opt[opt.index("--len") + 1]) if "--len" in opt else 150
+    rmdup = "--rmdup" in opt
+    dupf = float(opt[opt.index("--dup") + 1]) if "--dup" in opt else 0.05
+    argv = [a for a in argv if a not in (str(L), str(dupf))] if ("--len" in opt or "--dup" in opt) else argv
+    n = int(argv[0]) if len(argv) > 0 else 256_000_000
+    T = int(argv[1]) if len(argv) > 1 else 16
     tmp = tempfile.mkdtemp(prefix="snkbig_", dir="/dev/shm")
-    res = {"pairs": n, "read_len": 150, "threads_T": T, "host_cores": os.cpu_count(), "where": "/dev/shm",
-           "params": "-f/-r README adapters -J -l 10 -q 0.1 -n 0.01 -m 20 -g 10 -X 50 -p 0.8 + trimBadTail=20,30 (BASELINE configs[2])",
+    res = {"pairs": n, "read_len": L, "threads_T": T, "host_cores": os.cpu_count(), "where": "/dev/shm",
+           "params": ("-f/-r README adapters -J -l 10 -q 0.1 + config key rmdup (BASELINE configs[4] shape), %.0f %% duplicate pairs" % (100 * dupf)) if rmdup else
+                     "-f/-r README adapters -J -l 10 -q 0.1 -n 0.01 -m 20 -g 10 -X 50 -p 0.8 + trimBadTail=20,30 (BASELINE configs[2])",
            "inputs": "multi-member .gz, one member per 1 M pairs"}
     try:
         u = 1_000_000
-        d = synth.make_batch(u, 150, paired=True)
+        d = synth.make_batch(u, L, paired=True)
+        if rmdup:                                           # duplicates by sequence (qualities differ), as rmdup sees them
+            import numpy as np
+            rng = np.random.default_rng(11)
+            dst = rng.choice(u, int(u * dupf), replace=False)
+            src = rng.integers(0, u, len(dst))
+            for m in range(2):
+                d["seq"][m][dst] = d["seq"][m][src]
+        # (every million-pair member repeats the same reads under new names: with rmdup all members behind the first are duplicates
+        #  of it -- the marking table and the side files get real work)
         f = [os.path.join(tmp, "r1.fq.gz"), os.path.join(tmp, "r2.fq.gz")]
         t0 = time.time()
         parts = (n + u - 1) // u
@@ -54,7 +73,7 @@ def main():
         def make(k, m):
             part = os.path.join(tmp, f"p{m}.{k}.fq")
             cnt = min(u, n - k * u)
-            synth.write_fastq(part, d["seq"][m][:cnt], d["qual"][m][:cnt], 150, m + 1, first_index=k * u)
+            synth.write_fastq(part, d["seq"][m][:cnt], d["qual"][m][:cnt], L, m + 1, first_index=k * u)
             subprocess.check_call(["gzip", "-1", "-f", part])
             return part + ".gz"
 
@@ -74,7 +93,8 @@ def main():
                             os.unlink(p)
         res["generate_and_gzip_s"] = round(time.time() - t0, 1)
         res["input_gz_bytes"] = [os.path.getsize(x) for x in f]
-        bench_e2e.C3 = True
+        bench_e2e.C3 = not rmdup
+        bench_e2e.EXTRA_CFG = ["rmdup"] if rmdup else []
         entry = {}
         for name, exe in (("ours", bench_e2e.OURS), ("reference", bench_e2e.REF)):
             o = os.path.join(tmp, name)
@@ -94,6 +114,14 @@ def main():
                 md = {k: v.result() for k, v in jobs.items()}
             entry["clean_fastq_identical"] = all(md[("ours", c)] == md[("reference", c)] for c in ("c1", "c2"))
             entry["clean_bytes"] = [md[("ours", c)][1] for c in ("c1", "c2")]
+            if rmdup:
+                names = sorted(x for x in os.listdir(os.path.join(tmp, "reference")) if x.startswith("dupReads."))
+                with cf.ThreadPoolExecutor(max_workers=8) as ex:
+                    dj = {(who, x): ex.submit(md5_gz, os.path.join(tmp, who, x)) for who in ("ours", "reference") for x in names}
+                    dm = {k: v.result() for k, v in dj.items()}
+                entry["dup_side_files"] = len(names)
+                entry["dup_side_files_identical"] = all(dm[("ours", x)] == dm[("reference", x)] for x in names)
+                entry["dup_side_bytes"] = sum(dm[("ours", x)][1] for x in names)
             # the rows where the reference's data_num * 9 wrapped (more than 238.6 M reads in a per-position bin set): keep one as evidence
             q = open(os.path.join(tmp, "ours", "Base_quality_value_distribution_by_read_position_1.txt")).read().splitlines()
             entry["quality_row_position_1"] = q[2][-80:] if len(q) > 2 else None
@@ -101,7 +129,7 @@ def main():
     finally:
         subprocess.call(["rm", "-rf", tmp])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"e2e_big_{n}.json"), "w") as fh:
+    with open(os.path.join(ROOT, "gpurun_out", f"e2e_big_{n}{'_L%d_rmdup' % L if rmdup else ''}.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps(res))
 
