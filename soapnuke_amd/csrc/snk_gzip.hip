@@ -193,30 +193,48 @@ __global__ void __launch_bounds__(256) dfl_hist_kernel(const uint8_t *text, cons
     if (threadIdx.x < NDIST && dh[threadIdx.x]) atomicAdd(&C->dist_hist[threadIdx.x], dh[threadIdx.x]);
 }
 
-// ---- Huffman code lengths of up to 288 symbols by one wavefront: nodes in LDS, the two lightest live nodes by wave argmin
+// ---- Huffman code lengths of up to 288 symbols by one wavefront.  The leaves are sorted by rank counting (every lane counts the
+// keys below its own: n * n / 64 compares), lane 0 merges with the two-queue method (leaves ascending, internal nodes in the order
+// they were made: both queues are sorted, the two lightest nodes are at their fronts), the depths are read off in parallel.
+// Lengths above `maxbits`: the counts are halved (rounding up) and the tree rebuilt; a floor of total / 2^(maxbits - 2) under the
+// counts makes the first tree fit in practice (a FASTQ batch has a few symbols with 10^7 occurrences and 250 with none).
 __device__ void wave_huff_lengths(const u32 *cnt, int n, int maxbits, u32 *len_out, u32 *w, int *par, u32 *scale_buf) {
     const int lane = threadIdx.x & 63;
-    for (int k = lane; k < n; k += 64) scale_buf[k] = cnt[k];
+    u32 *sorted = scale_buf + 288;                        // leaf indices by ascending weight
+    {
+        u64 tot = 0;
+        for (int k = lane; k < n; k += 64) tot += cnt[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 64);
+        const u32 floor_ = (u32)(tot >> (maxbits - 2)) + 1u;
+        for (int k = lane; k < n; k += 64) scale_buf[k] = cnt[k] > floor_ ? cnt[k] : floor_;
+    }
     __syncthreads();
     for (;;) {
-        for (int k = lane; k < 2 * n; k += 64) { w[k] = k < n ? scale_buf[k] : 0u; par[k] = -1; }
-        __syncthreads();
-        int live_hi = n;                                  // nodes [0, live_hi) exist; a node is live while it has no parent
-        for (int it = 0; it < n - 1; ++it) {
-            // the two lightest live nodes (ties: the lower index)
-            int a = -1, b = -1;
-            for (int pass = 0; pass < 2; ++pass) {
-                u64 best = ~0ull;
-                for (int k = lane; k < live_hi; k += 64)
-                    if (par[k] < 0 && k != a) { const u64 key = ((u64)w[k] << 32) | (u32)k; best = key < best ? key : best; }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) { const u64 x = __shfl_xor(best, o, 64); best = x < best ? x : best; }
-                if (pass == 0) a = (int)(u32)best; else b = (int)(u32)best;
-            }
-            if (lane == 0) { w[live_hi] = w[a] + w[b]; par[a] = live_hi; par[b] = live_hi; }
-            ++live_hi;
-            __syncthreads();
+        for (int k = lane; k < n; k += 64) {
+            const u64 key = ((u64)scale_buf[k] << 9) | (u32)k;
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += ((((u64)scale_buf[j] << 9) | (u32)j) < key) ? 1 : 0;
+            sorted[rank] = (u32)k;
         }
+        for (int k = lane; k < 2 * n; k += 64) par[k] = -1;
+        __syncthreads();
+        if (lane == 0) {
+            int lf = 0, in_f = n, in_b = n;               // leaf queue front; internal nodes [in_f, in_b) live in w[] / par[] at n..
+            auto take = [&]() -> int {                    // the lighter of the two fronts (ties: the leaf)
+                const bool have_leaf = lf < n, have_in = in_f < in_b;
+                if (have_leaf && (!have_in || scale_buf[sorted[lf]] <= w[in_f])) return (int)sorted[lf++];
+                return in_f++;
+            };
+            for (int it = 0; it < n - 1; ++it) {
+                const int x = take(), y = take();
+                w[in_b] = (x < n ? scale_buf[x] : w[x]) + (y < n ? scale_buf[y] : w[y]);
+                par[x] = in_b;
+                par[y] = in_b;
+                ++in_b;
+            }
+        }
+        __syncthreads();
         u32 mx = 0;
         for (int k = lane; k < n; k += 64) {
             u32 d = 0;
@@ -245,7 +263,7 @@ __device__ void canon_codes(const u32 *len, int n, u32 *code) {
 }
 
 __global__ void __launch_bounds__(64) dfl_build_kernel(DfCode *C) {
-    __shared__ u32 w[2 * 288], scale_buf[288], cnt[288], cl_len[NCL], cl_code[NCL];
+    __shared__ u32 w[2 * 288], scale_buf[2 * 288], cnt[288], cl_len[NCL], cl_code[NCL];
     __shared__ int par[2 * 288];
     const int lane = threadIdx.x;
     // every symbol gets a code (a later batch position may need any of them): counts + 1

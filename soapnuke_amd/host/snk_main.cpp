@@ -2161,6 +2161,8 @@ int main(int argc, char **argv) {
     // everything is on disk: the process image goes away as a whole (unpinning and freeing a GB buffer by buffer, then the
     // runtime's own exit handlers, is a tenth of a second of a short run)
     for (auto &t : slot_makers) t.join();
+    slot_makers.clear();
+    if (getenv("SNK_CLEAN_EXIT")) { teardown(); return 0; }      // (profilers collect their data in exit handlers)
     log.flush();
     log.close();
     cout.flush();

@@ -64,15 +64,37 @@ def main():
             src = rng.integers(0, u, len(dst))
             for m in range(2):
                 d["seq"][m][dst] = d["seq"][m][src]
-        # (every million-pair member repeats the same reads under new names: with rmdup all members behind the first are duplicates
-        #  of it -- the marking table and the side files get real work)
+
         f = [os.path.join(tmp, "r1.fq.gz"), os.path.join(tmp, "r2.fq.gz")]
         t0 = time.time()
         parts = (n + u - 1) // u
 
+        import threading
+        lock, blocks = threading.Lock(), {}
+
+        def block(k):                                       # rmdup: every million pairs its own reads (duplicates only inside it)
+            if not rmdup:
+                return d
+            with lock:
+                if k not in blocks:
+                    import numpy as np
+                    b = synth.make_batch(u, L, paired=True, seed=synth.SEED + 1 + k)
+                    rng = np.random.default_rng(11 + k)
+                    dst = rng.choice(u, int(u * dupf), replace=False)
+                    src = rng.integers(0, u, len(dst))
+                    for mm in range(2):
+                        b["seq"][mm][dst] = b["seq"][mm][src]
+                    blocks[k] = [b, 2]
+                e = blocks[k]
+                e[1] -= 1
+                if e[1] == 0:
+                    del blocks[k]
+                return e[0]
+
         def make(k, m):
             part = os.path.join(tmp, f"p{m}.{k}.fq")
             cnt = min(u, n - k * u)
+            d = block(k)
             synth.write_fastq(part, d["seq"][m][:cnt], d["qual"][m][:cnt], L, m + 1, first_index=k * u)
             subprocess.check_call(["gzip", "-1", "-f", part])
             return part + ".gz"
