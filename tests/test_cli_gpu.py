@@ -649,3 +649,26 @@ def test_cli_adapter_list_files_of_any_length(tmp_path):
     ref = R.run_reference_cli(case, d, work, gz_input=True)
     ours = _run_ours(case, work, gz=False)
     _compare_dirs(ours, ref, True)
+
+
+def test_cli_device_gzip_and_its_host_fallback(tmp_path):
+    """.gz output of device-text mode: gzip members made on the device (default), by the host encoder (SNK_HOST_DEFLATE=1), and the
+    fallback when the members do not fit their buffer (forced with SNK_GZ_CAP_TEST=1) -- `gzip -t` accepts all three (CRC-32 and
+    ISIZE of every member), the decompressed bytes are the reference's."""
+    case = R.REPORT_CASES[1]
+    d, p = R.case_inputs(case)
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    name, paired, L, n, threads, patch, skw, pkw, cli, cfg = case
+    sizes = {}
+    for tag, extra in (("dev", {}), ("host", {"SNK_HOST_DEFLATE": "1"}), ("fallback", {"SNK_GZ_CAP_TEST": "1"})):
+        out = os.path.join(work, tag)
+        cmd = [CLI, "filter", "-1", os.path.join(work, "r1.fq.gz"), "-2", os.path.join(work, "r2.fq.gz"), "-C", "c1.fq.gz", "-D", "c2.fq.gz", "-o", out,
+               "-T", str(threads), "-c", os.path.join(work, "cfg")]
+        r = subprocess.run(cmd + cli, capture_output=True, env=dict(os.environ, SNK_BATCH_PAIRS="8192", **extra))
+        assert r.returncode == 0, (tag, r.stderr[-400:])
+        for c in ("c1.fq", "c2.fq"):
+            assert subprocess.run(["gzip", "-t", os.path.join(out, c + ".gz")]).returncode == 0, (tag, c)
+            assert _cat(os.path.join(out, c + ".gz")) == _cat(os.path.join(ref, c)), (tag, c)
+        sizes[tag] = os.path.getsize(os.path.join(out, "c1.fq.gz"))
+    assert sizes["dev"] < 1.10 * sizes["host"], sizes
