@@ -1216,6 +1216,28 @@ bool rccl_allreduce_blocks(const std::vector<int> &devices, const std::function<
     return true;
 }
 
+// bytes the rmdup pre-pass may keep of the inflated input for the main pass (SNK_RMDUP_CACHE_GB, else 40 % of what the host /
+// the cgroup has available)
+size_t rmdup_cache_budget() {
+    if (const char *e = getenv("SNK_RMDUP_CACHE_GB")) return (size_t)(atof(e) * 1073741824.0);
+    double avail = 0;
+    if (FILE *f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) { unsigned long long kb; if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) avail = (double)kb * 1024.0; }
+        fclose(f);
+    }
+    if (FILE *f = fopen("/sys/fs/cgroup/memory.max", "r")) {
+        char a[64] = "";
+        if (fscanf(f, "%63s", a) == 1 && strcmp(a, "max") != 0 && atof(a) > 0) {
+            double lim = atof(a), used = 0;
+            if (FILE *g = fopen("/sys/fs/cgroup/memory.current", "r")) { char b[64]; if (fscanf(g, "%63s", b) == 1) used = atof(b); fclose(g); }
+            if (avail == 0 || lim - used < avail) avail = lim - used;
+        }
+        fclose(f);
+    }
+    return avail > 0 ? (size_t)(avail * 0.4) : 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -1493,6 +1515,10 @@ int main(int argc, char **argv) {
         uint64_t nall = 0;
         RawChunk *c[2] = {first[0], first[1]};
         bool have = true;
+        std::vector<RawChunk *> cached[2];
+        size_t cache_bytes = 0;
+        const size_t cache_budget = rmdup_cache_budget();
+        bool cache_on = cache_budget > 0 && is_gzip_file(inputs[0]);
         HIPCHK(hipSetDevice(devs[0].id));                   // the pre-pass runs on the first device (1 ms of kernel per 10 M pairs)
         snk_ctx *ctx = devs[0].ctx;
         while (have) {
@@ -1526,7 +1552,17 @@ int main(int argc, char **argv) {
             chunks.push_back(dh);
             chunk_n.push_back(s.n);
             nall += (uint64_t)s.n;
-            for (int m = 0; m < mates; ++m) RawChunk::put(c[m]);
+            // .gz input: the inflated batches are kept for the main pass as long as they fit the budget (the reference reads and
+            // inflates its input twice with rmdup, src/peprocess.cpp:3071-3152; here the second inflate is the larger half of the run)
+            if (cache_on) {
+                for (int m = 0; m < mates; ++m) { cached[m].push_back(c[m]); cache_bytes += c[m]->own_cap + (c[m]->ls.capacity() + c[m]->le.capacity()) * 4; }
+                if (cache_bytes > cache_budget) {
+                    cache_on = false;
+                    for (int m = 0; m < mates; ++m) { for (RawChunk *q : cached[m]) RawChunk::put(q); cached[m].clear(); }
+                }
+            } else {
+                for (int m = 0; m < mates; ++m) RawChunk::put(c[m]);
+            }
             have = next_chunks(c);
         }
         join_readers();
@@ -1572,8 +1608,16 @@ int main(int argc, char **argv) {
         slot_makers.clear();
         for (Dev &d : devs) for (Slot &sl : d.slots) for (int m = 0; m < mates; ++m) memset(sl.h_seq[m], 0, plane);
         for (Dev &d : devs) for (Slot &sl : d.slots) { sl.raw[0] = sl.raw[1] = nullptr; }
-        // second pass over the input
-        start_readers();
+        // second pass over the input: from the kept batches, or through the readers again
+        if (cache_on && !cached[0].empty()) {
+            log << local_time() << "\trmdup: " << cached[0].size() << " inflated batches kept for the main pass (" << (cache_bytes >> 20) << " MB)" << endl;
+            for (int m = 0; m < mates; ++m) {
+                chan[m].reset(new Channel<RawChunk *>(2));
+                readers.emplace_back([&, m, list = std::move(cached[m])] { for (RawChunk *q : list) chan[m]->push(q); chan[m]->close(); });
+            }
+        } else {
+            start_readers();
+        }
         if (!next_chunks(first)) die("no data");
     }
 
