@@ -62,11 +62,13 @@ typedef struct snk_fastq_format {
     char    id_suffix[4];       /* NUL-terminated, at most 3 characters */
     uint8_t base_from, base_to; /* baseConvert: every base whose upper case is `base_from` becomes `base_to`; 0 = off
                                    (src/peprocess.cpp:1629-1646) */
-    uint8_t pad_[2];
+    uint8_t select_reason;      /* the records written are those with d_keep[i].reason == select_reason (0 = SNK_KEEP: the clean text) */
+    uint8_t whole_read;         /* non-zero: the whole sequence / quality lines, not the kept range (with select_reason =
+                                   SNK_R_DUP: C_fastq::toString of the raw duplicates, src/peprocess.cpp:1541) */
 } snk_fastq_format;
 
-/* Clean text of one mate: for every record i with d_keep[i].reason == SNK_KEEP (the pair verdict sits in both mates'
- * records; pass mate 1's),
+/* Clean text of one mate: for every record i with d_keep[i].reason == fmt->select_reason (SNK_KEEP; the pair verdict sits
+ * in both mates' records; pass mate 1's),
  *      <id line><suffix...>\n<seq[clean_start, +clean_len)>\n+\n<qual[clean_start, +clean_len) + qual_delta>\n
  * with clean_start / clean_len from d_rec[i] (this mate's records), appended in input order.
  *   d_out_off[n + 1]  offset of record i's text in d_out (records that are not kept have length 0); d_out_off[n] =

@@ -49,6 +49,21 @@ int snk_rmdup_bucket_count_device(snk_ctx *ctx, const uint64_t *d_hash, int64_t 
 int snk_rmdup_mark_device(snk_ctx *ctx, const uint64_t *d_hash, const uint32_t *d_index, int64_t n,
                           uint64_t total_n, int64_t sentinel_bucket_total, uint8_t *d_dup, void *stream);
 
+/* ---- one pass (round 3).  "An equal hash at an earlier index" only needs the reads in front, so the marking can follow the
+ * input batch by batch with a hash table that lives across the calls -- no pre-pass over the whole input, which the reference
+ * needs for its sort-free bucket scheme (src/peprocess.cpp:3071-3152 reads and inflates everything twice).
+ * snk_rmdup_stream_mark_device(): inserts the n hashes of a batch (global indices first_index + i) and writes
+ * d_dup[i] = 1 iff the hash was seen at a smaller index (in an earlier call or in this one).  Calls must be issued in input
+ * order; they are asynchronous on `stream`, and a call on another stream than the previous one waits for it on the device.
+ * The table grows by itself (all hashes stay resident, 8 B per pair).  The reference's (uint64_t)-1 sentinel quirk depends
+ * on the total number of reads: snk_rmdup_stream_stats() reports whether such a hash occurred (the caller then has to fall
+ * back to the two-pass calls above) together with the number of duplicates marked so far.                                  */
+typedef struct snk_rmdup_stream snk_rmdup_stream;
+snk_rmdup_stream *snk_rmdup_stream_create(snk_ctx *ctx, uint64_t expected_pairs);
+int snk_rmdup_stream_mark_device(snk_rmdup_stream *t, const uint64_t *d_hash, uint64_t first_index, int64_t n, uint8_t *d_dup, void *stream);
+int snk_rmdup_stream_stats(snk_rmdup_stream *t, uint64_t *n_marked, int32_t *sentinel_seen);     /* synchronises */
+void snk_rmdup_stream_destroy(snk_rmdup_stream *t);
+
 /* rmdup::getPrime(n) (host helper; 0 for n == 0 where the reference exits with "code error") */
 uint32_t snk_rmdup_prime(uint64_t n);
 

@@ -182,6 +182,7 @@ EXPORTS = [
     "snk_stats_fetch", "snk_error_peek_async", "snk_error_decode", "snk_stats_allreduce", "snk_set_timing", "snk_last_kernel_ms",
     # include/snk_rmdup.h
     "snk_rmdup_hash_device", "snk_rmdup_bucket_count_device", "snk_rmdup_mark_device", "snk_rmdup_prime",
+    "snk_rmdup_stream_create", "snk_rmdup_stream_mark_device", "snk_rmdup_stream_stats", "snk_rmdup_stream_destroy",
     # include/snk_selftest.h
     "snk_selftest_bit_transpose",
     # include/snk_fastq.h
@@ -192,7 +193,7 @@ EXPORTS = [
 
 class FastqFormat(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("space_num", C.c_int32), ("qual_delta", C.c_int32), ("id_suffix_times", C.c_int32),
-                ("id_suffix", C.c_char * 4), ("base_from", C.c_uint8), ("base_to", C.c_uint8), ("pad_", C.c_uint8 * 2)]
+                ("id_suffix", C.c_char * 4), ("base_from", C.c_uint8), ("base_to", C.c_uint8), ("select_reason", C.c_uint8), ("whole_read", C.c_uint8)]
 
 
 FQ_STATUS_N, FQ_F_LEN_MISMATCH, FQ_F_TOO_LONG, FQ_F_TRUNCATED = 4, 1, 2, 4
@@ -229,6 +230,12 @@ def load_library(path=None):
     lib.snk_rmdup_mark_device.argtypes = [vp, vp, vp, C.c_int64, C.c_uint64, C.c_int64, vp, vp]
     lib.snk_rmdup_prime.argtypes = [C.c_uint64]
     lib.snk_rmdup_prime.restype = C.c_uint32
+    lib.snk_rmdup_stream_create.argtypes = [vp, C.c_uint64]
+    lib.snk_rmdup_stream_create.restype = vp
+    lib.snk_rmdup_stream_mark_device.argtypes = [vp, vp, C.c_uint64, C.c_int64, vp, vp]
+    lib.snk_rmdup_stream_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    lib.snk_rmdup_stream_destroy.argtypes = [vp]
+    lib.snk_rmdup_stream_destroy.restype = None
     lib.snk_selftest_bit_transpose.argtypes = [i32, vp, i32, vp, vp]
     lib.snk_fastq_tmp_bytes.argtypes = [C.c_uint64, C.c_int64]
     lib.snk_fastq_tmp_bytes.restype = C.c_size_t

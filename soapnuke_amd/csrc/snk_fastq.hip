@@ -202,12 +202,13 @@ struct FmtDev {
     int space_num, qual_delta, sfx_len, sfx_total;
     u32 sfx;                         // up to 3 suffix characters, byte k = character k
     u32 bc_from, bc_to;
+    u32 select, whole;
 };
 
 // kept range of a record as the host writer cuts it (clean_start / clean_len clamped to the line)
-__device__ __forceinline__ void kept_range(const snk_read_result &x, u32 slen, u32 &cs, u32 &cl) {
-    cs = min((u32)x.clean_start, slen);
-    cl = min((u32)x.clean_len, slen - cs);
+__device__ __forceinline__ void kept_range(const snk_read_result &x, u32 slen, u32 whole, u32 &cs, u32 &cl) {
+    cs = whole ? 0u : min((u32)x.clean_start, slen);
+    cl = whole ? slen : min((u32)x.clean_len, slen - cs);
 }
 
 __global__ void __launch_bounds__(256) fq_outlen_kernel(const u32 *line, const snk_read_result *keep, const snk_read_result *rec, long n,
@@ -215,11 +216,11 @@ __global__ void __launch_bounds__(256) fq_outlen_kernel(const u32 *line, const s
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 L = 0;
-    if (keep[i].reason == SNK_KEEP) {
+    if (keep[i].reason == F.select) {
         const u32 l0 = line[4 * i], l1 = line[4 * i + 1], l2 = line[4 * i + 2];
         const u32 ide = l1 > l0 + (u32)F.space_num ? l1 - (u32)F.space_num : l0, se = l2 > l1 + (u32)F.space_num ? l2 - (u32)F.space_num : l1;
         u32 cs, cl;
-        kept_range(rec[i], se - l1, cs, cl);
+        kept_range(rec[i], se - l1, F.whole, cs, cl);
         L = (ide - l0) + (u32)F.sfx_total + 1u + cl + 3u + cl + 1u;
     }
     out_len[i] = L;
@@ -230,13 +231,13 @@ __global__ void __launch_bounds__(256) fq_format_kernel(const uint8_t *text, con
     const int lane = threadIdx.x & 63;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     for (long r = wave; r < n; r += nwaves) {
-        if (keep[r].reason != SNK_KEEP) continue;
+        if (keep[r].reason != F.select) continue;
         const u32 l0 = line[4 * r], l1 = line[4 * r + 1], l2 = line[4 * r + 2], l3 = line[4 * r + 3];
         const u32 sp = (u32)F.space_num;
         const u32 ide = l1 > l0 + sp ? l1 - sp : l0, se = l2 > l1 + sp ? l2 - sp : l1;
         const u32 idl = ide - l0;
         u32 cs, cl;
-        kept_range(rec[r], se - l1, cs, cl);
+        kept_range(rec[r], se - l1, F.whole, cs, cl);
         const u32 a = idl + (u32)F.sfx_total;             // '\n' behind the id line
         const u32 b = a + 1 + cl;                         // "\n+\n"
         const u32 c = b + 3 + cl;                         // final '\n'
@@ -322,6 +323,8 @@ int snk_fastq_format_device(const uint8_t *d_text, const uint32_t *d_line, const
     for (int k = 0; k < 3 && fmt->id_suffix[k]; ++k) F.sfx |= (u32)(uint8_t)fmt->id_suffix[k] << (8 * k);
     F.bc_from = fmt->base_from;
     F.bc_to = fmt->base_to;
+    F.select = fmt->select_reason;
+    F.whole = fmt->whole_read;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) { (void)hipMemsetAsync(d_out_off, 0, sizeof(u32), s); return SNK_OK; }
     hipLaunchKernelGGL(fq_outlen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const u32 *)d_line, d_keep, d_rec, (long)n, F, d_out_off);

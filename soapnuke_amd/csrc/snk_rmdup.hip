@@ -209,6 +209,40 @@ __global__ void __launch_bounds__(256) snk_mark_lookup_kernel(const u64 *__restr
     dup[i] = minidx[s] != my ? 1 : 0;
 }
 
+// ---- one pass: the table lives across the batches (include/snk_rmdup.h, snk_rmdup_stream_*)
+__global__ void __launch_bounds__(256) snk_stream_insert_kernel(const u64 *__restrict__ hash, u32 base, long n, u64 *keys, u32 *minidx,
+                                                                u64 mask, int shift, u32 *flag) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 h = hash[i];
+    if (h == EMPTY) { atomicOr(flag, 1u); return; }             // the reference's sentinel value: the caller falls back to two passes
+    u64 s = slot_of(h, shift) & mask;
+    for (u64 probes = 0; probes <= mask; ++probes) {            // (the table is at most half full: bounded all the same, a wedged GPU helps nobody)
+        const u64 k = atomicCAS(&keys[s], EMPTY, h);
+        if (k == EMPTY || k == h) { atomicMin(&minidx[s], base + (u32)i); return; }
+        s = (s + 1) & mask;
+    }
+    atomicOr(flag, 2u);
+}
+__global__ void __launch_bounds__(256) snk_stream_lookup_kernel(const u64 *__restrict__ hash, u32 base, long n, const u64 *__restrict__ keys,
+                                                                const u32 *__restrict__ minidx, u64 mask, int shift, uint8_t *dup, u64 *marked,
+                                                                u32 *flag) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool d = false;
+    if (i < n) {
+        const u64 h = hash[i];
+        if (h != EMPTY) {
+            u64 s = slot_of(h, shift) & mask, probes = 0;
+            while (keys[s] != h && keys[s] != EMPTY && probes <= mask) { s = (s + 1) & mask; ++probes; }
+            if (keys[s] == h) d = minidx[s] != base + (u32)i;
+            else atomicOr(flag, 2u);                             // not there: the insert of this batch did not run before (never expected)
+        }
+        dup[i] = d ? 1 : 0;
+    }
+    const u64 b = __ballot(d);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(marked, (u64)__popcll(b));
+}
+
 }  // namespace
 
 #define RM_OK(call)                                      \
@@ -286,3 +320,111 @@ int snk_launch_mark(const unsigned long long *hash, const unsigned *index, long 
     RM_OK(hipFreeAsync(minidx, st));
     return 0;
 }
+
+
+// ---------------------------------------------------------------- one pass (snk_rmdup_stream_*)
+#include <vector>
+#include "../../include/snk_rmdup.h"
+void snk_set_error(const char *msg);
+
+struct snk_rmdup_stream {
+    int device = 0;
+    u64 *keys = nullptr;
+    u32 *minidx = nullptr;
+    u64 cap = 0;
+    int lg = 0;
+    u64 count = 0;                                   // hashes inserted so far
+    struct Chunk { u64 *d; long n; u32 base; };
+    std::vector<Chunk> chunks;                       // all hashes stay resident: a grown table is refilled from them
+    u64 *d_marked = nullptr;                         // [marked u64][flag u32]
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool have_ev = false;
+};
+
+static int stream_alloc_table(snk_rmdup_stream *t, u64 want_pairs, hipStream_t st) {
+    int lg = 16;
+    while ((1ull << lg) < 4ull * want_pairs) ++lg;   // load <= 0.25 when fresh, grown at 0.5
+    t->lg = lg;
+    t->cap = 1ull << lg;
+    RM_OK(hipMalloc((void **)&t->keys, t->cap * sizeof(u64)));
+    RM_OK(hipMalloc((void **)&t->minidx, t->cap * sizeof(u32)));
+    RM_OK(hipMemsetAsync(t->keys, 0xFF, t->cap * sizeof(u64), st));
+    RM_OK(hipMemsetAsync(t->minidx, 0xFF, t->cap * sizeof(u32), st));
+    return 0;
+}
+
+extern "C" {
+
+snk_rmdup_stream *snk_rmdup_stream_create(snk_ctx *, uint64_t expected_pairs) {
+    snk_rmdup_stream *t = new snk_rmdup_stream();
+    if (hipGetDevice(&t->device) != hipSuccess || stream_alloc_table(t, expected_pairs > 1024 ? expected_pairs : 1024, nullptr) != 0 ||
+        hipMalloc((void **)&t->d_marked, 16) != hipSuccess || hipMemset(t->d_marked, 0, 16) != hipSuccess ||
+        hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        snk_set_error("snk_rmdup_stream_create: device allocation failed");
+        snk_rmdup_stream_destroy(t);
+        return nullptr;
+    }
+    return t;
+}
+
+void snk_rmdup_stream_destroy(snk_rmdup_stream *t) {
+    if (!t) return;
+    (void)hipDeviceSynchronize();
+    if (t->keys) (void)hipFree(t->keys);
+    if (t->minidx) (void)hipFree(t->minidx);
+    if (t->d_marked) (void)hipFree(t->d_marked);
+    for (auto &c : t->chunks) (void)hipFree(c.d);
+    if (t->ev) (void)hipEventDestroy(t->ev);
+    delete t;
+}
+
+int snk_rmdup_stream_mark_device(snk_rmdup_stream *t, const uint64_t *d_hash, uint64_t first_index, int64_t n, uint8_t *d_dup, void *stream) {
+    if (!t || !d_hash || !d_dup || n < 0) { snk_set_error("snk_rmdup_stream_mark_device: bad argument"); return SNK_E_PARAM; }
+    if (first_index + (uint64_t)n > 4294967295ull) {           // src/peprocess.cpp:3094
+        snk_set_error("snk_rmdup_stream_mark_device: reads number is too large to do remove duplication (limit 2^32-1)");
+        return SNK_E_PARAM;
+    }
+    if (n == 0) return SNK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    auto fail = [](const char *what) { snk_set_error(what); return SNK_E_HIP; };
+    if (t->have_ev && st != t->last && hipStreamWaitEvent(st, t->ev, 0) != hipSuccess) return fail("snk_rmdup_stream_mark_device: hipStreamWaitEvent failed");
+    // the batch's hashes stay resident
+    snk_rmdup_stream::Chunk c{nullptr, (long)n, (u32)first_index};
+    if (hipMalloc((void **)&c.d, (size_t)n * sizeof(u64)) != hipSuccess) { snk_set_error("snk_rmdup_stream_mark_device: out of device memory"); return SNK_E_NOMEM; }
+    if (hipMemcpyAsync(c.d, d_hash, (size_t)n * sizeof(u64), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("snk_rmdup_stream_mark_device: copy failed");
+    u32 *flag = reinterpret_cast<u32 *>(t->d_marked + 1);
+    if ((t->count + (u64)n) * 2 > t->cap) {                    // grow: a fresh table, refilled from the resident hashes
+        if (hipStreamSynchronize(st) != hipSuccess) return fail("snk_rmdup_stream_mark_device: synchronise failed");
+        (void)hipFree(t->keys);
+        (void)hipFree(t->minidx);
+        t->keys = nullptr; t->minidx = nullptr;
+        if (stream_alloc_table(t, 2 * (t->count + (u64)n), st) != 0) { snk_set_error("snk_rmdup_stream_mark_device: out of device memory (table)"); return SNK_E_NOMEM; }
+        for (const auto &o : t->chunks)
+            hipLaunchKernelGGL(snk_stream_insert_kernel, dim3((unsigned)((o.n + 255) / 256)), dim3(256), 0, st, (const u64 *)o.d, o.base, o.n, t->keys,
+                               t->minidx, t->cap - 1, 64 - t->lg, flag);
+    }
+    t->chunks.push_back(c);
+    t->count += (u64)n;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(snk_stream_insert_kernel, dim3(grid), dim3(256), 0, st, (const u64 *)c.d, c.base, (long)n, t->keys, t->minidx, t->cap - 1, 64 - t->lg, flag);
+    hipLaunchKernelGGL(snk_stream_lookup_kernel, dim3(grid), dim3(256), 0, st, (const u64 *)c.d, c.base, (long)n, (const u64 *)t->keys, (const u32 *)t->minidx,
+                       t->cap - 1, 64 - t->lg, d_dup, t->d_marked, flag);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(t->ev, st) != hipSuccess) return fail("snk_rmdup_stream_mark_device: launch failed");
+    t->have_ev = true;
+    t->last = st;
+    return SNK_OK;
+}
+
+int snk_rmdup_stream_stats(snk_rmdup_stream *t, uint64_t *n_marked, int32_t *sentinel_seen) {
+    if (!t) return SNK_E_PARAM;
+    if (t->have_ev && hipEventSynchronize(t->ev) != hipSuccess) { snk_set_error("snk_rmdup_stream_stats: synchronise failed"); return SNK_E_HIP; }
+    uint64_t h[2] = {0, 0};
+    if (hipMemcpy(h, t->d_marked, 16, hipMemcpyDeviceToHost) != hipSuccess) { snk_set_error("snk_rmdup_stream_stats: copy failed"); return SNK_E_HIP; }
+    if (n_marked) *n_marked = h[0];
+    if (sentinel_seen) *sentinel_seen = (int32_t)(h[1] & 1u);
+    if (h[1] & 2u) { snk_set_error("snk_rmdup_stream_stats: a hash was not found in the table (internal error)"); return SNK_E_HIP; }
+    return SNK_OK;
+}
+
+}  // extern "C"

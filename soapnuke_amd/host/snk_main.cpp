@@ -23,6 +23,8 @@
 #include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <spawn.h>
+#include <sys/wait.h>
 #include <time.h>
 #include <zlib.h>
 
@@ -1126,6 +1128,10 @@ struct Slot {                                           // one batch in flight
     void *d_ztmp = nullptr;
     size_t ztmp_bytes = 0;
     hipEvent_t parsed = nullptr;
+    // one-pass rmdup: the batch's hashes, and the raw text of its duplicate pairs for the dupReads side files
+    uint64_t *d_hash = nullptr;
+    uint8_t *d_dupout[2] = {nullptr, nullptr};
+    uint32_t *d_dupoff[2] = {nullptr, nullptr}, *h_dupoff[2] = {nullptr, nullptr};
 };
 
 // One-shot sanity check of the quality system on the first patch of fq1 (stat_pe_fqs / stat_se_fqs run it once,
@@ -1275,8 +1281,13 @@ int main(int argc, char **argv) {
     // line index, fills the SoA planes and, behind the filter kernels, gathers the clean text; the host only reads, counts
     // newlines, (de)compresses and writes.  The output variants that need per-record work on the names or several outputs
     // per read keep the host formatter (same bytes either way; SNK_HOST_TEXT=1 forces it).
-    const bool dev_text = !getenv("SNK_HOST_TEXT") && !o.streaming && !o.p.rmdup && o.trim_fq[0].empty() && o.clean_out_split == 0 &&
+    // rmdup of paired input in device-text mode is one pass (include/snk_rmdup.h, snk_rmdup_stream_*): every batch is hashed and
+    // looked up in a table that stays in HBM; the other rmdup runs keep the reference's two passes (SE: its flags are shifted by
+    // one read inside full patches, see below; several devices: the table lives on one).  SNK_RMDUP_TWO_PASS=1 forces them.
+    const bool rmdup_one_pass = o.p.rmdup && mates == 2 && o.devices.size() == 1 && !getenv("SNK_RMDUP_TWO_PASS");
+    const bool dev_text = !getenv("SNK_HOST_TEXT") && !o.streaming && (!o.p.rmdup || rmdup_one_pass) && o.trim_fq[0].empty() && o.clean_out_split == 0 &&
                           !(o.total_reads > 0) && o.out_file_type != "fasta" && !o.index_remove && o.tile.empty() && o.fov.empty();
+    const bool rmdup_stream = dev_text && o.p.rmdup;
     // .gz output of device-text mode: the gzip members are made on the device too (SNK_HOST_DEFLATE=1: by the host's encoder)
     const bool dev_gz = dev_text && o.out_gz && !getenv("SNK_HOST_DEFLATE");
     const int GZ_RPM = 512;                                 // records per gzip member
@@ -1375,6 +1386,10 @@ int main(int argc, char **argv) {
                         if (dev_gz) {
                             HIPCHK(hipMalloc(&sl.d_gz[m], text_cap + 64)); HIPCHK(hipMalloc(&sl.d_gzinfo[m], 16)); HIPCHK(hipHostMalloc(&sl.h_gzinfo[m], 16));
                         }
+                        if (rmdup_stream) {
+                            HIPCHK(hipMalloc(&sl.d_dupout[m], text_cap + 64)); HIPCHK(hipMalloc(&sl.d_dupoff[m], ((size_t)B + 1) * 4));
+                            HIPCHK(hipHostMalloc(&sl.h_dupoff[m], ((size_t)B + 1) * 4));
+                        }
                         continue;
                     }
                     HIPCHK(hipHostMalloc(&sl.h_seq[m], plane)); HIPCHK(hipHostMalloc(&sl.h_qual[m], plane));
@@ -1386,6 +1401,7 @@ int main(int argc, char **argv) {
                     HIPCHK(hipMalloc(&sl.d_tmp, sl.tmp_bytes));
                     if (dev_gz) { sl.ztmp_bytes = snk_fastq_deflate_tmp_bytes(B, GZ_RPM); HIPCHK(hipMalloc(&sl.d_ztmp, sl.ztmp_bytes)); }
                     HIPCHK(hipEventCreateWithFlags(&sl.parsed, hipEventDisableTiming));
+                    if (rmdup_stream) HIPCHK(hipMalloc(&sl.d_hash, (size_t)B * sizeof(uint64_t)));
                 }
                 HIPCHK(hipHostMalloc(&sl.h_flags, (size_t)B)); HIPCHK(hipMalloc(&sl.d_flags, (size_t)B));
                 HIPCHK(hipHostMalloc(&sl.h_err, sizeof(uint64_t)));
@@ -1410,11 +1426,13 @@ int main(int argc, char **argv) {
                         HIPCHK(hipHostFree(sl.h_text[m])); HIPCHK(hipFree(sl.d_text[m])); HIPCHK(hipFree(sl.d_out[m])); HIPCHK(hipFree(sl.d_line[m]));
                         HIPCHK(hipFree(sl.d_outoff[m])); HIPCHK(hipHostFree(sl.h_outoff[m])); HIPCHK(hipFree(sl.d_status[m])); HIPCHK(hipHostFree(sl.h_status[m]));
                         if (dev_gz) { HIPCHK(hipFree(sl.d_gz[m])); HIPCHK(hipFree(sl.d_gzinfo[m])); HIPCHK(hipHostFree(sl.h_gzinfo[m])); }
+                        if (rmdup_stream) { HIPCHK(hipFree(sl.d_dupout[m])); HIPCHK(hipFree(sl.d_dupoff[m])); HIPCHK(hipHostFree(sl.h_dupoff[m])); }
                         continue;
                     }
                     HIPCHK(hipHostFree(sl.h_seq[m])); HIPCHK(hipHostFree(sl.h_qual[m])); HIPCHK(hipHostFree(sl.h_len[m])); HIPCHK(hipHostFree(sl.h_rec[m]));
                 }
                 if (dev_text) { HIPCHK(hipFree(sl.d_tmp)); HIPCHK(hipEventDestroy(sl.parsed)); }
+                if (rmdup_stream) HIPCHK(hipFree(sl.d_hash));
                 if (dev_gz) HIPCHK(hipFree(sl.d_ztmp));
                 HIPCHK(hipHostFree(sl.h_flags)); HIPCHK(hipFree(sl.d_flags)); HIPCHK(hipHostFree(sl.h_err));
                 HIPCHK(hipStreamDestroy(sl.stream));
@@ -1509,7 +1527,24 @@ int main(int argc, char **argv) {
     uint8_t *d_dup_all = nullptr;
     std::vector<uint8_t> dup_host;                        // the same flags on the host (combined with tile/fov bits per batch)
     std::vector<OutFile> dupw[2];
-    if (o.p.rmdup) {
+    snk_rmdup_stream *dup_table = nullptr;
+    if (rmdup_stream) {
+        HIPCHK(hipSetDevice(devs[0].id));
+        uint64_t guess = 1u << 20;                          // pairs in the input, from the file sizes and the first batch (the table grows if it was short)
+        struct stat st;
+        if (stat(inputs[0].c_str(), &st) == 0 && first[0]->n > 0 && first[0]->nbytes > 0) {
+            const double per = (double)first[0]->nbytes / (double)first[0]->n;
+            guess = (uint64_t)((double)st.st_size * (is_gzip_file(inputs[0]) ? 6.0 : 1.05) / per) + 1024;
+        }
+        dup_table = snk_rmdup_stream_create(devs[0].ctx, std::min<uint64_t>(guess, 4294967295ull));
+        if (!dup_table) die(snk_last_error());
+        for (int m = 0; m < mates; ++m) {                   // dupReads.<thread>.<mate>.gz, src/peprocess.cpp:167-174
+            dupw[m].resize(T);
+            for (int t = 0; t < T; ++t) dupw[m][t].open(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz", true);
+        }
+    }
+    if (o.p.rmdup && !rmdup_stream) {
+        if (const char *e = getenv("SNK_RMDUP_TWO_PASS")) if (!strcmp(e, "restarted")) log << local_time() << "\trmdup: two passes (restarted: sentinel hash in the input)" << endl;
         std::vector<uint64_t *> chunks;
         std::vector<int> chunk_n;
         uint64_t nall = 0;
@@ -1651,6 +1686,8 @@ int main(int argc, char **argv) {
     uint64_t ndup_written = 0;
     // device-text mode: the clean text of a batch arrives whole (h_text, record offsets in h_outoff); plain output is written
     // as it is, .gz output is cut at record boundaries into one gzip member per worker
+    uint8_t *dup_stage[2] = {nullptr, nullptr};            // (pinned landing buffers of the duplicates' text, grown on demand)
+    size_t dup_stage_cap[2] = {0, 0};
     auto writer_dev = [&] {
         Slot *sp;
         std::vector<string> zbuf[2];
@@ -1727,6 +1764,45 @@ int main(int argc, char **argv) {
                 parallel_for((int)pieces.size(), (int)pieces.size(), [&](int, int lo, int hi) {
                     for (int k = lo; k < hi; ++k) OutFile::put_at(pieces[(size_t)k].fd, pieces[(size_t)k].p, pieces[(size_t)k].n, pieces[(size_t)k].at);
                 });
+            }
+            if (rmdup_stream && s.h_dupoff[0][n]) {
+                // the duplicates' raw text is in HBM, one run per mate; cut like the host formatter cuts it: a gzip member per
+                // (worker slice, virtual thread) run, appended to that thread's side file in input order
+                HIPCHK(hipSetDevice(devs[(size_t)s.dev].id));
+                for (int m = 0; m < mates; ++m) {
+                    const size_t tot = s.h_dupoff[m][n];
+                    if (tot > dup_stage_cap[m]) {
+                        if (dup_stage[m]) HIPCHK(hipHostFree(dup_stage[m]));
+                        dup_stage_cap[m] = tot + tot / 4 + 4096;
+                        HIPCHK(hipHostMalloc(&dup_stage[m], dup_stage_cap[m]));
+                    }
+                    HIPCHK(hipMemcpyAsync(dup_stage[m], s.d_dupout[m], tot, hipMemcpyDeviceToHost, s.stream));
+                }
+                HIPCHK(hipStreamSynchronize(s.stream));
+                struct DupRun { int vt; uint32_t a[2], b[2]; string z[2]; };
+                std::vector<std::vector<DupRun>> runs((size_t)WK);
+                std::vector<uint64_t> cnt((size_t)WK, 0);
+                parallel_for(WK, n, [&](int w, int lo, int hi) {
+                    int cur = -1;
+                    for (int i = lo; i < hi; ++i) {
+                        if (s.h_dupoff[0][i + 1] == s.h_dupoff[0][i]) continue;
+                        const int vt = (int)(((s.first + (uint64_t)i) / (uint64_t)vblock) % (uint64_t)T);
+                        if (vt != cur) {
+                            runs[(size_t)w].emplace_back();
+                            runs[(size_t)w].back().vt = cur = vt;
+                            for (int m = 0; m < mates; ++m) runs[(size_t)w].back().a[m] = s.h_dupoff[m][i];
+                        }
+                        for (int m = 0; m < mates; ++m) runs[(size_t)w].back().b[m] = s.h_dupoff[m][i + 1];
+                        ++cnt[(size_t)w];
+                    }
+                    for (DupRun &r : runs[(size_t)w])
+                        for (int m = 0; m < mates; ++m) gzip_member((const char *)dup_stage[m] + r.a[m], (size_t)(r.b[m] - r.a[m]), r.z[m]);
+                });
+                for (int w = 0; w < WK; ++w) {
+                    for (const DupRun &r : runs[(size_t)w])
+                        for (int m = 0; m < mates; ++m) dupw[m][(size_t)r.vt].write_bytes(r.z[m]);
+                    ndup_written += cnt[(size_t)w];
+                }
             }
             log << local_time() << " processed_reads:\t" << s.first + (uint64_t)n << endl;
             devs[(size_t)s.dev].free_slots->push(sp);
@@ -1913,6 +1989,12 @@ int main(int argc, char **argv) {
             fmt[m].id_suffix[0] = '/'; fmt[m].id_suffix[1] = m == 0 ? '1' : '2';
             fmt[m].base_from = (uint8_t)bc_from; fmt[m].base_to = (uint8_t)bc_to;
         }
+        snk_fastq_format fmt_dup;                             // C_fastq::toString of the raw records, src/peprocess.cpp:1541
+        memset(&fmt_dup, 0, sizeof fmt_dup);
+        fmt_dup.struct_size = (int32_t)sizeof(snk_fastq_format);
+        fmt_dup.space_num = space_num;
+        fmt_dup.select_reason = SNK_R_DUP;
+        fmt_dup.whole_read = 1;
         // raw text -> pinned -> device; line index + SoA planes by the device (asynchronous; s.parsed marks the end)
         auto stage = [&](Slot &s, RawChunk *const ch[2]) {
             s.n = ch[0]->n;
@@ -1950,6 +2032,15 @@ int main(int argc, char **argv) {
             }
             if (too_long) return too_long;
             const int n = s.n;
+            if (rmdup_stream) {                              // hash the raw pairs, look them up in (and add them to) the resident table
+                snk_batch hb;
+                memset(&hb, 0, sizeof hb);
+                hb.n = n;
+                hb.pitch = pitch;
+                for (int m = 0; m < mates; ++m) { hb.seq[m] = s.d_seq[m]; hb.qual[m] = s.d_qual[m]; hb.len[m] = s.d_len[m]; }
+                if (snk_rmdup_hash_device(dv.ctx, &hb, s.d_hash, s.stream) != SNK_OK) die(snk_last_error());
+                if (snk_rmdup_stream_mark_device(dup_table, s.d_hash, s.first, n, s.d_flags, s.stream) != SNK_OK) die(snk_last_error());
+            }
             for (int lo = 0; lo < n;) {                      // split at virtual-thread block boundaries (appendix C)
                 const uint64_t g = s.first + (uint64_t)lo;
                 const int vt = (int)((g / (uint64_t)vblock) % (uint64_t)T);
@@ -1965,10 +2056,16 @@ int main(int argc, char **argv) {
                     b.len[m] = s.d_len[m] + lo;
                 }
                 b.first_index = g;
+                if (rmdup_stream) b.dup = s.d_flags + lo;
                 if (snk_bind_stats(dv.ctx, dv.d_sum[(size_t)vt], dv.d_max[(size_t)vt]) != SNK_OK) die(snk_last_error());
                 if (snk_filter_batch_device(dv.ctx, &b, s.d_rec[0] + lo, mates == 2 ? s.d_rec[1] + lo : nullptr, s.stream, 0) != SNK_OK)
                     die(snk_last_error());
                 lo = hi;
+            }
+            for (int m = 0; m < mates && rmdup_stream; ++m) {  // the duplicate pairs' raw records, for the side files
+                if (snk_fastq_format_device(s.d_text[m], s.d_line[m], s.d_rec[0], s.d_rec[m], n, &fmt_dup, s.d_dupout[m], s.d_dupoff[m], s.d_tmp, s.tmp_bytes,
+                                            s.stream) != SNK_OK) die(snk_last_error());
+                HIPCHK(hipMemcpyAsync(s.h_dupoff[m], s.d_dupoff[m], ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, s.stream));
             }
             for (int m = 0; m < mates; ++m) {
                 if (snk_fastq_format_device(s.d_text[m], s.d_line[m], s.d_rec[0], s.d_rec[m], n, &fmt[m], s.d_out[m], s.d_outoff[m], s.d_tmp, s.tmp_bytes,
@@ -2162,7 +2259,37 @@ int main(int argc, char **argv) {
     join_readers();
     for (int m = 0; m < mates; ++m) wr[m].close();
     if (trim_out) for (int m = 0; m < mates; ++m) trimw[m].close();
-    if (rmdup_on) {
+    if (rmdup_stream) {
+        uint64_t marked = 0;
+        int32_t sentinel = 0;
+        HIPCHK(hipSetDevice(devs[0].id));
+        if (snk_rmdup_stream_stats(dup_table, &marked, &sentinel) != SNK_OK) die(snk_last_error());
+        if (sentinel || getenv("SNK_RMDUP_SENTINEL_TEST")) {
+            // a pair hashed to 2^64 - 1, the value the reference's duplicate search treats as "already removed": what it marks
+            // then depends on the whole input's sort order (oracle: mark_duplicates), which only the two-pass path reproduces.
+            // Run again that way; every output file is rewritten from the start.
+            log << local_time() << "\trmdup: sentinel hash in the input, running again with two passes" << endl;
+            log.close();
+            cout.flush();
+            for (int m = 0; m < mates; ++m) for (int t = 0; t < T; ++t) dupw[m][t].close();
+            snk_rmdup_stream_destroy(dup_table);
+            for (auto &t : slot_makers) t.join();
+            slot_makers.clear();
+            teardown();                                       // (the second run gets the device and the pinned memory to itself)
+            setenv("SNK_RMDUP_TWO_PASS", "restarted", 1);
+            unsetenv("SNK_RMDUP_SENTINEL_TEST");
+            pid_t child = 0;
+            int status = 0;
+            if (posix_spawn(&child, "/proc/self/exe", nullptr, nullptr, argv, environ) != 0 || waitpid(child, &status, 0) != child) {
+                cerr << "cannot start the two-pass rmdup run" << endl;
+                _exit(1);
+            }
+            _exit(WIFEXITED(status) ? WEXITSTATUS(status) : 1);
+        }
+        cout << "totalReadsNum:\t" << total << endl;
+        log << "duplicate reads number:\t" << marked << endl;
+    }
+    if (rmdup_on || rmdup_stream) {
         for (int m = 0; m < mates; ++m) for (int t = 0; t < T; ++t) dupw[m][t].close();
         log << "dup number:\t" << ndup_written << endl;
     }

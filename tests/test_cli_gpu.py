@@ -23,7 +23,7 @@ def _cat(path):
     return gzip.open(path, "rb").read() if path.endswith(".gz") else open(path, "rb").read()
 
 
-def _run_ours(case, work, gz):
+def _run_ours(case, work, gz, env=None):
     name, paired, L, n, threads, patch, skw, pkw, cli, cfg = case
     ext = ".fq.gz" if gz else ".fq"
     cmd = [CLI, "filter", "-1", os.path.join(work, "r1" + ext), "-C", "c1" + ext, "-o", os.path.join(work, "ours"), "-T", str(threads)]
@@ -31,7 +31,7 @@ def _run_ours(case, work, gz):
         cmd += ["-2", os.path.join(work, "r2" + ext), "-D", "c2" + ext]
     if os.path.exists(os.path.join(work, "cfg")):
         cmd += ["-c", os.path.join(work, "cfg")]
-    r = subprocess.run(cmd + cli, capture_output=True)
+    r = subprocess.run(cmd + cli, capture_output=True, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, (r.stdout[-300:], r.stderr[-500:])
     return os.path.join(work, "ours")
 
@@ -109,6 +109,43 @@ def test_cli_rmdup_matches_reference_binary(paired, n, tmp_path):
             ndup += a.count(b"\n") // 4
     assert ndup == 2520 * (2 if paired else 1)
     assert b"dup number:\t2520" in open(os.path.join(ours, "log"), "rb").read()
+
+
+@pytest.mark.parametrize("mode", ["one_pass_gz", "two_pass", "sentinel_restart", "small_batches"])
+def test_cli_rmdup_one_pass_variants(mode, tmp_path):
+    """Paired rmdup is one pass in device-text mode (a hash table resident in HBM, include/snk_rmdup.h snk_rmdup_stream_*):
+    .gz output, the retained two-pass path (SNK_RMDUP_TWO_PASS=1), the restart a sentinel hash forces, and batches much
+    smaller than the duplicates' distance (table growth, duplicates across batches) -- same bytes as the reference binary."""
+    L, threads, patch, n = 150, 3, 250, 20000
+    d = synth.make_batch(n, L, paired=True, seed=62)
+    for m in range(2):
+        d["seq"][m][10000:12000] = d["seq"][m][0:2000]
+        d["seq"][m][15000:15500] = d["seq"][m][0:500]
+        d["seq"][m][n - 40:n - 20] = d["seq"][m][700:720]
+    cli = ["-f", synth.ADAPTER1, "-J", "-r", synth.ADAPTER2]
+    env = {}
+    if mode == "two_pass":
+        env["SNK_RMDUP_TWO_PASS"] = "1"
+    if mode == "sentinel_restart":
+        env["SNK_RMDUP_SENTINEL_TEST"] = "1"
+    if mode == "small_batches":
+        env["SNK_BATCH_PAIRS"] = "1536"
+    case = ("rmdup1", True, L, n, threads, patch, {}, {}, cli, ["rmdup"])
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    gz = mode == "one_pass_gz"
+    ours = _run_ours(case, work, gz=gz, env=env)
+    for f in R.REPORT_FILES_PE:
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in ("c1.fq", "c2.fq"):
+        assert _cat(os.path.join(ours, c + (".gz" if gz else ""))) == _cat(os.path.join(ref, c)), c
+    for t in range(threads):
+        for m in range(2):
+            f = f"dupReads.{t}.{m + 1}.gz"
+            assert _cat(os.path.join(ours, f)) == _cat(os.path.join(ref, f)), f
+    log = open(os.path.join(ours, "log"), "rb").read()
+    assert b"dup number:\t2520" in log and b"duplicate reads number:\t2520" in log
+    assert (b"restarted" in log) == (mode == "sentinel_restart")
 
 
 def test_cli_pe_info_outqual_and_crlf(tmp_path):

@@ -245,3 +245,23 @@ def test_device_gzip_members_round_trip(n, rpm, kind):
         t.cuda.synchronize()
         assert rc == 0 and info.cpu().numpy()[2] != 0
         assert bytes(d_gz[small:small + 64].cpu().numpy()) == b"\x5a" * 64 or True
+
+
+def test_format_selects_other_verdicts_whole():
+    """snk_fastq_format.select_reason / whole_read: the raw records of the pairs with one verdict (the duplicates' side
+    files, src/peprocess.cpp:1541) -- untrimmed, qualities as they came, whatever the records' kept ranges say."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    recs, text = _records(rng, n, 20, 150)
+    dev = Dev()
+    P = dev.parse(text, n, 1, 150)
+    keep = np.zeros(n, dtype=abi.record_dtype())
+    keep["reason"] = rng.integers(0, 4, n)
+    keep["clean_start"] = rng.integers(0, 10, n)
+    keep["clean_len"] = rng.integers(0, 50, n)
+    fmt = _fmt(1)
+    fmt.select_reason, fmt.whole_read = 1, 1
+    got, off = dev.format(P, keep, keep, n, fmt)
+    want = b"".join(b"\n".join([r[0], r[1], b"+", r[3]]) + b"\n" for i, r in enumerate(recs) if keep["reason"][i] == 1)
+    assert got == want
+    assert all((off[i + 1] > off[i]) == (keep["reason"][i] == 1) for i in range(n))

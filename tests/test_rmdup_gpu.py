@@ -172,3 +172,61 @@ def test_exchange_path_single_rank_nccl():
         assert np.array_equal(flags.cpu().numpy(), T.oracle_markdup(h))
     finally:
         dist.destroy_process_group()
+
+
+def test_one_pass_table_vs_oracle():
+    """snk_rmdup_stream_*: the table lives across batches, fed in file order from alternating streams; the
+    verdicts equal the two-pass ones (the first occurrence stays, every later one is marked), the table
+    grows from its resident hashes, and the reference's sentinel hash is reported, not mis-marked."""
+    import ctypes as C
+    import torch
+    lib = abi.load_library()
+    rng = np.random.default_rng(21)
+    for n, expected, sentinel in ((200_000, 1024, False), (1_500_000, 400_000, False), (50_000, 50_000, True), (1, 0, False)):
+        h = rng.integers(0, max(2, n // 3), n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1)
+        h[h == np.uint64(0xFFFFFFFFFFFFFFFF)] = np.uint64(5)
+        want = T.oracle_markdup(h)
+        if sentinel:
+            h[n // 2] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        t = lib.snk_rmdup_stream_create(None, expected)
+        assert t
+        streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+        got = np.zeros(n, np.uint8)
+        outs, pos, k = [], 0, 0
+        while pos < n:
+            m = int(min(n - pos, rng.integers(1, 150_000)))
+            st = streams[k % 3]
+            with torch.cuda.stream(st):
+                hb = torch.from_numpy(h[pos:pos + m].view(np.int64).copy()).cuda()
+                db = torch.empty(m, dtype=torch.uint8, device="cuda")
+            rc = lib.snk_rmdup_stream_mark_device(t, hb.data_ptr(), pos, m, db.data_ptr(), st.cuda_stream)
+            assert rc == 0, lib.snk_last_error()
+            outs.append((pos, m, db, hb))
+            pos += m
+            k += 1
+        marked, seen = C.c_uint64(0), C.c_int32(0)
+        assert lib.snk_rmdup_stream_stats(t, C.byref(marked), C.byref(seen)) == 0
+        torch.cuda.synchronize()
+        for p0, m, db, _ in outs:
+            got[p0:p0 + m] = db.cpu().numpy()
+        lib.snk_rmdup_stream_destroy(t)
+        assert seen.value == (1 if sentinel else 0)
+        if sentinel:
+            keep = np.arange(n) != n // 2
+            # the sentinel element itself is left unmarked and takes no part
+            assert got[n // 2] == 0
+            assert np.array_equal(got[keep], T.oracle_markdup(h[keep]))
+        else:
+            assert np.array_equal(got, want), n
+            assert marked.value == int(want.sum())
+
+
+def test_one_pass_table_refuses_too_many_reads():
+    import torch
+    lib = abi.load_library()
+    t = lib.snk_rmdup_stream_create(None, 1024)
+    hb = torch.zeros(8, dtype=torch.int64, device="cuda")
+    db = torch.zeros(8, dtype=torch.uint8, device="cuda")
+    assert lib.snk_rmdup_stream_mark_device(t, hb.data_ptr(), 4294967290, 8, db.data_ptr(), None) != 0
+    assert b"2^32-1" in lib.snk_last_error()
+    lib.snk_rmdup_stream_destroy(t)
