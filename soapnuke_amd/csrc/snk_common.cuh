@@ -378,6 +378,43 @@ __device__ __forceinline__ int reason_family(int reason) {
     }
 }
 
+// ++*p for every lane that gets here (all of them with the same p), as one atomic
+__device__ __forceinline__ void agg_inc(unsigned long long *p) {
+    const u64 same = __ballot(1);
+    if ((int)__lane_id() == __ffsll((long long)same) - 1) atomicAdd(p, (unsigned long long)__popcll(same));
+}
+
+// atomicMax of a "last read" word (index + 1 in the high bits, see DevStats::maxb) for every lane that gets here: the lanes of a
+// wavefront walk consecutive reads, so the highest of them carries the largest word -- one atomic instead of up to 64
+__device__ __forceinline__ void agg_max_last(unsigned long long *p, unsigned long long v) {
+    const u64 same = __ballot(1);
+    if ((int)__lane_id() == 63 - __clzll((long long)same)) atomicMax(p, v);
+}
+
+// the filter-statistics counters of one verdict (C_filter_stat, src/peprocess.cpp:1535-1600): the reason's family, and for a pair
+// which mate(s) gave it.  One atomic per counter and wavefront: the lanes that get here agree on the counters present (a uniform
+// loop over them, ballots for the counts).  The counters are a handful of words -- one atomic per read to the same few addresses
+// serialises in L2: 4.8 ms per 1 M long pairs went there (rocprof: 79 % of the wave cycles waiting).
+__device__ inline void count_reason(unsigned long long *fs, bool pe, int reason, int v) {
+    int idx = reason == SNK_R_DUP ? SNK_FS_DUP : reason == SNK_R_TILE ? SNK_FS_TILE : reason == SNK_R_FOV ? SNK_FS_FOV : reason_family(reason);
+    const int vv = (pe && idx >= 0 && reason != SNK_R_DUP && reason != SNK_R_TILE && reason != SNK_R_FOV) ? v : 0;
+    const int lane = (int)__lane_id();
+    u64 todo = __ballot(idx >= 0);
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const int f = __shfl(idx, lead, 64);
+        const u64 same = __ballot(idx == f);
+        const u64 s1 = __ballot(idx == f && (vv & 1)), s2 = __ballot(idx == f && (vv & 2)), s3 = __ballot(idx == f && vv == 3);
+        if (lane == lead) {
+            atomicAdd(&fs[f], (unsigned long long)__popcll(same));
+            if (s1) atomicAdd(&fs[f + 1], (unsigned long long)__popcll(s1));
+            if (s2) atomicAdd(&fs[f + 2], (unsigned long long)__popcll(s2));
+            if (s3) atomicAdd(&fs[f + 3], (unsigned long long)__popcll(s3));
+        }
+        todo &= ~same;
+    }
+}
+
 // CT = u64 (the stats block itself) or u32 (the tiled kernel's per-workgroup copy)
 template <class CT>
 __device__ __forceinline__ void ts_inc(CT *ts, long idx) {

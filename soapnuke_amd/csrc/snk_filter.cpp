@@ -287,6 +287,8 @@ struct snk_ctx {
     unsigned ts_next = 0;
     unsigned char *d_cf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // contaminant verdicts, per stream slot
     size_t cf_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned *d_pl[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};         // long reads: the plane store, per stream slot
+    size_t pl_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool own_stats = false;
     // staging for the host-pointer entry point
     uint8_t *st_buf = nullptr;
@@ -534,6 +536,7 @@ void snk_destroy(snk_ctx *c) {
     if (c->d_gct) (void)hipFree(c->d_gct);
     if (c->d_tsw) (void)hipFree(c->d_tsw);
     for (int k = 0; k < 8; ++k) if (c->d_cf[k]) (void)hipFree(c->d_cf[k]);
+    for (int k = 0; k < 8; ++k) if (c->d_pl[k]) (void)hipFree(c->d_pl[k]);
 
     if (c->st_buf) (void)hipFree(c->st_buf);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -661,14 +664,26 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         done = snk_launch_tiled(c->hp, c->ta, D, st, c->lcap, c->nq, c->n_cu, stream);
         D.cf = nullptr;
         // reads of 257..1024 positions: the block-wise bit-sliced path (snk_long.hip); it writes the stats block directly
-        if (!done) done = snk_launch_long(c->d_params, c->hp, c->ta, D, DevStats{c->d_sum, c->d_max, c->d_err, c->d_tsw}, c->lcap, c->nq, c->n_cu, stream);
+        if (!done && c->hp.tile_ok && c->lcap > 256 && c->lcap <= 1024 && b->n > 0) {
+            // (the plane store of the batch: scratch of this stream slot, grown on demand and kept)
+            const size_t need = snk_long_scratch_bytes((long)b->n, c->p.paired ? 1 : 0);
+            if (need > c->pl_cap[slot]) {
+                HIP_OK(hipStreamSynchronize(s));
+                if (c->d_pl[slot]) (void)hipFree(c->d_pl[slot]);
+                c->d_pl[slot] = nullptr;
+                c->pl_cap[slot] = 0;
+                if (hipMalloc((void **)&c->d_pl[slot], need) != hipSuccess) { set_err("snk_filter_batch_device: out of device memory (long-read plane store)"); return fail(SNK_E_NOMEM); }
+                c->pl_cap[slot] = need;
+            }
+            done = snk_launch_long(c->d_params, c->hp, c->ta, D, DevStats{c->d_sum, c->d_max, c->d_err, c->d_tsw}, c->lcap, c->nq, c->n_cu, c->d_pl[slot], stream);
+        }
         if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return fail(SNK_E_UNSUPPORTED); }
     }
     if (!done) {
         // the generic kernel decides; the per-position histograms come from the LDS histogram kernel behind it (kernel == 3:
         // the generic kernel's own global atomics -- the anchor -- as whenever that kernel cannot take the batch)
         const DevStats gst{c->d_sum, c->d_max, c->d_err, c->d_tsw};
-        const size_t hist_lds = (size_t)2 * (5 + c->nq + 1) * 128 * sizeof(uint32_t);
+        const size_t hist_lds = (size_t)3 * (5 + c->nq + 1) * 128 * sizeof(uint32_t);
         const bool split = kernel != 3 && hist_lds <= 150 * 1024 && (b->pitch & 3) == 0 &&
                            ((((uintptr_t)D.seq[0] | (uintptr_t)D.qual[0] | (uintptr_t)D.seq[1] | (uintptr_t)D.qual[1]) & 3) == 0);
         snk_launch_generic(c->d_params, D, st, c->lcap, c->nq, split ? 0 : 1, stream);

@@ -23,20 +23,6 @@ using namespace snk;
 
 namespace {
 
-__device__ void count_reason(unsigned long long *fs, bool pe, int reason, int v) {
-    if (reason == SNK_R_DUP) { atomicAdd(&fs[SNK_FS_DUP], 1ull); return; }
-    if (reason == SNK_R_TILE) { atomicAdd(&fs[SNK_FS_TILE], 1ull); return; }
-    if (reason == SNK_R_FOV) { atomicAdd(&fs[SNK_FS_FOV], 1ull); return; }
-    const int f = reason_family(reason);
-    if (f < 0) return;
-    atomicAdd(&fs[f], 1ull);
-    if (pe) {
-        if (v & 1) atomicAdd(&fs[f + 1], 1ull);
-        if (v & 2) atomicAdd(&fs[f + 2], 1ull);
-        if (v == 3) atomicAdd(&fs[f + 3], 1ull);
-    }
-}
-
 // own_hist == 0: the per-position histograms (and the quality-range check that comes with them) are left to
 // snk_long_hist_kernel, which runs behind this kernel on the records it wrote -- one global atomic per base and quality was
 // nine tenths of this kernel's time
@@ -52,7 +38,7 @@ __device__ int hist_read(const DevParams &P, unsigned long long *file, int lcap,
         if (bq < 0 || bq >= nq) { rc = SNK_E_QUAL_RANGE; continue; }
         atomicAdd(&qs[(long)i * nq + bq], 1ull);
     }
-    atomicAdd(&file[SNK_GS_READS], 1ull);
+    agg_inc(&file[SNK_GS_READS]);
     return rc;
 }
 
@@ -100,7 +86,7 @@ snk_generic_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int n
             ts_update(file + ts_off, hh, lh, ht, lt, ad, (pe && m == 1) ? r[m].len : 0, !pe);
             const int rc = hist_read(P, file, lcap, nq, s[m], q[m], 0, r[m].len, own_hist);
             if (rc) report_err(st, gidx, m, rc);
-            atomicMax(&st.maxb[m], key | (unsigned long long)r[m].len);
+            agg_max_last(&st.maxb[m], key | (unsigned long long)r[m].len);
         }
         if (reason == SNK_KEEP) {
             for (int m = 0; m <= pe; ++m) {
@@ -108,7 +94,7 @@ snk_generic_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int n
                 ts_update(file + ts_off, r[m].hd_h, r[m].lq_h, r[m].hd_t, r[m].lq_t, r[m].adacut,
                           (pe && m == 1) ? r[m].clen : r[m].len, !pe);
                 hist_read(P, file, lcap, nq, s[m], q[m], r[m].start, r[m].clen, own_hist);
-                atomicMax(&st.maxb[2 + m], key | (unsigned long long)r[m].clen);
+                agg_max_last(&st.maxb[2 + m], key | (unsigned long long)r[m].clen);
             }
         }
     }

@@ -1,21 +1,26 @@
 // snk_long.hip -- the fast path for reads of 257..1024 positions (reference limit READ_MAX_LEN 1000,
 // src/global_variable.h:9).  The wave-tiled kernel keeps a read's bit planes in registers and its histograms in LDS, both
-// sized for <= 256 positions; long reads take two kernels instead:
+// sized for <= 256 positions; long reads take three kernels instead:
 //
-//   snk_long_decide_kernel   lane = read (one work-item per pair).  Every lane streams its own row with 16-byte loads
-//       (64 rows per wave-load: the row pitch is the stride).  The adapter search (A2, src/read_filter.cpp:707-790) is the
-//       bit-sliced one of the tiled kernel (snk_adapter_bits.cuh) on BLOCKS of the read: planes of 320 positions (10
-//       words) serve the 256 candidate offsets of a block plus the 64 positions an adapter can reach past them; a block in
-//       the middle of a read has phase B offsets only, phase A belongs to the first block, phase C to the last one, which
-//       ends with the read.  A1 stat_read (:80-313) comes out of the same planes -- the A / N counts are popcounts, a
-//       position that is neither ACGT nor N sends the read to the sequential functions of snk_common.cuh in its lane
-//       (lower case, other letters; also reads shorter than 64) -- plus one byte-parallel pass over the qualities
-//       (low-quality count, sum by v_sad_u8) and, when poly-X is asked for, one over the characters.  Trimming (A3), the
-//       discard cascade (A6), the reason counters and the trimming-position counters follow as in the generic kernel.
+//   snk_long_prep_kernel     one workgroup per 64 reads of a mate, one wavefront per read and trip, 16 bytes per lane: rows
+//       arrive as coalesced kilobytes.  It leaves the quality half of A1 stat_read (src/read_filter.cpp:80-313: low-quality
+//       count, quality sum) in the read's record and the read's five bit planes (A C G T N over the positions) in the
+//       batch's plane store, laid out so that 64 consecutive reads fetch a quad of plane words as one contiguous kilobyte.
+//   snk_long_decide_kernel   lane = read (one work-item per pair), on the plane store.  The adapter search (A2,
+//       src/read_filter.cpp:707-790) is the bit-sliced one of the tiled kernel (snk_adapter_bits.cuh) on BLOCKS of the
+//       read: planes of 320 positions (10 words) serve the 256 candidate offsets of a block plus the 64 positions an
+//       adapter can reach past them; a block in the middle of a read has phase B offsets only, phase A belongs to the first
+//       block, phase C to the last one, which ends with the read.  The A / N counts of A1 are popcounts of the same planes;
+//       a position that is neither ACGT nor N sends the read to the sequential functions of snk_common.cuh in its lane
+//       (lower case, other letters; also reads shorter than 64), which walk the row; so does poly-X when it is asked
+//       for.  Trimming (A3), the discard cascade (A6), the reason counters (one atomic per counter and wavefront:
+//       agg_inc) and the trimming-position counters follow as in the generic kernel.
 //   snk_long_hist_kernel     lane = four positions.  A workgroup owns 128 positions of one mate for a slice of the batch:
 //       raw and clean per-position base / quality histograms (A8, src/peprocess.cpp:1182-1201 and the clean twin) in LDS
-//       (u32, 49 KB); one dword load per lane covers the 128 positions of two reads, clean counts come from the records of
-//       the decision kernel (the kept reads, at the shifted positions), the adds are branch-free.  Flushed once per
+//       (u32, 74 KB: raw-only / both / clean-only -- a kept, untrimmed read is added once; 16 wavefronts per workgroup, two
+//       workgroups per CU: the kernel lives on loads in flight); one dword load per lane covers
+//       the 128 positions of two reads, clean counts come from the records of the decision kernel (the trimmed kept reads,
+//       at the shifted positions: a step most wavefronts skip), the adds are branch-free.  Flushed once per
 //       workgroup.  It also runs behind the generic kernel (any capacity), which then only decides.
 #include <hip/hip_runtime.h>
 #include "snk_common.cuh"
@@ -42,85 +47,44 @@ __device__ __forceinline__ u32 valid80(int len, int pos) {
 typedef u32 v4u32 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) v4u32 *gl_uint4_p;
 
-// the quality half of A1 alone: low-quality count and quality sum of one read
-__device__ __forceinline__ void scan_quals(const DevParams &P, const uint8_t *q, int len, int &lowq, int &sumq) {
-    const gl_uint4_p q4 = (gl_uint4_p)q;
-    const u32 KL = ((u32)min(max(P.phred + P.low_qual, 0), 127) * 0x01010101u) | 0x80808080u;
-    const bool lq_any = P.phred + P.low_qual >= 0;
-    u32 qsum = 0;
-    int lq = 0;
-    for (int pos0 = 0; pos0 < len; pos0 += 128) {
-        v4u32 qvv[8];
+// ---- the plane store of a batch (snk_long_prep_kernel writes it, the decide kernel reads it): for every group of 64
+// consecutive reads of a mate, 8 quads of 4 plane words (32 positions each) x 5 planes (A C G T N) x 64 reads x 16 bytes, so that
+// the 64 lanes of a wavefront -- 64 consecutive reads -- fetch one quad of one plane as one contiguous kilobyte.
+constexpr int PL_QUADS = 8, PL_PLANES = 5;
+constexpr long PL_GROUP_DWORDS = (long)PL_QUADS * PL_PLANES * 64 * 4;      // 40 KB per group
+__host__ __device__ inline long plane_store_dwords(long n, int mates) { return (long)mates * ((n + 63) / 64) * PL_GROUP_DWORDS; }
+
+// planes of the block [p0, p0 + 320) of a read from the plane store: X[k] bit j = read[p0 + j] == "ACGT"[k], XN likewise for 'N';
+// ones from vlen on.  Also the A1 base counts of a read of upper-case ACGTN only (src/read_filter.cpp:258-308), which are
+// popcounts of its planes: cntA / cntN += the 'A' / 'N' of the block's own positions (256, or all of a final block), other |=
+// positions that are neither ACGT nor N (lower case included: such a read takes the sequential path, where case is folded).
+__device__ __forceinline__ void block_planes(const u32 *grp, int r, int p0, int vlen, bool final, u32 (&X)[4][LNW], u32 (&XN)[LNW],
+                                             int &cntA, int &cntN, u32 &other) {
+    const int q0 = p0 >> 7;                                          // first quad of the block (p0 is a multiple of 256)
+    u32 W[PL_PLANES][12];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) qvv[g] = pos0 + 16 * g < len ? q4[(pos0 >> 4) + g] : v4u32{0, 0, 0, 0};
-        if (pos0 + 128 <= len) {                                     // whole trip inside the read: no masks
+    for (int k = 0; k < PL_PLANES; ++k) {
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const u32 qd[4] = {qvv[g].x, qvv[g].y, qvv[g].z, qvv[g].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    lq += __popc((KL - (qd[k] & 0x7F7F7F7Fu)) & ~qd[k] & 0x80808080u);
-                    qsum = __builtin_amdgcn_sad_u8(qd[k], 0u, qsum);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const u32 qd[4] = {qvv[g].x, qvv[g].y, qvv[g].z, qvv[g].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const u32 ok = valid80(len, pos0 + 16 * g + 4 * k);
-                    lq += __popc((KL - (qd[k] & 0x7F7F7F7Fu)) & ~qd[k] & ok);
-                    qsum = __builtin_amdgcn_sad_u8(qd[k] & ((ok >> 7) * 0xFFu), 0u, qsum);
-                }
-            }
+        for (int qq = 0; qq < 3; ++qq) {
+            v4u32 v = {0, 0, 0, 0};
+            if (q0 + qq < PL_QUADS && 128 * qq < vlen) v = *(gl_uint4_p)(grp + ((long)((q0 + qq) * PL_PLANES + k) * 64 + r) * 4);
+            W[k][4 * qq] = v.x; W[k][4 * qq + 1] = v.y; W[k][4 * qq + 2] = v.z; W[k][4 * qq + 3] = v.w;
         }
     }
-    lowq = lq_any ? lq : 0;
-    sumq = (int)qsum - P.phred * len;
-}
-
-// planes of the block [p0, p0 + 320) of a read: X[k] bit j = read[p0 + j] == "ACGT"[k], XN likewise for 'N'; ones from vlen on
-// Also the A1 base counts of a read of upper-case ACGTN only (src/read_filter.cpp:258-308), which are popcounts of its planes:
-// cntA / cntN += the 'A' / 'N' of the block's own positions (256, or all of a final block), other |= positions that are neither
-// ACGT nor N (lower case included: such a read takes the sequential path, where case is folded).
-__device__ __forceinline__ void block_planes(const uint8_t *s, int p0, int vlen, int pitch, bool final, u32 (&X)[4][LNW], u32 (&XN)[LNW],
-                                             int &cntA, int &cntN, u32 &other) {
-    const gl_uint4_p s4 = (gl_uint4_p)(s + p0);                         // p0 is a multiple of 256
 #pragma unroll
     for (int w = 0; w < LNW; ++w) {
-        u32 e = 0, c1 = 0, c2 = 0, nn = 0;
-        if (32 * w < vlen) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                v4u32 sv = {0, 0, 0, 0};
-                if (p0 + 32 * w + 16 * h + 16 <= pitch) sv = s4[2 * w + h];          // (the last word of the last block may reach past the row)
-                const u32 sd[4] = {sv.x, sv.y, sv.z, sv.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int d = 4 * h + k;
-                    const u32 v = sd[k];
-                    const u32 t = v & 0x06060606u;
-                    const u32 ex = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);
-                    e |= pack4(zero_bytes(ex ^ v)) << (4 * d);
-                    nn |= pack4(zero_bytes(v ^ 0x4E4E4E4Eu)) << (4 * d);
-                    c1 |= pack4((v << 6) & 0x80808080u) << (4 * d);
-                    c2 |= pack4((v << 5) & 0x80808080u) << (4 * d);
-                }
-            }
-        }
         const u32 in = lowmask32(vlen - 32 * w);
-        e &= in;
+        const u32 x0 = W[0][w] & in, x1 = W[1][w] & in, x2 = W[2][w] & in, x3 = W[3][w] & in, xn = W[4][w] & in;
         if (w < 8 || final) {
-            cntA += __popc(e & ~c1 & ~c2);
-            cntN += __popc(nn & in);
-            other |= in & ~(e | nn);
+            cntA += __popc(x0);
+            cntN += __popc(xn);
+            other |= in & ~(x0 | x1 | x2 | x3 | xn);
         }
-        X[0][w] = (e & ~c1 & ~c2) | ~in;
-        X[1][w] = (e & c1 & ~c2) | ~in;
-        X[2][w] = (e & c1 & c2) | ~in;
-        X[3][w] = (e & ~c1 & c2) | ~in;
-        XN[w] = (nn & in) | ~in;
+        X[0][w] = x0 | ~in;
+        X[1][w] = x1 | ~in;
+        X[2][w] = x2 | ~in;
+        X[3][w] = x3 | ~in;
+        XN[w] = xn | ~in;
     }
 }
 
@@ -133,22 +97,102 @@ __device__ __forceinline__ u64 wave_max64(u64 v) {
     return v;
 }
 
-__device__ void count_reason_long(unsigned long long *fs, bool pe, int reason, int v) {
-    if (reason == SNK_R_DUP) { atomicAdd(&fs[SNK_FS_DUP], 1ull); return; }
-    if (reason == SNK_R_TILE) { atomicAdd(&fs[SNK_FS_TILE], 1ull); return; }
-    if (reason == SNK_R_FOV) { atomicAdd(&fs[SNK_FS_FOV], 1ull); return; }
-    const int f = reason_family(reason);
-    if (f < 0) return;
-    atomicAdd(&fs[f], 1ull);
-    if (pe) {
-        if (v & 1) atomicAdd(&fs[f + 1], 1ull);
-        if (v & 2) atomicAdd(&fs[f + 2], 1ull);
-        if (v == 3) atomicAdd(&fs[f + 3], 1ull);
+// ---- ahead of the decisions, everything the decide kernel would otherwise walk its rows for: one workgroup per group of 64
+// reads of a mate, one wavefront per read and trip, 16 bytes per lane -- a row arrives as one coalesced kilobyte instead of 64
+// lanes walking 64 rows (a lane-per-read kernel asks L2 for a sector per 16 bytes: 5.1 ms of waiting per 1 M PE1000 pairs).
+//   * the quality half of A1: low-quality count and quality sum, packed (count << 20 | sum: a row holds at most 1024 qualities
+//     of at most 255) into the first word of the read's record, which the decide kernel rewrites at its end;
+//   * the base planes: every lane turns its 16 characters into 16 bits of each of the 5 planes, two lanes make a word, the
+//     workgroup collects the group's words in LDS (40 KB) in the plane store's order and copies them out as one contiguous block.
+__global__ void __launch_bounds__(256)
+snk_long_prep_kernel(const DevParams *Pp, DevBatch B, int lcap, u32 *planes, long ngroups) {
+    __shared__ u32 lds[PL_GROUP_DWORDS + 32];                        // block (quad, plane) at (quad * 5 + plane) * 256 + quad * 4: the +4 per quad
+                                                                     // spreads the 32 words of a read over the 32 banks
+    const DevParams &P = *Pp;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int mates = P.paired ? 2 : 1;
+    const u32 KL = ((u32)min(max(P.phred + P.low_qual, 0), 127) * 0x01010101u) | 0x80808080u;
+    const int pitch = B.pitch, pos = 16 * lane;
+    const bool in_row = pos + 16 <= pitch;
+    constexpr int U = 4;
+    for (long gi = blockIdx.x; gi < ngroups * mates; gi += gridDim.x) {
+        const int m = (int)(gi / ngroups);
+        const long g = gi - (long)m * ngroups;
+        for (int t0 = 0; t0 < 16; t0 += U) {
+            v4u32 qv[U], sv[U];
+            int ln[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const long i = g * 64 + wv * 16 + t0 + k;
+                const bool have = i < B.n;
+                int len = !have ? 0 : (B.len[m] ? (int)B.len[m][i] : B.fixed_len[m]);
+                if (len > lcap) len = 0;                             // (too long: reported by the decide kernel)
+                ln[k] = len;
+                const long row = (have ? i : 0) * (long)pitch;
+                const bool on = in_row && pos < len;
+                qv[k] = on ? ((gl_uint4_p)(B.qual[m] + row))[lane] : v4u32{0, 0, 0, 0};
+                sv[k] = on ? ((gl_uint4_p)(B.seq[m] + row))[lane] : v4u32{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int r = wv * 16 + t0 + k;
+                const long i = g * 64 + r;
+                // qualities
+                const u32 qd[4] = {qv[k].x, qv[k].y, qv[k].z, qv[k].w};
+                u32 lq = 0, qsum = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const u32 ok = valid80(ln[k], pos + 4 * d);
+                    lq += (u32)__popc((KL - (qd[d] & 0x7F7F7F7Fu)) & ~qd[d] & ok);
+                    qsum = __builtin_amdgcn_sad_u8(qd[d] & ((ok >> 7) * 0xFFu), 0u, qsum);
+                }
+                u32 v = (lq << 20) + qsum;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v += (u32)__shfl_xor((int)v, o, 64);
+                if (lane == 0 && i < B.n) reinterpret_cast<u32 *>(B.out[m] + i)[0] = v;
+                // bases: 16 bits of every plane
+                const u32 sd[4] = {sv[k].x, sv[k].y, sv[k].z, sv[k].w};
+                u32 e = 0, c1 = 0, c2 = 0, nn = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const u32 x = sd[d];
+                    const u32 t = x & 0x06060606u;
+                    const u32 ex = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);
+                    e |= pack4(zero_bytes(ex ^ x)) << (4 * d);
+                    nn |= pack4(zero_bytes(x ^ 0x4E4E4E4Eu)) << (4 * d);
+                    c1 |= pack4((x << 6) & 0x80808080u) << (4 * d);
+                    c2 |= pack4((x << 5) & 0x80808080u) << (4 * d);
+                }
+                const u32 in = lowmask32(ln[k] - pos) & 0xFFFFu;
+                e &= in;
+                const u32 a01 = (e & ~c1 & ~c2) | ((e & c1 & ~c2) << 16);      // plane 0 | plane 1 << 16
+                const u32 a23 = (e & c1 & c2) | ((e & ~c1 & c2) << 16);
+                const u32 a4 = nn & in;
+                const u32 b01 = (u32)__shfl_xor((int)a01, 1, 64), b23 = (u32)__shfl_xor((int)a23, 1, 64), b4 = (u32)__shfl_xor((int)a4, 1, 64);
+                // an even lane 2w and its odd neighbour hold positions [32w, 32w + 16) and [32w + 16, 32w + 32)
+                const int w = lane >> 1, quad = w >> 2;
+                const bool odd = lane & 1;
+                u32 *cell = lds + (long)quad * PL_PLANES * 256 + quad * 4 + r * 4 + (w & 3);
+                const u32 wA = odd ? ((b01 >> 16) | (a01 & 0xFFFF0000u)) : ((a01 & 0xFFFFu) | (b01 << 16));      // plane 1 (odd) / plane 0 (even)
+                const u32 wB = odd ? ((b23 >> 16) | (a23 & 0xFFFF0000u)) : ((a23 & 0xFFFFu) | (b23 << 16));      // plane 3 / plane 2
+                cell[(odd ? 1 : 0) * 256] = wA;
+                cell[(odd ? 3 : 2) * 256] = wB;
+                if (!odd) cell[4 * 256] = (a4 & 0xFFFFu) | (b4 << 16);
+            }
+        }
+        __syncthreads();
+        u32 *dst = planes + ((long)m * ngroups + g) * PL_GROUP_DWORDS;
+        for (int blk = wv; blk < PL_QUADS * PL_PLANES; blk += 4) {     // 40 blocks of 1 KB
+            const int quad = blk / PL_PLANES;
+            const v4u32 x = *reinterpret_cast<const v4u32 *>(lds + (long)blk * 256 + quad * 4 + lane * 4);
+            *reinterpret_cast<v4u32 *>(dst + (long)blk * 256 + lane * 4) = x;
+        }
+        __syncthreads();
     }
 }
 
 __global__ void __launch_bounds__(256)
-snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, DevStats st, int lcap, int nq) {
+snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, DevStats st, int lcap, int nq, const u32 *planes, long ngroups) {
     const DevParams &P = *Pp;
     const long fb = file_block(lcap, nq);
     const long ts_off = SNK_GS_N + (long)lcap * 5 + (long)lcap * nq;
@@ -187,7 +231,7 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
                 const bool here = longish && !through, final = rem <= LVLEN;
                 const int vlen = here ? (final ? rem : LVLEN) : 0;
                 u32 X[4][LNW], XN[LNW];
-                block_planes(here ? s[m] : B.seq[m], here ? p0 : 0, vlen, B.pitch, final, X, XN, cntA, cntN, other);
+                block_planes(planes + ((long)m * ngroups + (i >> 6)) * PL_GROUP_DWORDS, (int)(i & 63), here ? p0 : 0, vlen, final, X, XN, cntA, cntN, other);
                 if (n_ada > 0) {
                     // the first adapter of the list with a hit decides, whatever block its hit is in (src/read_filter.cpp:175-188):
                     // only adapters in front of the best one so far are still searched
@@ -211,7 +255,11 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
             if (fast) {
                 r[m].n_a = cntA;
                 r[m].n_n = cntN;
-                scan_quals(P, q[m], len, r[m].lowq, r[m].sumq);
+                {                                                   // the quality half: from snk_long_qstat_kernel
+                    const u32 qs = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(B.out[m] + i));
+                    r[m].lowq = P.phred + P.low_qual >= 0 ? (int)(qs >> 20) : 0;
+                    r[m].sumq = (int)(qs & 0xFFFFFu) - P.phred * len;
+                }
                 if (P.polyX_num != -1) {                            // contig_base (:262-268): one character at a time
                     int last = 'Q', run = 0, maxrun = 1;
                     const gl_uint4_p s4 = (gl_uint4_p)s[m];
@@ -242,7 +290,7 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
         if (ok) {
             reason = pe ? discard_reason(P, r[0], r[1], B.dup ? B.dup[i] : 0, v, cf[0], cf[1])
                         : discard_reason(P, r[0], r[0], B.dup ? B.dup[i] : 0, v, cf[0], cf[0]);
-            count_reason_long(st.sum, pe, reason, v);
+            count_reason(st.sum, pe, reason, v);
         }
         if (exists) {                                                // (a pair that raised an error gets a record no later pass uses)
             store_rec(B.out[0], i, r[0], reason, v);
@@ -298,15 +346,24 @@ __device__ __forceinline__ void hist_add(u32 *hh, int slot, int trash, int nq, i
 // Every lane takes FOUR positions of a read as one dword load (lanes 0-31: the 128 positions of one read, lanes 32-63: of
 // the next one) -- 256 bytes per load instruction instead of 64, which is what the kernel lives on: it is bound by the bytes
 // in flight.  Position 4j + k sits in column 32k + j of a bin row, so the 32 lanes of a half hit 32 different banks.
-__global__ void __launch_bounds__(256)
+#ifndef SNK_HIST_U
+#define SNK_HIST_U 2
+#endif
+#ifndef SNK_HIST_T
+#define SNK_HIST_T 1024
+#endif
+__global__ void __launch_bounds__(SNK_HIST_T)
 snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int nq, int nblk, int slices) {
-    extern __shared__ u32 h[];                       // raw[(5 + nq + 1)][128] | clean[(5 + nq + 1)][128]
+    // Three histograms: a kept read that nothing was cut from counts the same in the raw and the clean statistics -- it is added
+    // once, to `both`; the other reads add their raw characters to `raw` and (kept, trimmed) their clean range to `clean`, in a
+    // second step that most wavefronts skip.  raw = raw + both, clean = clean + both at the flush.
+    extern __shared__ u32 h[];                       // raw[(5 + nq + 1)][128] | both[...] | clean[...]
     const int rows = 5 + nq, words = (rows + 1) * HPB;
-    u32 *hraw = h, *hcl = h + words;
+    u32 *hraw = h, *hcl = h + 2 * words;
     int id = blockIdx.x;
     const int slice = id % slices; id /= slices;
     const int pb = id % nblk, m = id / nblk;
-    for (int k = threadIdx.x; k < 2 * words; k += blockDim.x) h[k] = 0;
+    for (int k = threadIdx.x; k < 3 * words; k += blockDim.x) h[k] = 0;
     __syncthreads();
     const long per = (B.n + slices - 1) / slices;
     const long r0 = (long)slice * per, r1 = min(B.n, r0 + per);
@@ -318,10 +375,10 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
     const uint16_t *lens = B.len[m];
     const int fixed = B.fixed_len[m], pitch = B.pitch;
     const long fb = file_block(lcap, nq);
-    constexpr int U = 4;                                            // pairs of reads per trip: their loads go out together
-    for (long rr = r0 + wave * 2 * U; rr < r1; rr += 4 * 2 * U) {
-        u32 cw[U], qw[U], ccw[U], cqw[U];
-        int nv[U], nc[U];
+    constexpr int U = SNK_HIST_U;                                   // pairs of reads per trip: their loads go out together
+    for (long rr = r0 + wave * 2 * U; rr < r1; rr += (SNK_HIST_T / 64) * 2 * U) {
+        u32 cw[U], qw[U];
+        int nv[U], nc[U], st0[U], sel[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const long rk = rr + 2 * k + half;
@@ -333,38 +390,44 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
             const int start = x.clean_start;
             int cl = (have && x.reason == SNK_KEEP) ? (int)x.clean_len : 0;
             if (start + cl > l) cl = 0;                             // (never for a record of the decision kernels)
+            const bool same = cl == l && start == 0;                 // (cl == l > 0: kept as it came)
             nv[k] = max(min(l - base - 4 * j, 4), 0);               // positions of this lane's dword the read has
-            nc[k] = max(min(cl - base - 4 * j, 4), 0);
+            nc[k] = same ? 0 : max(min(cl - base - 4 * j, 4), 0);   // ... its clean range has, when that is not the same thing
+            st0[k] = start;
+            sel[k] = same ? words : 0;
             const uint8_t *ps = seq + r * (long)pitch, *pq = qual + r * (long)pitch;
             const int off = base + 4 * j;
             cw[k] = nv[k] ? *reinterpret_cast<const u32 *>(ps + off) : 0u;
             qw[k] = nv[k] ? *reinterpret_cast<const u32 *>(pq + off) : 0u;
-            ccw[k] = cw[k];
-            cqw[k] = qw[k];
-            if (start != 0 && nc[k]) {                              // head-trimmed: the clean read sits at shifted positions
-                const int so = start + off, al = so & ~3, sh = 8 * (so & 3);
-                const u32 s0 = *reinterpret_cast<const u32 *>(ps + al), q0 = *reinterpret_cast<const u32 *>(pq + al);
-                const u32 s1 = (sh && al + 8 <= pitch) ? *reinterpret_cast<const u32 *>(ps + al + 4) : 0u;
-                const u32 q1 = (sh && al + 8 <= pitch) ? *reinterpret_cast<const u32 *>(pq + al + 4) : 0u;
-                ccw[k] = __builtin_amdgcn_alignbit(s1, s0, sh);
-                cqw[k] = __builtin_amdgcn_alignbit(q1, q0, sh);
-            }
         }
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             bool e = false, ec = false;
+            u32 *hh = hraw + sel[k];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int col = 32 * b + j;
-                hist_add(hraw, col, rows, nq, phred, (cw[k] >> (8 * b)) & 0xFFu, (qw[k] >> (8 * b)) & 0xFFu, b < nv[k], e);
-                hist_add(hcl, col, rows, nq, phred, (ccw[k] >> (8 * b)) & 0xFFu, (cqw[k] >> (8 * b)) & 0xFFu, b < nc[k], ec);
-            }
+            for (int b = 0; b < 4; ++b)
+                hist_add(hh, 32 * b + j, rows, nq, phred, (cw[k] >> (8 * b)) & 0xFFu, (qw[k] >> (8 * b)) & 0xFFu, b < nv[k], e);
             // a quality outside [0, nq) of the RAW pass is the reference's heap corruption (src/peprocess.cpp:1196): first one reported
             const unsigned long long em = __ballot(e);
             if (em && lane == 0) {
                 if (em & 0xFFFFFFFFull) report_err(st, B.first_index + (u64)(rr + 2 * k), m, SNK_E_QUAL_RANGE);
                 if (em >> 32) report_err(st, B.first_index + (u64)(rr + 2 * k + 1), m, SNK_E_QUAL_RANGE);
             }
+            if (__ballot(nc[k] != 0) == 0) continue;                // (uniform) nobody's clean range differs from the read here
+            u32 ccw = cw[k], cqw = qw[k];
+            if (st0[k] != 0 && nc[k]) {                             // head-trimmed: the clean read sits at shifted positions
+                const long r = rr + 2 * k + half;
+                const uint8_t *ps = seq + r * (long)pitch, *pq = qual + r * (long)pitch;
+                const int so = st0[k] + base + 4 * j, al = so & ~3, sh = 8 * (so & 3);
+                const u32 s0 = *reinterpret_cast<const u32 *>(ps + al), q0 = *reinterpret_cast<const u32 *>(pq + al);
+                const u32 s1 = (sh && al + 8 <= pitch) ? *reinterpret_cast<const u32 *>(ps + al + 4) : 0u;
+                const u32 q1 = (sh && al + 8 <= pitch) ? *reinterpret_cast<const u32 *>(pq + al + 4) : 0u;
+                ccw = __builtin_amdgcn_alignbit(s1, s0, sh);
+                cqw = __builtin_amdgcn_alignbit(q1, q0, sh);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                hist_add(hcl, 32 * b + j, rows, nq, phred, (ccw >> (8 * b)) & 0xFFu, (cqw >> (8 * b)) & 0xFFu, b < nc[k], ec);
         }
     }
     __syncthreads();
@@ -373,7 +436,7 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
         const int row = k / HPB, col = k - row * HPB, p = base + 4 * (col & 31) + (col >> 5);
         if (p >= lcap) continue;
         const long off = row < 5 ? (long)p * 5 + row : (long)lcap * 5 + (long)p * nq + (row - 5);
-        const u32 a = hraw[k], b = hcl[k];
+        const u32 both = h[words + k], a = hraw[k] + both, b = hcl[k] + both;
         if (a) atomicAdd(&fraw[off], (unsigned long long)a);
         if (b) atomicAdd(&fcl[off], (unsigned long long)b);
     }
@@ -382,14 +445,22 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
 }  // namespace
 
 // returns 0 when this path cannot take the batch (the caller falls back to the generic kernel)
+size_t snk_long_scratch_bytes(long n, int paired) { return (size_t)plane_store_dwords(n, paired ? 2 : 1) * sizeof(u32); }
+
 int snk_launch_long(const DevParams *dp, const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, int lcap, int nq,
-                    int n_cu, void *stream) {
-    if (!hp.tile_ok || lcap <= 256 || lcap > 1024 || b.n <= 0) return 0;
+                    int n_cu, unsigned *planes, void *stream) {
+    if (!hp.tile_ok || lcap <= 256 || lcap > 1024 || b.n <= 0 || !planes) return 0;
     if (b.pitch % 16 != 0 || b.pitch < ((lcap + 15) & ~15)) return 0;
     if ((((uintptr_t)b.seq[0] | (uintptr_t)b.qual[0] | (uintptr_t)b.seq[1] | (uintptr_t)b.qual[1]) % 16) != 0) return 0;
     long wgs = (b.n + 255) / 256;
     if (wgs > (long)n_cu * 8) wgs = (long)n_cu * 8;
-    hipLaunchKernelGGL(snk_long_decide_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, dp, ta, b, st, lcap, nq);
+    const long ngroups = (b.n + 63) / 64;
+    {
+        long pw = ngroups * (hp.paired ? 2 : 1);
+        if (pw > (long)n_cu * 16) pw = (long)n_cu * 16;
+        hipLaunchKernelGGL(snk_long_prep_kernel, dim3((unsigned)pw), dim3(256), 0, (hipStream_t)stream, dp, b, lcap, planes, ngroups);
+    }
+    hipLaunchKernelGGL(snk_long_decide_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, dp, ta, b, st, lcap, nq, (const u32 *)planes, ngroups);
     return snk_launch_hist(dp, hp.paired, b, st, lcap, nq, n_cu, stream);
 }
 
@@ -398,9 +469,9 @@ int snk_launch_hist(const DevParams *dp, int paired, const DevBatch &b, const De
     if (b.n <= 0 || lcap <= 0 || (b.pitch & 3)) return 0;
     if ((((uintptr_t)b.seq[0] | (uintptr_t)b.qual[0] | (uintptr_t)b.seq[1] | (uintptr_t)b.qual[1]) & 3) != 0) return 0;
     const int nblk = (lcap + HPB - 1) / HPB, mates = paired ? 2 : 1;
-    const size_t shmem = (size_t)2 * (5 + nq + 1) * HPB * sizeof(u32);
+    const size_t shmem = (size_t)3 * (5 + nq + 1) * HPB * sizeof(u32);
     if (shmem > 150 * 1024) return 0;
-    int slices = (int)((long)n_cu * 3 / (nblk * mates));
+    int slices = (int)((long)n_cu * 2 / (nblk * mates));
     if (slices < 1) slices = 1;
     while (slices > 1 && b.n / slices < 512) --slices;              // a flush per workgroup wants some reads behind it
     static bool attr_done = false;
@@ -408,7 +479,7 @@ int snk_launch_hist(const DevParams *dp, int paired, const DevBatch &b, const De
         (void)hipFuncSetAttribute((const void *)snk_long_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(snk_long_hist_kernel, dim3((unsigned)(mates * nblk * slices)), dim3(256), shmem, (hipStream_t)stream, dp, b, st, lcap, nq,
+    hipLaunchKernelGGL(snk_long_hist_kernel, dim3((unsigned)(mates * nblk * slices)), dim3(SNK_HIST_T), shmem, (hipStream_t)stream, dp, b, st, lcap, nq,
                        nblk, slices);
     return 1;
 }
