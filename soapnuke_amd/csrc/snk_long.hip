@@ -106,8 +106,8 @@ __device__ __forceinline__ u64 wave_max64(u64 v) {
 //     workgroup collects the group's words in LDS (40 KB) in the plane store's order and copies them out as one contiguous block.
 __global__ void __launch_bounds__(256)
 snk_long_prep_kernel(const DevParams *Pp, DevBatch B, int lcap, u32 *planes, long ngroups) {
-    __shared__ u32 lds[PL_GROUP_DWORDS + 32];                        // block (quad, plane) at (quad * 5 + plane) * 256 + quad * 4: the +4 per quad
-                                                                     // spreads the 32 words of a read over the 32 banks
+    __shared__ u32 lds[PL_GROUP_DWORDS];                             // block (quad, plane) at (quad * 5 + plane) * 256, its cells XOR-skewed by
+                                                                     // quad * 4: the 32 words of a read fall into the 32 banks (40 KB: 4 per CU)
     const DevParams &P = *Pp;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int mates = P.paired ? 2 : 1;
@@ -172,7 +172,7 @@ snk_long_prep_kernel(const DevParams *Pp, DevBatch B, int lcap, u32 *planes, lon
                 // an even lane 2w and its odd neighbour hold positions [32w, 32w + 16) and [32w + 16, 32w + 32)
                 const int w = lane >> 1, quad = w >> 2;
                 const bool odd = lane & 1;
-                u32 *cell = lds + (long)quad * PL_PLANES * 256 + quad * 4 + r * 4 + (w & 3);
+                u32 *cell = lds + (long)quad * PL_PLANES * 256 + ((r * 4 + (w & 3)) ^ (quad * 4));
                 const u32 wA = odd ? ((b01 >> 16) | (a01 & 0xFFFF0000u)) : ((a01 & 0xFFFFu) | (b01 << 16));      // plane 1 (odd) / plane 0 (even)
                 const u32 wB = odd ? ((b23 >> 16) | (a23 & 0xFFFF0000u)) : ((a23 & 0xFFFFu) | (b23 << 16));      // plane 3 / plane 2
                 cell[(odd ? 1 : 0) * 256] = wA;
@@ -184,14 +184,17 @@ snk_long_prep_kernel(const DevParams *Pp, DevBatch B, int lcap, u32 *planes, lon
         u32 *dst = planes + ((long)m * ngroups + g) * PL_GROUP_DWORDS;
         for (int blk = wv; blk < PL_QUADS * PL_PLANES; blk += 4) {     // 40 blocks of 1 KB
             const int quad = blk / PL_PLANES;
-            const v4u32 x = *reinterpret_cast<const v4u32 *>(lds + (long)blk * 256 + quad * 4 + lane * 4);
+            const v4u32 x = *reinterpret_cast<const v4u32 *>(lds + (long)blk * 256 + ((lane * 4) ^ (quad * 4)));
             *reinterpret_cast<v4u32 *>(dst + (long)blk * 256 + lane * 4) = x;
         }
         __syncthreads();
     }
 }
 
-__global__ void __launch_bounds__(256)
+#ifndef SNK_LONG_WPE
+#define SNK_LONG_WPE 2           // waves per SIMD the decide kernel's register allocation aims at
+#endif
+__global__ void __launch_bounds__(256, SNK_LONG_WPE)
 snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, DevStats st, int lcap, int nq, const u32 *planes, long ngroups) {
     const DevParams &P = *Pp;
     const long fb = file_block(lcap, nq);
@@ -343,6 +346,30 @@ __device__ __forceinline__ void hist_add(u32 *hh, int slot, int trash, int nq, i
     atomicAdd(&hh[qrow * HPB + slot], 1u);
 }
 
+// The same for the four positions of a dword at once (columns 32 b + j, b = 0..3; the first nv of them exist): rows as bytes by
+// SWAR -- v_perm picks letter and row of four codes at a time, the quality range test is two byte-wise subtractions that cannot
+// borrow (needs phred + nq <= 128: the caller checks) -- then one shift-add per LDS add.  38 VALU per dword instead of 64.
+__device__ __forceinline__ void hist_add4(u32 *hh, int j, int trash, int nq, int phred, u32 cw, u32 qw, int nv, bool &err) {
+    const u32 validm = nv >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nv)) - 1u);
+    const u32 u4 = cw & 0xDFDFDFDFu, t4 = (u4 >> 1) & 0x03030303u;       // A 0, C 1, T 2, G 3
+    const u32 ex4 = __builtin_amdgcn_perm(0u, 0x47544341u, t4);           // the letters of those codes ("ACTG")
+    const u32 bt4 = __builtin_amdgcn_perm(0u, 0x02030100u, t4);           // their rows: A C G T -> 0 1 2 3
+    const u32 eqm = (zero_bytes(u4 ^ ex4) >> 7) * 0xFFu;
+    const u32 q7 = qw & 0x7F7F7F7Fu;
+    const u32 ge = (q7 | 0x80808080u) - (u32)phred * 0x01010101u;        // bit 7 of a byte: q7 >= phred; its low bits: q7 - phred then
+    const u32 lt = (((u32)(phred + nq - 1) * 0x01010101u) | 0x80808080u) - q7;   // bit 7: q7 <= phred + nq - 1
+    const u32 okm = ((ge & lt & ~qw & 0x80808080u) >> 7) * 0xFFu & validm;
+    err |= (validm & ~okm) != 0;
+    const u32 tr4 = (u32)trash * 0x01010101u;
+    const u32 b4 = (((bt4 & eqm) | (0x04040404u & ~eqm)) & validm) | (tr4 & ~validm);
+    const u32 q4 = (((ge & 0x7F7F7F7Fu) + 0x05050505u) & okm) | (tr4 & ~okm);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        atomicAdd(&hh[((b4 >> (8 * b)) & 0xFFu) * HPB + 32 * b + j], 1u);
+        atomicAdd(&hh[((q4 >> (8 * b)) & 0xFFu) * HPB + 32 * b + j], 1u);
+    }
+}
+
 // Every lane takes FOUR positions of a read as one dword load (lanes 0-31: the 128 positions of one read, lanes 32-63: of
 // the next one) -- 256 bytes per load instruction instead of 64, which is what the kernel lives on: it is bound by the bytes
 // in flight.  Position 4j + k sits in column 32k + j of a bin row, so the 32 lanes of a half hit 32 different banks.
@@ -370,6 +397,7 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int half = lane >> 5, j = lane & 31;
     const int base = pb * HPB, phred = __builtin_amdgcn_readfirstlane(Pp->phred);
+    const bool swar = phred >= 0 && phred + nq <= 128 && rows < 256;   // (uniform) what hist_add4's byte arithmetic needs
     const uint8_t *seq = B.seq[m], *qual = B.qual[m];
     const snk_read_result *rec = B.out[m];
     const uint16_t *lens = B.len[m];
@@ -404,9 +432,12 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
         for (int k = 0; k < U; ++k) {
             bool e = false, ec = false;
             u32 *hh = hraw + sel[k];
+            if (swar) hist_add4(hh, j, rows, nq, phred, cw[k], qw[k], nv[k], e);
+            else {
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                hist_add(hh, 32 * b + j, rows, nq, phred, (cw[k] >> (8 * b)) & 0xFFu, (qw[k] >> (8 * b)) & 0xFFu, b < nv[k], e);
+                for (int b = 0; b < 4; ++b)
+                    hist_add(hh, 32 * b + j, rows, nq, phred, (cw[k] >> (8 * b)) & 0xFFu, (qw[k] >> (8 * b)) & 0xFFu, b < nv[k], e);
+            }
             // a quality outside [0, nq) of the RAW pass is the reference's heap corruption (src/peprocess.cpp:1196): first one reported
             const unsigned long long em = __ballot(e);
             if (em && lane == 0) {
@@ -425,9 +456,12 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
                 ccw = __builtin_amdgcn_alignbit(s1, s0, sh);
                 cqw = __builtin_amdgcn_alignbit(q1, q0, sh);
             }
+            if (swar) hist_add4(hcl, j, rows, nq, phred, ccw, cqw, nc[k], ec);
+            else {
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                hist_add(hcl, 32 * b + j, rows, nq, phred, (ccw >> (8 * b)) & 0xFFu, (cqw >> (8 * b)) & 0xFFu, b < nc[k], ec);
+                for (int b = 0; b < 4; ++b)
+                    hist_add(hcl, 32 * b + j, rows, nq, phred, (ccw >> (8 * b)) & 0xFFu, (cqw >> (8 * b)) & 0xFFu, b < nc[k], ec);
+            }
         }
     }
     __syncthreads();

@@ -122,3 +122,26 @@ def test_long_reads_quality_range_error():
     assert got["err"][0] == abi.SNK_E_QUAL_RANGE if hasattr(abi, "SNK_E_QUAL_RANGE") else got["err"][0] != 0
     want = T.run_oracle(p, d)
     assert tuple(got["err"]) == tuple(want["err"])
+
+
+def test_long_reads_plane_store_group_edges_and_regrowth():
+    """the plane store holds groups of 64 reads (snk_long_prep_kernel): batches that end inside a group, one read, and batches
+    growing through one context (the scratch is regrown) -- SE and PE"""
+    from soapnuke_amd.filter import FilterContext, records_to_numpy
+    L = 1000
+    for paired in (True, False):
+        kw = PE_CASES["C3_full"] if paired else se_kwargs(PE_CASES["C3_full"])
+        p = abi.default_params(paired=paired, max_read_len=L, **kw)
+        ctx = FilterContext(p, device=0)
+        for n in (1, 63, 64, 65, 129, 1000):
+            d = synth.make_batch(n, L, paired=paired, var_len=True, seed=500 + n)
+            if n >= 63:
+                plant_everywhere(d, (kw["adapters1"][0], kw.get("adapters2", kw["adapters1"])[0]), n, L)
+            dev = ctx.upload(d)
+            rec = ctx.alloc_records(n)
+            ctx.clear()
+            ctx.filter_batch(ctx.make_batch(dev), rec, kernel=2)
+            s, mx, err = ctx.fetch()
+            got = dict(rec=[records_to_numpy(rec[0]), records_to_numpy(rec[1])], sum=s, max=mx, err=err)
+            assert_same(p, got, T.run_oracle(p, d), paired)
+        ctx.close()
