@@ -1,14 +1,14 @@
 #!/bin/bash
-# Profiles the long-read path (snk_long.hip) on the GPU box:  tools/prof_long.sh <tag> [L=1000] [pairs=1000000] [c2|c3] [pmc=1]
+# Profiles the long-read path (snk_long.hip) on the GPU box:  tools/prof_long.sh <tag> [L=1000] [pairs=1000000] [c2|c3|contam] [pmc=1] [kernel=0]
 # kernel trace (+ three PMC passes when pmc=1) of tools/bench_long.py; per-kernel summary in gpurun_out/<tag>/summary.txt
 set -u
-TAG=${1:-long}; L=${2:-1000}; N=${3:-1000000}; WL=${4:-c2}; PMC=${5:-1}
+TAG=${1:-long}; L=${2:-1000}; N=${3:-1000000}; WL=${4:-c2}; PMC=${5:-1}; KERN=${6:-0}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/tools/bench_long.py $L $N $WL"
+CMD="python $ROOT/tools/bench_long.py $L $N $WL $KERN"
 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o long -- $CMD > "$OUT/bench_trace.log" 2>&1
 if [ "$PMC" = "1" ]; then
   i=0
