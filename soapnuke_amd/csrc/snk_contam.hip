@@ -20,9 +20,11 @@
 //               equality bits of their lay.
 //
 // What the bit paths do not cover (contaminants over 64 characters or with anything but ACGTN, reads shorter than the
-// contaminant, reads over 256 nt) goes to the sequential matchers of snk_common.cuh, per lane.
+// contaminant) goes to the sequential matchers of snk_common.cuh, per lane.  Reads over 256 nt: the same bit paths block by
+// block on the plane store of the long-read path (snk_long_contam_kernel below).
 #include <hip/hip_runtime.h>
 #include "snk_common.cuh"
+#include "snk_planes.cuh"
 
 using namespace snk;
 
@@ -172,12 +174,15 @@ __device__ __forceinline__ bool contam_accept(u64 m, u64 n, int ncells, int T, i
 // against its budget(r1) -- through their monotone envelopes (rT, rk: DevContam), so that "cell c counts for this
 // offset" and "this offset's budget is at least b" are prefix masks over the offsets.
 template <int NW, int NC, bool BIG = false>      // BIG: budgets of 4 and more exist -- NC == 4 planes count to four, such offsets are never screened out
-__device__ bool has_contam_bits(const DevContam &C, const DevContam &L, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active) {
+// do_head (uniform) / do_tail (per lane): the planes start at the read's first character / end at its last one.  A block in the
+// middle of a long read (snk_long_contam_kernel) has neither: only the alignments of the middle section exist there.
+__device__ bool has_contam_bits(const DevContam &C, const DevContam &L, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
+                                bool do_head = true, bool do_tail = true) {
     const int cl = C.len, edge = C.edge, nC = C.nC;
     const u64 cm0 = C.cm[0], cm1 = C.cm[1], cm2 = C.cm[2], cm3 = C.cm[3], nm = C.nm;
     bool hit = false;
     // ---- head (:523-547): the last k = r1 + edge characters of the contaminant on read[0, k)
-    if (nC > 0 && SNK_CABL != 1) {
+    if (nC > 0 && SNK_CABL != 1 && do_head) {
         const u64 x0 = cat64(X[0][1], X[0][0]), x1 = cat64(X[1][1], X[1][0]), x2 = cat64(X[2][1], X[2][0]), x3 = cat64(X[3][1], X[3][0]);
         const u64 xn = cat64(XN[1], XN[0]);
         u64 cand = 0;
@@ -249,7 +254,7 @@ __device__ bool has_contam_bits(const DevContam &C, const DevContam &L, const u3
             steps(nm & sm);
         }
         // an offset is out when its count exceeds its budget: budgets as thermometer planes [budget >= b]
-        const int nvalid = (nC > 0 ? len - edge : len - cl) + 1, mis = max(C.mis, 0);
+        const int nvalid = ((nC > 0 && do_tail) ? len - edge : len - cl) + 1, mis = max(C.mis, 0);
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             u32 rej = Cn[NC - 1][j];
@@ -284,13 +289,14 @@ __device__ bool has_contam_bits(const DevContam &C, const DevContam &L, const u3
 }
 
 template <int NW>
-__device__ bool has_contam_bits_nc(const DevContam &C, const DevContam &L, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active) {
+__device__ bool has_contam_bits_nc(const DevContam &C, const DevContam &L, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
+                                   bool do_head = true, bool do_tail = true) {
     const int b = __builtin_amdgcn_readfirstlane(C.bmax);
-    if (b <= 0) return has_contam_bits<NW, 1>(C, L, X, XN, len, active);
-    if (b == 1) return has_contam_bits<NW, 2>(C, L, X, XN, len, active);
-    if (b == 2) return has_contam_bits<NW, 3>(C, L, X, XN, len, active);
-    if (b == 3) return has_contam_bits<NW, 4>(C, L, X, XN, len, active);
-    return has_contam_bits<NW, 4, true>(C, L, X, XN, len, active);
+    if (b <= 0) return has_contam_bits<NW, 1>(C, L, X, XN, len, active, do_head, do_tail);
+    if (b == 1) return has_contam_bits<NW, 2>(C, L, X, XN, len, active, do_head, do_tail);
+    if (b == 2) return has_contam_bits<NW, 3>(C, L, X, XN, len, active, do_head, do_tail);
+    if (b == 3) return has_contam_bits<NW, 4>(C, L, X, XN, len, active, do_head, do_tail);
+    return has_contam_bits<NW, 4, true>(C, L, X, XN, len, active, do_head, do_tail);
 }
 
 // x = ~(plane >> c) for a uniform c in [0, 64): the offsets whose cell at contaminant position c is NOT that letter;
@@ -331,7 +337,11 @@ __device__ __forceinline__ void mism_plane(const u32 (&XP)[5][NQ], int letter, i
 // mismatches.  The offsets that pass are decided exactly with the window walk (gc_walk) on the 64 equality bits of their
 // lay: one lay for an offset of the first two sections, the whole last section once one of its offsets passes.
 template <int NW, int NB, int NQ>
-__device__ bool gcontam_bits(const DevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active) {
+// do_head (uniform) / do_tail (per lane) as in has_contam_bits: a block in the middle of a long read has the whole lays only
+// (offsets p >= 0 that end inside the block), the lays hanging off the read's start belong to its first block, the last section to
+// its final one.
+__device__ bool gcontam_bits(const DevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
+                             bool do_head = true, bool do_tail = true) {
     constexpr int NP = NW + 2;                       // plane words: read positions + PAD
     const int cl = G.len, mml = G.min_match_len, mmn = G.mm, PAD = cl - mml;
     const int Ls = min(mml, (1 << NB) - 1);
@@ -404,8 +414,8 @@ __device__ bool gcontam_bits(const DevGContam &G, int d, const u32 (&X)[4][NW], 
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const u32 all = active ? lowmask32(len - mml + PAD + 1 - 32 * j) : 0u, front = lowmask32(len - cl + PAD + 1 - 32 * j);
-        tail |= ((W[j] | J[j]) & all & ~front) != 0;
-        W[j] &= all & front;
+        tail |= do_tail && ((W[j] | J[j]) & all & ~front) != 0;
+        W[j] &= all & front & (do_head ? 0xFFFFFFFFu : ~lowmask32(PAD - 32 * j));
     }
     const int tms = -200 * mmn, lower = (mml - mmn) + tms;
     bool hit = false;
@@ -449,17 +459,19 @@ __device__ bool gcontam_bits(const DevGContam &G, int d, const u32 (&X)[4][NW], 
 }
 
 template <int NW, int NB>
-__device__ bool gcontam_bits_nq(const DevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, int lcap, bool active) {
+__device__ bool gcontam_bits_nq(const DevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, int lcap, bool active,
+                                bool do_head = true, bool do_tail = true) {
     const int need = __builtin_amdgcn_readfirstlane((lcap - 2 * G.min_match_len + G.len + 32) >> 5);   // words of offsets -PAD .. lcap - mml
-    if (need <= NW) return gcontam_bits<NW, NB, NW>(G, d, X, XN, len, active);
-    if (need == NW + 1) return gcontam_bits<NW, NB, NW + 1>(G, d, X, XN, len, active);
-    return gcontam_bits<NW, NB, NW + 2>(G, d, X, XN, len, active);
+    if (need <= NW) return gcontam_bits<NW, NB, NW>(G, d, X, XN, len, active, do_head, do_tail);
+    if (need == NW + 1) return gcontam_bits<NW, NB, NW + 1>(G, d, X, XN, len, active, do_head, do_tail);
+    return gcontam_bits<NW, NB, NW + 2>(G, d, X, XN, len, active, do_head, do_tail);
 }
 template <int NW>
-__device__ bool gcontam_bits_nb(const DevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, int lcap, bool active) {
+__device__ bool gcontam_bits_nb(const DevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, int lcap, bool active,
+                                bool do_head = true, bool do_tail = true) {
     const int mml = __builtin_amdgcn_readfirstlane(G.min_match_len), mmn = __builtin_amdgcn_readfirstlane(G.mm);
-    if (mml < 16 || mmn <= 2) return gcontam_bits_nq<NW, 4>(G, d, X, XN, len, lcap, active);
-    return gcontam_bits_nq<NW, 5>(G, d, X, XN, len, lcap, active);
+    if (mml < 16 || mmn <= 2) return gcontam_bits_nq<NW, 4>(G, d, X, XN, len, lcap, active, do_head, do_tail);
+    return gcontam_bits_nq<NW, 5>(G, d, X, XN, len, lcap, active, do_head, do_tail);
 }
 
 // One work-item per pair.  The workgroup first copies its 256 rows (coalesced) and the contaminant tables into LDS --
@@ -532,7 +544,92 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SNK_CW
     }
 }
 
+// Reads of 257..1024 positions: the same bit paths on BLOCKS of a read, from the plane store the long-read prep kernel wrote
+// (snk_planes.cuh): planes of 320 positions serve the 256 alignment offsets of a block and the 64 positions a contaminant reaches
+// past them.  Contaminant alignments that hang off the read's start belong to its first block, those hanging off its end to its
+// final block (which is cut so that it ends with the read and holds at least 64 positions), whole alignments to the block of
+// their offset: only the verdict is ever used, so a hit in any block is the hit.  One work-item per pair; reads shorter than a
+// contaminant and contaminants outside the bit paths take the sequential matchers on the read's row, per lane.
+__global__ void __launch_bounds__(256) snk_long_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, const u32 *planes, long ngroups) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
+    const DevParams &P = *Pp;
+    const int pe = P.paired ? 1 : 0, tid = threadIdx.x;
+    DevContam *lct = reinterpret_cast<DevContam *>(sm);
+    DevGContam *lg = reinterpret_cast<DevGContam *>(lct + max(P.n_ct[0], P.n_ct[1]));
+    const int n_gct = P.n_gct;
+    for (int k = tid; k < (int)(n_gct * sizeof(DevGContam) / 4); k += 256)
+        reinterpret_cast<uint32_t *>(lg)[k] = reinterpret_cast<const uint32_t *>(P.gct)[k];
+    const long nround = (B.n + 255) / 256 * 256;
+    for (long base = (long)blockIdx.x * 256; base < nround; base += (long)gridDim.x * 256) {
+        const long i = base + tid;
+        const bool exists = i < B.n;
+        int f = 0;
+        for (int m = 0; m <= pe; ++m) {
+            const int n_ct = P.n_ct[m];
+            __syncthreads();
+            for (int k = tid; k < (int)(n_ct * sizeof(DevContam) / 4); k += 256)
+                reinterpret_cast<uint32_t *>(lct)[k] = reinterpret_cast<const uint32_t *>(P.ct + m * SNK_MAX_CONTAMS)[k];
+            __syncthreads();
+            const int len = exists ? min(B.len[m] ? (int)B.len[m][i] : B.fixed_len[m], P.lcap) : 0;
+            const uint8_t *row = B.seq[m] + (exists ? i : 0) * (long)B.pitch;
+            const u32 *grp = planes + ((long)m * ngroups + (i >> 6)) * PL_GROUP_DWORDS;
+            int fm = 0;
+            // the sequential share first: reads shorter than 64 (no block decomposition), contaminants the bit paths do not cover
+            const bool blocks = exists && len >= 64;
+            for (int c = 0; c < n_ct; ++c)
+                if (exists && !(fm & 1) && (!blocks || !lct[c].bits_ok) && has_contam_seq(row, len, lct[c]) >= 0) fm |= 1;
+            for (int c = 0; c < n_gct; ++c)
+                for (int d = 0; d < 2; ++d)
+                    if (exists && !(fm & 2) && (!blocks || !lg[c].bits_ok) &&
+                        global_contam_hit(row, len, lg[c].seq[d], lg[c].len, lg[c].min_match_len, lg[c].mm)) fm |= 2;
+            bool through = false;
+            for (int p0 = 0; __any(blocks && !through); p0 += PL_BLK) {
+                const int rem = len - p0;
+                const bool here = blocks && !through, final = rem <= PL_VLEN;
+                const int vlen = here ? (final ? rem : PL_VLEN) : 0;
+                u32 W[PL_PLANES][12], X[4][PL_NW], XN[PL_NW];
+                plane_block_words(grp, (int)(i & 63), here ? p0 : 0, vlen, W);
+#pragma unroll
+                for (int w = 0; w < PL_NW; ++w) {
+                    const u32 in = lowmask32(vlen - 32 * w);
+                    X[0][w] = W[0][w] & in; X[1][w] = W[1][w] & in; X[2][w] = W[2][w] & in; X[3][w] = W[3][w] & in;
+                    XN[w] = W[4][w] & in;
+                }
+                for (int c = 0; c < n_ct; ++c) {
+                    const DevContam &C = P.ct[m * SNK_MAX_CONTAMS + c];
+                    const bool want = here && !(fm & 1) && C.bits_ok != 0;
+                    if (__any(want) && has_contam_bits_nc<PL_NW>(C, lct[c], X, XN, vlen, want, p0 == 0, final)) fm |= 1;
+                }
+                for (int c = 0; c < n_gct; ++c) {
+                    const DevGContam &G = P.gct[c];
+                    for (int d = 0; d < 2; ++d) {
+                        const bool want = here && !(fm & 2) && G.bits_ok != 0;
+                        if (__any(want) && gcontam_bits_nb<PL_NW>(G, d, X, XN, vlen, PL_VLEN + 1, want, p0 == 0, final)) fm |= 2;
+                    }
+                }
+                through |= here && final;
+            }
+            f |= fm << (2 * m);
+        }
+        if (exists) cf[i] = (unsigned char)f;
+    }
+}
+
 }  // namespace
+
+// the long-read variant: verdicts from the plane store (snk_long.hip wrote it on the same stream)
+void snk_launch_long_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int n_ct, int n_gct, const unsigned *planes, void *stream) {
+    if (b.n <= 0) return;
+    long blocks = (b.n + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const size_t shmem = (size_t)n_ct * sizeof(DevContam) + (size_t)n_gct * sizeof(DevGContam) + 16;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)snk_long_contam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(snk_long_contam_kernel, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, dp, b, cf, (const u32 *)planes, (b.n + 63) / 64);
+}
 
 void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int lcap, int n_ct, int n_gct, void *stream) {
     if (b.n <= 0) return;

@@ -675,7 +675,22 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
                 if (hipMalloc((void **)&c->d_pl[slot], need) != hipSuccess) { set_err("snk_filter_batch_device: out of device memory (long-read plane store)"); return fail(SNK_E_NOMEM); }
                 c->pl_cap[slot] = need;
             }
-            done = snk_launch_long(c->d_params, c->hp, c->ta, D, DevStats{c->d_sum, c->d_max, c->d_err, c->d_tsw}, c->lcap, c->nq, c->n_cu, c->d_pl[slot], stream);
+            unsigned char *cfl = nullptr;
+#ifndef SNK_LONG_SEQ_CONTAM                                   // (A/B builds: the sequential matchers inside the decide kernel)
+            if (c->hp.n_ct[0] | c->hp.n_ct[1] | c->hp.n_gct) {   // contaminant verdicts: their own pass over the plane store, as for the tiled kernel
+                if ((size_t)b->n > c->cf_cap[slot]) {
+                    HIP_OK(hipStreamSynchronize(s));
+                    if (c->d_cf[slot]) (void)hipFree(c->d_cf[slot]);
+                    c->d_cf[slot] = nullptr;
+                    c->cf_cap[slot] = 0;
+                    const size_t cap = ((size_t)b->n + 65535) & ~(size_t)65535;
+                    HIP_OK(hipMalloc((void **)&c->d_cf[slot], cap));
+                    c->cf_cap[slot] = cap;
+                }
+                cfl = c->d_cf[slot];
+            }
+#endif
+            done = snk_launch_long(c->d_params, c->hp, c->ta, D, DevStats{c->d_sum, c->d_max, c->d_err, c->d_tsw}, c->lcap, c->nq, c->n_cu, c->d_pl[slot], cfl, stream);
         }
         if (!done && kernel == 2) { set_err("snk_filter_batch_device: tiled kernel does not support this configuration"); return fail(SNK_E_UNSUPPORTED); }
     }

@@ -25,14 +25,15 @@
 #include <hip/hip_runtime.h>
 #include "snk_common.cuh"
 #include "snk_adapter_bits.cuh"
+#include "snk_planes.cuh"
 
 using namespace snk;
 
 
 namespace {
 
-constexpr int LNW = 10;            // plane words of a block: 256 candidate offsets + 64 positions behind them
-constexpr int LBLK = 256;          // candidate offsets per block
+constexpr int LNW = PL_NW;         // plane words of a block: 256 candidate offsets + 64 positions behind them
+constexpr int LBLK = PL_BLK;       // candidate offsets per block
 constexpr int LVLEN = 32 * LNW - 1;   // characters a non-final block shows to the adapter search
 
 __device__ __forceinline__ u32 zero_bytes(u32 x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); }   // 0x80 per zero byte
@@ -47,30 +48,14 @@ __device__ __forceinline__ u32 valid80(int len, int pos) {
 typedef u32 v4u32 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) v4u32 *gl_uint4_p;
 
-// ---- the plane store of a batch (snk_long_prep_kernel writes it, the decide kernel reads it): for every group of 64
-// consecutive reads of a mate, 8 quads of 4 plane words (32 positions each) x 5 planes (A C G T N) x 64 reads x 16 bytes, so that
-// the 64 lanes of a wavefront -- 64 consecutive reads -- fetch one quad of one plane as one contiguous kilobyte.
-constexpr int PL_QUADS = 8, PL_PLANES = 5;
-constexpr long PL_GROUP_DWORDS = (long)PL_QUADS * PL_PLANES * 64 * 4;      // 40 KB per group
-__host__ __device__ inline long plane_store_dwords(long n, int mates) { return (long)mates * ((n + 63) / 64) * PL_GROUP_DWORDS; }
-
 // planes of the block [p0, p0 + 320) of a read from the plane store: X[k] bit j = read[p0 + j] == "ACGT"[k], XN likewise for 'N';
 // ones from vlen on.  Also the A1 base counts of a read of upper-case ACGTN only (src/read_filter.cpp:258-308), which are
 // popcounts of its planes: cntA / cntN += the 'A' / 'N' of the block's own positions (256, or all of a final block), other |=
 // positions that are neither ACGT nor N (lower case included: such a read takes the sequential path, where case is folded).
 __device__ __forceinline__ void block_planes(const u32 *grp, int r, int p0, int vlen, bool final, u32 (&X)[4][LNW], u32 (&XN)[LNW],
                                              int &cntA, int &cntN, u32 &other) {
-    const int q0 = p0 >> 7;                                          // first quad of the block (p0 is a multiple of 256)
     u32 W[PL_PLANES][12];
-#pragma unroll
-    for (int k = 0; k < PL_PLANES; ++k) {
-#pragma unroll
-        for (int qq = 0; qq < 3; ++qq) {
-            v4u32 v = {0, 0, 0, 0};
-            if (q0 + qq < PL_QUADS && 128 * qq < vlen) v = *(gl_uint4_p)(grp + ((long)((q0 + qq) * PL_PLANES + k) * 64 + r) * 4);
-            W[k][4 * qq] = v.x; W[k][4 * qq + 1] = v.y; W[k][4 * qq + 2] = v.z; W[k][4 * qq + 3] = v.w;
-        }
-    }
+    plane_block_words(grp, r, p0, vlen, W);
 #pragma unroll
     for (int w = 0; w < LNW; ++w) {
         const u32 in = lowmask32(vlen - 32 * w);
@@ -220,7 +205,8 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
             }
             const bool live = exists && !bad;
             rs_init(r[m], len);
-            if (live && (P.n_ct[m] | P.n_gct)) cf[m] = contam_flags(P.ct + m * SNK_MAX_CONTAMS, P.n_ct[m], P.gct, P.n_gct, s[m], len);
+            if (live && (P.n_ct[m] | P.n_gct))                       // verdicts of snk_long_contam_kernel (snk_contam.hip), bits 2m, 2m + 1
+                cf[m] = B.cf ? ((int)B.cf[i] >> (2 * m)) & 3 : contam_flags(P.ct + m * SNK_MAX_CONTAMS, P.n_ct[m], P.gct, P.n_gct, s[m], len);
             // ---- the read in blocks of 256 positions (uniform control flow: every lane walks along): its planes give the base
             // counts and the adapter search; the qualities are a pass of their own; the poly-X run, when asked for, too
             const bool longish = live && len >= 64;                  // (shorter: the sequential functions)
@@ -482,7 +468,7 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
 size_t snk_long_scratch_bytes(long n, int paired) { return (size_t)plane_store_dwords(n, paired ? 2 : 1) * sizeof(u32); }
 
 int snk_launch_long(const DevParams *dp, const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, int lcap, int nq,
-                    int n_cu, unsigned *planes, void *stream) {
+                    int n_cu, unsigned *planes, unsigned char *cf, void *stream) {
     if (!hp.tile_ok || lcap <= 256 || lcap > 1024 || b.n <= 0 || !planes) return 0;
     if (b.pitch % 16 != 0 || b.pitch < ((lcap + 15) & ~15)) return 0;
     if ((((uintptr_t)b.seq[0] | (uintptr_t)b.qual[0] | (uintptr_t)b.seq[1] | (uintptr_t)b.qual[1]) % 16) != 0) return 0;
@@ -494,7 +480,13 @@ int snk_launch_long(const DevParams *dp, const DevParams &hp, const TileAdapters
         if (pw > (long)n_cu * 16) pw = (long)n_cu * 16;
         hipLaunchKernelGGL(snk_long_prep_kernel, dim3((unsigned)pw), dim3(256), 0, (hipStream_t)stream, dp, b, lcap, planes, ngroups);
     }
-    hipLaunchKernelGGL(snk_long_decide_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, dp, ta, b, st, lcap, nq, (const u32 *)planes, ngroups);
+    DevBatch bd = b;
+    bd.cf = nullptr;
+    if (cf && (hp.n_ct[0] | hp.n_ct[1] | hp.n_gct)) {
+        snk_launch_long_contam(dp, b, cf, hp.n_ct[0] > hp.n_ct[1] ? hp.n_ct[0] : hp.n_ct[1], hp.n_gct, planes, stream);
+        bd.cf = cf;
+    }
+    hipLaunchKernelGGL(snk_long_decide_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, dp, ta, bd, st, lcap, nq, (const u32 *)planes, ngroups);
     return snk_launch_hist(dp, hp.paired, b, st, lcap, nq, n_cu, stream);
 }
 

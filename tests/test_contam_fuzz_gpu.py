@@ -80,10 +80,12 @@ def low_complexity(rng, seq, lens, L, frac):
         seq[r, :rl] = row
 
 
-def context(i):
+def context(i, long_L=None, reads=READS):
     rng = np.random.default_rng(5100 + i)
     paired = i % 4 != 3
     L = 250 if i % 5 == 4 else (150 if i % 2 == 0 else 100)
+    if long_L:
+        L = long_L
     var = i % 3 == 1
     kw = dict(low_qual=10, low_qual_ratio=0.5, min_read_length=15,
               ada_mis=(int(rng.integers(0, 4)), int(rng.integers(0, 4))),
@@ -129,14 +131,27 @@ def context(i):
         cts += [g.encode().translate(comp)[::-1].decode() for g in gs]
     if i % 6 == 0:
         kw["contam_trim"] = 1
-    d = synth.make_batch(READS, L, paired=paired, var_len=var, seed=6100 + i)
+    d = synth.make_batch(reads, L, paired=paired, var_len=var, seed=6100 + i)
     for m in range(2 if paired else 1):
         low_complexity(rng, d["seq"][m], d["len"][m], L, 0.1)
         plant(rng, d["seq"][m], d["len"][m], L, cts, 0.3)
+        if long_L:                                          # copies across the 256-offset blocks of the long-read kernel and their 64-position reach
+            S, lens = d["seq"][m], d["len"][m]
+            for r in rng.choice(reads, reads // 4, replace=False):
+                a = np.frombuffer(cts[int(rng.integers(0, len(cts)))].upper().encode(), dtype=np.uint8).copy()
+                rl = int(lens[r]) if lens is not None else L
+                for k in rng.integers(0, len(a), int(rng.choice([0, 0, 1, 2]))):
+                    a[int(k)] = B4[rng.integers(0, 4)]
+                q = int(rng.choice([256, 320, 512, 576, 768, 832])) + int(rng.integers(-len(a) - 2, 3))
+                if 0 <= q and q + len(a) <= rl:
+                    S[r, q:q + len(a)] = a
     if var:                                                 # some reads shorter than any contaminant
         for m in range(2 if paired else 1):
-            rows = rng.choice(READS, READS // 50, replace=False)
+            rows = rng.choice(reads, reads // 50, replace=False)
             d["len"][m][rows] = rng.integers(1, 12, len(rows))
+            if long_L:                                      # ... and some between a contaminant's length and one block
+                rows = rng.choice(reads, reads // 20, replace=False)
+                d["len"][m][rows] = np.minimum(d["len"][m][rows], rng.integers(12, 331, len(rows)))   # (only ever shorter: the rows end where the reads did)
     p = abi.default_params(paired=paired, max_read_len=L, **kw)
     return p, d, paired, kw
 
@@ -148,6 +163,20 @@ def test_contam_fuzz(i):
     got = run_hip_device(p, d, 2, chunks=2)                 # the tiled path: verdicts from snk_contam.hip
     assert_same(p, got, want, paired)
     if not kw.get("contam_trim"):                           # ... and the screen did see contaminated reads
+        assert int(want["sum"][abi.FS_CONTAM]) + int(want["sum"][abi.FS_GCONTAM]) > 0
+
+
+@pytest.mark.parametrize("i", range(20))
+def test_contam_fuzz_long_reads(i):
+    """reads of 257..1000 positions: the same bit paths block by block on the plane store of the long-read path
+    (snk_long_contam_kernel) -- alignments hanging off the read's start in the first block, off its end in the final one, whole ones
+    in the block of their offset -- against the oracle"""
+    L = (300, 320, 321, 500, 576, 700, 1000)[i % 7]
+    p, d, paired, kw = context(100 + i, long_L=L, reads=2000 if L <= 576 else 1200)
+    want = T.run_oracle(p, d)
+    got = run_hip_device(p, d, 2, chunks=2)
+    assert_same(p, got, want, paired)
+    if not kw.get("contam_trim"):
         assert int(want["sum"][abi.FS_CONTAM]) + int(want["sum"][abi.FS_GCONTAM]) > 0
 
 
