@@ -206,11 +206,11 @@ def test_cli_index_removal(seq_type, tmp_path):
         assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
 
 
-@pytest.mark.parametrize("paired", [True, False])
-def test_cli_contaminants_match_reference_binary(paired, tmp_path):
-    """config keys contam1/contam2/ctMatchR + global_contams/glob_cotm_mR/glob_cotm_mM"""
+@pytest.mark.parametrize("paired,L,n", [(True, 150, 12000), (False, 150, 12000), (True, 700, 4000), (False, 400, 4000)])
+def test_cli_contaminants_match_reference_binary(paired, L, n, tmp_path):
+    """config keys contam1/contam2/ctMatchR + global_contams/glob_cotm_mR/glob_cotm_mM; reads of 400 / 700
+    positions: the block-wise bit paths on the long-read plane store (snk_long_contam_kernel)"""
     from cases import CT1, CT2, GC1, plant_contams
-    n, L = 12000, 150
     kw = dict(contam1=CT1 + ",GGGGGGGGGGGGGGGGGGGGGGGG", contam2=CT2 + ",CCCCCCCCCCCCCCCCCCCCCC", global_contams=GC1)
     d = synth.make_batch(n, L, paired=paired, seed=93)
     plant_contams(d, kw)
