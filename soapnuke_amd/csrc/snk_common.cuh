@@ -395,7 +395,8 @@ __device__ __forceinline__ void agg_max_last(unsigned long long *p, unsigned lon
 // which mate(s) gave it.  One atomic per counter and wavefront: the lanes that get here agree on the counters present (a uniform
 // loop over them, ballots for the counts).  The counters are a handful of words -- one atomic per read to the same few addresses
 // serialises in L2: 4.8 ms per 1 M long pairs went there (rocprof: 79 % of the wave cycles waiting).
-__device__ inline void count_reason(unsigned long long *fs, bool pe, int reason, int v) {
+template <class CT>                    // CT: u64 (the stats block) or u32 (a workgroup's LDS copy of its first SNK_FS_N words)
+__device__ inline void count_reason(CT *fs, bool pe, int reason, int v) {
     int idx = reason == SNK_R_DUP ? SNK_FS_DUP : reason == SNK_R_TILE ? SNK_FS_TILE : reason == SNK_R_FOV ? SNK_FS_FOV : reason_family(reason);
     const int vv = (pe && idx >= 0 && reason != SNK_R_DUP && reason != SNK_R_TILE && reason != SNK_R_FOV) ? v : 0;
     const int lane = (int)__lane_id();
@@ -406,10 +407,10 @@ __device__ inline void count_reason(unsigned long long *fs, bool pe, int reason,
         const u64 same = __ballot(idx == f);
         const u64 s1 = __ballot(idx == f && (vv & 1)), s2 = __ballot(idx == f && (vv & 2)), s3 = __ballot(idx == f && vv == 3);
         if (lane == lead) {
-            atomicAdd(&fs[f], (unsigned long long)__popcll(same));
-            if (s1) atomicAdd(&fs[f + 1], (unsigned long long)__popcll(s1));
-            if (s2) atomicAdd(&fs[f + 2], (unsigned long long)__popcll(s2));
-            if (s3) atomicAdd(&fs[f + 3], (unsigned long long)__popcll(s3));
+            atomicAdd(&fs[f], (CT)__popcll(same));
+            if (s1) atomicAdd(&fs[f + 1], (CT)__popcll(s1));
+            if (s2) atomicAdd(&fs[f + 2], (CT)__popcll(s2));
+            if (s3) atomicAdd(&fs[f + 3], (CT)__popcll(s3));
         }
         todo &= ~same;
     }

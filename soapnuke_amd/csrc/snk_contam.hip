@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SNK_CW
 // final block (which is cut so that it ends with the read and holds at least 64 positions), whole alignments to the block of
 // their offset: only the verdict is ever used, so a hit in any block is the hit.  One work-item per pair; reads shorter than a
 // contaminant and contaminants outside the bit paths take the sequential matchers on the read's row, per lane.
-__global__ void __launch_bounds__(256) snk_long_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, const u32 *planes, long ngroups) {
+__global__ void __launch_bounds__(256) snk_long_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, const u32 *planes, long ngroups, int nquads) {
     extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
     const DevParams &P = *Pp;
     const int pe = P.paired ? 1 : 0, tid = threadIdx.x;
@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(256) snk_long_contam_kernel(const DevParams *P
             __syncthreads();
             const int len = exists ? min(B.len[m] ? (int)B.len[m][i] : B.fixed_len[m], P.lcap) : 0;
             const uint8_t *row = B.seq[m] + (exists ? i : 0) * (long)B.pitch;
-            const u32 *grp = planes + ((long)m * ngroups + (i >> 6)) * PL_GROUP_DWORDS;
+            const u32 *grp = planes + ((long)m * ngroups + (i >> 6)) * nquads * PL_QUAD_DWORDS;
             int fm = 0;
             // the sequential share first: reads shorter than 64 (no block decomposition), contaminants the bit paths do not cover
             const bool blocks = exists && len >= 64;
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256) snk_long_contam_kernel(const DevParams *P
                 const bool here = blocks && !through, final = rem <= PL_VLEN;
                 const int vlen = here ? (final ? rem : PL_VLEN) : 0;
                 u32 W[PL_PLANES][12], X[4][PL_NW], XN[PL_NW];
-                plane_block_words(grp, (int)(i & 63), here ? p0 : 0, vlen, W);
+                plane_block_words(grp, nquads, (int)(i & 63), here ? p0 : 0, vlen, W);
 #pragma unroll
                 for (int w = 0; w < PL_NW; ++w) {
                     const u32 in = lowmask32(vlen - 32 * w);
@@ -618,7 +618,7 @@ __global__ void __launch_bounds__(256) snk_long_contam_kernel(const DevParams *P
 }  // namespace
 
 // the long-read variant: verdicts from the plane store (snk_long.hip wrote it on the same stream)
-void snk_launch_long_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int n_ct, int n_gct, const unsigned *planes, void *stream) {
+void snk_launch_long_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int n_ct, int n_gct, const unsigned *planes, int nquads, void *stream) {
     if (b.n <= 0) return;
     long blocks = (b.n + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
@@ -628,7 +628,7 @@ void snk_launch_long_contam(const DevParams *dp, const DevBatch &b, unsigned cha
         (void)hipFuncSetAttribute((const void *)snk_long_contam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(snk_long_contam_kernel, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, dp, b, cf, (const u32 *)planes, (b.n + 63) / 64);
+    hipLaunchKernelGGL(snk_long_contam_kernel, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, dp, b, cf, (const u32 *)planes, (b.n + 63) / 64, nquads);
 }
 
 void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int lcap, int n_ct, int n_gct, void *stream) {

@@ -143,15 +143,15 @@ int snk_launch_tiled(const DevParams &dp_host, const TileAdapters &ta, const Dev
                      const DevStats &st, int lcap, int nq, int n_cu, void *stream);
 void snk_launch_finalize(const DevStats &st, int lcap, int nq, void *stream);
 // reads of 257..1024 positions (snk_long.hip); returns 0 when it cannot take the batch
-// (`planes`: snk_long_scratch_bytes(n, paired) bytes of scratch the launch owns until it has run; `cf`: n bytes for the
+// (`planes`: snk_long_scratch_bytes(n, paired, lcap) bytes of scratch the launch owns until it has run; `cf`: n bytes for the
 // contaminant verdicts when contaminants are configured, else null)
 int snk_launch_long(const DevParams *dp, const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, int lcap, int nq,
                     int n_cu, unsigned *planes, unsigned char *cf, void *stream);
-size_t snk_long_scratch_bytes(long n, int paired);
+size_t snk_long_scratch_bytes(long n, int paired, int lcap);
 // contaminant verdicts of a batch (one work-item per pair) into cf[n], for the tiled kernel
 void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int lcap, int n_ct, int n_gct, void *stream);   // snk_contam.hip
 // the same for reads of 257..1024 positions, block-wise from the plane store of snk_launch_long (which calls it)
-void snk_launch_long_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int n_ct, int n_gct, const unsigned *planes, void *stream);
+void snk_launch_long_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf, int n_ct, int n_gct, const unsigned *planes, int nquads, void *stream);
 
 // rmdup pre-pass (snk_rmdup.hip); return 0 or a hipError_t
 int snk_launch_hash(const uint8_t *const seq[2], const uint16_t *const len[2], const int fixed_len[2], int pitch, long n,

@@ -666,7 +666,7 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         // reads of 257..1024 positions: the block-wise bit-sliced path (snk_long.hip); it writes the stats block directly
         if (!done && c->hp.tile_ok && c->lcap > 256 && c->lcap <= 1024 && b->n > 0) {
             // (the plane store of the batch: scratch of this stream slot, grown on demand and kept)
-            const size_t need = snk_long_scratch_bytes((long)b->n, c->p.paired ? 1 : 0);
+            const size_t need = snk_long_scratch_bytes((long)b->n, c->p.paired ? 1 : 0, c->lcap);
             if (need > c->pl_cap[slot]) {
                 HIP_OK(hipStreamSynchronize(s));
                 if (c->d_pl[slot]) (void)hipFree(c->d_pl[slot]);

@@ -52,10 +52,10 @@ typedef const __attribute__((address_space(1))) v4u32 *gl_uint4_p;
 // ones from vlen on.  Also the A1 base counts of a read of upper-case ACGTN only (src/read_filter.cpp:258-308), which are
 // popcounts of its planes: cntA / cntN += the 'A' / 'N' of the block's own positions (256, or all of a final block), other |=
 // positions that are neither ACGT nor N (lower case included: such a read takes the sequential path, where case is folded).
-__device__ __forceinline__ void block_planes(const u32 *grp, int r, int p0, int vlen, bool final, u32 (&X)[4][LNW], u32 (&XN)[LNW],
+__device__ __forceinline__ void block_planes(const u32 *grp, int nquads, int r, int p0, int vlen, bool final, u32 (&X)[4][LNW], u32 (&XN)[LNW],
                                              int &cntA, int &cntN, u32 &other) {
     u32 W[PL_PLANES][12];
-    plane_block_words(grp, r, p0, vlen, W);
+    plane_block_words(grp, nquads, r, p0, vlen, W);
 #pragma unroll
     for (int w = 0; w < LNW; ++w) {
         const u32 in = lowmask32(vlen - 32 * w);
@@ -89,38 +89,42 @@ __device__ __forceinline__ u64 wave_max64(u64 v) {
 //     of at most 255) into the first word of the read's record, which the decide kernel rewrites at its end;
 //   * the base planes: every lane turns its 16 characters into 16 bits of each of the 5 planes, two lanes make a word, the
 //     workgroup collects the group's words in LDS (40 KB) in the plane store's order and copies them out as one contiguous block.
+// SEG = lanes per read: 64, or 32 when the rows are at most 512 bytes -- two reads per wavefront and trip then.
+template <int SEG>
 __global__ void __launch_bounds__(256)
-snk_long_prep_kernel(const DevParams *Pp, DevBatch B, int lcap, u32 *planes, long ngroups) {
-    __shared__ u32 lds[PL_GROUP_DWORDS];                             // block (quad, plane) at (quad * 5 + plane) * 256, its cells XOR-skewed by
-                                                                     // quad * 4: the 32 words of a read fall into the 32 banks (40 KB: 4 per CU)
+snk_long_prep_kernel(const DevParams *Pp, DevBatch B, int lcap, u32 *planes, long ngroups, int nquads) {
+    extern __shared__ u32 lds[];                                     // nquads * 5 KB: block (quad, plane) at (quad * 5 + plane) * 256, its cells XOR-skewed
+                                                                     // by quad * 4: the 32 words of a read fall into the 32 banks (8 quads: 40 KB, 4 per CU)
     const DevParams &P = *Pp;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int mates = P.paired ? 2 : 1;
     const u32 KL = ((u32)min(max(P.phred + P.low_qual, 0), 127) * 0x01010101u) | 0x80808080u;
-    const int pitch = B.pitch, pos = 16 * lane;
+    constexpr int RPT = 64 / SEG;                                    // reads per wavefront and trip
+    const int sub = lane / SEG, ll = lane % SEG;                     // which of them, and the lane's 16-byte piece of its row
+    const int pitch = B.pitch, pos = 16 * ll;
     const bool in_row = pos + 16 <= pitch;
     constexpr int U = 4;
     for (long gi = blockIdx.x; gi < ngroups * mates; gi += gridDim.x) {
         const int m = (int)(gi / ngroups);
         const long g = gi - (long)m * ngroups;
-        for (int t0 = 0; t0 < 16; t0 += U) {
+        for (int t0 = 0; t0 < 16; t0 += U * RPT) {
             v4u32 qv[U], sv[U];
             int ln[U];
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                const long i = g * 64 + wv * 16 + t0 + k;
+                const long i = g * 64 + wv * 16 + t0 + k * RPT + sub;
                 const bool have = i < B.n;
                 int len = !have ? 0 : (B.len[m] ? (int)B.len[m][i] : B.fixed_len[m]);
                 if (len > lcap) len = 0;                             // (too long: reported by the decide kernel)
                 ln[k] = len;
                 const long row = (have ? i : 0) * (long)pitch;
                 const bool on = in_row && pos < len;
-                qv[k] = on ? ((gl_uint4_p)(B.qual[m] + row))[lane] : v4u32{0, 0, 0, 0};
-                sv[k] = on ? ((gl_uint4_p)(B.seq[m] + row))[lane] : v4u32{0, 0, 0, 0};
+                qv[k] = on ? ((gl_uint4_p)(B.qual[m] + row))[ll] : v4u32{0, 0, 0, 0};
+                sv[k] = on ? ((gl_uint4_p)(B.seq[m] + row))[ll] : v4u32{0, 0, 0, 0};
             }
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                const int r = wv * 16 + t0 + k;
+                const int r = wv * 16 + t0 + k * RPT + sub;
                 const long i = g * 64 + r;
                 // qualities
                 const u32 qd[4] = {qv[k].x, qv[k].y, qv[k].z, qv[k].w};
@@ -133,8 +137,8 @@ snk_long_prep_kernel(const DevParams *Pp, DevBatch B, int lcap, u32 *planes, lon
                 }
                 u32 v = (lq << 20) + qsum;
 #pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) v += (u32)__shfl_xor((int)v, o, 64);
-                if (lane == 0 && i < B.n) reinterpret_cast<u32 *>(B.out[m] + i)[0] = v;
+                for (int o = SEG / 2; o >= 1; o >>= 1) v += (u32)__shfl_xor((int)v, o, 64);
+                if (ll == 0 && i < B.n) reinterpret_cast<u32 *>(B.out[m] + i)[0] = v;
                 // bases: 16 bits of every plane
                 const u32 sd[4] = {sv[k].x, sv[k].y, sv[k].z, sv[k].w};
                 u32 e = 0, c1 = 0, c2 = 0, nn = 0;
@@ -155,19 +159,22 @@ snk_long_prep_kernel(const DevParams *Pp, DevBatch B, int lcap, u32 *planes, lon
                 const u32 a4 = nn & in;
                 const u32 b01 = (u32)__shfl_xor((int)a01, 1, 64), b23 = (u32)__shfl_xor((int)a23, 1, 64), b4 = (u32)__shfl_xor((int)a4, 1, 64);
                 // an even lane 2w and its odd neighbour hold positions [32w, 32w + 16) and [32w + 16, 32w + 32)
-                const int w = lane >> 1, quad = w >> 2;
-                const bool odd = lane & 1;
-                u32 *cell = lds + (long)quad * PL_PLANES * 256 + ((r * 4 + (w & 3)) ^ (quad * 4));
+                const int w = ll >> 1, quad = w >> 2;
+                const bool odd = ll & 1;
+                u32 *cell = lds + (long)(quad < nquads ? quad : 0) * PL_PLANES * 256 + ((r * 4 + (w & 3)) ^ (quad * 4));
+                const bool keep = quad < nquads;                     // (words past the capacity are not stored)
                 const u32 wA = odd ? ((b01 >> 16) | (a01 & 0xFFFF0000u)) : ((a01 & 0xFFFFu) | (b01 << 16));      // plane 1 (odd) / plane 0 (even)
                 const u32 wB = odd ? ((b23 >> 16) | (a23 & 0xFFFF0000u)) : ((a23 & 0xFFFFu) | (b23 << 16));      // plane 3 / plane 2
-                cell[(odd ? 1 : 0) * 256] = wA;
-                cell[(odd ? 3 : 2) * 256] = wB;
-                if (!odd) cell[4 * 256] = (a4 & 0xFFFFu) | (b4 << 16);
+                if (keep) {
+                    cell[(odd ? 1 : 0) * 256] = wA;
+                    cell[(odd ? 3 : 2) * 256] = wB;
+                    if (!odd) cell[4 * 256] = (a4 & 0xFFFFu) | (b4 << 16);
+                }
             }
         }
         __syncthreads();
-        u32 *dst = planes + ((long)m * ngroups + g) * PL_GROUP_DWORDS;
-        for (int blk = wv; blk < PL_QUADS * PL_PLANES; blk += 4) {     // 40 blocks of 1 KB
+        u32 *dst = planes + ((long)m * ngroups + g) * nquads * PL_QUAD_DWORDS;
+        for (int blk = wv; blk < nquads * PL_PLANES; blk += 4) {       // blocks of 1 KB
             const int quad = blk / PL_PLANES;
             const v4u32 x = *reinterpret_cast<const v4u32 *>(lds + (long)blk * 256 + ((lane * 4) ^ (quad * 4)));
             *reinterpret_cast<v4u32 *>(dst + (long)blk * 256 + lane * 4) = x;
@@ -180,11 +187,19 @@ snk_long_prep_kernel(const DevParams *Pp, DevBatch B, int lcap, u32 *planes, lon
 #define SNK_LONG_WPE 2           // waves per SIMD the decide kernel's register allocation aims at
 #endif
 __global__ void __launch_bounds__(256, SNK_LONG_WPE)
-snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, DevStats st, int lcap, int nq, const u32 *planes, long ngroups) {
+snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, DevStats st, int lcap, int nq, const u32 *planes, long ngroups, int nquads) {
     const DevParams &P = *Pp;
     const long fb = file_block(lcap, nq);
     const long ts_off = SNK_GS_N + (long)lcap * 5 + (long)lcap * nq;
     const int pe = P.paired ? 1 : 0;
+    // the workgroup's share of the counters every pair touches -- filter statistics, reads numbers, "last read" words -- collects in
+    // LDS and goes out once at the end: one global atomic per wavefront and trip on the same dozen words was most of this kernel's
+    // time (same-address atomics run at some 25 M/s: 62 k trips of 4 M PE300 pairs = 2.5 of its 3.0 ms)
+    __shared__ u32 wfs[SNK_FS_N], wreads[4];
+    __shared__ unsigned long long wmax[4];
+    if (threadIdx.x < SNK_FS_N) wfs[threadIdx.x] = 0;
+    if (threadIdx.x < 4) { wreads[threadIdx.x] = 0; wmax[threadIdx.x] = 0; }
+    __syncthreads();
     const long nround = (B.n + 255) / 256 * 256;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nround; i += (long)gridDim.x * blockDim.x) {
         const bool exists = i < B.n;
@@ -220,7 +235,7 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
                 const bool here = longish && !through, final = rem <= LVLEN;
                 const int vlen = here ? (final ? rem : LVLEN) : 0;
                 u32 X[4][LNW], XN[LNW];
-                block_planes(planes + ((long)m * ngroups + (i >> 6)) * PL_GROUP_DWORDS, (int)(i & 63), here ? p0 : 0, vlen, final, X, XN, cntA, cntN, other);
+                block_planes(planes + ((long)m * ngroups + (i >> 6)) * nquads * PL_QUAD_DWORDS, nquads, (int)(i & 63), here ? p0 : 0, vlen, final, X, XN, cntA, cntN, other);
                 if (n_ada > 0) {
                     // the first adapter of the list with a hit decides, whatever block its hit is in (src/read_filter.cpp:175-188):
                     // only adapters in front of the best one so far are still searched
@@ -279,7 +294,7 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
         if (ok) {
             reason = pe ? discard_reason(P, r[0], r[1], B.dup ? B.dup[i] : 0, v, cf[0], cf[1])
                         : discard_reason(P, r[0], r[0], B.dup ? B.dup[i] : 0, v, cf[0], cf[0]);
-            count_reason(st.sum, pe, reason, v);
+            count_reason(wfs, pe, reason, v);
         }
         if (exists) {                                                // (a pair that raised an error gets a record no later pass uses)
             store_rec(B.out[0], i, r[0], reason, v);
@@ -300,8 +315,8 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
             const u64 kraw = wave_max64(ok ? (key | (u64)r[m].len) : 0ull);
             const u64 kcl = wave_max64((ok && reason == SNK_KEEP) ? (key | (u64)r[m].clen) : 0ull);
             if ((threadIdx.x & 63) == 0) {
-                if (nraw) { atomicAdd(&st.sum[SNK_FS_N + m * fb + SNK_GS_READS], nraw); atomicMax(&st.maxb[m], kraw); }
-                if (ncl) { atomicAdd(&st.sum[SNK_FS_N + (2 + m) * fb + SNK_GS_READS], ncl); atomicMax(&st.maxb[2 + m], kcl); }
+                if (nraw) { atomicAdd(&wreads[m], (u32)nraw); atomicMax(&wmax[m], kraw); }
+                if (ncl) { atomicAdd(&wreads[2 + m], (u32)ncl); atomicMax(&wmax[2 + m], kcl); }
             }
             if (ok && reason == SNK_KEEP) {
                 unsigned long long *file = st.sum + SNK_FS_N + (2 + m) * fb;
@@ -309,6 +324,13 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
                           (pe && m == 1) ? r[m].clen : r[m].len, !pe);
             }
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < SNK_FS_N && wfs[threadIdx.x]) atomicAdd(&st.sum[threadIdx.x], (unsigned long long)wfs[threadIdx.x]);
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;                                   // 0, 1: raw files of the mates; 2, 3: clean files
+        if (wreads[k]) atomicAdd(&st.sum[SNK_FS_N + k * fb + SNK_GS_READS], (unsigned long long)wreads[k]);
+        if (wmax[k]) atomicMax(&st.maxb[k], wmax[k]);
     }
 }
 
@@ -465,7 +487,7 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
 }  // namespace
 
 // returns 0 when this path cannot take the batch (the caller falls back to the generic kernel)
-size_t snk_long_scratch_bytes(long n, int paired) { return (size_t)plane_store_dwords(n, paired ? 2 : 1) * sizeof(u32); }
+size_t snk_long_scratch_bytes(long n, int paired, int lcap) { return (size_t)plane_store_dwords(n, paired ? 2 : 1, plane_quads(lcap)) * sizeof(u32); }
 
 int snk_launch_long(const DevParams *dp, const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, int lcap, int nq,
                     int n_cu, unsigned *planes, unsigned char *cf, void *stream) {
@@ -475,18 +497,21 @@ int snk_launch_long(const DevParams *dp, const DevParams &hp, const TileAdapters
     long wgs = (b.n + 255) / 256;
     if (wgs > (long)n_cu * 8) wgs = (long)n_cu * 8;
     const long ngroups = (b.n + 63) / 64;
+    const int nquads = plane_quads(lcap);
     {
         long pw = ngroups * (hp.paired ? 2 : 1);
         if (pw > (long)n_cu * 16) pw = (long)n_cu * 16;
-        hipLaunchKernelGGL(snk_long_prep_kernel, dim3((unsigned)pw), dim3(256), 0, (hipStream_t)stream, dp, b, lcap, planes, ngroups);
+        const size_t lds = (size_t)nquads * PL_QUAD_DWORDS * sizeof(u32);
+        if (b.pitch <= 512) hipLaunchKernelGGL(snk_long_prep_kernel<32>, dim3((unsigned)pw), dim3(256), lds, (hipStream_t)stream, dp, b, lcap, planes, ngroups, nquads);
+        else hipLaunchKernelGGL(snk_long_prep_kernel<64>, dim3((unsigned)pw), dim3(256), lds, (hipStream_t)stream, dp, b, lcap, planes, ngroups, nquads);
     }
     DevBatch bd = b;
     bd.cf = nullptr;
     if (cf && (hp.n_ct[0] | hp.n_ct[1] | hp.n_gct)) {
-        snk_launch_long_contam(dp, b, cf, hp.n_ct[0] > hp.n_ct[1] ? hp.n_ct[0] : hp.n_ct[1], hp.n_gct, planes, stream);
+        snk_launch_long_contam(dp, b, cf, hp.n_ct[0] > hp.n_ct[1] ? hp.n_ct[0] : hp.n_ct[1], hp.n_gct, planes, nquads, stream);
         bd.cf = cf;
     }
-    hipLaunchKernelGGL(snk_long_decide_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, dp, ta, bd, st, lcap, nq, (const u32 *)planes, ngroups);
+    hipLaunchKernelGGL(snk_long_decide_kernel, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, dp, ta, bd, st, lcap, nq, (const u32 *)planes, ngroups, nquads);
     return snk_launch_hist(dp, hp.paired, b, st, lcap, nq, n_cu, stream);
 }
 
