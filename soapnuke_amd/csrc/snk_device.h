@@ -129,6 +129,8 @@ struct DevStats {
     unsigned long long *err;   // 1 word: min over offending reads of (index<<8 | mate<<4 | code)
     unsigned *tsw;             // tiled kernel: one private uint32 copy of the 4 x SNK_TS_N trimming-position
                                // counters per workgroup (n_cu of them), drained into `sum` at the end of a launch
+    unsigned *part;            // tiled kernel: every workgroup's flushed histogram words (snk_tiled_part_bytes(); zero between launches),
+                               // summed into `sum` by a small kernel behind it
 };
 
 #define SNK_ERR_NONE 0xFFFFFFFFFFFFFFFFull
@@ -141,6 +143,7 @@ int snk_launch_hist(const DevParams *dp, int paired, const DevBatch &b, const De
 // returns 0 when the tiled kernel cannot run this configuration
 int snk_launch_tiled(const DevParams &dp_host, const TileAdapters &ta, const DevBatch &b,
                      const DevStats &st, int lcap, int nq, int n_cu, void *stream);
+size_t snk_tiled_part_bytes(int lcap, int nq, int n_cu);      // DevStats::part of a stream slot
 void snk_launch_finalize(const DevStats &st, int lcap, int nq, void *stream);
 // reads of 257..1024 positions (snk_long.hip); returns 0 when it cannot take the batch
 // (`planes`: snk_long_scratch_bytes(n, paired, lcap) bytes of scratch the launch owns until it has run; `cf`: n bytes for the

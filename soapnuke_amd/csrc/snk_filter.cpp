@@ -287,6 +287,7 @@ struct snk_ctx {
     unsigned ts_next = 0;
     unsigned char *d_cf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // contaminant verdicts, per stream slot
     size_t cf_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned *d_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};       // tiled kernel: DevStats::part, per stream slot
     unsigned *d_pl[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};         // long reads: the plane store, per stream slot
     size_t pl_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool own_stats = false;
@@ -537,6 +538,7 @@ void snk_destroy(snk_ctx *c) {
     if (c->d_tsw) (void)hipFree(c->d_tsw);
     for (int k = 0; k < 8; ++k) if (c->d_cf[k]) (void)hipFree(c->d_cf[k]);
     for (int k = 0; k < 8; ++k) if (c->d_pl[k]) (void)hipFree(c->d_pl[k]);
+    for (int k = 0; k < 8; ++k) if (c->d_part[k]) (void)hipFree(c->d_part[k]);
 
     if (c->st_buf) (void)hipFree(c->st_buf);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -646,6 +648,16 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         c->ts_used[slot] = true;
         c->ts_stream[slot] = stream;
         st.tsw = c->d_tsw + (size_t)slot * c->n_cu * 4 * SNK_TS_N;
+        if (c->hp.tile_ok && c->lcap <= 256) {
+            // the workgroups' flushed histogram words (summed behind the tiled kernel): allocated with the slot's first launch,
+            // zero whenever no launch is in flight
+            if (!c->d_part[slot]) {
+                const size_t pb = snk_tiled_part_bytes(c->lcap, c->nq, c->n_cu);
+                if (hipMalloc((void **)&c->d_part[slot], pb) != hipSuccess) { set_err("snk_filter_batch_device: out of device memory (histogram partials)"); return fail(SNK_E_NOMEM); }
+                HIP_OK(hipMemsetAsync(c->d_part[slot], 0, pb, s));
+            }
+            st.part = c->d_part[slot];
+        }
         if ((c->hp.n_ct[0] | c->hp.n_ct[1] | c->hp.n_gct) && c->hp.tile_ok && c->lcap <= 256) {
             // contaminant screening: the matchers run as their own pass, the tiled kernel consumes the verdicts.
             // One verdict buffer per launching stream (like the trimming-position counters), grown on demand and kept.

@@ -1011,33 +1011,33 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
         if ((it + 1) % flush_every == 0 || it + 1 == iters) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm histogram adds
             __syncthreads();
-            // flush: global raw += raw ; global clean += raw - removed
+            // flush: the workgroup's histogram words are added to its own slice of DevStats::part (plain adds: nobody else touches
+            // it); snk_tiled_reduce_kernel sums the slices behind this kernel (global raw += raw ; global clean += raw - removed).
+            // One 64-bit atomic per word and workgroup on the same 28 k counters (6 M atomics per launch, 256 deep per address)
+            // cost 0.14 of the 2.89 ms of a 10 M-pair launch.
             int ovf = 0;
             for (int m = 0; m < mates; ++m) {
                 u32 *raw = lds + (m * 2 + 0) * G.SET, *remv = lds + (m * 2 + 1) * G.SET;
-                u64 *fraw = st.sum + SNK_FS_N + m * fb, *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
+                uint2 *praw = reinterpret_cast<uint2 *>(st.part) + ((size_t)blockIdx.x * 4 + (m * 2 + 0)) * G.SET;
+                uint2 *prem = reinterpret_cast<uint2 *>(st.part) + ((size_t)blockIdx.x * 4 + (m * 2 + 1)) * G.SET;
                 for (int w = threadIdx.x; w < G.SET; w += blockDim.x) {
                     const u32 a = raw[w], b = remv[w];
                     if (a | b) {
-                        long off;
                         int pm, bin;
-                        if (w < G.WB) { bin = w >> G.lg; pm = w - (bin << G.lg); off = SNK_GS_N + (long)(bin ^ ((bin >> 1) & (bin < 4))); }
-                        else { const int ww = w - G.WB; bin = ww >> G.lg; pm = ww - (bin << G.lg); off = SNK_GS_N + (long)G.lcap * 5 + bin; }
-                        const long stride = w < G.WB ? 5 : G.nq;
+                        if (w < G.WB) { bin = w >> G.lg; pm = w - (bin << G.lg); }
+                        else { const int ww = w - G.WB; bin = ww >> G.lg; pm = ww - (bin << G.lg); }
                         // slots of positions >= lcap hold the spill-over of lanes past the read end: dropped
                         // (quality rows of 129..160-position batches: phase 1 counts the third strip of the odd reads in the slots of
                         // positions 160..191 -- PAIR -- which such a batch does not have)
                         const bool pq = G.pairq && (w >= G.WB || bin == 5) && pm >= 96;   // raw set only: the removed set's slots there hold spill-over
-                        const u32 alo = a & 0xFFFFu, blo = pq ? 0u : (b & 0xFFFFu), ahi = pq ? 0u : (a >> 16), bhi = pq ? 0u : (b >> 16);
+                        const u32 alo = a & 0xFFFFu, ahi = pq ? 0u : (a >> 16);
                         const int plo = 128 * (pm >> 6) + (pm & 63) - (pq ? 32 : 0), phi = plo + 64;
                         const bool lo_ok = plo < G.lcap, hi_ok = phi < G.lcap;
                         if ((w >= G.WB && bin == G.nq) || (w < G.WB && bin == 5)) {
                             if ((alo && lo_ok) || (ahi && hi_ok)) ovf = 1;       // quality outside [0,nq): overflow / underflow row
                         } else {
-                            if (alo && lo_ok) atomicAdd(&fraw[off + plo * stride], (u64)alo);
-                            if (alo != blo && lo_ok) atomicAdd(&fcl[off + plo * stride], (u64)alo - (u64)blo);
-                            if (ahi && hi_ok) atomicAdd(&fraw[off + phi * stride], (u64)ahi);
-                            if (ahi != bhi && hi_ok) atomicAdd(&fcl[off + phi * stride], (u64)ahi - (u64)bhi);
+                            if (a) { uint2 x = praw[w]; x.x += a & 0xFFFFu; x.y += a >> 16; praw[w] = x; }
+                            if (b) { uint2 x = prem[w]; x.x += b & 0xFFFFu; x.y += b >> 16; prem[w] = x; }
                         }
                         raw[w] = 0;
                         remv[w] = 0;
@@ -1106,6 +1106,53 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
     }
 }
 
+// Behind the tiled kernel: the workgroups' flushed histogram words (DevStats::part: [workgroup][mate x {raw, removed}][word]
+// [half]) summed over the workgroups -- 16 words x 16 workgroup lanes per block, an LDS tree across the lanes -- mapped to their
+// counters like the flush used to and added to the bound statistics: global raw += raw, global clean += raw - removed.  The
+// slices are zero again afterwards.
+__global__ void __launch_bounds__(256) snk_tiled_reduce_kernel(const DevStats st, const TileGeom G, const int nwg, const int mates) {
+    __shared__ u32 acc[4][16][17];
+    const int wx = threadIdx.x & 15, gy = threadIdx.x >> 4;
+    const int per = (G.SET + 15) / 16;
+    const int m = blockIdx.x / per, w = (blockIdx.x - m * per) * 16 + wx;
+    u32 alo = 0, ahi = 0, blo = 0, bhi = 0;
+    if (w < G.SET) {
+        for (int g = gy; g < nwg; g += 16) {
+            uint2 *praw = reinterpret_cast<uint2 *>(st.part) + ((size_t)g * 4 + (m * 2 + 0)) * G.SET + w;
+            uint2 *prem = reinterpret_cast<uint2 *>(st.part) + ((size_t)g * 4 + (m * 2 + 1)) * G.SET + w;
+            const uint2 a = *praw, b = *prem;
+            if (a.x | a.y) *praw = make_uint2(0u, 0u);
+            if (b.x | b.y) *prem = make_uint2(0u, 0u);
+            alo += a.x; ahi += a.y; blo += b.x; bhi += b.y;     // (a workgroup flushes before 65 536 adds: 256 of them stay below 2^32)
+        }
+    }
+    acc[0][wx][gy] = alo; acc[1][wx][gy] = ahi; acc[2][wx][gy] = blo; acc[3][wx][gy] = bhi;
+    __syncthreads();
+    if (gy != 0 || w >= G.SET) return;
+    u64 A0 = 0, A1 = 0, B0 = 0, B1 = 0;
+    for (int k = 0; k < 16; ++k) { A0 += acc[0][wx][k]; A1 += acc[1][wx][k]; B0 += acc[2][wx][k]; B1 += acc[3][wx][k]; }
+    if (!(A0 | A1 | B0 | B1)) return;
+    const long fb = file_block(G.lcap, G.nq);
+    u64 *fraw = st.sum + SNK_FS_N + m * fb, *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
+    long off;
+    int pm, bin;
+    if (w < G.WB) { bin = w >> G.lg; pm = w - (bin << G.lg); off = SNK_GS_N + (long)(bin ^ ((bin >> 1) & (bin < 4))); }
+    else { const int ww = w - G.WB; bin = ww >> G.lg; pm = ww - (bin << G.lg); off = SNK_GS_N + (long)G.lcap * 5 + bin; }
+    if ((w >= G.WB && bin == G.nq) || (w < G.WB && bin == 5)) return;     // overflow / underflow rows: the tiled kernel reported them
+    const long stride = w < G.WB ? 5 : G.nq;
+    // slots of positions >= lcap hold the spill-over of lanes past the read end: dropped (quality rows of 129..160-position
+    // batches: phase 1 counts the third strip of the odd reads in the slots of positions 160..191 -- PAIR -- which such a batch
+    // does not have; raw set only: the removed set's slots there hold spill-over)
+    const bool pq = G.pairq && (w >= G.WB || bin == 5) && pm >= 96;
+    if (pq) { B0 = 0; A1 = 0; B1 = 0; }
+    const int plo = 128 * (pm >> 6) + (pm & 63) - (pq ? 32 : 0), phi = plo + 64;
+    const bool lo_ok = plo < G.lcap, hi_ok = phi < G.lcap;
+    if (A0 && lo_ok) atomicAdd(&fraw[off + plo * stride], A0);
+    if (A0 != B0 && lo_ok) atomicAdd(&fcl[off + plo * stride], A0 - B0);
+    if (A1 && hi_ok) atomicAdd(&fraw[off + phi * stride], A1);
+    if (A1 != B1 && hi_ok) atomicAdd(&fcl[off + phi * stride], A1 - B1);
+}
+
 template <int NW, bool FULL, bool STAGED, int MAXW = 16>
 void go(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, const TileGeom &G, int iters,
         int flush_every, unsigned wgs, int threads, size_t shmem, void *stream) {
@@ -1117,6 +1164,8 @@ void go(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const De
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), shmem, (hipStream_t)stream, hp, ta, b, st, G, iters, flush_every);
+    const int mates = hp.paired ? 2 : 1, per = (G.SET + 15) / 16;
+    hipLaunchKernelGGL(snk_tiled_reduce_kernel, dim3((unsigned)(mates * per)), dim3(256), 0, (hipStream_t)stream, st, G, (int)wgs, mates);
 }
 
 // reads per staging chunk: a power of two <= 32, so that read 32 (where the bit collectors are parked) opens a chunk
@@ -1175,9 +1224,15 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
 
 }  // namespace
 
+// bytes of DevStats::part: per workgroup (n_cu of them at most) 4 histogram sets x SET words x 2 halves
+size_t snk_tiled_part_bytes(int lcap, int nq, int n_cu) {
+    const int Lh = 64 * (((lcap + 63) / 64 + 1) / 2);
+    return (size_t)n_cu * 4 * ((size_t)Lh * 6 + (size_t)Lh * (nq + 1)) * 2 * sizeof(u32);
+}
+
 int snk_launch_tiled(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st,
                      int lcap, int nq, int n_cu, void *stream) {
-    if (!hp.tile_ok || lcap > 256 || b.n <= 0) return 0;
+    if (!hp.tile_ok || lcap > 256 || b.n <= 0 || !st.part) return 0;
     TileGeom G;
     G.lcap = lcap;
     G.nq = nq;
