@@ -1035,6 +1035,9 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
                         const bool lo_ok = plo < G.lcap, hi_ok = phi < G.lcap;
                         if ((w >= G.WB && bin == G.nq) || (w < G.WB && bin == 5)) {
                             if ((alo && lo_ok) || (ahi && hi_ok)) ovf = 1;       // quality outside [0,nq): overflow / underflow row
+                        } else if (flush_lo == 0) {                             // the launch's first flush (mostly its only one): the slice is zero
+                            if (a) praw[w] = make_uint2(a & 0xFFFFu, a >> 16);
+                            if (b) prem[w] = make_uint2(b & 0xFFFFu, b >> 16);
                         } else {
                             if (a) { uint2 x = praw[w]; x.x += a & 0xFFFFu; x.y += a >> 16; praw[w] = x; }
                             if (b) { uint2 x = prem[w]; x.x += b & 0xFFFFu; x.y += b >> 16; prem[w] = x; }

@@ -5,7 +5,7 @@ for wl in $1; do
   for v in $2; do
     name=${v%%=*}; rest=${v#*=}; lib=${rest%%:*}; envs=""
     if [[ "$rest" == *:* ]]; then envs=${rest#*:}; fi
-    ms=$(env ${lib:+SNK_LIB=$ROOT/$lib} ${envs//:/ } python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload $wl | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['roofline']['kernel_ms'])")
+    ms=$(timeout 150 env ${lib:+SNK_LIB=$ROOT/$lib} ${envs//:/ } python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload $wl | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['roofline']['kernel_ms'])")
     echo "$wl $name $ms"
   done
 done
