@@ -63,6 +63,10 @@ snk_rmdup_stream *snk_rmdup_stream_create(snk_ctx *ctx, uint64_t expected_pairs)
 int snk_rmdup_stream_mark_device(snk_rmdup_stream *t, const uint64_t *d_hash, uint64_t first_index, int64_t n, uint8_t *d_dup, void *stream);
 int snk_rmdup_stream_stats(snk_rmdup_stream *t, uint64_t *n_marked, int32_t *sentinel_seen);     /* synchronises */
 void snk_rmdup_stream_destroy(snk_rmdup_stream *t);
+/* device bytes a one-pass table for `pairs` pairs holds at its largest (resident hashes 8 B per pair + the open-addressing table,
+ * 12 B per slot at load 0.25..0.5): lets the caller choose the memory-lean two-pass calls up front.  A call that cannot get its
+ * memory returns SNK_E_NOMEM and leaves the table unusable (later calls repeat the code): fall back to the two passes then.  */
+uint64_t snk_rmdup_stream_bytes(uint64_t pairs);
 
 /* rmdup::getPrime(n) (host helper; 0 for n == 0 where the reference exits with "code error") */
 uint32_t snk_rmdup_prime(uint64_t n);

@@ -182,7 +182,7 @@ EXPORTS = [
     "snk_stats_fetch", "snk_error_peek_async", "snk_error_decode", "snk_stats_allreduce", "snk_set_timing", "snk_last_kernel_ms",
     # include/snk_rmdup.h
     "snk_rmdup_hash_device", "snk_rmdup_bucket_count_device", "snk_rmdup_mark_device", "snk_rmdup_prime",
-    "snk_rmdup_stream_create", "snk_rmdup_stream_mark_device", "snk_rmdup_stream_stats", "snk_rmdup_stream_destroy",
+    "snk_rmdup_stream_create", "snk_rmdup_stream_mark_device", "snk_rmdup_stream_stats", "snk_rmdup_stream_destroy", "snk_rmdup_stream_bytes",
     # include/snk_selftest.h
     "snk_selftest_bit_transpose",
     # include/snk_fastq.h

@@ -6,8 +6,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsnk_filter.so")
 SOURCES = ["snk_filter.cpp", "snk_generic.hip", "snk_tiled.hip", "snk_rmdup.hip", "snk_contam.hip", "snk_long.hip", "snk_fastq.hip", "snk_gzip.hip"]
-HEADERS = ["snk_device.h", "snk_common.cuh", "snk_bittr.cuh", "snk_adapter_bits.cuh", os.path.join("..", "..", "include", "snk_filter.h"),
-           os.path.join("..", "..", "include", "snk_rmdup.h"), os.path.join("..", "..", "include", "snk_selftest.h"), os.path.join("..", "..", "include", "snk_fastq.h")]
+def _headers():
+    """every header a kernel source can include: csrc/*.cuh|*.h and include/*.h (a missing entry once let a stale
+    library survive a plane-store layout change)"""
+    import glob
+    inc = os.path.join(HERE, "..", "include")
+    return sorted(glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(inc, "*.h")))
+
+
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
@@ -16,7 +22,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, f) for f in SOURCES] + _headers())
 
 
 def build(force=False, verbose=False):
@@ -37,7 +43,8 @@ REPORT_LIB = os.path.join(HERE, "libsnk_report.so")
 def build_host(force=False, verbose=False):
     """The C++ host side: report writer library (plain g++) and the `SOAPnuke filter` CLI (links the
     C-ABI library with an $ORIGIN rpath)."""
-    srcs = [os.path.join(HOST, f) for f in ("snk_main.cpp", "snk_report.cpp", "snk_report.h", "snk_inflate.h", "snk_pgunzip.h", "snk_deflate.h")]
+    srcs = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith((".cpp", ".h"))] + \
+           [f for f in _headers() if os.sep + "include" + os.sep in f]
     newest = max(os.path.getmtime(f) for f in srcs + [LIB])
     if force or not os.path.exists(REPORT_LIB) or os.path.getmtime(REPORT_LIB) < newest:
         cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", REPORT_LIB, "snk_report.cpp"]

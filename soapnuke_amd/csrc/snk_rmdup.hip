@@ -336,19 +336,42 @@ struct snk_rmdup_stream {
     u64 count = 0;                                   // hashes inserted so far
     struct Chunk { u64 *d; long n; u32 base; };
     std::vector<Chunk> chunks;                       // all hashes stay resident: a grown table is refilled from them
+    // the resident hashes live in slabs of 2^23 words (64 MB) carved up batch by batch: no hipMalloc on the per-batch path
+    // (a fresh slab every ~30 batches of the CLI), nothing to free on an error path
+    std::vector<u64 *> slabs;
+    size_t slab_used = 0, slab_words = 0;            // of the newest slab
     u64 *d_marked = nullptr;                         // [marked u64][flag u32]
     hipEvent_t ev = nullptr;
     hipStream_t last = nullptr;
     bool have_ev = false;
+    bool dead = false;                               // a failed growth left no table: every later call reports SNK_E_NOMEM
 };
+
+static u64 *stream_hash_room(snk_rmdup_stream *t, size_t n) {
+    if (t->slabs.empty() || t->slab_used + n > t->slab_words) {
+        const size_t words = n > ((size_t)1 << 23) ? n : ((size_t)1 << 23);
+        u64 *d = nullptr;
+        if (hipMalloc((void **)&d, words * sizeof(u64)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        t->slabs.push_back(d);
+        t->slab_used = 0;
+        t->slab_words = words;
+    }
+    u64 *r = t->slabs.back() + t->slab_used;
+    t->slab_used += n;
+    return r;
+}
 
 static int stream_alloc_table(snk_rmdup_stream *t, u64 want_pairs, hipStream_t st) {
     int lg = 16;
     while ((1ull << lg) < 4ull * want_pairs) ++lg;   // load <= 0.25 when fresh, grown at 0.5
     t->lg = lg;
     t->cap = 1ull << lg;
-    RM_OK(hipMalloc((void **)&t->keys, t->cap * sizeof(u64)));
-    RM_OK(hipMalloc((void **)&t->minidx, t->cap * sizeof(u32)));
+    if (hipMalloc((void **)&t->keys, t->cap * sizeof(u64)) != hipSuccess || hipMalloc((void **)&t->minidx, t->cap * sizeof(u32)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (t->keys) (void)hipFree(t->keys);
+        t->keys = nullptr; t->minidx = nullptr;
+        return (int)hipErrorOutOfMemory;
+    }
     RM_OK(hipMemsetAsync(t->keys, 0xFF, t->cap * sizeof(u64), st));
     RM_OK(hipMemsetAsync(t->minidx, 0xFF, t->cap * sizeof(u32), st));
     return 0;
@@ -368,13 +391,19 @@ snk_rmdup_stream *snk_rmdup_stream_create(snk_ctx *, uint64_t expected_pairs) {
     return t;
 }
 
+uint64_t snk_rmdup_stream_bytes(uint64_t pairs) {
+    int lg = 16;
+    while ((1ull << lg) < 4ull * pairs) ++lg;        // stream_alloc_table()
+    return pairs * 8ull + (1ull << lg) * 12ull;
+}
+
 void snk_rmdup_stream_destroy(snk_rmdup_stream *t) {
     if (!t) return;
     (void)hipDeviceSynchronize();
     if (t->keys) (void)hipFree(t->keys);
     if (t->minidx) (void)hipFree(t->minidx);
     if (t->d_marked) (void)hipFree(t->d_marked);
-    for (auto &c : t->chunks) (void)hipFree(c.d);
+    for (auto d : t->slabs) (void)hipFree(d);
     if (t->ev) (void)hipEventDestroy(t->ev);
     delete t;
 }
@@ -389,9 +418,10 @@ int snk_rmdup_stream_mark_device(snk_rmdup_stream *t, const uint64_t *d_hash, ui
     hipStream_t st = (hipStream_t)stream;
     auto fail = [](const char *what) { snk_set_error(what); return SNK_E_HIP; };
     if (t->have_ev && st != t->last && hipStreamWaitEvent(st, t->ev, 0) != hipSuccess) return fail("snk_rmdup_stream_mark_device: hipStreamWaitEvent failed");
+    if (t->dead) { snk_set_error("snk_rmdup_stream_mark_device: out of device memory (table)"); return SNK_E_NOMEM; }
     // the batch's hashes stay resident
-    snk_rmdup_stream::Chunk c{nullptr, (long)n, (u32)first_index};
-    if (hipMalloc((void **)&c.d, (size_t)n * sizeof(u64)) != hipSuccess) { snk_set_error("snk_rmdup_stream_mark_device: out of device memory"); return SNK_E_NOMEM; }
+    snk_rmdup_stream::Chunk c{stream_hash_room(t, (size_t)n), (long)n, (u32)first_index};
+    if (!c.d) { snk_set_error("snk_rmdup_stream_mark_device: out of device memory (resident hashes)"); return SNK_E_NOMEM; }
     if (hipMemcpyAsync(c.d, d_hash, (size_t)n * sizeof(u64), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("snk_rmdup_stream_mark_device: copy failed");
     u32 *flag = reinterpret_cast<u32 *>(t->d_marked + 1);
     if ((t->count + (u64)n) * 2 > t->cap) {                    // grow: a fresh table, refilled from the resident hashes
@@ -399,7 +429,11 @@ int snk_rmdup_stream_mark_device(snk_rmdup_stream *t, const uint64_t *d_hash, ui
         (void)hipFree(t->keys);
         (void)hipFree(t->minidx);
         t->keys = nullptr; t->minidx = nullptr;
-        if (stream_alloc_table(t, 2 * (t->count + (u64)n), st) != 0) { snk_set_error("snk_rmdup_stream_mark_device: out of device memory (table)"); return SNK_E_NOMEM; }
+        if (stream_alloc_table(t, 2 * (t->count + (u64)n), st) != 0) {     // (the old table is gone: the caller falls back to two passes)
+            t->dead = true;
+            snk_set_error("snk_rmdup_stream_mark_device: out of device memory (table)");
+            return SNK_E_NOMEM;
+        }
         for (const auto &o : t->chunks)
             hipLaunchKernelGGL(snk_stream_insert_kernel, dim3((unsigned)((o.n + 255) / 256)), dim3(256), 0, st, (const u64 *)o.d, o.base, o.n, t->keys,
                                t->minidx, t->cap - 1, 64 - t->lg, flag);

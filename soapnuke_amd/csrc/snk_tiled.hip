@@ -1216,9 +1216,15 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
     const long tiles = (b.n + 63) / 64;
     long wgs = (tiles + W - 1) / W;
     if (wgs > n_cu) wgs = n_cu;
+    // test hooks (tests/test_gpu_parity.py::test_multi_flush_launches): fewer workgroups / an earlier flush make a small batch walk
+    // the multi-iteration and the read-modify-write flush branches that otherwise need > 16.5 M pairs per launch
+    static const int hook_wgs = getenv("SNK_TEST_MAX_WGS") ? atoi(getenv("SNK_TEST_MAX_WGS")) : 0;
+    static const int hook_flush = getenv("SNK_TEST_FLUSH_EVERY") ? atoi(getenv("SNK_TEST_FLUSH_EVERY")) : 0;
+    if (hook_wgs > 0 && wgs > hook_wgs) wgs = hook_wgs;
     const long GW = wgs * W;
     const int iters = (int)((tiles + GW - 1) / GW);
-    const int flush_every = 65535 / (W * 64);
+    int flush_every = 65535 / (W * 64);
+    if (hook_flush > 0 && hook_flush < flush_every) flush_every = hook_flush;
     G.pairq = (SNK_PAIR && NW == 5 && G.rb) ? 1 : 0;
     if (G.rb) go<NW, FULL, true, MAXW>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
     else go<NW, FULL, false, MAXW>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);

@@ -999,15 +999,21 @@ struct OutFile {                                        // clean / dup output: b
     off_t pos = 0;
     bool gz = false;
     bool is_open() const { return fd >= 0; }
+    // an output that is not a regular file (a named pipe into `md5sum`, /dev/stdout ...) cannot be written at offsets: its
+    // pieces go out in order through write()
+    static bool &is_stream(int fd) { static bool t[4096]; return t[fd >= 0 && fd < 4096 ? fd : 0]; }
     void open(const string &path, bool gzip) {
         fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) die("cannot write to the file," + path);
+        if (fd >= 4096) die("too many open files");
+        struct stat st;
+        is_stream(fd) = fstat(fd, &st) == 0 && !S_ISREG(st.st_mode);
         pos = 0;
         gz = gzip;
     }
     static void put_at(int fd, const char *p, size_t n, off_t at) {
         while (n) {
-            const ssize_t w = pwrite(fd, p, n, at);
+            const ssize_t w = is_stream(fd) ? ::write(fd, p, n) : pwrite(fd, p, n, at);
             if (w <= 0) die("write error (disk full?)");
             p += w; n -= (size_t)w; at += w;
         }
@@ -1023,7 +1029,7 @@ struct OutFile {                                        // clean / dup output: b
         off_t p = pos;
         size_t total = 0;
         for (size_t i = 0; i < parts.size(); ++i) { at[i] = p; p += (off_t)parts[i].size(); total += parts[i].size(); }
-        if (total < ((size_t)8 << 20) || parts.size() < 2) {
+        if (total < ((size_t)8 << 20) || parts.size() < 2 || is_stream(fd)) {
             for (size_t i = 0; i < parts.size(); ++i) if (!parts[i].empty()) put_at(fd, parts[i].data(), parts[i].size(), at[i]);
         } else {
             const int fdc = fd;
@@ -1242,6 +1248,18 @@ size_t rmdup_cache_budget() {
         fclose(f);
     }
     return avail > 0 ? (size_t)(avail * 0.4) : 0;
+}
+
+// rmdup in one pass keeps a table and every hash resident in HBM; when that memory is not there (or a sentinel hash shows up, see
+// the end of main) the run starts over with the reference's two passes: same process image, every output rewritten from the start
+[[noreturn]] void restart_two_pass(char **argv, const char *why) {
+    setenv("SNK_RMDUP_TWO_PASS", "restarted", 1);
+    setenv("SNK_RMDUP_RESTART_WHY", why, 1);
+    cout.flush();
+    cerr.flush();
+    execv("/proc/self/exe", argv);
+    cerr << "cannot start the two-pass rmdup run" << endl;
+    _exit(1);
 }
 
 }  // namespace
@@ -1536,6 +1554,18 @@ int main(int argc, char **argv) {
             const double per = (double)first[0]->nbytes / (double)first[0]->n;
             guess = (uint64_t)((double)st.st_size * (is_gzip_file(inputs[0]) ? 6.0 : 1.05) / per) + 1024;
         }
+        {   // the table at its largest against what the device has left (the stream slots come on top: ~1.5 GB each)
+            size_t free_b = 0, total_b = 0;
+            const uint64_t want = snk_rmdup_stream_bytes(std::min<uint64_t>(2 * guess, 4294967295ull));
+            if (getenv("SNK_RMDUP_NOMEM_TEST") && !strcmp(getenv("SNK_RMDUP_NOMEM_TEST"), "upfront")) free_b = 1;
+            else HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            if ((double)want > 0.85 * (double)free_b) {
+                log << local_time() << "\trmdup: the one-pass table would need " << (want >> 20) << " MB of device memory, " << (free_b >> 20) << " MB are free" << endl;
+                log.close();
+                unsetenv("SNK_RMDUP_NOMEM_TEST");
+                restart_two_pass(argv, "not enough device memory for the one-pass table");
+            }
+        }
         dup_table = snk_rmdup_stream_create(devs[0].ctx, std::min<uint64_t>(guess, 4294967295ull));
         if (!dup_table) die(snk_last_error());
         for (int m = 0; m < mates; ++m) {                   // dupReads.<thread>.<mate>.gz, src/peprocess.cpp:167-174
@@ -1544,7 +1574,7 @@ int main(int argc, char **argv) {
         }
     }
     if (o.p.rmdup && !rmdup_stream) {
-        if (const char *e = getenv("SNK_RMDUP_TWO_PASS")) if (!strcmp(e, "restarted")) log << local_time() << "\trmdup: two passes (restarted: sentinel hash in the input)" << endl;
+        if (const char *e = getenv("SNK_RMDUP_TWO_PASS")) if (!strcmp(e, "restarted")) log << local_time() << "\trmdup: two passes (restarted: " << (getenv("SNK_RMDUP_RESTART_WHY") ? getenv("SNK_RMDUP_RESTART_WHY") : "sentinel hash in the input") << ")" << endl;
         std::vector<uint64_t *> chunks;
         std::vector<int> chunk_n;
         uint64_t nall = 0;
@@ -1730,7 +1760,8 @@ int main(int argc, char **argv) {
                         }
                         wr[m].pos += (off_t)tot;
                     }
-                    parallel_for((int)pieces.size(), (int)pieces.size(), [&](int, int lo, int hi) {
+                    const bool serial = OutFile::is_stream(wr[0].fd) || (mates == 2 && OutFile::is_stream(wr[1].fd));
+                    parallel_for(serial ? 1 : (int)pieces.size(), (int)pieces.size(), [&](int, int lo, int hi) {
                         for (int k = lo; k < hi; ++k) OutFile::put_at(pieces[(size_t)k].fd, pieces[(size_t)k].p, pieces[(size_t)k].n, pieces[(size_t)k].at);
                     });
                 }
@@ -1761,7 +1792,8 @@ int main(int argc, char **argv) {
                     }
                     wr[m].pos += (off_t)tot;
                 }
-                parallel_for((int)pieces.size(), (int)pieces.size(), [&](int, int lo, int hi) {
+                const bool serial = OutFile::is_stream(wr[0].fd) || (mates == 2 && OutFile::is_stream(wr[1].fd));
+                parallel_for(serial ? 1 : (int)pieces.size(), (int)pieces.size(), [&](int, int lo, int hi) {
                     for (int k = lo; k < hi; ++k) OutFile::put_at(pieces[(size_t)k].fd, pieces[(size_t)k].p, pieces[(size_t)k].n, pieces[(size_t)k].at);
                 });
             }
@@ -2039,7 +2071,15 @@ int main(int argc, char **argv) {
                 hb.pitch = pitch;
                 for (int m = 0; m < mates; ++m) { hb.seq[m] = s.d_seq[m]; hb.qual[m] = s.d_qual[m]; hb.len[m] = s.d_len[m]; }
                 if (snk_rmdup_hash_device(dv.ctx, &hb, s.d_hash, s.stream) != SNK_OK) die(snk_last_error());
-                if (snk_rmdup_stream_mark_device(dup_table, s.d_hash, s.first, n, s.d_flags, s.stream) != SNK_OK) die(snk_last_error());
+                int mrc = snk_rmdup_stream_mark_device(dup_table, s.d_hash, s.first, n, s.d_flags, s.stream);
+                if (mrc == SNK_OK && s.first > 0 && getenv("SNK_RMDUP_NOMEM_TEST") && !strcmp(getenv("SNK_RMDUP_NOMEM_TEST"), "midrun")) mrc = SNK_E_NOMEM;
+                if (mrc == SNK_E_NOMEM) {                    // the resident hashes / a grown table do not fit: the memory-lean two passes instead
+                    log << local_time() << "\trmdup: out of device memory in the one-pass table after " << s.first << " pairs, running again with two passes" << endl;
+                    log.close();
+                    unsetenv("SNK_RMDUP_NOMEM_TEST");
+                    restart_two_pass(argv, "out of device memory in the one-pass table");
+                }
+                if (mrc != SNK_OK) die(snk_last_error());
             }
             for (int lo = 0; lo < n;) {                      // split at virtual-thread block boundaries (appendix C)
                 const uint64_t g = s.first + (uint64_t)lo;
@@ -2277,6 +2317,7 @@ int main(int argc, char **argv) {
             slot_makers.clear();
             teardown();                                       // (the second run gets the device and the pinned memory to itself)
             setenv("SNK_RMDUP_TWO_PASS", "restarted", 1);
+            setenv("SNK_RMDUP_RESTART_WHY", "sentinel hash in the input", 1);
             unsetenv("SNK_RMDUP_SENTINEL_TEST");
             pid_t child = 0;
             int status = 0;

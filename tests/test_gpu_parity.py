@@ -2,6 +2,7 @@
 oracle on the same seeded inputs -- bit-exact on per-read records, every stats
 counter and the max block."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -225,6 +226,22 @@ def test_polyx_runs_of_every_kind(kernel, polyx):
     kw = dict(PE_CASES["C2_adatrim_lowq"], polyX_num=polyx, n_ratio=0.9)
     p = abi.default_params(paired=True, max_read_len=L, **kw)
     assert_same(p, run_hip_device(p, d, kernel), T.run_oracle(p, d), True)
+
+
+@pytest.mark.parametrize("case,var_len", [("C2_adatrim_lowq", 0), ("C3_full", 1)])
+@pytest.mark.parametrize("wgs,every", [(2, 3), (5, 1), (256, 2)])
+def test_multi_flush_launches(case, var_len, wgs, every):
+    """The read-modify-write branch of the tiled kernel's histogram flush (a launch's second and later flushes) and the zero
+    invariant of the per-workgroup partials across launches need > 16.5 M pairs per launch at their natural settings
+    (ADVICE r3); the library's test hooks force them on 150 k pairs: few workgroups -> many iterations, a flush every
+    `every` iterations.  Three launches on one stream slot against the oracle run three times."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SNK_TEST_MAX_WGS=str(wgs), SNK_TEST_FLUSH_EVERY=str(every),
+               PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), T.ROOT, os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "flush_hook_child.py"), case, str(var_len)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "multi-flush OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_full_size_properties():

@@ -3,7 +3,7 @@
 #   tools/ablate_run.sh <workload> <abl> ...      (workload: bench.py --workload)
 ROOT=$(pwd); WL=$1; shift; OUT=$ROOT/gpurun_out/abl_$WL; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 for a in 0 "$@"; do
-  if [ $a = 0 ]; then unset SNK_LIB; else export SNK_LIB=$ROOT/soapnuke_amd/abl/libsnk_abl$a.so; fi
+  if [ $a = 0 ]; then unset SNK_LIB; else export SNK_LIB=$ROOT/ab/libsnk_abl$a.so; fi
   ms=$(python $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --workload $WL | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['roofline']['kernel_ms'])")
   rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY \
      -d $OUT/p$a -o t -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $WL > $OUT/log$a 2>&1

@@ -42,8 +42,17 @@ def md5_of(path):
     return h.hexdigest()
 
 
-def make_inputs(tmp, n, modes):
-    d = synth.make_batch(min(n, 1_000_000), 150, paired=True)
+def make_inputs(tmp, n, modes, L=150, dup_frac=0.0):
+    """n pairs of PE<L> FASTQ: the first million synthetic pairs repeated with new read names; dup_frac > 0: that fraction of
+    the pairs of the million carries the SEQUENCE of another pair (what rmdup keys on; the qualities differ)"""
+    d = synth.make_batch(min(n, 1_000_000), L, paired=True)
+    if dup_frac > 0:
+        import numpy as np
+        rng = np.random.default_rng(11)
+        dst = rng.choice(d["n"], int(d["n"] * dup_frac), replace=False)
+        src = rng.integers(0, d["n"], len(dst))
+        for m in range(2):
+            d["seq"][m][dst] = d["seq"][m][src]
     f = [os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")]
     u = d["n"]
     t0 = time.time()
@@ -51,7 +60,7 @@ def make_inputs(tmp, n, modes):
         cnt = min(u, n - k * u)
         for m in range(2):
             part = f[m] + ".part"
-            synth.write_fastq(part, d["seq"][m][:cnt], d["qual"][m][:cnt], 150, m + 1, first_index=k * u)
+            synth.write_fastq(part, d["seq"][m][:cnt], d["qual"][m][:cnt], L, m + 1, first_index=k * u)
             with open(f[m], "ab") as out, open(part, "rb") as src:
                 while True:
                     b = src.read(1 << 26)
@@ -75,26 +84,58 @@ REPORTS = ["Statistics_of_Filtered_Reads.txt", "Basic_Statistics_of_Sequencing_Q
     f"{n}_{m}.txt" for n in ("Base_distributions_by_read_position", "Base_quality_value_distribution_by_read_position",
                              "Distribution_of_Q20_Q30_bases_by_read_position", "Statistics_of_Trimming_Position_of_Reads") for m in (1, 2)]
 
+C3_ARGS = ["-n", "0.01", "-m", "20", "-g", "10", "-X", "50", "-p", "0.8"]
 
-def run(exe, inputs, out_dir, ext, threads, env=None):
+
+def command(exe, inputs, out_dir, ext, threads, c3=None, extra_cfg=None):
+    """the command line of one run (both tools take the same); c3 / extra_cfg default to the module switches"""
+    c3 = C3 if c3 is None else c3
+    extra_cfg = EXTRA_CFG if extra_cfg is None else extra_cfg
     args = ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-l", "10", "-q", "0.1", "-T", str(threads)]
-    if C3 or EXTRA_CFG:
-        cfg = os.path.join(os.path.dirname(inputs[0]), "c3.cfg")
+    if c3 or extra_cfg:
+        cfg = os.path.join(os.path.dirname(inputs[0]), "c3.cfg" if c3 else "extra.cfg")
         with open(cfg, "w") as fh:
-            fh.write("".join(x + "\n" for x in (["trimBadTail=20,30"] if C3 else []) + list(EXTRA_CFG)))
-        args += (["-n", "0.01", "-m", "20", "-g", "10", "-X", "50", "-p", "0.8"] if C3 else []) + ["-c", cfg]
+            fh.write("".join(x + "\n" for x in (["trimBadTail=20,30"] if c3 else []) + list(extra_cfg)))
+        args += (C3_ARGS if c3 else []) + ["-c", cfg]
+    return [exe, "filter", "-1", inputs[0], "-2", inputs[1], "-C", "c1" + ext, "-D", "c2" + ext, "-o", out_dir] + args, None
+
+
+def run(exe, inputs, out_dir, ext, threads, env=None, c3=None, extra_cfg=None):
+    cmd, _ = command(exe, inputs, out_dir, ext, threads, c3, extra_cfg)
     t0 = time.time()
-    r = subprocess.run([exe, "filter", "-1", inputs[0], "-2", inputs[1], "-C", "c1" + ext, "-D", "c2" + ext, "-o", out_dir] + args,
-                       capture_output=True, env=env)
+    r = subprocess.run(cmd, capture_output=True, env=env)
     return time.time() - t0, r
 
 
-def measure(tmp, n, T, modes):
-    res = {"pairs": n, "read_len": 150, "threads_T": T, "host_cores": os.cpu_count(),
-           "params": "-f/-r README adapters -J -l 10 -q 0.1" + (" -n 0.01 -m 20 -g 10 -X 50 -p 0.8 + trimBadTail=20,30 (configs[2])" if C3 else ""),
+def params_text(c3, extra_cfg):
+    return ("-f/-r README adapters -J -l 10 -q 0.1" + (" -n 0.01 -m 20 -g 10 -X 50 -p 0.8 + trimBadTail=20,30 (configs[2])" if c3 else "") +
+            ("".join(" + config key " + x for x in extra_cfg)))
+
+
+def compare(tmp, mode, ext, entry, side_prefix=None):
+    """clean FASTQ (decompressed bytes), the ten reports and -- side_prefix -- the side files of both tools' output directories"""
+    a, b = os.path.join(tmp, f"ours_{mode}"), os.path.join(tmp, f"reference_{mode}")
+    entry["clean_fastq_identical"] = all(md5_of(os.path.join(a, c + ext)) == md5_of(os.path.join(b, c + ext)) for c in ("c1", "c2"))
+    differing = [rep for rep in REPORTS if open(os.path.join(a, rep), "rb").read() != open(os.path.join(b, rep), "rb").read()]
+    entry["report_identical"] = not differing          # all ten report files, byte for byte
+    entry["reports_compared"] = len(REPORTS)
+    if differing:
+        entry["reports_differing"] = differing
+    if side_prefix:
+        names = sorted(x for x in os.listdir(b) if x.startswith(side_prefix))
+        entry["side_files"] = len(names)
+        entry["side_files_identical"] = all(os.path.exists(os.path.join(a, x)) and md5_of(os.path.join(a, x)) == md5_of(os.path.join(b, x)) for x in names)
+
+
+def measure(tmp, n, T, modes, c3=None, extra_cfg=None, L=150, dup_frac=0.0):
+    c3 = C3 if c3 is None else c3
+    extra_cfg = EXTRA_CFG if extra_cfg is None else extra_cfg
+    res = {"pairs": n, "read_len": L, "threads_T": T, "host_cores": os.cpu_count(), "params": params_text(c3, extra_cfg),
            "where": "/dev/shm", "modes": {}}
+    if dup_frac > 0:
+        res["duplicate_pairs"] = dup_frac
     if True:
-        f, t_gen, t_gz = make_inputs(tmp, n, ["gz"] if any(m in ("gz", "gz2plain") for m in modes) else [])
+        f, t_gen, t_gz = make_inputs(tmp, n, ["gz"] if any(m in ("gz", "gz2plain") for m in modes) else [], L, dup_frac)
         res["generate_s"] = round(t_gen, 1)
         res["gzip_inputs_s"] = round(t_gz, 1)
         for mode in modes:
@@ -107,7 +148,7 @@ def measure(tmp, n, T, modes):
                 if not os.path.exists(exe):
                     continue
                 o = os.path.join(tmp, f"{name}_{mode}")
-                w, r = run(exe, inputs, o, ext, T)
+                w, r = run(exe, inputs, o, ext, T, c3=c3, extra_cfg=extra_cfg)
                 entry[name] = {"wall_s": round(w, 2), "Mreads_per_s": round(2 * n / w / 1e6, 3), "rc": r.returncode}
                 if r.returncode != 0:
                     entry[name]["stderr"] = r.stderr[-300:].decode(errors="replace")
@@ -117,15 +158,7 @@ def measure(tmp, n, T, modes):
                 # the reference's plain-input runs drop a patch past one merge cycle (Q10): compare only what is comparable
                 comparable = mode != "plain" or n <= 6_000_000
                 if comparable:
-                    same = all(md5_of(os.path.join(tmp, f"ours_{mode}", c + ext)) == md5_of(os.path.join(tmp, f"reference_{mode}", c + ext))
-                               for c in ("c1", "c2"))
-                    entry["clean_fastq_identical"] = same
-                    differing = [rep for rep in REPORTS
-                                 if open(os.path.join(tmp, f"ours_{mode}", rep), "rb").read() != open(os.path.join(tmp, f"reference_{mode}", rep), "rb").read()]
-                    entry["report_identical"] = not differing          # all ten report files, byte for byte
-                    entry["reports_compared"] = len(REPORTS)
-                    if differing:
-                        entry["reports_differing"] = differing
+                    compare(tmp, mode, ext, entry, "dupReads." if "rmdup" in extra_cfg else None)
             for name in ("ours", "reference"):
                 subprocess.call(["rm", "-rf", os.path.join(tmp, f"{name}_{mode}")])
             res["modes"][mode] = entry
