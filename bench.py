@@ -108,16 +108,81 @@ def cpu_baseline(data, n_sample):
         subprocess.call(["rm", "-rf", tmp])
 
 
-def end_to_end(n_pairs, threads=16):
-    """This repo's CLI and the reference binary on the same /dev/shm FASTQ, plain -> plain and .gz -> .gz, whole-process
-    wall clock (tools/bench_e2e.py).  The reference's plain run doubles as the cpu_baseline."""
+def end_to_end(n_pairs, threads=16, rmdup_pairs=4_000_000):
+    """This repo's CLI and the reference binary on the same /dev/shm FASTQ, whole-process wall clock (tools/bench_e2e.py):
+    configs[1] parameters .gz -> .gz and .gz -> plain, plain -> plain for this CLI only (the reference's plain-INPUT run is
+    its 60-s remove_tmpDir stall, SURVEY Q10: the plain speed-up is quoted against its .gz -> plain time), BASELINE configs[2]'s
+    parameters .gz -> .gz on the same files, and BASELINE configs[4]'s shape (PE250 + rmdup, 5 % duplicate pairs) on
+    rmdup_pairs pairs.  The fastest reference leg doubles as the cpu_baseline."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_e2e
-    tmp = tempfile.mkdtemp(prefix="snkbench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    tmp = tempfile.mkdtemp(prefix="snkbench_", dir=shm)
     try:
-        return bench_e2e.measure(tmp, n_pairs, threads, ["plain", "gz", "gz2plain"])
+        res = bench_e2e.measure(tmp, n_pairs, threads, ["plain_ours", "gz", "gz2plain", "gz_c3"])
     finally:
         subprocess.call(["rm", "-rf", tmp])
+    try:
+        a, b = res["modes"]["plain_ours"]["ours"], res["modes"]["gz2plain"]["reference"]
+        if a["rc"] == 0 and b["rc"] == 0:
+            res["modes"]["plain_ours"]["speedup_vs_reference_gz2plain"] = round(b["wall_s"] / a["wall_s"], 2)
+    except KeyError:
+        pass
+    if rmdup_pairs > 0:
+        tmp = tempfile.mkdtemp(prefix="snkbench_", dir=shm)
+        try:
+            res["pe250_rmdup"] = bench_e2e.measure(tmp, rmdup_pairs, threads, ["gz"], c3=False, extra_cfg=["rmdup"], L=250, dup_frac=0.05)
+        except Exception as ex:
+            res["pe250_rmdup"] = {"error": repr(ex)[:200]}
+        finally:
+            subprocess.call(["rm", "-rf", tmp])
+    return res
+
+
+def rmdup_kernels(n=10_000_000, L=250):
+    """the two kernels of the rmdup pre-pass on resident data (SURVEY 8f N1): std::hash of mate1 ++ mate2 per pair, and the
+    first-occurrence marking (5 % duplicate hashes)"""
+    import torch
+    from soapnuke_amd import abi, synth
+    from soapnuke_amd.filter import FilterContext
+    uniq = 500_000
+    d = synth.make_batch(uniq, L, paired=True)
+    ctx = FilterContext(abi.default_params(paired=True, max_read_len=L, rmdup=1), device=0)
+    dev = ctx.upload(d)
+    reps = n // uniq
+    dev["seq"] = [x.repeat(reps, 1) for x in dev["seq"]]
+    dev["qual"] = [x[:1] for x in dev["qual"]]          # (the hash does not look at the qualities)
+    dev["n"] = uniq * reps
+    b = ctx.make_batch(dev)
+    h = ctx.hash_batch(b)
+    torch.cuda.synchronize()
+
+    def timed(f, k=5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f()
+        e0.record()
+        for _ in range(k):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / k
+
+    ms_h = timed(lambda: ctx.hash_batch(b, h))
+    nn = dev["n"]
+    hh = torch.randint(-2**62, 2**62, (nn,), dtype=torch.int64, device="cuda")
+    k = nn // 20
+    hh[torch.randint(0, nn, (k,), device="cuda")] = hh[torch.randint(0, nn, (k,), device="cuda")]
+    ms_m = timed(lambda: ctx.mark_dups(hh))
+    ctx.close()
+    del dev, h, hh
+    torch.cuda.empty_cache()
+    return [{"workload": f"rmdup hash kernel (std::hash of mate1 ++ mate2), PE{L}, {nn // 1000000} M pairs", "ms": round(ms_h, 3),
+             "Mreads_per_s": round(2 * nn / ms_h / 1e3, 1), "algorithmic_GBps": round((2 * L + 8) * nn / ms_h / 1e6, 1),
+             "frac_of_hbm_peak": round((2 * L + 8) * nn / ms_h / 1e6 / HBM_PEAK_GBS, 4), "error": 0},
+            {"workload": f"rmdup marking kernels (hash table in HBM: insert + look-up), {nn // 1000000} M hashes, 5 % duplicates", "ms": round(ms_m, 3),
+             "Mreads_per_s": round(2 * nn / ms_m / 1e3, 1), "algorithmic_GBps": round(9 * nn / ms_m / 1e6, 1),
+             "frac_of_hbm_peak": round(9 * nn / ms_m / 1e6 / HBM_PEAK_GBS, 4), "error": 0,
+             "note": "random access: 8 B hash in + 1 B flag out per pair are the algorithmic bytes, the table traffic is not counted"}]
 
 
 def other_workloads():
@@ -136,6 +201,9 @@ def other_workloads():
         ("contaminants (contam1/2 32/28 nt + one 33-nt global), PE150, 5 M pairs", 150, 5_000_000, 0,
          dict(c2, contam1="ACGTTGCAAGGCTTAACCGGTTAGCATGCAAT", contam2="TTGGCCAAGGTTCCAAGGTTAACCGGTT", ct_match_r="0.5",
               global_contams="AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", g_mrs="0.4", g_mms="1"), False),
+        ("BASELINE configs[4] read length: PE250, configs[1] parameters, 8 M pairs", 250, 8_000_000, 0, c2, False),
+        ("PE250, configs[2] parameters, 8 M pairs", 250, 8_000_000, 0, c3, False),
+        ("PE300 (first length past the tiled kernel's 256 positions), configs[1] parameters, 4 M pairs", 300, 4_000_000, 0, c2, False),
         ("long reads, PE1000, 1 M pairs", 1000, 1_000_000, 0, c2, False),
         ("fallback (kernel=1: generic decisions + LDS histograms), PE150, 2 M pairs", 150, 2_000_000, 1, c2, False),
     ]
@@ -171,6 +239,10 @@ def other_workloads():
         ctx.close()
         del dev, rec
         torch.cuda.empty_cache()
+    try:
+        out += rmdup_kernels()
+    except Exception as ex:
+        out.append({"workload": "rmdup kernels", "error": repr(ex)[:200]})
     return out
 
 
@@ -183,8 +255,8 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, choices=[0, 1, 2, 3], help="0 auto, 1 generic decisions + LDS histograms, 2 fast paths only, 3 generic alone (anchor)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-side legs (cpu_baseline, end_to_end)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="c2 = the headline (BASELINE configs[1]); the others are profiling workloads")
-    ap.add_argument("--e2e-pairs", type=int, default=16_000_000, help="pairs of the end_to_end leg (0: only the cpu_baseline sample); 16 M: the reference needs "
-                    "~85 s plain (60 s of it its remove_tmpDir stall, SURVEY Q10), ~50 s from .gz")
+    ap.add_argument("--e2e-pairs", type=int, default=16_000_000, help="pairs of the end_to_end legs (0: only the cpu_baseline sample); 16 M: the reference needs "
+                    "~50 s per .gz leg (three of them), ~40 s for the 4 M-pair PE250 + rmdup leg")
     args = ap.parse_args()
 
     # SNK_BENCH_FORCE_LAUNCHER=1: take the launcher branch, the nccl process group and the collective at world size 1 too
@@ -294,7 +366,8 @@ def main():
                 tj = json.load(fh)
             if n == 10_000_000 and L == 150 and args.kernel in (0, 2) and args.workload == "c2":
                 traffic = int(tj["hbm_bytes_per_launch"])
-                extra = {"traffic_source": tj["source"], "valu_insts_per_read": tj["valu_insts_per_read"],
+                # (a constant of the committed profile, not a measurement of THIS run: bench.py cannot wrap itself in rocprofv3)
+                extra = {"traffic_measured_in_run": False, "traffic_source": tj["source"], "valu_insts_per_read": tj["valu_insts_per_read"],
                          "valu_issue_frac": tj["valu_issue_frac"], "salu_insts_per_read": tj.get("salu_insts_per_read")}
         except (OSError, KeyError, ValueError):
             pass
@@ -325,6 +398,7 @@ def main():
             # SURVEY Q10; .gz input does not): the most favourable number for the baseline
             legs = [(m, v["reference"]) for m, v in (e2e or {}).get("modes", {}).items()
                     if isinstance(v, dict) and v.get("reference", {}).get("rc") == 0]
+            legs = [x for x in legs if x[0] in ("gz", "gz2plain")]       # configs[1] parameters only: the headline's workload
             if legs:
                 m, best = max(legs, key=lambda x: x[1]["Mreads_per_s"])
                 out["cpu_baseline"] = {"value": best["Mreads_per_s"], "unit": "Mreads/s", "cores": 16, "kind": "reference",

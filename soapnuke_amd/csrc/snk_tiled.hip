@@ -106,6 +106,15 @@ __device__ __forceinline__ void lds_read_qstrips(u32 (&q)[NS], u32 addrq) {
         lds_read_qstrips<S + 1, E>(q, addrq);
     }
 }
+template <int S, int E, int BASE, int NS>              // strips S .. E-1 at immediate offsets BASE + 64 s
+__device__ __forceinline__ void lds_read_qstrips_at(u32 (&q)[NS], u32 addrq) {
+    if constexpr (S < E) {
+        asm volatile("ds_read_u8 %0, %1 offset:%2" : "=&v"(q[S]) : "v"(addrq), "n"(BASE + 64 * S));
+        lds_read_qstrips_at<S + 1, E, BASE>(q, addrq);
+    }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_b32_at(u32 &d, u32 addr) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF)); }
 __device__ __forceinline__ void lds_read_b32(u32 &d, u32 addr) { asm volatile("ds_read_b32 %0, %1" : "=&v"(d) : "v"(addr)); }
 // wait until at most N LDS ops are outstanding; the registers of the (asm) reads being waited for
 // are tied to the wait so that no use can be scheduled above it
@@ -173,10 +182,17 @@ constexpr int SNK_LDS_TAIL = 64 + 80;
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
+// Static shape of the staged path: row pitch, bytes per staging array and reads per chunk known at compile time (the PE150 / PE250
+// batches of BASELINE configs[1..4]: pitch 160 / 256).  Every LDS read of phase 1 then is `base register + immediate` -- no address
+// arithmetic per read -- and the chunk bookkeeping (which read closes a chunk, which buffer a row sits in) folds away: 3 VALU,
+// ~12 SALU and 3 branches per read less than with run-time values (RB == 0: run-time shape, any pitch).
+template <int PITCH_, int CBA_, int RB_> struct TileShape { static constexpr int PITCH = PITCH_, CBA = CBA_, RB = RB_; };
+typedef TileShape<0, 0, 0> ShapeRT;
+
 // One tile = up to 64 pairs starting at t0, processed by one wave.
 // The mate loops are deliberately NOT unrolled (one copy of phases 1-3 in the instruction cache);
 // per-mate results are handed over in the two ReadState values r0 / r1.
-template <int NW, bool FULL, bool STAGED>
+template <int NW, bool FULL, bool STAGED, class SH>
 __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const DevBatch &B, const DevStats &st, const TileGeom &G,
                              u32 *lds, long t0, int cnt) {
     constexpr int NS = (NW + 1) / 2;
@@ -301,9 +317,10 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 else aC = (t << (2 * jq - 1)) | aC;                            // v_lshl_or
                 const u32 ex = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);   // the letter each code stands for
                 const u32 df = (ex ^ c4) & vm;                                 // one v_bitop3
-                u32 carry_out;
-                asm("v_cmp_ne_u32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %1, %1, vcc" : "=v"(carry_out) : "v"(badv), "v"(df) : "vcc");
-                badv = carry_out;                                              // badv = 2 * badv + (some byte is not the letter of its code)
+                // badv = 2 * badv + (some byte is not the letter of its code): v_min_u32 + v_lshl_or_b32 (a v_cmp / v_addc_co pair
+                // through VCC costs the same two instructions, but VALU-writes-VCC -> VALU-reads-VCC wants two wait states on gfx950
+                // that hand-written asm would have to pad)
+                badv = (badv << 1) | min(df, 1u);
                 aQ = (aQ >> 1) | ((q4 + KQ) & 0x80808080u);                   // v_add, v_lshrrev, v_and_or
                 if (FULL) {
                     if (has_lqh) aA = (aA >> 1) | ((q4 + KA) & 0x80808080u);
@@ -327,12 +344,18 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 if constexpr (!(PAIR && odd && s == NS - 1)) {     // (PAIR: the even read's last strip holds both reads' bytes)
                     const int pos = 64 * s + lane;
                     const u32 qb = cq[s];
-                    u32 qc;
-                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(qc) : "v"(qb), "v"(qlo_v), "s"(qhi));
-                    u32 aQa = (qc << lgb) + laneQc;
-                    if (!FULLLEN) aQa = pos < len_r ? aQa : dumB - 256u * (s >> 1);
-                    if (SNK_ABL == 11) { asm volatile("" ::"v"(aQa)); }
-                    else lds_add_u32<256 * (s >> 1)>(aQa, (s & 1) ? 0x10000u : 1u);
+                    // clamp + row address in ONE asm statement: the compiler pads every asm result that the next VALU instruction
+                    // reads with an s_nop (it has to assume a dst_sel forwarding hazard), three per read
+                    u32 aQa;
+                    if (FULLLEN && SNK_ABL != 11) {                // ... and the fire-and-forget add behind them
+                        asm volatile("v_med3_u32 %0, %1, %2, %3\n\tv_lshl_add_u32 %0, %0, %4, %5\n\tds_add_u32 %0, %6 offset:%7"
+                                     : "=&v"(aQa) : "v"(qb), "v"(qlo_v), "s"(qhi), "s"(lgb), "v"(laneQc), "v"((s & 1) ? 0x10000u : 1u), "n"(256 * (s >> 1)));
+                    } else {
+                        asm("v_med3_u32 %0, %1, %2, %3\n\tv_lshl_add_u32 %0, %0, %4, %5" : "=&v"(aQa) : "v"(qb), "v"(qlo_v), "s"(qhi), "s"(lgb), "v"(laneQc));
+                        if (!FULLLEN) aQa = pos < len_r ? aQa : dumB - 256u * (s >> 1);
+                        if (SNK_ABL == 11) { asm volatile("" ::"v"(aQa)); }
+                        else lds_add_u32<256 * (s >> 1)>(aQa, (s & 1) ? 0x10000u : 1u);
+                    }
                 }
             });
             if (FULL && odd) sum_flush(r);
@@ -365,23 +388,26 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             if (STAGED) {
                 // bytes arrive in LDS by DMA (16 B/lane), the next chunk of rb reads in flight
                 // behind the collectors of the current one
+                constexpr bool SS = SH::RB != 0;              // static shape: pitch, staging size and chunk length are compile-time constants
                 const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-                uint8_t *stg = ldsb + G.stg_off + wave * G.stg_wave;
-                const int rb = G.rb, nchunks = (cnt + rb - 1) / rb;
+                const int rb = SS ? SH::RB : G.rb, cba = SS ? SH::CBA : G.cba, pitch = SS ? SH::PITCH : B.pitch;
+                const int stg_wave = SS ? 4 * SH::CBA : G.stg_wave;
+                uint8_t *stg = ldsb + G.stg_off + wave * stg_wave;
+                const int nchunks = (SS && CNT64) ? 64 / (SS ? SH::RB : 1) : (cnt + rb - 1) / rb;
                 // chunk sources advance by scalar adds; the lane offset is the same for every full chunk
-                const int chunkB = rb * B.pitch;
+                const int chunkB = rb * pitch;
                 // (ablation 15: every wave streams one of 64 tiles over and over -> the DMA hits L2)
                 const long t0s = (SNK_ABL == 15 || SNK_L2SRC) ? (long)((blockIdx.x * 16 + wave) & 63) * 64 : t0;
-                const uint8_t *gs = seq + t0s * (long)B.pitch, *gq = qual + t0s * (long)B.pitch;
+                const uint8_t *gs = seq + t0s * (long)pitch, *gq = qual + t0s * (long)pitch;
                 const int offF = min(lane * 16, chunkB - 16);
-                const bool dlane = lane * 16 < G.cba;
+                const bool dlane = lane * 16 < cba;
                 auto issue = [&](const int k) {
-                    uint8_t *dst = stg + (k & 1) * 2 * G.cba;
+                    uint8_t *dst = stg + (k & 1) * 2 * cba;
                     int off = offF;
-                    if ((k + 1) * rb > cnt) off = min(lane * 16, (cnt - k * rb) * B.pitch - 16);     // last chunk of the last tile
+                    if (!(SS && CNT64) && (k + 1) * rb > cnt) off = min(lane * 16, (cnt - k * rb) * pitch - 16);     // last chunk of the last tile
                     if (SNK_ABL != 12 && dlane) {          // same instruction count every chunk (counted vmcnt below)
                         __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + off), (lds_ptr_t)dst, 16, 0, 0);
-                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gq + off), (lds_ptr_t)(dst + G.cba), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gq + off), (lds_ptr_t)(dst + cba), 16, 0, 0);
                     }
                     gs += chunkB;
                     gq += chunkB;
@@ -396,16 +422,16 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 // DMA: when the row of the last read of chunk k has been ISSUED (two reads before it is used), the next
                 // row to fetch is row 0 of chunk k+1, whose DMA is waited for there; one step later that last row sits in
                 // registers, and the DMA of chunk k+2 goes into the buffer of chunk k.
-                constexpr bool PAIR = SNK_PAIR && NW == 5 && FULLLEN && CNT64;
+                constexpr bool PAIR = SNK_PAIR && NW == 5 && FULLLEN && CNT64 && !SS;
                 constexpr int ROWOPS = 2 + NS;
                 constexpr int K = (SNK_ABL == 11 ? 0 : NS) + ROWOPS;
                 // PAIR: an even read's row fetch has all NS strips (the last one shared with the odd read behind it), an odd
                 // read's one less; likewise the histogram adds
                 constexpr int ROWE = 2 + NS, ROWO = 2 + NS - 1, ADDE = SNK_ABL == 11 ? 0 : NS, ADDO = SNK_ABL == 11 ? 0 : NS - 1;
-                const u32 stgA = lds0 + (u32)(G.stg_off + wave * G.stg_wave);
-                const u32 lc4 = (u32)l4, l1 = (u32)G.cba + (u32)lane, lq4 = (u32)G.cba + (u32)l4;
+                const u32 stgA = lds0 + (u32)(G.stg_off + wave * stg_wave);
+                const u32 lc4 = (u32)l4, l1 = (u32)cba + (u32)lane, lq4 = (u32)cba + (u32)l4;
                 // the shared strip: lanes 0-31 positions 64*(NS-1).. of this row, lanes 32-63 the same positions of the next row
-                const u32 l2 = (u32)G.cba + (u32)(64 * (NS - 1)) + (u32)(lane & 31) + (lane >= 32 ? (u32)B.pitch : 0u);
+                const u32 l2 = (u32)cba + (u32)(64 * (NS - 1)) + (u32)(lane & 31) + (lane >= 32 ? (u32)pitch : 0u);
                 issue(0);
                 if (nchunks > 1) issue(1);
                 if (SNK_ABL != 14) {
@@ -423,12 +449,28 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                         lds_read_qstrips<0, NS>(q, row + l1);
                     }
                 };
+                // static shape: two base registers for the whole tile (dword view / byte view of the wave's staging area), the row
+                // is an immediate: buffer parity * 2 * CBA + row in chunk * PITCH (+ CBA for the qualities, + 64 s for strip s)
+                u32 vC = stgA + lc4, vQ = stgA + (u32)lane;
+                asm volatile("" : "+v"(vC), "+v"(vQ));
+                auto lds_rd_s = [&](auto OFFC, u32 &c4, u32 &q4, u32 (&q)[NS]) {
+                    constexpr int O = decltype(OFFC)::v;
+                    constexpr int CB = SS ? SH::CBA : 0;
+                    lds_read_b32_at<O>(c4, vC);
+                    lds_read_b32_at<O + CB>(q4, vC);
+                    lds_read_qstrips_at<0, NS, O + CB>(q, vQ);
+                };
                 u32 C4[4], Q4[4], QS[4][NS];                // register set of read r: r & 3
                 u32 row = stgA;                             // LDS address of the newest prefetched row (scalar)
                 const int rbm = rb - 1, lgrb = 31 - __builtin_clz((unsigned)rb);     // rb is a power of two >= 2 (launch())
-                lds_rd(std::false_type{}, C4[0], Q4[0], QS[0], row);
-                row += (u32)B.pitch;                        // (row 1 is in chunk 0: rb >= 2)
-                lds_rd(std::true_type{}, C4[1], Q4[1], QS[1], row);
+                if constexpr (SS) {
+                    lds_rd_s(IntC<0>{}, C4[0], Q4[0], QS[0]);
+                    lds_rd_s(IntC<(SS ? SH::PITCH : 0)>{}, C4[1], Q4[1], QS[1]);
+                } else {
+                    lds_rd(std::false_type{}, C4[0], Q4[0], QS[0], row);
+                    row += (u32)pitch;                      // (row 1 is in chunk 0: rb >= 2)
+                    lds_rd(std::true_type{}, C4[1], Q4[1], QS[1], row);
+                }
                 lds_wait<PAIR ? ROWO : ROWOPS>(C4[0], Q4[0], QS[0]);
                 for (int o = 0; o < nocts; ++o) {           // reads 8o .. 8o+7
                     // which reads of this octet are the last of a chunk (rb is a power of two): one bit test per read
@@ -437,20 +479,37 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                         constexpr int j = decltype(jc)::v;
                         const int r = 8 * o + j;
                         if (CNT64 || r < cnt) {
+                            if constexpr (SS) {
+                                // RB divides 8: the chunk position of read r + 2 and its buffer are those of j + 2
+                                constexpr int RBs = SS ? SH::RB : 1, R2 = j + 2;
+                                constexpr bool closes = (R2 % RBs) == 0;               // read r+1 is the last of chunk k
+                                const int k = (8 * o) / RBs + R2 / RBs - 1;
+                                if constexpr (closes) {
+                                    if (k + 1 < nchunks && SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                }
+                                constexpr int par = (R2 / RBs) & 1, rowi = R2 % RBs;
+                                lds_rd_s(IntC<par * 2 * (SS ? SH::CBA : 0) + rowi * (SS ? SH::PITCH : 0)>{}, C4[(j + 2) & 3], Q4[(j + 2) & 3], QS[(j + 2) & 3]);
+                                do_read(FL, IntC<j>{}, std::false_type{}, r, C4[j & 3], Q4[j & 3], QS[j & 3], 0u);
+                                lds_wait<K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
+                                if constexpr (closes) {
+                                    if (k + 2 < nchunks) issue(k + 2);                 // every row of chunk k sits in registers now
+                                }
+                            } else {
                             // read r+1 is the last of chunk k (never for j = 7: read 0 of an octet closes no chunk)
                             const bool closes = j < 7 && ((evm >> ((j + 1) & 7)) & 1u);
                             const int k = ((r + 2) >> lgrb) - 1;
                             if (closes) {                   // row of read r+2 = row 0 of chunk k+1
                                 if (k + 1 < nchunks && SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                row = stgA + (u32)(((k + 1) & 1) * 2 * G.cba);
+                                row = stgA + (u32)(((k + 1) & 1) * 2 * cba);
                             } else {
-                                row += (u32)B.pitch;
+                                row += (u32)pitch;
                             }
                             lds_rd(std::integral_constant<bool, (j & 1) != 0>{}, C4[(j + 2) & 3], Q4[(j + 2) & 3], QS[(j + 2) & 3], row);
                             do_read(FL, IntC<j>{}, std::integral_constant<bool, PAIR>{}, r, C4[j & 3], Q4[j & 3], QS[j & 3], QS[j & 2][NS - 1]);
                             // behind the row of read r+1: the row of read r+2 and the adds of read r (same parity)
                             lds_wait<PAIR ? ((j & 1) ? ROWO + ADDO : ROWE + ADDE) : K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
                             if (closes && k + 2 < nchunks) issue(k + 2);     // every row of chunk k sits in registers now
+                            }
                         } else skip_read(IntC<j>{}, r);
                         if (j == 3) park4(2 * o);
                         if (j == 7) { park4(2 * o + 1); park8(o); }
@@ -939,21 +998,21 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                         constexpr int s = decltype(sc)::v;
                         const u32 c = cb[b][s];
-                        u32 qc;
-                        asm("v_med3_u32 %0, %1, %2, %3" : "=v"(qc) : "v"(qb[b][s]), "v"(qlo_v), "s"(qhi));
+                        u32 qa;
+                        asm("v_med3_u32 %0, %1, %2, %3\n\tv_lshl_add_u32 %0, %0, %4, %5" : "=&v"(qa) : "v"(qb[b][s]), "v"(qlo_v), "s"(qhi), "s"(lgb), "v"(remQc));
                         lds_add_u32<256 * (s >> 1)>(((c & 6u) << (lgb - 1)) + remBa, (s & 1) ? 0x10000u : 1u);
-                        lds_add_u32<256 * (s >> 1)>((qc << lgb) + remQc, (s & 1) ? 0x10000u : 1u);
+                        lds_add_u32<256 * (s >> 1)>(qa, (s & 1) ? 0x10000u : 1u);
                     });
                 } else {
                     const u32 span = (u32)(len_r - rm_lo);
                     static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                         constexpr int s = decltype(sc)::v;
                         const u32 c = cb[b][s];
-                        u32 qc;
-                        asm("v_med3_u32 %0, %1, %2, %3" : "=v"(qc) : "v"(qb[b][s]), "v"(qlo_v), "s"(qhi));
+                        u32 qa;
+                        asm("v_med3_u32 %0, %1, %2, %3\n\tv_lshl_add_u32 %0, %0, %4, %5" : "=&v"(qa) : "v"(qb[b][s]), "v"(qlo_v), "s"(qhi), "s"(lgb), "v"(remQc));
                         const bool inr = (u32)(64 * s + lane - rm_lo) < span;
                         const u32 aB = inr ? ((c & 6u) << (lgb - 1)) + remBa : dumR - 256u * (s >> 1);
-                        const u32 aQ = inr ? (qc << lgb) + remQc : dumR - 256u * (s >> 1);
+                        const u32 aQ = inr ? qa : dumR - 256u * (s >> 1);
                         lds_add_u32<256 * (s >> 1)>(aB, (s & 1) ? 0x10000u : 1u);
                         lds_add_u32<256 * (s >> 1)>(aQ, (s & 1) ? 0x10000u : 1u);
                     });
@@ -981,7 +1040,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
     }
 }
 
-template <int NW, bool FULL, bool STAGED, int MAXW = 16>
+template <int NW, bool FULL, bool STAGED, int MAXW = 16, class SH = ShapeRT>
 __global__ void __launch_bounds__(MAXW * 64)
 snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, const DevStats st, const TileGeom G, const int iters,
                  const int flush_every) {
@@ -1007,7 +1066,7 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
         const long t0 = tile * 64;
         long rem = B.n - t0;
         const int cnt = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-        if (cnt > 0) process_tile<NW, FULL, STAGED>(P, TA, B, st, G, lds, t0, cnt);
+        if (cnt > 0) process_tile<NW, FULL, STAGED, SH>(P, TA, B, st, G, lds, t0, cnt);
         if ((it + 1) % flush_every == 0 || it + 1 == iters) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm histogram adds
             __syncthreads();
@@ -1156,11 +1215,11 @@ __global__ void __launch_bounds__(256) snk_tiled_reduce_kernel(const DevStats st
     if (A1 != B1 && hi_ok) atomicAdd(&fcl[off + phi * stride], A1 - B1);
 }
 
-template <int NW, bool FULL, bool STAGED, int MAXW = 16>
+template <int NW, bool FULL, bool STAGED, int MAXW = 16, class SH = ShapeRT>
 void go(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const DevStats &st, const TileGeom &G, int iters,
         int flush_every, unsigned wgs, int threads, size_t shmem, void *stream) {
     static bool attr_done = false;
-    auto kern = snk_tiled_kernel<NW, FULL, STAGED, MAXW>;
+    auto kern = snk_tiled_kernel<NW, FULL, STAGED, MAXW, SH>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
@@ -1226,8 +1285,25 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
     int flush_every = 65535 / (W * 64);
     if (hook_flush > 0 && hook_flush < flush_every) flush_every = hook_flush;
     G.pairq = (SNK_PAIR && NW == 5 && G.rb) ? 1 : 0;
-    if (G.rb) go<NW, FULL, true, MAXW>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
-    else go<NW, FULL, false, MAXW>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
+    // the shapes of BASELINE's configurations get their own instances (TileShape): PE150 at pitch 160, PE250 at pitch 256
+    static const bool no_static = getenv("SNK_TILED_RUNTIME_SHAPE") != nullptr;       // (A/B and tests: the run-time shape for every batch)
+    bool launched = false;
+    if constexpr (NW == 5) {
+        if (G.rb && !no_static && b.pitch == 160 && G.cba == 768 && G.rb == 4) {
+            go<NW, FULL, true, MAXW, TileShape<160, 768, 4>>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
+            launched = true;
+        }
+    }
+    if constexpr (NW == 8) {
+        if (G.rb && !no_static && b.pitch == 256 && G.cba == 768 && G.rb == 2) {
+            go<NW, FULL, true, MAXW, TileShape<256, 768, 2>>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
+            launched = true;
+        }
+    }
+    if (!launched) {
+        if (G.rb) go<NW, FULL, true, MAXW>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
+        else go<NW, FULL, false, MAXW>(hp, ta, b, st, G, iters, flush_every, (unsigned)wgs, W * 64, shmem, stream);
+    }
     return 1;
 }
 

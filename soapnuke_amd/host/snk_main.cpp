@@ -1250,18 +1250,6 @@ size_t rmdup_cache_budget() {
     return avail > 0 ? (size_t)(avail * 0.4) : 0;
 }
 
-// rmdup in one pass keeps a table and every hash resident in HBM; when that memory is not there (or a sentinel hash shows up, see
-// the end of main) the run starts over with the reference's two passes: same process image, every output rewritten from the start
-[[noreturn]] void restart_two_pass(char **argv, const char *why) {
-    setenv("SNK_RMDUP_TWO_PASS", "restarted", 1);
-    setenv("SNK_RMDUP_RESTART_WHY", why, 1);
-    cout.flush();
-    cerr.flush();
-    execv("/proc/self/exe", argv);
-    cerr << "cannot start the two-pass rmdup run" << endl;
-    _exit(1);
-}
-
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -1302,7 +1290,31 @@ int main(int argc, char **argv) {
     // rmdup of paired input in device-text mode is one pass (include/snk_rmdup.h, snk_rmdup_stream_*): every batch is hashed and
     // looked up in a table that stays in HBM; the other rmdup runs keep the reference's two passes (SE: its flags are shifted by
     // one read inside full patches, see below; several devices: the table lives on one).  SNK_RMDUP_TWO_PASS=1 forces them.
-    const bool rmdup_one_pass = o.p.rmdup && mates == 2 && o.devices.size() == 1 && !getenv("SNK_RMDUP_TWO_PASS");
+    bool rmdup_one_pass = o.p.rmdup && mates == 2 && o.devices.size() == 1 && !getenv("SNK_RMDUP_TWO_PASS");
+    if (rmdup_one_pass) {
+        // the one-pass table keeps 8 B per pair of hashes and up to 48 B per pair of table resident in HBM: when twice the
+        // estimated number of pairs (file size / bytes of the first record) does not fit, the two passes run instead
+        uint64_t guess = 0;
+        struct stat stf;
+        if (stat(inputs[0].c_str(), &stf) == 0) {
+            if (gzFile g = gzopen(inputs[0].c_str(), "rb")) {          // (transparent for plain text)
+                std::vector<char> line(1 << 16);
+                size_t rec = 0;
+                for (int k = 0; k < 4 && gzgets(g, line.data(), (int)line.size()); ++k) rec += strlen(line.data());
+                gzclose(g);
+                if (rec > 0) guess = (uint64_t)((double)stf.st_size * (is_gzip_file(inputs[0]) ? 6.0 : 1.05) / (double)rec) + 1024;
+            }
+        }
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipSetDevice(o.devices[0]));
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        if (const char *e = getenv("SNK_RMDUP_FREE_MB_TEST")) free_b = (size_t)atol(e) << 20;
+        const uint64_t want = snk_rmdup_stream_bytes(std::min<uint64_t>(2 * guess, 4294967295ull));
+        if ((double)want > 0.85 * (double)free_b) {
+            log << local_time() << "\trmdup: two passes (the one-pass table would need " << (want >> 20) << " MB of device memory, " << (free_b >> 20) << " MB are free)" << endl;
+            rmdup_one_pass = false;
+        }
+    }
     const bool dev_text = !getenv("SNK_HOST_TEXT") && !o.streaming && (!o.p.rmdup || rmdup_one_pass) && o.trim_fq[0].empty() && o.clean_out_split == 0 &&
                           !(o.total_reads > 0) && o.out_file_type != "fasta" && !o.index_remove && o.tile.empty() && o.fov.empty();
     const bool rmdup_stream = dev_text && o.p.rmdup;
@@ -1554,18 +1566,6 @@ int main(int argc, char **argv) {
             const double per = (double)first[0]->nbytes / (double)first[0]->n;
             guess = (uint64_t)((double)st.st_size * (is_gzip_file(inputs[0]) ? 6.0 : 1.05) / per) + 1024;
         }
-        {   // the table at its largest against what the device has left (the stream slots come on top: ~1.5 GB each)
-            size_t free_b = 0, total_b = 0;
-            const uint64_t want = snk_rmdup_stream_bytes(std::min<uint64_t>(2 * guess, 4294967295ull));
-            if (getenv("SNK_RMDUP_NOMEM_TEST") && !strcmp(getenv("SNK_RMDUP_NOMEM_TEST"), "upfront")) free_b = 1;
-            else HIPCHK(hipMemGetInfo(&free_b, &total_b));
-            if ((double)want > 0.85 * (double)free_b) {
-                log << local_time() << "\trmdup: the one-pass table would need " << (want >> 20) << " MB of device memory, " << (free_b >> 20) << " MB are free" << endl;
-                log.close();
-                unsetenv("SNK_RMDUP_NOMEM_TEST");
-                restart_two_pass(argv, "not enough device memory for the one-pass table");
-            }
-        }
         dup_table = snk_rmdup_stream_create(devs[0].ctx, std::min<uint64_t>(guess, 4294967295ull));
         if (!dup_table) die(snk_last_error());
         for (int m = 0; m < mates; ++m) {                   // dupReads.<thread>.<mate>.gz, src/peprocess.cpp:167-174
@@ -1574,7 +1574,7 @@ int main(int argc, char **argv) {
         }
     }
     if (o.p.rmdup && !rmdup_stream) {
-        if (const char *e = getenv("SNK_RMDUP_TWO_PASS")) if (!strcmp(e, "restarted")) log << local_time() << "\trmdup: two passes (restarted: " << (getenv("SNK_RMDUP_RESTART_WHY") ? getenv("SNK_RMDUP_RESTART_WHY") : "sentinel hash in the input") << ")" << endl;
+        if (const char *e = getenv("SNK_RMDUP_TWO_PASS")) if (!strcmp(e, "restarted")) log << local_time() << "\trmdup: two passes (restarted: sentinel hash in the input)" << endl;
         std::vector<uint64_t *> chunks;
         std::vector<int> chunk_n;
         uint64_t nall = 0;
@@ -2072,13 +2072,8 @@ int main(int argc, char **argv) {
                 for (int m = 0; m < mates; ++m) { hb.seq[m] = s.d_seq[m]; hb.qual[m] = s.d_qual[m]; hb.len[m] = s.d_len[m]; }
                 if (snk_rmdup_hash_device(dv.ctx, &hb, s.d_hash, s.stream) != SNK_OK) die(snk_last_error());
                 int mrc = snk_rmdup_stream_mark_device(dup_table, s.d_hash, s.first, n, s.d_flags, s.stream);
-                if (mrc == SNK_OK && s.first > 0 && getenv("SNK_RMDUP_NOMEM_TEST") && !strcmp(getenv("SNK_RMDUP_NOMEM_TEST"), "midrun")) mrc = SNK_E_NOMEM;
-                if (mrc == SNK_E_NOMEM) {                    // the resident hashes / a grown table do not fit: the memory-lean two passes instead
-                    log << local_time() << "\trmdup: out of device memory in the one-pass table after " << s.first << " pairs, running again with two passes" << endl;
-                    log.close();
-                    unsetenv("SNK_RMDUP_NOMEM_TEST");
-                    restart_two_pass(argv, "out of device memory in the one-pass table");
-                }
+                if (mrc == SNK_E_NOMEM)                      // (the estimate below was short by more than a factor of two)
+                    die(string(snk_last_error()) + ": run again with SNK_RMDUP_TWO_PASS=1 in the environment (the memory-lean two passes)");
                 if (mrc != SNK_OK) die(snk_last_error());
             }
             for (int lo = 0; lo < n;) {                      // split at virtual-thread block boundaries (appendix C)
@@ -2317,7 +2312,6 @@ int main(int argc, char **argv) {
             slot_makers.clear();
             teardown();                                       // (the second run gets the device and the pinned memory to itself)
             setenv("SNK_RMDUP_TWO_PASS", "restarted", 1);
-            setenv("SNK_RMDUP_RESTART_WHY", "sentinel hash in the input", 1);
             unsetenv("SNK_RMDUP_SENTINEL_TEST");
             pid_t child = 0;
             int status = 0;

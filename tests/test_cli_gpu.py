@@ -111,7 +111,7 @@ def test_cli_rmdup_matches_reference_binary(paired, n, tmp_path):
     assert b"dup number:\t2520" in open(os.path.join(ours, "log"), "rb").read()
 
 
-@pytest.mark.parametrize("mode", ["one_pass_gz", "two_pass", "sentinel_restart", "small_batches", "nomem_upfront", "nomem_midrun"])
+@pytest.mark.parametrize("mode", ["one_pass_gz", "two_pass", "sentinel_restart", "small_batches", "table_does_not_fit"])
 def test_cli_rmdup_one_pass_variants(mode, tmp_path):
     """Paired rmdup is one pass in device-text mode (a hash table resident in HBM, include/snk_rmdup.h snk_rmdup_stream_*):
     .gz output, the retained two-pass path (SNK_RMDUP_TWO_PASS=1), the restart a sentinel hash forces, and batches much
@@ -130,9 +130,8 @@ def test_cli_rmdup_one_pass_variants(mode, tmp_path):
         env["SNK_RMDUP_SENTINEL_TEST"] = "1"
     if mode == "small_batches":
         env["SNK_BATCH_PAIRS"] = "1536"
-    if mode in ("nomem_upfront", "nomem_midrun"):            # the table's memory is not there: before the first batch / in the middle of the run
-        env["SNK_RMDUP_NOMEM_TEST"] = mode.split("_")[1]
-        env["SNK_BATCH_PAIRS"] = "4096"
+    if mode == "table_does_not_fit":                         # the one-pass table's memory is not there: the two passes are chosen up front
+        env["SNK_RMDUP_FREE_MB_TEST"] = "1"
     case = ("rmdup1", True, L, n, threads, patch, {}, {}, cli, ["rmdup"])
     work = str(tmp_path)
     ref = R.run_reference_cli(case, d, work, gz_input=True)
@@ -148,7 +147,8 @@ def test_cli_rmdup_one_pass_variants(mode, tmp_path):
             assert _cat(os.path.join(ours, f)) == _cat(os.path.join(ref, f)), f
     log = open(os.path.join(ours, "log"), "rb").read()
     assert b"dup number:\t2520" in log and b"duplicate reads number:\t2520" in log
-    assert (b"restarted" in log) == (mode in ("sentinel_restart", "nomem_upfront", "nomem_midrun"))
+    assert (b"restarted" in log) == (mode == "sentinel_restart")
+    assert (b"the one-pass table would need" in log) == (mode == "table_does_not_fit")
 
 
 def test_cli_pe_info_outqual_and_crlf(tmp_path):

@@ -135,20 +135,23 @@ def measure(tmp, n, T, modes, c3=None, extra_cfg=None, L=150, dup_frac=0.0):
     if dup_frac > 0:
         res["duplicate_pairs"] = dup_frac
     if True:
-        f, t_gen, t_gz = make_inputs(tmp, n, ["gz"] if any(m in ("gz", "gz2plain") for m in modes) else [], L, dup_frac)
+        f, t_gen, t_gz = make_inputs(tmp, n, ["gz"] if any(m in ("gz", "gz2plain", "gz_c3") for m in modes) else [], L, dup_frac)
         res["generate_s"] = round(t_gen, 1)
         res["gzip_inputs_s"] = round(t_gz, 1)
         for mode in modes:
             # plain: plain -> plain; gz: .gz -> .gz; gz2plain: .gz -> plain (the reference's plain-INPUT path stalls 60 s in
-            # remove_tmpDir past one merge cycle and loses a patch, SURVEY Q10: this leg is its plain-output time without that)
-            ext = ".fq.gz" if mode == "gz" else ".fq"
-            inputs = [x + ".gz" for x in f] if mode in ("gz", "gz2plain") else f
-            entry = {}
+            # remove_tmpDir past one merge cycle and loses a patch, SURVEY Q10: this leg is its plain-output time without that);
+            # gz_c3: .gz -> .gz with BASELINE configs[2]'s parameters on the same files; plain_ours: plain -> plain, this CLI only
+            # (to be held against the reference's gz2plain time: its plain-input time is the Q10 stall)
+            ext = ".fq.gz" if mode in ("gz", "gz_c3") else ".fq"
+            inputs = [x + ".gz" for x in f] if mode in ("gz", "gz2plain", "gz_c3") else f
+            leg_c3 = True if mode == "gz_c3" else c3
+            entry = {"params": params_text(leg_c3, extra_cfg)} if mode == "gz_c3" else {}
             for name, exe in (("ours", OURS), ("reference", REF)):
-                if not os.path.exists(exe):
+                if not os.path.exists(exe) or (mode == "plain_ours" and name == "reference"):
                     continue
                 o = os.path.join(tmp, f"{name}_{mode}")
-                w, r = run(exe, inputs, o, ext, T, c3=c3, extra_cfg=extra_cfg)
+                w, r = run(exe, inputs, o, ext, T, c3=leg_c3, extra_cfg=extra_cfg)
                 entry[name] = {"wall_s": round(w, 2), "Mreads_per_s": round(2 * n / w / 1e6, 3), "rc": r.returncode}
                 if r.returncode != 0:
                     entry[name]["stderr"] = r.stderr[-300:].decode(errors="replace")
