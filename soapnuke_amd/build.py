@@ -25,13 +25,46 @@ def needs_build():
     return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, f) for f in SOURCES] + _headers())
 
 
-def build(force=False, verbose=False):
+OBJ = os.path.join(CSRC, "build")            # objects + the tiled kernel's gfx950 assembly (git-ignored, not shipped to the GPU box)
+TILED_ASM = os.path.join(OBJ, "snk_tiled-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def build(force=False, verbose=False, lint=True):
+    """every source to its own object (in parallel), one link; the tiled kernel's device assembly is kept (-save-temps) and
+    checked by tools/isa_lint.py: no use of an LDS row register ahead of the s_waitcnt that covers it"""
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + ["-o", LIB] + SOURCES + ["-ldl"]
+    import concurrent.futures as cf
+    os.makedirs(OBJ, exist_ok=True)
+    flags = [f for f in FLAGS if f != "-shared"]
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, src.replace(".", "_") + ".o")
+        cmd = [HIPCC] + flags + ["-c", os.path.join("..", src), "-o", obj] + (["-save-temps=obj"] if src == "snk_tiled.hip" else [])
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, cwd=OBJ, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{src}:\n{r.stdout[-4000:]}")
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    subprocess.check_call(cmd, cwd=OBJ)
+    if lint and os.path.exists(TILED_ASM):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(HERE, "..", "tools", "isa_lint.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        funcs, report = mod.lint_file(TILED_ASM)
+        if verbose:
+            print(f"isa_lint: {funcs} snk_tiled_kernel instances, {len(report)} finding(s)")
+        if funcs == 0 or report:
+            os.unlink(LIB)
+            raise RuntimeError("tools/isa_lint.py: " + ("no kernel found in " + TILED_ASM if funcs == 0 else "\n".join(report[:20])))
     return LIB
 
 

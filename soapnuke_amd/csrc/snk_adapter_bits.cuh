@@ -8,6 +8,9 @@
 #ifndef SNK_ABL
 #define SNK_ABL 0
 #endif
+#ifndef SNK_SCREEN_BIN
+#define SNK_SCREEN_BIN 1     // 0: unary counter planes for every budget (A/B builds)
+#endif
 
 namespace snk {
 namespace {
@@ -123,7 +126,9 @@ __device__ __forceinline__ void shr_plane(u32 (&R)[NW], int st) {
     for (int j = 0; j < NW; ++j) R[j] = __builtin_amdgcn_alignbit(T[j + 1], T[j], r);
 }
 
-// one screening step: x = ~(plane >> c) (ones shifted in), C_k |= C_{k-1} & x  (NC unary counter planes)
+// one screening step: x = ~(plane >> c) (ones shifted in), C_k |= C_{k-1} & x  (NC unary counter planes).
+// NC == 3 (budgets up to 2, the default adaMis): the count 0..3 is kept as a saturating BINARY counter in C[0] (low bit) and C[1]
+// -- two 3-input operations per word and step instead of three; screen_planes() turns it back into the thermometer
 template <int NW, int CQ, int NC>
 __device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C)[NC][NW]) {
 #pragma unroll
@@ -131,9 +136,15 @@ __device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C
         const u32 lo = (j + CQ < NW) ? Pl[(j + CQ < NW) ? j + CQ : 0] : 0xFFFFFFFFu;
         const u32 hi = (j + CQ + 1 < NW) ? Pl[(j + CQ + 1 < NW) ? j + CQ + 1 : 0] : 0xFFFFFFFFu;
         const u32 x = ~__builtin_amdgcn_alignbit(hi, lo, cr);
+        if constexpr (NC == 3 && SNK_SCREEN_BIN) {
+            const u32 c0 = C[0][j], c1 = C[1][j];
+            C[0][j] = (c0 ^ x) | (c1 & c0);          // 00 -> 01 -> 10 -> 11 -> 11
+            C[1][j] = c1 | (c0 & x);
+        } else {
 #pragma unroll
-        for (int k = NC - 1; k >= 1; --k) C[k][j] |= C[k - 1][j] & x;
-        C[0][j] |= x;
+            for (int k = NC - 1; k >= 1; --k) C[k][j] |= C[k - 1][j] & x;
+            C[0][j] |= x;
+        }
     }
 }
 
@@ -187,6 +198,12 @@ __device__ __forceinline__ void screen_planes(const AD &A, const u32 (&NX)[4][NW
     const int rk1 = A.rk[1], rk2 = A.rk[2], rk3 = A.rk[3], rk4 = A.rk[0];     // (rk[0]: budgets >= 4, nC when there is none)
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
+        if constexpr (NC == 3 && SNK_SCREEN_BIN) {             // binary counter -> "at least 1 / 2 / 3 mismatches"
+            const u32 c0 = C[0][j], c1 = C[1][j];
+            C[0][j] = c0 | c1;
+            C[1][j] = c1;
+            C[2][j] = c0 & c1;
+        }
         const u32 valid = lowmask32(len - edge + 1 - 32 * j);
         const u32 bm = lowmask32(len - al + 1 - 32 * j);                    // phase B region
         const u32 t1 = lowmask32(len - edge - rk1 + 1 - 32 * j) & (mis >= 1 ? 0xFFFFFFFFu : ~bm);

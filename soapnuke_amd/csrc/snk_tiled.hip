@@ -167,6 +167,39 @@ __device__ __forceinline__ u32 wave_or(u32 x) {
     return (u32)rl(v, 63);
 }
 
+// A mate's ReadState between its phase 2 and the pair level, four registers instead of fourteen (the first mate's state has to
+// survive the second mate's phases 1 and 2; kept whole it was spilled at the top of every mate iteration: 26 scratch stores per
+// lane and tile-mate, 2.1 GB of scratch writes per 10 M pairs in the FULL variant).  Every count is at most the tile kernel's 256
+// positions (9 bits); inc_ada <=> adacut >= 0; hd_h / hd_t are parameters (trim_finish) and are not stored.
+struct PackedRS { u64 a; u32 lq; int sumq; };
+__device__ __forceinline__ PackedRS rs_pack(const ReadState &r) {
+    PackedRS p;
+    const u32 lo = (u32)r.len | ((u32)r.n_a << 9) | ((u32)r.n_n << 18) | ((u32)r.lowq << 27);                  // lowq: low 5 bits here
+    const u32 hi = ((u32)r.lowq >> 5) | ((u32)r.clen << 4) | ((u32)r.start << 13) | ((u32)(r.adacut + 1) << 22) | ((u32)r.polyx << 31);
+    p.a = ((u64)hi << 32) | lo;
+    p.lq = ((u32)r.lq_h << 16) | ((u32)r.lq_t & 0xFFFFu);
+    p.sumq = r.sumq;
+    return p;
+}
+__device__ __forceinline__ void rs_unpack(const DevParams &P, int mate, const PackedRS &p, ReadState &r) {
+    const u32 lo = (u32)p.a, hi = (u32)(p.a >> 32);
+    r.len = (int)(lo & 511u);
+    r.n_a = (int)((lo >> 9) & 511u);
+    r.n_n = (int)((lo >> 18) & 511u);
+    r.lowq = (int)((lo >> 27) | ((hi & 15u) << 5));
+    r.clen = (int)((hi >> 4) & 511u);
+    r.start = (int)((hi >> 13) & 511u);
+    r.adacut = (int)((hi >> 22) & 511u) - 1;
+    r.polyx = (int)(hi >> 31);
+    r.inc_ada = r.adacut >= 0 ? 1 : 0;
+    r.lq_h = (int)(short)(p.lq >> 16);
+    r.lq_t = (int)(short)(p.lq & 0xFFFFu);
+    r.sumq = p.sumq;
+    const bool hard = P.trim_on && P.has_hard;                         // trim_finish(), snk_common.cuh
+    r.hd_h = hard ? P.hard[P.paired ? 2 * mate : 0] : -1;
+    r.hd_t = hard ? P.hard[P.paired ? 2 * mate + 1 : 1] : -1;
+}
+
 struct TileGeom {
     int lcap, nq, Lh, lg, WB, WQ, SET;   // Lh = 1 << lg dwords per histogram bin row
     int pairq;                           // 129..160 positions, staged path: the raw quality rows' slots of positions 160..191 count positions 128..159 too (PAIR, phase 1)
@@ -206,9 +239,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
     const u64 gidx = B.first_index + (u64)(t0 + lane);
     const int lgb = G.lg + 2;                         // log2(bytes per histogram bin row)
 
-    ReadState r0, r1;
-    rs_init(r0, 0);
-    rs_init(r1, 0);
+    PackedRS p0 = {0ull, 0u, 0}, p1 = {0ull, 0u, 0};
     int e0 = 0, e1 = 0;
     const bool oobH = (0 - phred) < P.lq_head_q, oobT = (0 - phred) < P.lq_tail_q;
 
@@ -471,7 +502,14 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     row += (u32)pitch;                      // (row 1 is in chunk 0: rb >= 2)
                     lds_rd(std::true_type{}, C4[1], Q4[1], QS[1], row);
                 }
-                lds_wait<PAIR ? ROWO : ROWOPS>(C4[0], Q4[0], QS[0]);
+                // The rows are written by the LDS unit BEHIND the compiler's back: to it an asm read's outputs are defined the moment
+                // the read is issued.  Whatever it does with such a register before the s_waitcnt that covers it -- a copy on a loop
+                // edge (phi), a spill -- moves stale bits (seen once: read 1 of a tile, whose row was still in flight at the loop
+                // entry, in one build of the FULL variant).  So nothing is in flight on a loop edge: both rows have landed before
+                // the loop is entered, and the last read of an octet waits for both rows fetched ahead (only its adds stay out).
+                // tools/isa_lint.py checks the generated code for any use of a row register ahead of its wait.
+                lds_wait<0>(C4[0], Q4[0], QS[0]);
+                lds_wait<0>(C4[1], Q4[1], QS[1]);
                 for (int o = 0; o < nocts; ++o) {           // reads 8o .. 8o+7
                     // which reads of this octet are the last of a chunk (rb is a power of two): one bit test per read
                     const u32 evm = rb == 2 ? 0xAAu : rb == 4 ? 0x88u : ((((8 * (o + 1)) & rbm) == 0) ? 0x80u : 0u);
@@ -490,7 +528,12 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                                 constexpr int par = (R2 / RBs) & 1, rowi = R2 % RBs;
                                 lds_rd_s(IntC<par * 2 * (SS ? SH::CBA : 0) + rowi * (SS ? SH::PITCH : 0)>{}, C4[(j + 2) & 3], Q4[(j + 2) & 3], QS[(j + 2) & 3]);
                                 do_read(FL, IntC<j>{}, std::false_type{}, r, C4[j & 3], Q4[j & 3], QS[j & 3], 0u);
-                                lds_wait<K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
+                                if constexpr (j == 7) {
+                                    lds_wait<K - ROWOPS>(C4[0], Q4[0], QS[0]);       // loop edge: rows of reads r+1 and r+2 both in
+                                    lds_wait<K - ROWOPS>(C4[1], Q4[1], QS[1]);
+                                } else {
+                                    lds_wait<K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
+                                }
                                 if constexpr (closes) {
                                     if (k + 2 < nchunks) issue(k + 2);                 // every row of chunk k sits in registers now
                                 }
@@ -507,7 +550,12 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                             lds_rd(std::integral_constant<bool, (j & 1) != 0>{}, C4[(j + 2) & 3], Q4[(j + 2) & 3], QS[(j + 2) & 3], row);
                             do_read(FL, IntC<j>{}, std::integral_constant<bool, PAIR>{}, r, C4[j & 3], Q4[j & 3], QS[j & 3], QS[j & 2][NS - 1]);
                             // behind the row of read r+1: the row of read r+2 and the adds of read r (same parity)
-                            lds_wait<PAIR ? ((j & 1) ? ROWO + ADDO : ROWE + ADDE) : K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
+                            if constexpr (j == 7) {          // loop edge: rows of reads r+1 and r+2 both in (see above)
+                                lds_wait<PAIR ? ADDO : K - ROWOPS>(C4[0], Q4[0], QS[0]);
+                                lds_wait<PAIR ? ADDO : K - ROWOPS>(C4[1], Q4[1], QS[1]);
+                            } else {
+                                lds_wait<PAIR ? ((j & 1) ? ROWO + ADDO : ROWE + ADDE) : K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
+                            }
                             if (closes && k + 2 < nchunks) issue(k + 2);     // every row of chunk k sits in registers now
                             }
                         } else skip_read(IntC<j>{}, r);
@@ -867,14 +915,13 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         }
         if (ada_pos >= 0) { R.inc_ada = 1; R.adacut = R.len - ada_pos; }
         if (SNK_ABL != 10 && P.trim_on) trim_finish(P, m, R, hix, tix, polyg);
-        if (m == 0) { r0 = R; e0 = estat; }
-        else { r1 = R; e1 = estat; }
+        if (m == 0) { p0 = rs_pack(R); e0 = estat; }
+        else { p1 = rs_pack(R); e1 = estat; }
     }
 
     if ((SNK_ABL == 1 || SNK_ABL >= 11)) return;
     if (SNK_ABL == 2) {
-        asm volatile("" ::"v"(r0.clen), "v"(r0.start), "v"(r0.n_a), "v"(r0.n_n), "v"(r0.lowq), "v"(r0.adacut), "v"(r0.inc_ada));
-        asm volatile("" ::"v"(r1.clen), "v"(r1.start), "v"(r1.n_a), "v"(r1.n_n), "v"(r1.lowq), "v"(r1.adacut), "v"(r1.inc_ada));
+        asm volatile("" ::"v"(p0.a), "v"(p0.lq), "v"(p0.sumq), "v"(p1.a), "v"(p1.lq), "v"(p1.sumq));
         return;
     }
     // ---------------------------------------------------------------- pair level
@@ -885,6 +932,9 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
     const bool live = lanev && !(e0 || (pe && e1));
     int v = 0, reason = SNK_KEEP;
     if (live) {
+        ReadState r0, r1;
+        rs_unpack(P, 0, p0, r0);
+        rs_unpack(P, 1, p1, r1);
         const int dup = B.dup ? (int)B.dup[t0 + lane] : 0;
         const int cfv = B.cf ? (int)B.cf[t0 + lane] : 0;      // contaminant verdicts (snk_contam_kernel), rare configuration
         reason = pe ? discard_reason(P, r0, r1, dup, v, cfv & 3, (cfv >> 2) & 3) : discard_reason(P, r0, r0, dup, v, cfv & 3, cfv & 3);
@@ -919,7 +969,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
 #pragma unroll 1
     for (int m = 0; m < mates; ++m) {
         asm volatile("" : "+v"(lane));
-        const ReadState R = m ? r1 : r0;
+        ReadState R;
+        rs_unpack(P, m, m ? p1 : p0, R);
         u64 *fraw = st.sum + SNK_FS_N + m * fb, *fcl = st.sum + SNK_FS_N + (2 + m) * fb;
         // trimming-position counters: a few dozen hot addresses -> the workgroup's private uint32 copy
         // (chip-wide atomics on them cost 4 ms per 10 M pairs with trimBadTail on); drained at the end
