@@ -45,6 +45,17 @@ __device__ inline bool accept_exact(u64 m, int n, int S, int budget) {
     return r != 0;
 }
 
+// The same outcome for ONE alignment walked character by character (adapters of more than 64 characters, whose survivors of the
+// screen do not fit the 64 match bits of accept_exact): adapter[a0 + c] against read[p + c], c = 0 .. n-1; outside the read: '\0'.
+__device__ inline bool accept_seq(const uint8_t *ada, int a0, const uint8_t *s, int len, int p, int n, int S, int budget) {
+    int mis = 0, run = 0;
+    for (int c = 0; c < n; ++c) {
+        if ((int)ada[a0 + c] == rdc(s, len, p + c)) { if (++run >= S) return true; }
+        else { ++mis; run = 0; if (mis > budget) break; }
+    }
+    return mis <= budget;
+}
+
 template <int NW>
 __device__ __forceinline__ int lowest_bit(const u32 (&w)[NW]) {
     int p = -1;
@@ -162,7 +173,7 @@ __device__ __forceinline__ void screen_planes(const AD &A, const u32 (&NX)[4][NW
         for (int k = 0; k < NC; ++k) C[k][j] = 0;
         BY[j] = ~lowmask32(len - 32 * j);                 // a character that matches nothing inside the read
     }
-    const int steps = min(S - 1, al);
+    const int steps = min(min(S - 1, al), 64);       // (the masks hold the adapter's first 64 characters: fewer cells is still a necessary condition)
     // The counters only count, so the order of the steps is free: one loop per plane over the adapter
     // positions holding that letter (a switch on the letter inside one loop over the positions costs
     // three times the instructions: register copies at every join of its arms)
@@ -204,23 +215,19 @@ __device__ __forceinline__ void screen_planes(const AD &A, const u32 (&NX)[4][NW
             C[1][j] = c1;
             C[2][j] = c0 & c1;
         }
-        const u32 valid = lowmask32(len - edge + 1 - 32 * j);
+        // candidates: phase B offsets 0 .. len - al (budget adaMis), phase C offsets len - al + 1 .. len - edge (budget of
+        // r1 = len - edge - p: at least k for r1 >= rk_k); adaEdge may exceed the adapter (then there is no phase C at all)
         const u32 bm = lowmask32(len - al + 1 - 32 * j);                    // phase B region
-        const u32 t1 = lowmask32(len - edge - rk1 + 1 - 32 * j) & (mis >= 1 ? 0xFFFFFFFFu : ~bm);
+        const u32 valid = bm | lowmask32(len - edge + 1 - 32 * j);
+        auto thermo = [&](const int rk, const int k) { return (mis >= k ? bm : 0u) | (~bm & lowmask32(len - edge - rk + 1 - 32 * j)); };
+        const u32 t1 = thermo(rk1, 1);
         u32 rej = C[0][j] & ~t1;
-        if (NC >= 3) {
-            const u32 t2 = lowmask32(len - edge - rk2 + 1 - 32 * j) & (mis >= 2 ? 0xFFFFFFFFu : ~bm);
-            rej |= C[1][j] & ~t2;
-        }
-        if (NC >= 4) {
-            const u32 t3 = lowmask32(len - edge - rk3 + 1 - 32 * j) & (mis >= 3 ? 0xFFFFFFFFu : ~bm);
-            rej |= C[NC >= 4 ? 2 : 0][j] & ~t3;
-        }
+        if (NC >= 3) rej |= C[1][j] & ~thermo(rk2, 2);
+        if (NC >= 4) rej |= C[NC >= 4 ? 2 : 0][j] & ~thermo(rk3, 3);
         if (NC >= 4) {
             // four or more mismatches: out, except where the budget itself is 4 or more -- the counters stop at four, those
             // offsets all go to the exact decision
-            const u32 t4 = lowmask32(len - edge - rk4 + 1 - 32 * j) & (mis >= 4 ? 0xFFFFFFFFu : ~bm);
-            rej |= C[NC >= 4 ? 3 : 0][j] & ~t4;
+            rej |= C[NC >= 4 ? 3 : 0][j] & ~thermo(rk4, 4);
         } else {
             rej |= C[NC - 1][j];                                             // more mismatches than any budget of this adapter
         }
@@ -258,7 +265,7 @@ __device__ int adapter_tile(const AD &A, const DevAdapter &AG, const u32 (&X)[4]
             const int n = al - r1, budget = A.budgetA[r1];
             const u64 m = ((x0 & (cm0 >> r1)) | (x1 & (cm1 >> r1)) | (x2 & (cm2 >> r1)) | (x3 & (cm3 >> r1)) |
                            (xn & (cmn >> r1)));
-            const u64 zz = ~m & lowmask64(min(n, S - 1));
+            const u64 zz = ~m & lowmask64(min(min(n, S - 1), 64 - r1));       // (the shifted masks hold 64 - r1 cells)
             if (__popcll(zz) <= max(budget, 0)) pa |= 1u << r1;
         }
         if (done || !doA) pa = 0;
@@ -307,7 +314,7 @@ __device__ int adapter_tile(const AD &A, const DevAdapter &AG, const u32 (&X)[4]
                 clear_bit(aliveC, p);
                 n = len - p;                                         // compared length, edge <= n < al
                 res = p;
-                if (n < S && A.maxb <= 3) { skip_eval = true; skip_ok = !A.negC; }  // no run possible: survived <=> mis <= budget (exact counters)
+                if (n < S && n <= 64 && A.maxb <= 3) { skip_eval = true; skip_ok = !A.negC; }  // no run possible and every cell screened: survived <=> mis <= budget (exact counters)
                 else budget = AG.budgetC[n - edge];
             } else {
                 have = false;
@@ -315,10 +322,16 @@ __device__ int adapter_tile(const AD &A, const DevAdapter &AG, const u32 (&X)[4]
             if (have) {
                 bool ok = skip_ok;
                 if (!skip_eval) {
-                    u64 m = (window64(X[0], p, ~0u) & (cm0 >> sh)) | (window64(X[1], p, ~0u) & (cm1 >> sh)) |
-                            (window64(X[2], p, ~0u) & (cm2 >> sh)) | (window64(X[3], p, ~0u) & (cm3 >> sh));
-                    if (FULL) m |= window64(XN, p, ~0u) & (cmn >> sh);
-                    ok = accept_exact(m, n, S, budget);
+                    if (al > 64) {
+                        // more cells than the 64 match bits hold: this one alignment character by character (adapter cell sh + c
+                        // against read[p + c]; phase A: sh = r1 at p = 0)
+                        ok = accept_seq(AG.seq, sh, sptr, len, p, n, S, budget);
+                    } else {
+                        u64 m = (window64(X[0], p, ~0u) & (cm0 >> sh)) | (window64(X[1], p, ~0u) & (cm1 >> sh)) |
+                                (window64(X[2], p, ~0u) & (cm2 >> sh)) | (window64(X[3], p, ~0u) & (cm3 >> sh));
+                        if (FULL) m |= window64(XN, p, ~0u) & (cmn >> sh);
+                        ok = accept_exact(m, n, S, budget);
+                    }
                 }
                 if (ok) { result = res; done = true; }
             }

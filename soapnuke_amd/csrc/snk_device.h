@@ -30,7 +30,7 @@ struct DevAdapter {
     uint64_t nmask;         // bit c = adapter[c] == 'N' (matches a read 'N' exactly)
     int32_t  has_lower;     // lower-case characters: they match lower-case read characters only (src/read_filter.cpp:728 compares bytes), which the
                             // letter planes do not hold -- a read with anything but upper-case ACGT takes the sequential matcher for this adapter
-    int32_t  pad_;
+    int32_t  long_ok;       // ... and the block-wise search of the long-read kernel (6..64 characters, adaEdge <= length)
 };
 
 // One hasContam() contaminant (src/read_filter.cpp:507-603): the per-r1 thresholds of its head and
@@ -95,6 +95,7 @@ struct DevParams {
     int32_t n_ada[2];
     int32_t ada_stride;                // adapters of mate m: ada[m * ada_stride + i], tile_ada likewise
     int32_t tile_ok;                   // every adapter can run in the wave-tiled kernel
+    int32_t long_ok;                   // ... and in the long-read kernel (snk_long.hip)
     int32_t need_n;                    // some adapter contains 'N' (needs the N plane)
     // per-length integer thresholds replacing the fp32 ratio compares:
     //   discard iff count >= thr_x[len]            (n_ratio, highA, low-quality ratio)

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "snk_device.h"
+#include "snk_tables.h"
 #include "../../include/snk_rmdup.h"
 #include "../../include/snk_selftest.h"
 
@@ -32,13 +33,6 @@ void set_err(const std::string &s) { g_err = s; }
             return SNK_E_HIP;                                                          \
         }                                                                              \
     } while (0)
-
-// float -> int as the x86-64 reference build does it (cvttss2si): NaN/overflow -> INT_MIN
-int f2i_x86(float f) {
-    if (!(f == f)) return INT_MIN;
-    if (f >= 2147483648.0f || f < -2147483648.0f) return INT_MIN;
-    return (int)f;
-}
 
 // min count c in [0,len] with float(c)/size_t(len) >= ratio  (src/read_filter.cpp:290-295,310
 // feeding src/sequence.cpp:292,306,333); INT_MAX when no count trips it.
@@ -215,48 +209,6 @@ std::string build_contams(const snk_params &P, std::vector<DevContam> &ct, int n
     return "";
 }
 
-void build_adapter(DevAdapter &A, const char *seq, int mis, float mr, int edge) {
-    memset(&A, 0, sizeof(A));
-    const int al = (int)strlen(seq);
-    A.len = al;
-    A.mis = mis;
-    A.edge = edge;
-    A.nC = al - edge;
-    memcpy(A.seq, seq, al);
-    // src/read_filter.cpp:714-717 : integer division, then float
-    const float misGrad5 = (float)((al - 5) / (mis + 1));
-    const float misGrad = (float)((al - edge) / (mis + 1));
-    A.S = (int)ceilf((float)al * mr);
-    int maxb = mis > 0 ? mis : 0;
-    for (int r1 = 1; r1 <= 5; ++r1) {
-        A.budgetA[r1] = f2i_x86((float)(al - r1) / misGrad5);
-        if (A.budgetA[r1] > maxb) maxb = A.budgetA[r1];
-    }
-    for (int r1 = 0; r1 < A.nC && r1 < SNK_DEV_MAX_ADA_LEN; ++r1) {
-        A.budgetC[r1] = f2i_x86((float)r1 / misGrad);
-        if (A.budgetC[r1] > maxb) maxb = A.budgetC[r1];
-    }
-    A.maxBudget = maxb;
-    A.negC = (misGrad == 0.0f) ? 1 : 0;
-    for (int k = 1; k <= 4; ++k) {                        // rk[0] holds k = 4
-        A.rk[k & 3] = A.nC > 0 ? A.nC : 0;
-        for (int r1 = 0; r1 < A.nC && r1 < SNK_DEV_MAX_ADA_LEN; ++r1)
-            if (A.budgetC[r1] >= k) { A.rk[k & 3] = r1; break; }
-    }
-    // bit-parallel view for the tiled kernel: code 0..3 = ACGT, 4 = matches no upper-case ACGT read base,
-    // 5 = 'N'.  A lower-case adapter character (code 4) can only match a lower-case read character: reads that
-    // hold anything but upper-case ACGT take the sequential matcher for such an adapter (has_lower).
-    A.tile_ok = (al >= 6 && al <= 64 && edge >= 1 && edge <= al && mis >= 0) ? 1 : 0;      // (any budget: beyond 3 the screen lets the offset through)
-    for (int c = 0; c < al; ++c) {
-        int k = 4;
-        switch (seq[c]) { case 'A': k = 0; break; case 'C': k = 1; break; case 'G': k = 2; break; case 'T': k = 3; break; case 'N': k = 5; break; default: break; }
-        A.code[c] = (uint8_t)k;
-        if (k < 4 && c < 64) A.cmask[k] |= 1ull << c;
-        if (k == 5 && c < 64) A.nmask |= 1ull << c;
-        if (seq[c] == 'a' || seq[c] == 'c' || seq[c] == 'g' || seq[c] == 't' || seq[c] == 'n') A.has_lower = 1;
-    }
-}
-
 }  // namespace
 
 void snk_set_error(const char *msg) { g_err = msg ? msg : ""; }      // snk_fastq.hip
@@ -412,6 +364,7 @@ static int build_ctx(snk_ctx *c) {
     D.n_ada[1] = P.n_adapters[1];
     D.ada_stride = stride;
     D.tile_ok = 1;
+    D.long_ok = 1;
     D.need_n = 0;
     D.n_ct[0] = n_ct[0]; D.n_ct[1] = n_ct[1]; D.n_gct = n_gct;
     D.contam_discard = P.contam_trim ? 0 : 1;        // gp.contam_discard_or_trim == "discard"
@@ -424,18 +377,11 @@ static int build_ctx(snk_ctx *c) {
         for (int i = 0; i < P.n_adapters[m]; ++i) {
             const DevAdapter &A = ada[(size_t)m * stride + i];
             if (!A.tile_ok) D.tile_ok = 0;
+            if (!A.long_ok) D.long_ok = 0;
             if (A.nmask) D.need_n = 1;
             {
                 TileAdapter &T = tile_ada[(size_t)m * stride + i];
-                T.has_lower = A.has_lower;
-                for (int k = 0; k < 4; ++k) T.cmask[k] = A.cmask[k];
-                T.nmask = A.nmask;
-                for (int ci = 0; ci < 64 && ci < A.len; ++ci) T.code4[ci >> 4] |= (uint64_t)(A.code[ci] & 15) << (4 * (ci & 15));
-                T.len = A.len; T.S = A.S; T.mis = A.mis; T.edge = A.edge; T.negC = A.negC;
-                T.maxb = A.mis > 0 ? A.mis : 0;
-                for (int r1 = 0; r1 < A.nC && r1 < SNK_DEV_MAX_ADA_LEN; ++r1) if (A.budgetC[r1] > T.maxb) T.maxb = A.budgetC[r1];
-                for (int k = 0; k < 6; ++k) T.budgetA[k] = A.budgetA[k];
-                for (int k = 0; k < 4; ++k) T.rk[k] = A.rk[k];
+                fill_tile_adapter(T, A);
                 if (i < SNK_TILE_MAX_ADA) c->ta.a[m][i] = T;
             }
         }
@@ -676,7 +622,7 @@ int snk_filter_batch_device(snk_ctx *c, const snk_batch *b, snk_read_result *d_o
         done = snk_launch_tiled(c->hp, c->ta, D, st, c->lcap, c->nq, c->n_cu, stream);
         D.cf = nullptr;
         // reads of 257..1024 positions: the block-wise bit-sliced path (snk_long.hip); it writes the stats block directly
-        if (!done && c->hp.tile_ok && c->lcap > 256 && c->lcap <= 1024 && b->n > 0) {
+        if (!done && c->hp.tile_ok && c->hp.long_ok && c->lcap > 256 && c->lcap <= 1024 && b->n > 0) {
             // (the plane store of the batch: scratch of this stream slot, grown on demand and kept)
             const size_t need = snk_long_scratch_bytes((long)b->n, c->p.paired ? 1 : 0, c->lcap);
             if (need > c->pl_cap[slot]) {
