@@ -208,7 +208,25 @@ def other_workloads():
         ("fallback (kernel=1: generic decisions + LDS histograms), PE150, 2 M pairs", 150, 2_000_000, 1, c2, False),
     ]
     out = []
-    for name, L, n, kern, kw, var_len in rows:
+    for row in rows:
+        try:
+            out.append(_workload_row(*row))
+        except Exception as ex:          # one row must not take the others down
+            out.append({"workload": row[0], "error": repr(ex)[:200]})
+        import torch
+        torch.cuda.empty_cache()
+    try:
+        out += rmdup_kernels()
+    except Exception as ex:
+        out.append({"workload": "rmdup kernels", "error": repr(ex)[:200]})
+    return out
+
+
+def _workload_row(name, L, n, kern, kw, var_len):
+    import torch
+    from soapnuke_amd import abi, synth
+    from soapnuke_amd.filter import FilterContext
+    if True:
         uniq = 500_000 if L <= 150 else 100_000
         d = synth.make_batch(uniq, L, paired=True, var_len=var_len)
         ctx = FilterContext(abi.default_params(paired=True, max_read_len=L, **kw), device=0)
@@ -233,17 +251,12 @@ def other_workloads():
         nbytes = 2 * dev["n"] * (2 * L + 16)
         if var_len:      # SURVEY 8(d)'s per-read figure on the real lengths
             nbytes = reps * int(sum(2 * int(x.astype(np.int64).sum()) + 16 * len(x) for x in d["len"]))
-        out.append({"workload": name, "ms": round(ms, 3), "Mreads_per_s": round(2 * dev["n"] / ms / 1e3, 1),
-                    "algorithmic_GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                    "error": int(err[0])})
+        res = {"workload": name, "ms": round(ms, 3), "Mreads_per_s": round(2 * dev["n"] / ms / 1e3, 1),
+               "algorithmic_GBps": round(nbytes / ms / 1e6, 1), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+               "error": int(err[0])}
         ctx.close()
         del dev, rec
-        torch.cuda.empty_cache()
-    try:
-        out += rmdup_kernels()
-    except Exception as ex:
-        out.append({"workload": "rmdup kernels", "error": repr(ex)[:200]})
-    return out
+        return res
 
 
 def main():

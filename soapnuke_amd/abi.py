@@ -188,6 +188,8 @@ EXPORTS = [
     # include/snk_fastq.h
     "snk_fastq_tmp_bytes", "snk_fastq_parse_device", "snk_fastq_format_device",
     "snk_fastq_deflate_tmp_bytes", "snk_fastq_deflate_device",
+    # include/snk_gunzip.h
+    "snk_gunzip_create", "snk_gunzip_destroy", "snk_gunzip_decode", "snk_gunzip_resolve",
 ]
 
 

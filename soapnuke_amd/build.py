@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsnk_filter.so")
-SOURCES = ["snk_filter.cpp", "snk_generic.hip", "snk_tiled.hip", "snk_rmdup.hip", "snk_contam.hip", "snk_long.hip", "snk_fastq.hip", "snk_gzip.hip"]
+SOURCES = ["snk_filter.cpp", "snk_generic.hip", "snk_tiled.hip", "snk_rmdup.hip", "snk_contam.hip", "snk_long.hip", "snk_fastq.hip", "snk_gzip.hip", "snk_inflate.hip"]
 def _headers():
     """every header a kernel source can include: csrc/*.cuh|*.h and include/*.h (a missing entry once let a stale
     library survive a plane-store layout change)"""

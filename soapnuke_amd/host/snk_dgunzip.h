@@ -1,0 +1,240 @@
+// snk_dgunzip.h -- one gzip stream decoded by the GPU (include/snk_gunzip.h), window by window, for the FASTQ readers.
+//
+// Same streaming interface as ParallelGunzip (snk_pgunzip.h: run(out, cap) / done() / error()), other engine: the host only cuts
+// the compressed file into windows, checks that the chunks of a window CHAIN (every chunk ends exactly where the next one starts;
+// block starts the chain steps over are false positives), verifies CRC-32 and ISIZE of every member on the resolved text, and
+// falls back to the sequential host decoder (snk_inflate.h) from the last good block on for whatever the device path refuses --
+// a chunk that overflowed its symbol slots, invalid data, a window without a single complete chunk.  The bytes are always
+// zlib's bytes or an error.  The device calls sit behind DgBackend so that tests/host_emul/ can run this very class on the CPU
+// with the same chunk decoder (csrc/snk_inflate_core.cuh) -- tests/test_inflate_emul.py.
+// Reference: the gzgets() reading loop, src/peprocess.cpp:2063-2113.
+#ifndef SNK_DGUNZIP_H
+#define SNK_DGUNZIP_H
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <thread>
+#include <vector>
+#include <zlib.h>
+
+#include "../../include/snk_gunzip.h"
+#include "snk_inflate.h"
+
+namespace snk {
+
+struct DgBackend {
+    virtual ~DgBackend() {}
+    virtual bool decode(const uint8_t *comp, uint64_t nbytes, uint64_t first_bit, bool first_of_member, snk_gunzip_chunk *chunks, snk_gunzip_member *ends) = 0;
+    virtual bool resolve(const uint32_t *order, uint32_t k, const uint8_t *win_in, uint8_t *text, uint64_t text_bytes, uint8_t *win_out) = 0;
+    virtual uint8_t *text_buffer(size_t bytes) = 0;       // at least `bytes` (pinned memory on the device backend, grown on demand); owned by the backend
+    virtual std::string error() = 0;
+};
+
+class DeviceGunzip {
+public:
+    enum { HIST = 32768 };
+    struct Geometry { uint64_t window_bytes; uint32_t chunk_bytes, syms_per_chunk, ends_per_chunk; };
+    DeviceGunzip(const uint8_t *in, size_t n, DgBackend *be, const Geometry &g, int crc_threads)
+        : in_(in), n_(n), be_(be), g_(g), crc_threads_(crc_threads < 1 ? 1 : crc_threads) {
+        win_.assign(HIST, 0);
+        const uint32_t maxc = (uint32_t)((g_.window_bytes + g_.chunk_bytes - 1) / g_.chunk_bytes);
+        chunks_.resize(maxc);
+        ends_.resize((size_t)maxc * g_.ends_per_chunk);
+        // the first member's header (the later ones are followed on the device)
+        if (!member_header_at(0, pos_bit_)) { seq_from_start(); return; }
+        first_of_member_ = true;
+    }
+    const char *error() const { return err_.empty() ? nullptr : err_.c_str(); }
+    bool done() const { return done_; }
+    uint64_t windows() const { return windows_; }
+    uint64_t fallback_bit() const { return fallback_bit_; }            // ~0: the device decoded everything
+
+    size_t run(uint8_t *out, size_t cap) {
+        size_t got = 0;
+        while (got < cap && !done_ && err_.empty()) {
+            if (seq_) { got += seq_run(out + got, cap - got); continue; }
+            if (t_off_ == t_have_ && !next_window()) continue;
+            const size_t k = std::min(cap - got, (size_t)(t_have_ - t_off_));
+            memcpy(out + got, text_ + t_off_, k);
+            got += k;
+            t_off_ += k;
+        }
+        return got;
+    }
+
+private:
+    const uint8_t *in_;
+    size_t n_;
+    DgBackend *be_;
+    Geometry g_;
+    int crc_threads_;
+    std::vector<uint8_t> win_;
+    std::vector<snk_gunzip_chunk> chunks_;
+    std::vector<snk_gunzip_member> ends_;
+    std::vector<uint32_t> order_;
+    uint8_t *text_ = nullptr;
+    uint64_t t_have_ = 0, t_off_ = 0;
+    uint64_t pos_bit_ = 0;                     // the next block header of the stream
+    bool first_of_member_ = false, stream_done_ = false;
+    bool done_ = false, seq_ = false;
+    std::string err_;
+    uint32_t mcrc_ = 0;                        // CRC-32 / length of the current member so far
+    uint64_t mlen_ = 0;
+    bool member_checkable_ = true;
+    uint64_t windows_ = 0, fallback_bit_ = ~0ull;
+    // sequential fallback
+    GzipInflate sq_;
+    std::vector<uint8_t> sbuf_;
+    size_t s_have_ = 0, s_off_ = 0;
+
+    void fail(const std::string &m) { if (err_.empty()) err_ = m; }
+
+    // gzip member header at byte p (RFC 1952): the bit offset of its first deflate block
+    bool member_header_at(uint64_t p, uint64_t &first_bit) const {
+        if (p + 18 > n_ || in_[p] != 0x1F || in_[p + 1] != 0x8B || in_[p + 2] != 8) return false;
+        const unsigned flg = in_[p + 3];
+        if (flg & 0xE0) return false;
+        p += 10;
+        if (flg & 4) { if (p + 2 > n_) return false; p += 2 + ((unsigned)in_[p] | ((unsigned)in_[p + 1] << 8)); }
+        if (flg & 8) { while (p < n_ && in_[p]) ++p; ++p; }
+        if (flg & 16) { while (p < n_ && in_[p]) ++p; ++p; }
+        if (flg & 2) p += 2;
+        if (p >= n_) return false;
+        first_bit = p * 8;
+        return true;
+    }
+
+    // CRC-32 of text_[lo, hi) on crc_threads_ threads (pieces combined in order)
+    uint32_t crc_range(uint64_t lo, uint64_t hi) const {
+        const uint64_t len = hi - lo;
+        const int T = (int)std::min<uint64_t>((uint64_t)crc_threads_, len / (4u << 20) + 1);
+        if (T <= 1) return snk::crc32_fast(0, text_ + lo, (size_t)len);
+        std::vector<uint32_t> part((size_t)T);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t)
+            th.emplace_back([&, t] {
+                const uint64_t a = lo + len * (uint64_t)t / (uint64_t)T, b = lo + len * (uint64_t)(t + 1) / (uint64_t)T;
+                part[(size_t)t] = snk::crc32_fast(0, text_ + a, (size_t)(b - a));
+            });
+        for (auto &x : th) x.join();
+        uint32_t c = 0;
+        for (int t = 0; t < T; ++t) {
+            const uint64_t a = lo + len * (uint64_t)t / (uint64_t)T, b = lo + len * (uint64_t)(t + 1) / (uint64_t)T;
+            c = t == 0 ? part[0] : (uint32_t)crc32_combine(c, part[(size_t)t], (z_off_t)(b - a));
+        }
+        return c;
+    }
+    void add_text(uint64_t lo, uint64_t hi) {
+        if (hi <= lo) return;
+        if (member_checkable_) mcrc_ = (uint32_t)crc32_combine(mcrc_, crc_range(lo, hi), (z_off_t)(hi - lo));
+        mlen_ += hi - lo;
+    }
+    bool end_member(uint32_t want_crc, uint32_t want_isize) {
+        if (member_checkable_ && (mcrc_ != want_crc || (uint32_t)mlen_ != want_isize)) { fail("invalid gzip data (CRC-32 / length of a member)"); return false; }
+        mcrc_ = 0; mlen_ = 0; member_checkable_ = true;
+        return true;
+    }
+
+    bool next_window() {
+        if (stream_done_) { done_ = true; return false; }
+        const uint64_t wb = (pos_bit_ >> 3) & ~3ull;
+        const uint64_t nbytes = std::min<uint64_t>(g_.window_bytes, n_ - wb);
+        const uint64_t first = pos_bit_ - wb * 8;
+        const uint32_t nc = (uint32_t)((nbytes + g_.chunk_bytes - 1) / g_.chunk_bytes);
+        if (!be_->decode(in_ + wb, nbytes, first, first_of_member_, chunks_.data(), ends_.data())) { to_sequential(); return false; }
+        ++windows_;
+        // the chain: chunks whose start is where the one before stopped
+        order_.clear();
+        uint64_t expect = first, text_bytes = 0;
+        bool at_file_end = false;
+        for (uint32_t c = 0; c < nc; ++c) {
+            const snk_gunzip_chunk &ck = chunks_[c];
+            if (ck.start_bit == ~0ull || ck.start_bit < expect) continue;     // no start found / a start inside a block already decoded
+            if (ck.start_bit != expect) break;                                 // the chain does not meet: what follows is not trusted
+            if (ck.status != SNK_GZ_OK) break;
+            order_.push_back(c);
+            text_bytes += ck.n_syms;
+            expect = ck.end_bit;
+            if (ck.stream_end) { at_file_end = true; break; }
+        }
+        // a chunk that ran into the end of the WINDOW (not of the file) reports invalid data and is decoded again by the next
+        // window; a window that yields nothing at all cannot make progress
+        if (order_.empty()) { to_sequential(); return false; }
+        text_ = be_->text_buffer((size_t)text_bytes + 64);      // (grown on demand: pinning gigabytes up front costs a second)
+        if (!text_) { to_sequential(); return false; }
+        std::vector<uint8_t> wout(HIST);
+        if (!be_->resolve(order_.data(), (uint32_t)order_.size(), first_of_member_ ? nullptr : win_.data(), text_, text_bytes, wout.data())) { to_sequential(); return false; }
+        // members that ended in this window: CRC-32 and ISIZE over the text
+        uint64_t at = 0, from = 0;
+        for (uint32_t c : order_) {
+            const snk_gunzip_chunk &ck = chunks_[c];
+            for (uint32_t e = 0; e < ck.n_ends; ++e) {
+                const snk_gunzip_member &m = ends_[(size_t)ck.ends_off + e];
+                add_text(from, at + m.sym_index);
+                from = at + m.sym_index;
+                if (!end_member(m.crc, m.isize)) return false;
+            }
+            at += ck.n_syms;
+        }
+        add_text(from, at);
+        win_.swap(wout);
+        t_have_ = text_bytes;
+        t_off_ = 0;
+        pos_bit_ = wb * 8 + expect;
+        // where the next window starts: inside a member, unless the last chunk ended exactly behind a member header
+        const snk_gunzip_chunk &last = chunks_[order_.back()];
+        first_of_member_ = last.known_from != 0xFFFFFFFFu && last.known_from == last.n_syms;
+        if (at_file_end) { stream_done_ = true; if (mlen_ != 0) { fail("device inflate: text behind the last member"); return false; } }
+        return true;
+    }
+
+    // ---- sequential host decoder from the block header at pos_bit_ on (the rest of the stream)
+    void to_sequential() {
+        fallback_bit_ = pos_bit_;
+        if (getenv("SNK_PGZ_DEBUG")) fprintf(stderr, "device inflate: sequential from bit %llu (%s)\n", (unsigned long long)pos_bit_, be_->error().c_str());
+        seq_ = true;
+        sq_.init(in_, n_);
+        sq_.set_verify_crc(false);
+        sq_.start_at_block(pos_bit_);
+        if (first_of_member_) { mcrc_ = 0; mlen_ = 0; }
+        sbuf_.assign(HIST + ((size_t)1 << 22), 0);
+        memcpy(sbuf_.data(), win_.data(), HIST);
+        s_have_ = s_off_ = 0;
+    }
+    void seq_from_start() {
+        seq_ = true;
+        fallback_bit_ = 0;
+        sq_.init(in_, n_);
+        sq_.set_verify_crc(false);
+        sbuf_.assign(HIST + ((size_t)1 << 22), 0);
+        s_have_ = s_off_ = 0;
+    }
+    size_t seq_run(uint8_t *out, size_t cap) {
+        if (s_off_ == s_have_) {
+            if (s_have_) memmove(sbuf_.data(), sbuf_.data() + s_have_, HIST);      // keep the window in front
+            uint8_t *p = sbuf_.data() + HIST;
+            s_have_ = sq_.run(p, sbuf_.size() - HIST);
+            s_off_ = 0;
+            if (sq_.error()) { fail(sq_.error()); return 0; }
+            size_t from = 0;
+            auto piece = [&](size_t a, size_t b) {
+                if (b > a) { mcrc_ = (uint32_t)crc32_combine(mcrc_, snk::crc32_fast(0, p + a, b - a), (z_off_t)(b - a)); mlen_ += b - a; }
+            };
+            for (const auto &e : sq_.member_ends()) {
+                piece(from, e.out_off);
+                if (!end_member(e.crc, e.isize)) return 0;
+                from = e.out_off;
+            }
+            piece(from, s_have_);
+            if (s_have_ == 0 && sq_.done()) { done_ = true; return 0; }
+        }
+        const size_t n = std::min(cap, s_have_ - s_off_);
+        memcpy(out, sbuf_.data() + HIST + s_off_, n);
+        s_off_ += n;
+        return n;
+    }
+};
+
+}  // namespace snk
+#endif

@@ -44,6 +44,7 @@
 #include "../../include/snk_filter.h"
 #include "snk_inflate.h"
 #include "snk_pgunzip.h"
+#include "snk_dgunzip.h"
 #include "snk_deflate.h"
 #include "snk_report.h"
 #include "../../include/snk_rmdup.h"
@@ -676,6 +677,75 @@ void index_chunk(RawChunk *c, int space_num, int workers) {
     if (c->ls.size() != (size_t)c->n * 4) die("truncated fastq record");
 }
 
+// ---- .gz input decoded on the GPU (include/snk_gunzip.h, host/snk_dgunzip.h; SNK_DEVICE_INFLATE=1): the reader's source of bytes is
+// either the host's parallel decoder or the device one -- same bytes, same errors
+struct HipGunzipBackend : snk::DgBackend {
+    snk_gunzip *g = nullptr;
+    uint8_t *pinned = nullptr;
+    size_t pinned_cap = 0;
+    string err;
+    HipGunzipBackend(int device, const snk::DeviceGunzip::Geometry &geo) {
+        g = snk_gunzip_create(device, geo.window_bytes, geo.chunk_bytes, geo.syms_per_chunk, geo.ends_per_chunk);
+        if (!g) err = snk_last_error();
+    }
+    ~HipGunzipBackend() override {
+        if (pinned) (void)hipHostFree(pinned);
+        snk_gunzip_destroy(g);
+    }
+    bool decode(const uint8_t *comp, uint64_t nbytes, uint64_t first_bit, bool first_of_member, snk_gunzip_chunk *chunks, snk_gunzip_member *ends) override {
+        if (!g) return false;
+        if (snk_gunzip_decode(g, comp, nbytes, first_bit, first_of_member ? 1 : 0, chunks, ends) != SNK_OK) { err = snk_last_error(); return false; }
+        return true;
+    }
+    bool resolve(const uint32_t *order, uint32_t k, const uint8_t *win_in, uint8_t *text, uint64_t text_bytes, uint8_t *win_out) override {
+        if (snk_gunzip_resolve(g, order, k, win_in, text, text_bytes, win_out) != SNK_OK) { err = snk_last_error(); return false; }
+        return true;
+    }
+    uint8_t *text_buffer(size_t bytes) override {
+        if (bytes > pinned_cap) {
+            if (pinned) (void)hipHostFree(pinned);
+            pinned = nullptr;
+            pinned_cap = 0;
+            const size_t cap = bytes + bytes / 4;
+            if (hipHostMalloc((void **)&pinned, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); err = "cannot pin the text buffer"; return nullptr; }
+            pinned_cap = cap;
+        }
+        return pinned;
+    }
+    std::string error() override { return err; }
+};
+
+struct GzSource {
+    std::unique_ptr<snk::ParallelGunzip> host;
+    std::unique_ptr<HipGunzipBackend> be;
+    std::unique_ptr<snk::DeviceGunzip> dev;
+    GzSource(const uint8_t *zin, size_t n, int workers) {
+        if (const char *e = getenv("SNK_DEVICE_INFLATE")) {
+            if (atoi(e) != 0) {
+                snk::DeviceGunzip::Geometry geo;
+                geo.window_bytes = (uint64_t)(getenv("SNK_DGZ_WINDOW_MB") ? atol(getenv("SNK_DGZ_WINDOW_MB")) : 128) << 20;
+                geo.chunk_bytes = (uint32_t)(getenv("SNK_DGZ_CHUNK_KB") ? atol(getenv("SNK_DGZ_CHUNK_KB")) : 128) << 10;
+                geo.syms_per_chunk = geo.chunk_bytes * (uint32_t)(getenv("SNK_DGZ_RATIO") ? atol(getenv("SNK_DGZ_RATIO")) : 12);
+                geo.ends_per_chunk = geo.chunk_bytes / 2048 + 4;
+                if (geo.window_bytes > n + geo.chunk_bytes) geo.window_bytes = ((n + geo.chunk_bytes) / geo.chunk_bytes) * geo.chunk_bytes;
+                int device = 0;
+                (void)hipGetDevice(&device);
+                be.reset(new HipGunzipBackend(device, geo));
+                if (be->g) dev.reset(new snk::DeviceGunzip(zin, n, be.get(), geo, std::max(1, workers)));
+                else cerr << "Warning:device inflate is not available (" << be->err << "), decoding on the host" << endl;
+            }
+        }
+        if (!dev) {
+            size_t pg_chunk = (size_t)2 << 20;
+            if (const char *e = getenv("SNK_GZ_CHUNK")) { const long v = atol(e); if (v >= 65536) pg_chunk = (size_t)v; }
+            host.reset(new snk::ParallelGunzip(zin, n, workers, pg_chunk));
+        }
+    }
+    size_t run(uint8_t *out, size_t cap) { return dev ? dev->run(out, cap) : host->run(out, cap); }
+    const char *error() const { return dev ? dev->error() : host->error(); }
+    bool done() const { return dev ? dev->done() : host->done(); }
+};
+
 void reader_gz_count(const string path, int batch, int workers, Channel<RawChunk *> *out) {
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) die("cannot open file," + path);
@@ -684,9 +754,7 @@ void reader_gz_count(const string path, int batch, int workers, Channel<RawChunk
     const uint8_t *zin = (const uint8_t *)mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (zin == MAP_FAILED) die("cannot map file," + path);
     madvise((void *)zin, (size_t)st.st_size, MADV_SEQUENTIAL);
-    size_t pg_chunk = (size_t)2 << 20;
-    if (const char *e = getenv("SNK_GZ_CHUNK")) { const long v = atol(e); if (v >= 65536) pg_chunk = (size_t)v; }
-    snk::ParallelGunzip z(zin, (size_t)st.st_size, workers, pg_chunk);
+    GzSource z(zin, (size_t)st.st_size, workers);
     const size_t H = snk::GzipInflate::HIST, block = (size_t)1 << 24;
     RawChunk *cur = RawChunk::get();
     const size_t cap0 = H + (size_t)batch * 400 + 2 * block;

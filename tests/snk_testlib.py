@@ -15,6 +15,13 @@ if ROOT not in sys.path:
 
 from soapnuke_amd import abi  # noqa: E402
 
+# GPU tests written while the GPU lease was closed (round 4): their logic is pinned on the CPU (tests/test_host_emul.py,
+# tests/test_inflate_emul.py), they have not met the hardware yet -- SNK_RUN_UNVERIFIED=1 runs them; the guard comes off once they
+# have passed there
+import pytest  # noqa: E402
+not_yet_on_hardware = pytest.mark.skipif(os.environ.get("SNK_RUN_UNVERIFIED") != "1",
+                                         reason="written while the GPU lease was closed: pinned on the CPU emulation, not yet run on hardware (SNK_RUN_UNVERIFIED=1)")
+
 ORACLE_SO = os.path.join(ROOT, "oracle", "libsnk_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libsnkref.so")
 REF_BIN = os.path.join(ROOT, "oracle", "_ref", "SOAPnuke")

@@ -1,0 +1,168 @@
+"""The chunk decoder of the DEVICE inflate (soapnuke_amd/csrc/snk_inflate_core.cuh: block-start probe, marker-mode DEFLATE decoding,
+gzip framing) compiled for the host and run chunk by chunk the way the device path runs it -- against zlib's bytes on every kind of
+stream the reader can meet (the vectors of tests/test_inflate.py), and errors on damaged ones.  No GPU needed."""
+import ctypes as C
+import gzip
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import snk_testlib as T
+from test_inflate import _fastq_bytes
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_emul")
+LIB = os.path.join(HERE, "libsnk_inflate_emul.so")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    srcs = [os.path.join(HERE, "inflate_emul.cpp"), os.path.join(T.ROOT, "soapnuke_amd", "csrc", "snk_inflate_core.cuh"),
+            os.path.join(T.ROOT, "soapnuke_amd", "host", "snk_dgunzip.h"), os.path.join(T.ROOT, "soapnuke_amd", "host", "snk_inflate.h")]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-w", "-fPIC", "-shared", "-I" + os.path.join(T.ROOT, "soapnuke_amd", "csrc"),
+                               "-x", "c++", "inflate_emul.cpp", "-o", LIB, "-lz", "-pthread"], cwd=HERE)
+    lib = C.CDLL(LIB)
+    lib.snk_emul_gunzip.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_long), C.c_long]
+    lib.snk_emul_gunzip.restype = C.c_long
+    lib.snk_emul_probe.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
+    return lib
+
+
+def _gunzip(lib, blob, chunk, cap, ends_cap=64):
+    out = np.zeros(cap + 16, dtype=np.uint8)
+    info = (C.c_long * 4)()
+    r = lib.snk_emul_gunzip(blob, len(blob), chunk, out.ctypes.data, cap, info, ends_cap)
+    return r, bytes(out[:max(r, 0)]), list(info)
+
+
+def _vectors():
+    raw = _fastq_bytes(5000)                                    # 1.6 MB of FASTQ
+    files = {f"l{lvl}": (gzip.compress(raw, compresslevel=lvl), raw) for lvl in (1, 2, 6, 9)}
+    co = zlib.compressobj(0, zlib.DEFLATED, 31)
+    files["stored"] = (co.compress(raw[:300000]) + co.flush(), raw[:300000])
+    files["multi"] = (gzip.compress(raw[:1000], 1) + gzip.compress(b"", 6) + gzip.compress(raw[1000:700_000], 2) + gzip.compress(raw[700_000:], 9), raw)
+    files["empty"] = (gzip.compress(b""), b"")
+    files["tiny"] = (gzip.compress(b"@r\nACGT\n+\nIIII\n"), b"@r\nACGT\n+\nIIII\n")
+    runs = b"A" * 300_000 + b"ACGT" * 50000
+    files["runs"] = (gzip.compress(runs, 9), runs)
+    rnd = np.random.default_rng(1).integers(0, 256, 200_000, dtype=np.uint8).tobytes()
+    files["random"] = (gzip.compress(rnd, 6), rnd)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)                  # fixed Huffman blocks
+    files["fixed"] = (co.compress(raw[:300000]) + co.flush(), raw[:300000])
+    files["named_header"] = (b"\x1f\x8b\x08\x08\x00\x00\x00\x00\x00\x03name.fq\x00" + gzip.compress(raw[:50000])[10:], raw[:50000])
+    many = b"".join(gzip.compress(raw[i:i + 20000], 1) for i in range(0, 400000, 20000))   # BGZF-like: a member per few KB
+    files["many_members"] = (many, raw[:400000])
+    return files
+
+
+def test_chunked_marker_decoding_is_zlibs_bytes(emul):
+    total_markers = 0
+    for name, (blob, raw) in _vectors().items():
+        assert zlib.decompress(blob, 47) == raw[:len(zlib.decompress(blob, 47))] or name in ("multi", "many_members")
+        for chunk in (1 << 30, 1 << 16, 20000):
+            r, got, info = _gunzip(emul, blob, chunk, len(raw) + 1000)
+            assert r == len(raw) and got == raw, (name, chunk, r, info)
+            if name == "many_members" and chunk > 400000:       # more member ends in one chunk than it was given slots for: refused, never wrong
+                assert _gunzip(emul, blob, chunk, len(raw) + 1000, ends_cap=8)[0] == -(1000 + 10 * 3 + 3)
+            total_markers += info[2]
+    assert total_markers > 300_000                              # the unknown-window path really ran
+
+
+def test_block_start_probe_finds_zlibs_blocks_and_little_else(emul):
+    """every dynamic block of a level-1 stream (found by decoding with zlib's Z_BLOCK-free cousin: the chain of the emulation
+    itself) answers the probe; random offsets practically never do"""
+    raw = _fastq_bytes(8000)
+    blob = gzip.compress(raw, 1)
+    rng = np.random.default_rng(5)
+    res = [emul.snk_emul_probe(blob, len(blob), int(b)) for b in rng.integers(100, len(blob) * 8 - 100, 100000)]
+    assert min(res) >= 0                                       # the lanes' quick screen never rejects what the full check accepts
+    assert sum(1 for r in res if r & 1) <= 2                   # (a true block start may be hit by chance: ~100 of 20 M offsets)
+    assert sum(1 for r in res if r & 2) < len(res) // 200      # the quick screen passes well under 1 % of the offsets
+    r, got, info = _gunzip(emul, blob, 1 << 16, len(raw) + 100)
+    assert got == raw and info[1] >= len(blob) // (1 << 16) - 1   # a start was found in (nearly) every 64 KiB chunk
+
+
+def test_damaged_streams_are_errors_or_zlibs_bytes(emul):
+    """bit flips anywhere in the deflate data: the decoder refuses exactly what zlib's inflate refuses, and where zlib decodes
+    (the damage only changed bytes: CRC-32 / ISIZE, which the caller checks, would catch it) it produces zlib's bytes"""
+    raw = _fastq_bytes(3000)
+    blob = bytearray(gzip.compress(raw, 6))
+    rng = np.random.default_rng(9)
+    refused = same = 0
+    for _ in range(120):
+        b = bytearray(blob)
+        for pos in rng.integers(12, len(b) - 8, int(rng.integers(1, 4))):
+            b[int(pos)] ^= 1 << int(rng.integers(0, 8))
+        b = bytes(b)
+        d = zlib.decompressobj(-15)
+        try:
+            want = d.decompress(b[10:])
+            ok = d.eof                                          # (not eof: the damaged stream runs off the end of the file)
+        except zlib.error:
+            want, ok = None, False
+        for chunk in (1 << 30, 1 << 16):
+            r, got, info = _gunzip(emul, b, chunk, len(raw) * 3)
+            if ok:
+                if r >= 0:                                      # (a chunked run may also refuse: a damaged block start nobody can find)
+                    assert got == want
+                    same += 1
+                else:
+                    assert chunk < len(b)
+                    refused += 1
+            else:
+                assert r < 0, (r, info)
+                refused += 1
+    assert refused >= 4 and same > 100
+    for cut in (20, len(blob) // 2, len(blob) - 4):            # truncated files
+        r, got, info = _gunzip(emul, bytes(blob[:cut]), 1 << 16, len(raw) * 2)
+        assert r < 0
+
+
+# ---- the host orchestration (soapnuke_amd/host/snk_dgunzip.h) over a CPU backend made of the same core functions
+def _dgunzip(lib, blob, window, chunk, spc, cap, epc=16):
+    out = np.zeros(cap + 16, dtype=np.uint8)
+    info = (C.c_long * 4)()
+    eb = C.create_string_buffer(256)
+    r = lib.snk_emul_dgunzip(blob, len(blob), window, chunk, spc, epc, out.ctypes.data, cap, info, eb, 256)
+    return r, bytes(out[:max(r, 0)]), list(info), eb.value.decode()
+
+
+@pytest.fixture(scope="module")
+def dg(emul):
+    emul.snk_emul_dgunzip.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t,
+                                      C.POINTER(C.c_long), C.c_char_p, C.c_size_t]
+    emul.snk_emul_dgunzip.restype = C.c_long
+    return emul
+
+
+def test_device_gunzip_orchestration_windows_chains_and_fallbacks(dg):
+    """DeviceGunzip: windows of several sizes (a window's last chunk is cut by the window and decoded again by the next), chunks
+    whose symbol slots overflow and BGZF-like files with more members per chunk than slots (both: sequential host decoder from the
+    last good block), empty and tiny files -- always zlib's bytes"""
+    vec = _vectors()
+    device_only = 0
+    for name, (blob, raw) in vec.items():
+        for window, chunk, spc, epc in ((1 << 22, 1 << 16, 1 << 20, 64), (200000, 1 << 16, 1 << 20, 64), (1 << 22, 1 << 17, 150000, 2)):
+            r, got, info, err = _dgunzip(dg, blob, window, chunk, spc, len(raw) + 1000, epc)
+            assert r == len(raw) and got == raw, (name, window, chunk, spc, r, info, err)
+            device_only += info[1] == -1
+    assert device_only >= 2 * len(vec)                         # most runs never needed the fallback
+
+
+def test_device_gunzip_checks_crc_and_length(dg):
+    raw = _fastq_bytes(3000)
+    co = zlib.compressobj(0, zlib.DEFLATED, 31)                 # stored blocks: a flipped payload bit decodes fine and must fail the CRC
+    blob = bytearray(co.compress(raw) + co.flush())
+    blob[5000] ^= 4
+    r, got, info, err = _dgunzip(dg, bytes(blob), 1 << 22, 1 << 16, 1 << 20, len(raw) + 100)
+    assert r == -1 and "CRC" in err
+    blob = bytearray(gzip.compress(raw, 6))
+    blob[-2] ^= 1                                               # ISIZE
+    r, got, info, err = _dgunzip(dg, bytes(blob), 1 << 22, 1 << 16, 1 << 20, len(raw) + 100)
+    assert r == -1
+    for cut in (30, len(blob) // 2, len(blob) - 3):             # truncated files: an error, like zlib's gzread
+        r, got, info, err = _dgunzip(dg, bytes(gzip.compress(raw, 6)[:cut]), 1 << 22, 1 << 16, 1 << 20, len(raw) + 100)
+        assert r == -1, (cut, r, err)

@@ -8,5 +8,5 @@ mkdir -p ../../ab
 only="-DSNK_ONLY_NW=5"
 for f in "$@"; do if [ "$f" = "-DSNK_ALL_NW" ]; then only=""; fi; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $only "$@" -o ../../ab/libsnk_$name.so \
-    snk_filter.cpp snk_generic.hip snk_tiled.hip snk_rmdup.hip snk_contam.hip snk_long.hip snk_fastq.hip snk_gzip.hip -ldl 2>&1 | grep -E "error" || true
+    snk_filter.cpp snk_generic.hip snk_tiled.hip snk_rmdup.hip snk_contam.hip snk_long.hip snk_fastq.hip snk_gzip.hip snk_inflate.hip -ldl 2>&1 | grep -E "error" || true
 ls -la ../../ab/libsnk_$name.so
