@@ -414,7 +414,9 @@ __global__ void __launch_bounds__(256) dfl_emit_kernel(const uint8_t *text, cons
     const u32 mo = moff[mem], msz = moff[mem + 1] - mo;
     if (mem == 0 && threadIdx.x == 0) { info[0] = moff[nmem]; info[1] = nmem; }
     if (!msz) return;
-    if ((u64)mo + msz > cap) { if (threadIdx.x == 0) atomicOr(&info[2], 1u); return; }
+    // whole 32-bit words are written: the capacity counts in words (a member that ends in the buffer's last, partial word is an
+    // overflow); a member offset scan that wrapped (more than 4 GB of members) is one too
+    if ((u64)mo + msz > (cap & ~3ull) || moff[mem + 1] < mo || moff[nmem] < mo) { if (threadIdx.x == 0) atomicOr(&info[2], 1u); return; }
     const long first = (long)mem * rpm;
     const int cnt = (int)((n - first) < rpm ? (n - first) : rpm);
     u32 *out = reinterpret_cast<u32 *>(gz);                    // (the buffer is 4-byte aligned and zeroed)
