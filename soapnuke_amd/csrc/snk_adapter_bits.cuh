@@ -159,6 +159,23 @@ __device__ __forceinline__ void screen_step(const u32 (&Pl)[NW], int cr, u32 (&C
     }
 }
 
+// two steps of the binary counter at once (NC == 3): the counter needs both of its old planes for either new one, so a single step
+// in place costs a register copy per word (round 4: 22 instead of 15 instructions per step, profiles/r04_isa_budget.md); with two steps
+// the intermediate pair lives in temporaries and the second step writes the planes back -- 6 instructions per word and two steps
+template <int NW, int CQ>
+__device__ __forceinline__ void screen_step2_bin(const u32 (&Pl)[NW], int cr1, int cr2, u32 (&C)[3][NW]) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const u32 lo = (j + CQ < NW) ? Pl[(j + CQ < NW) ? j + CQ : 0] : 0xFFFFFFFFu;
+        const u32 hi = (j + CQ + 1 < NW) ? Pl[(j + CQ + 1 < NW) ? j + CQ + 1 : 0] : 0xFFFFFFFFu;
+        const u32 x1 = ~__builtin_amdgcn_alignbit(hi, lo, cr1), x2 = ~__builtin_amdgcn_alignbit(hi, lo, cr2);
+        const u32 c0 = C[0][j], c1 = C[1][j];
+        const u32 t0 = (c0 ^ x1) | (c1 & c0), t1 = c1 | (c0 & x1);
+        C[0][j] = (t0 ^ x2) | (t1 & t0);
+        C[1][j] = t1 | (t0 & x2);
+    }
+}
+
 // Bit-sliced screening of the candidates p = 0 .. len-edge of phases B and C over the first S-1 adapter
 // characters with NC unary mismatch-counter planes.
 // NC = largest budget + 1 counter planes, at most 4: offsets whose own budget is 4 or more are not screened out by the count.
@@ -180,12 +197,30 @@ __device__ __forceinline__ void screen_planes(const AD &A, const u32 (&NX)[4][NW
     const u64 sm = lowmask64(steps);
     auto run = [&](const u32 (&Pl)[NW], u64 m64) {
         u32 m = __builtin_amdgcn_readfirstlane((u32)m64);
+        if constexpr (NC == 3 && SNK_SCREEN_BIN) {
+            while (m & (m - 1)) {                                // two positions at a time while there are two
+                const int c = __ffs((int)m) - 1;
+                m &= m - 1;
+                const int c2 = __ffs((int)m) - 1;
+                m &= m - 1;
+                screen_step2_bin<NW, 0>(Pl, c, c2, C);
+            }
+        }
         while (m) {
             const int c = __ffs((int)m) - 1;
             m &= m - 1;
             screen_step<NW, 0, NC>(Pl, c, C);
         }
         m = __builtin_amdgcn_readfirstlane((u32)(m64 >> 32));
+        if constexpr (NC == 3 && SNK_SCREEN_BIN) {
+            while (m & (m - 1)) {
+                const int c = __ffs((int)m) - 1;
+                m &= m - 1;
+                const int c2 = __ffs((int)m) - 1;
+                m &= m - 1;
+                screen_step2_bin<NW, 1>(Pl, c, c2, C);
+            }
+        }
         while (m) {
             const int c = __ffs((int)m) - 1;
             m &= m - 1;
