@@ -259,6 +259,11 @@ void snk_error_decode(uint64_t word, snk_error *err);
  * (ncclComm_t) -- the only collective on this path.             */
 int snk_stats_allreduce(snk_ctx *ctx, void *nccl_comm, void *hip_stream);
 
+/* Sizes the per-stream scratch the launch path would otherwise grow on demand (a hipMalloc + a stream synchronisation in the middle
+ * of a run: contaminant verdicts, the long-read plane store, the tiled kernel's histogram partials) for batches of up to max_pairs
+ * pairs on up to n_streams launching streams (1..8).  Optional: without it the first large batch of a stream pays for the growth. */
+int snk_reserve(snk_ctx *ctx, int64_t max_pairs, int n_streams);
+
 /* ms spent in the hot-path kernels of the last snk_filter_batch_device() call
  * measured with hipEvents on the launch stream (0 when timing is disabled).  */
 int snk_set_timing(snk_ctx *ctx, int enabled);

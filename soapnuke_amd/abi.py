@@ -179,7 +179,7 @@ EXPORTS = [
     "snk_params_default", "snk_create", "snk_destroy", "snk_last_error",
     "snk_stats_geometry", "snk_bind_stats", "snk_stats_clear",
     "snk_filter_batch_device", "snk_filter_batch", "snk_stats_finalize",
-    "snk_stats_fetch", "snk_error_peek_async", "snk_error_decode", "snk_stats_allreduce", "snk_set_timing", "snk_last_kernel_ms",
+    "snk_stats_fetch", "snk_error_peek_async", "snk_error_decode", "snk_stats_allreduce", "snk_set_timing", "snk_last_kernel_ms", "snk_reserve",
     # include/snk_rmdup.h
     "snk_rmdup_hash_device", "snk_rmdup_bucket_count_device", "snk_rmdup_mark_device", "snk_rmdup_prime",
     "snk_rmdup_stream_create", "snk_rmdup_stream_mark_device", "snk_rmdup_stream_stats", "snk_rmdup_stream_destroy", "snk_rmdup_stream_bytes",

@@ -521,6 +521,39 @@ int snk_stats_clear(snk_ctx *c, void *stream) {
     return SNK_OK;
 }
 
+int snk_reserve(snk_ctx *c, int64_t max_pairs, int n_streams) {
+    if (!c || max_pairs < 1 || n_streams < 1 || n_streams > 8) { set_err("snk_reserve: bad argument"); return SNK_E_PARAM; }
+    HIP_OK(hipSetDevice(c->device));
+    const bool contam = (c->hp.n_ct[0] | c->hp.n_ct[1] | c->hp.n_gct) != 0;
+    for (int k = 0; k < n_streams; ++k) {
+        if (c->hp.tile_ok && c->lcap <= 256 && !c->d_part[k]) {
+            const size_t pb = snk_tiled_part_bytes(c->lcap, c->nq, c->n_cu);
+            if (hipMalloc((void **)&c->d_part[k], pb) != hipSuccess) { (void)hipGetLastError(); set_err("snk_reserve: out of device memory (histogram partials)"); return SNK_E_NOMEM; }
+            HIP_OK(hipMemset(c->d_part[k], 0, pb));
+        }
+        if (contam && c->hp.tile_ok && (size_t)max_pairs > c->cf_cap[k]) {
+            if (c->d_cf[k]) (void)hipFree(c->d_cf[k]);
+            c->d_cf[k] = nullptr;
+            c->cf_cap[k] = 0;
+            const size_t cap = ((size_t)max_pairs + 65535) & ~(size_t)65535;
+            if (hipMalloc((void **)&c->d_cf[k], cap) != hipSuccess) { (void)hipGetLastError(); set_err("snk_reserve: out of device memory (contaminant verdicts)"); return SNK_E_NOMEM; }
+            c->cf_cap[k] = cap;
+        }
+        if (c->hp.tile_ok && c->hp.long_ok && c->lcap > 256 && c->lcap <= 1024) {
+            const size_t need = snk_long_scratch_bytes((long)max_pairs, c->p.paired ? 1 : 0, c->lcap);
+            if (need > c->pl_cap[k]) {
+                if (c->d_pl[k]) (void)hipFree(c->d_pl[k]);
+                c->d_pl[k] = nullptr;
+                c->pl_cap[k] = 0;
+                if (hipMalloc((void **)&c->d_pl[k], need) != hipSuccess) { (void)hipGetLastError(); set_err("snk_reserve: out of device memory (long-read plane store)"); return SNK_E_NOMEM; }
+                c->pl_cap[k] = need;
+            }
+        }
+    }
+    HIP_OK(hipDeviceSynchronize());
+    return SNK_OK;
+}
+
 int snk_set_timing(snk_ctx *c, int enabled) {
     if (!c) return SNK_E_PARAM;
     c->timing = enabled != 0;

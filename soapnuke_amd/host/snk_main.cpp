@@ -1456,6 +1456,7 @@ int main(int argc, char **argv) {
             HIPCHK(hipSetDevice(d.id));
             d.ctx = snk_create(&o.p, d.id);
             if (!d.ctx) die(snk_last_error());
+            if (snk_reserve(d.ctx, B, std::min(8, NSLOT)) != SNK_OK) die(snk_last_error());      // (no allocation on the launch path)
             snk_stats_geometry(d.ctx, &lcap, &nq, &nsum);
             d.d_sum.assign((size_t)T, nullptr);
             d.d_max.assign((size_t)T, nullptr);
