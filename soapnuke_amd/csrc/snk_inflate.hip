@@ -3,6 +3,7 @@
 // stream; the parallelism is the thousands of chunks of a window -- one wavefront each, its Huffman tables in LDS, 11 per CU).
 // Replaces the reference's gzgets() reading loop, src/peprocess.cpp:2063-2113.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -51,6 +52,21 @@ __global__ void __launch_bounds__(64) inf_decode_kernel(const u8 *comp, u64 nbyt
         decode_chunk(comp, nbytes, ck, syms, ends, W.T, W.S, W.cl_tab);
         chunks[blockIdx.x] = ck;
     }
+}
+
+// The same with the whole wavefront at work: all 64 lanes run the decoder in lockstep on the same values (its tables, header
+// workspace and decisions are uniform), and share the I/O -- compressed bytes through an LDS ring refilled 1 KB at a time by all
+// lanes, symbols through an LDS buffer flushed by all lanes, matches copied 64 symbols at a time (snk_inflate_core.cuh, Coop).
+// A lane on its own pays a global-memory round trip per bit-buffer refill and per copied symbol.
+__global__ void __launch_bounds__(64) inf_decode_coop_kernel(const u8 *comp, u64 nbytes, Chunk *chunks, u16 *syms, MemberEnd *ends) {
+    __shared__ WaveSpace W;
+    __shared__ __attribute__((aligned(16))) u8 ring[2 * HALF];
+    __shared__ u16 ob[OBCAP];
+    Coop co;
+    co.ring = ring; co.ob = ob; co.ring_lo = co.ring_end = 0; co.ob_n = 0;
+    Chunk ck = chunks[blockIdx.x];
+    decode_chunk(comp, nbytes, ck, syms, ends, W.T, W.S, W.cl_tab, &co);
+    if (threadIdx.x == 0) chunks[blockIdx.x] = ck;
 }
 
 // The windows in front of the chunks of a chain: wins[0] is given; wins[j + 1] = the last 32 KiB of (wins[j] ++ text of chunk j).
@@ -188,7 +204,9 @@ int snk_gunzip_decode(snk_gunzip *g, const uint8_t *h_comp, uint64_t nbytes, uin
         if (start[c] != ~0ull) next = start[c];
     }
     GZ_OK(hipMemcpyAsync(g->d_chunks, g->h_chunks.data(), nc * sizeof(Chunk), hipMemcpyHostToDevice, g->stream));
-    hipLaunchKernelGGL(inf_decode_kernel, dim3(nc), dim3(64), 0, g->stream, (const u8 *)g->d_comp, (u64)nbytes, g->d_chunks, g->d_syms, g->d_ends);
+    static const bool coop = !(getenv("SNK_DGZ_COOP") && atoi(getenv("SNK_DGZ_COOP")) == 0);      // (SNK_DGZ_COOP=0: one lane per chunk does everything)
+    if (coop) hipLaunchKernelGGL(inf_decode_coop_kernel, dim3(nc), dim3(64), 0, g->stream, (const u8 *)g->d_comp, (u64)nbytes, g->d_chunks, g->d_syms, g->d_ends);
+    else hipLaunchKernelGGL(inf_decode_kernel, dim3(nc), dim3(64), 0, g->stream, (const u8 *)g->d_comp, (u64)nbytes, g->d_chunks, g->d_syms, g->d_ends);
     GZ_OK(hipGetLastError());
     GZ_OK(hipMemcpyAsync(g->h_chunks.data(), g->d_chunks, nc * sizeof(Chunk), hipMemcpyDeviceToHost, g->stream));
     GZ_OK(hipMemcpyAsync(h_ends, g->d_ends, (size_t)nc * g->epc * sizeof(MemberEnd), hipMemcpyDeviceToHost, g->stream));

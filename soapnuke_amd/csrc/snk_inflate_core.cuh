@@ -29,7 +29,7 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-enum { LIT_ROOT = 10, DIST_ROOT = 7, LIT_CAP = 2048, DIST_CAP = 1024, WIN = 32768, PAD = 32 };   // PAD: zero bytes the caller keeps behind the compressed bytes
+enum { LIT_ROOT = 10, DIST_ROOT = 7, LIT_CAP = 2048, DIST_CAP = 1024, WIN = 32768, PAD = 4096 };   // PAD: zero bytes the caller keeps behind the compressed bytes
 enum { INF_OK = 0, INF_FULL = 1, INF_BAD = 2, INF_TOO_MANY_MEMBERS = 3, INF_NOT_STARTED = 4 };
 enum { T_INVALID = 0, T_LIT = 1, T_LEN = 2, T_EOB = 3, T_SUB = 4, T_DIST = 5 };
 
@@ -55,6 +55,28 @@ struct Chunk {
 struct Tables { u32 lit[LIT_CAP]; u32 dist[DIST_CAP]; };
 struct Scratch { u8 lens[320]; u16 count[16], offs[16]; u16 sorted[288]; u8 submax[1 << LIT_ROOT]; };   // header / table-building workspace
 
+// ---------------------------------------------------------------- wave-cooperative I/O (optional)
+// The plain form of the decoder is one thread that loads its input from global memory and stores every symbol there.  On the GPU
+// a chunk is decoded by a whole wavefront whose 64 lanes run the same (uniform) code; with a Coop they share the I/O: the compressed
+// bytes come through a 2 KB ring in LDS that all lanes refill with 16-byte loads, symbols collect in an LDS buffer that all lanes
+// flush with coalesced stores, and matches are copied 64 elements at a time.  SNKI_LANES(lane): the statement runs for this lane on
+// the device and for lanes 0..63 in turn on the host (the emulation), where every lane-parallel step below is written so that its
+// iterations do not depend on each other.
+#if defined(__HIPCC__)
+#define SNKI_LANES(lane) for (int lane = (int)(threadIdx.x & 63), once_ = 1; once_; once_ = 0)
+#define SNKI_FENCE() __threadfence_block()
+#else
+#define SNKI_LANES(lane) for (int lane = 0; lane < 64; ++lane)
+#define SNKI_FENCE() ((void)0)
+#endif
+enum { HALF = 1024, OBCAP = 1024 };
+struct Coop {
+    u8 *ring;                 // LDS, 2 * HALF bytes: compressed bytes [ring_lo, ring_end), byte p at ring[p % (2 * HALF)]
+    u64 ring_lo, ring_end;    // multiples of HALF, ring_end - ring_lo <= 2 * HALF
+    u16 *ob;                  // LDS, OBCAP symbols not yet in global memory
+    u32 ob_n;
+};
+
 // ---------------------------------------------------------------- bit input
 // 8 bytes from any address out of aligned dword loads (the compressed buffer is padded with PAD zero bytes behind its end)
 SNKI_DEV u64 load64(const u8 *base, u64 pos) {
@@ -70,15 +92,42 @@ struct Bits {
     u64 pos;                  // next byte to load
     u64 bb;
     int bc;                   // valid bits in bb
+    Coop *co;                 // null: loads straight from global memory
 };
-SNKI_DEV void bits_init(Bits &b, const u8 *base, u64 nbytes, u64 bit) {
-    b.base = base; b.nbytes = nbytes; b.pos = bit >> 3; b.bb = 0; b.bc = 0;
-    const int skip = (int)(bit & 7);
-    if (skip) { b.bb = load64(base, b.pos); b.pos += 7; b.bc = 56; b.bb &= (1ull << 56) - 1; b.bb >>= skip; b.bc -= skip; }
+// the same 8 bytes through the ring
+SNKI_DEV u64 ring64(Bits &b, u64 pos) {
+    Coop &c = *b.co;
+    if (pos < c.ring_lo || (pos & ~(u64)(HALF - 1)) > c.ring_end)
+        c.ring_lo = c.ring_end = pos & ~(u64)(HALF - 1);                      // a jump (stored block, member header): start over at its half
+    while (pos + 12 > c.ring_end) {                                          // (uniform) the next half, 16 bytes per lane
+        const u64 from = c.ring_end;
+        SNKI_LANES(lane) {
+            const u32 *src = reinterpret_cast<const u32 *>(b.base + from + (u64)lane * 16);
+            u32 *dst = reinterpret_cast<u32 *>(c.ring + (from & (u64)HALF) + (u64)lane * 16);
+            const u32 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+            dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
+        }
+        c.ring_end = from + HALF;
+        if (c.ring_end - c.ring_lo > 2 * HALF) c.ring_lo = c.ring_end - 2 * HALF;
+    }
+    const u32 a = (u32)(pos & ~3ull), M = 2 * HALF - 1;
+    const u32 w0 = *reinterpret_cast<const u32 *>(c.ring + (a & M)), w1 = *reinterpret_cast<const u32 *>(c.ring + ((a + 4) & M)),
+              w2 = *reinterpret_cast<const u32 *>(c.ring + ((a + 8) & M));
+    const u32 sh = (u32)(pos & 3) * 8;
+    const u64 lo = ((u64)w1 << 32) | w0;
+    return sh ? (lo >> sh) | ((u64)w2 << (64 - sh)) : lo;
 }
-SNKI_DEV void refill(Bits &b) {                     // at least 56 valid bits afterwards (zeros behind the end of the input)
-    const u64 p = b.pos < b.nbytes + 8 ? b.pos : b.nbytes + 8;
-    b.bb |= load64(b.base, p) << b.bc;
+SNKI_DEV u64 fetch64(Bits &b, u64 pos) {            // zeros behind the end of the input (the caller notices with past_end())
+    const u64 p = pos < b.nbytes + 8 ? pos : b.nbytes + 8;
+    return b.co ? ring64(b, p) : load64(b.base, p);
+}
+SNKI_DEV void bits_init(Bits &b, const u8 *base, u64 nbytes, u64 bit, Coop *co = nullptr) {
+    b.base = base; b.nbytes = nbytes; b.pos = bit >> 3; b.bb = 0; b.bc = 0; b.co = co;
+    const int skip = (int)(bit & 7);
+    if (skip) { b.bb = fetch64(b, b.pos); b.pos += 7; b.bc = 56; b.bb &= (1ull << 56) - 1; b.bb >>= skip; b.bc -= skip; }
+}
+SNKI_DEV void refill(Bits &b) {                     // at least 56 valid bits afterwards
+    b.bb |= fetch64(b, b.pos) << b.bc;
     b.pos += (u64)((63 - b.bc) >> 3);
     b.bc |= 56;
 }
@@ -311,21 +360,93 @@ SNKI_DEV bool gzip_header(Bits &b) {
     if (flg & 16) { while (p < n && d[p]) ++p; ++p; }
     if (flg & 2) p += 2;
     if (p > n) return false;
-    bits_init(b, d, n, p * 8);
+    bits_init(b, d, n, p * 8, b.co);
     return true;
 }
 
 // ---------------------------------------------------------------- the chunk
-// Decodes chunk ck (see its fields) to syms[ck.out_off ...].  One thread; T and S are its workspace (LDS on the device).
-SNKI_DEV void decode_chunk(const u8 *comp, u64 nbytes, Chunk &ck, u16 *syms_all, MemberEnd *ends_all, Tables &T, Scratch &S, u32 *cl_tab) {
+// symbol output: straight to global memory, or through a Coop's LDS buffer
+struct Out {
+    u16 *out;                 // the chunk's symbol slots
+    u32 n;                    // symbols so far
+    u32 flushed;              // ... of which in global memory (Coop)
+    Coop *co;
+};
+SNKI_DEV void out_flush(Out &o) {
+    if (!o.co || o.co->ob_n == 0) return;
+    Coop &c = *o.co;
+    SNKI_LANES(lane) {
+        for (u32 k = (u32)lane; k < c.ob_n; k += 64) o.out[o.flushed + k] = c.ob[k];
+    }
+    o.flushed += c.ob_n;
+    c.ob_n = 0;
+    SNKI_FENCE();                                      // later matches read these symbols back (other lanes' stores)
+}
+SNKI_DEV void out_put(Out &o, u16 v) {
+    if (o.co) {
+        o.co->ob[o.co->ob_n++] = v;
+        ++o.n;
+        if (o.co->ob_n == OBCAP) out_flush(o);
+    } else {
+        o.out[o.n++] = v;
+    }
+}
+// a match of len symbols at distance dist; sources in front of the chunk (index < 0) become markers
+SNKI_DEV void out_match(Out &o, u32 len, u32 dist) {
+    const long first = (long)o.n - (long)dist;
+    if (o.co) {
+        Coop &c = *o.co;
+        if (c.ob_n + len > OBCAP) out_flush(o);
+        const u32 at = c.ob_n;
+        SNKI_LANES(lane) {
+            for (u32 i = (u32)lane; i < len; i += 64) {
+                const long src = first + (long)(i % dist);            // (i % dist: an overlapping match repeats its first dist symbols)
+                u16 v;
+                if (src < 0) v = (u16)(256 + WIN + src);
+                else if ((u32)src >= o.flushed) v = c.ob[(u32)src - o.flushed];
+                else v = o.out[src];
+                c.ob[at + i] = v;
+            }
+        }
+        c.ob_n += len;
+        o.n += len;
+        if (c.ob_n == OBCAP) out_flush(o);
+    } else {
+        for (u32 i = 0; i < len; ++i) {
+            const long src = first + (long)i;
+            o.out[o.n + i] = src < 0 ? (u16)(256 + WIN + src) : o.out[src];
+        }
+        o.n += len;
+    }
+}
+SNKI_DEV void out_stored(Out &o, const u8 *comp, u64 p, u32 len) {
+    if (o.co) {
+        out_flush(o);
+        SNKI_LANES(lane) {
+            for (u32 i = (u32)lane; i < len; i += 64) o.out[o.flushed + i] = comp[p + i];
+        }
+        o.flushed += len;
+        o.n += len;
+        SNKI_FENCE();
+    } else {
+        for (u32 i = 0; i < len; ++i) o.out[o.n + i] = comp[p + i];
+        o.n += len;
+    }
+}
+
+// Decodes chunk ck (see its fields) to syms[ck.out_off ...].  One thread -- or, with a Coop, the 64 lanes of a wavefront running
+// it in lockstep on the same values; T and S are the workspace (LDS on the device).
+SNKI_DEV void decode_chunk(const u8 *comp, u64 nbytes, Chunk &ck, u16 *syms_all, MemberEnd *ends_all, Tables &T, Scratch &S, u32 *cl_tab,
+                           Coop *co = nullptr) {
     ck.n_syms = 0; ck.status = INF_OK; ck.end_bit = ck.start_bit; ck.known_from = 0xFFFFFFFFu; ck.n_ends = 0; ck.stream_end = 0;
     if (ck.start_bit == ~0ull) { ck.status = INF_NOT_STARTED; return; }
-    u16 *const out = syms_all + ck.out_off;
+    Out o;
+    o.out = syms_all + ck.out_off; o.n = 0; o.flushed = 0; o.co = co;
+    if (co) { co->ob_n = 0; co->ring_lo = co->ring_end = 0; }
     const u32 cap = ck.out_cap;
-    u32 n = 0;
     u32 known_from = ck.first_of_member ? 0u : 0xFFFFFFFFu;
     Bits b;
-    bits_init(b, comp, nbytes, ck.start_bit);
+    bits_init(b, comp, nbytes, ck.start_bit, co);
     for (;;) {
         // ---- block header
         const u64 at = bitpos(b);
@@ -339,12 +460,11 @@ SNKI_DEV void decode_chunk(const u8 *comp, u64 nbytes, Chunk &ck, u16 *syms_all,
             refill(b);
             const u32 len = take(b, 16), nlen = take(b, 16);
             if ((len ^ 0xFFFFu) != nlen) { ck.status = INF_BAD; break; }
-            if (n + len > cap) { ck.status = INF_FULL; break; }
-            u64 p = bitpos(b) >> 3;
+            if (o.n + len > cap) { ck.status = INF_FULL; break; }
+            const u64 p = bitpos(b) >> 3;
             if (p + len > nbytes) { ck.status = INF_BAD; break; }
-            for (u32 i = 0; i < len; ++i) out[n + i] = comp[p + i];
-            n += len;
-            bits_init(b, comp, nbytes, (p + len) * 8);
+            out_stored(o, comp, p, len);
+            bits_init(b, comp, nbytes, (p + len) * 8, co);
         } else {
             int nlit = 288, ndist = 32;
             if (type == 1) fixed_lengths(S);
@@ -354,16 +474,16 @@ SNKI_DEV void decode_chunk(const u8 *comp, u64 nbytes, Chunk &ck, u16 *syms_all,
             // ---- symbols
             bool bad = false, full = false;
             for (;;) {
-                if (n + 260 > cap) { full = true; break; }
+                if (o.n + 260 > cap) { full = true; break; }
                 refill(b);
                 u32 e = lookup(T.lit, LIT_ROOT, b);
                 u32 t = (e >> 8) & 15;
                 if (t == T_LIT) {
-                    out[n++] = (u16)(e >> 16);
+                    out_put(o, (u16)(e >> 16));
                     // a second literal from the same refill (56 bits cover two 15-bit codes and a length's extras)
                     e = lookup(T.lit, LIT_ROOT, b);
                     t = (e >> 8) & 15;
-                    if (t == T_LIT) { out[n++] = (u16)(e >> 16); continue; }
+                    if (t == T_LIT) { out_put(o, (u16)(e >> 16)); continue; }
                 }
                 if (t == T_EOB) break;
                 if (t != T_LEN) { bad = true; break; }
@@ -373,18 +493,9 @@ SNKI_DEV void decode_chunk(const u8 *comp, u64 nbytes, Chunk &ck, u16 *syms_all,
                 if (((de >> 8) & 15) != T_DIST) { bad = true; break; }
                 const u32 dist = (de >> 16) + take(b, (int)((de >> 12) & 15));
                 if (known_from != 0xFFFFFFFFu) {
-                    if (dist > n - known_from) { bad = true; break; }          // reaches in front of its member: zlib's "too far back"
-                    for (u32 i = 0; i < len; ++i) out[n + i] = out[n + i - dist];
-                } else if (dist <= n) {
-                    for (u32 i = 0; i < len; ++i) out[n + i] = out[n + i - dist];
-                } else {
-                    if (dist > (u32)WIN) { bad = true; break; }
-                    for (u32 i = 0; i < len; ++i) {
-                        const long src = (long)n + (long)i - (long)dist;
-                        out[n + i] = src < 0 ? (u16)(256 + WIN + src) : out[src];
-                    }
-                }
-                n += len;
+                    if (dist > o.n - known_from) { bad = true; break; }        // reaches in front of its member: zlib's "too far back"
+                } else if (dist > o.n && dist > (u32)WIN) { bad = true; break; }
+                out_match(o, len, dist);
             }
             if (b.bc < 0 || past_end(b)) bad = true;
             if (bad) { ck.status = INF_BAD; break; }
@@ -397,18 +508,19 @@ SNKI_DEV void decode_chunk(const u8 *comp, u64 nbytes, Chunk &ck, u16 *syms_all,
             if (p + 8 > nbytes) { ck.status = INF_BAD; break; }
             if (ck.n_ends == ck.ends_cap) { ck.status = INF_TOO_MANY_MEMBERS; break; }
             MemberEnd &m = ends_all[ck.ends_off + ck.n_ends++];
-            m.sym_index = n;
+            m.sym_index = o.n;
             m.crc = (u32)comp[p] | ((u32)comp[p + 1] << 8) | ((u32)comp[p + 2] << 16) | ((u32)comp[p + 3] << 24);
             m.isize = (u32)comp[p + 4] | ((u32)comp[p + 5] << 8) | ((u32)comp[p + 6] << 16) | ((u32)comp[p + 7] << 24);
-            bits_init(b, comp, nbytes, (p + 8) * 8);
+            bits_init(b, comp, nbytes, (p + 8) * 8, co);
             ck.end_bit = (p + 8) * 8;
             if (p + 8 >= nbytes) { ck.stream_end = 1; break; }
             if (!gzip_header(b)) { ck.status = INF_BAD; break; }
-            known_from = n;
-            ck.known_from = n;
+            known_from = o.n;
+            ck.known_from = o.n;
         }
     }
-    ck.n_syms = n;
+    out_flush(o);
+    ck.n_syms = o.n;
 }
 
 // ---------------------------------------------------------------- windows and markers

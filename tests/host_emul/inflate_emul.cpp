@@ -8,6 +8,19 @@
 
 using namespace snkinf;
 
+// the wave-cooperative I/O of the decoder (Coop: LDS ring for the input, LDS buffer + lane-parallel copies for the output), lanes
+// emulated in turn; snk_emul_set_coop(1) selects it for every decode below
+static int g_coop = 0;
+static uint8_t g_ring[2 * HALF];
+static u16 g_ob[OBCAP];
+extern "C" void snk_emul_set_coop(int on) { g_coop = on; }
+static Coop *coop() {
+    static Coop c;
+    if (!g_coop) return nullptr;
+    c.ring = g_ring; c.ob = g_ob; c.ring_lo = c.ring_end = 0; c.ob_n = 0;
+    return &c;
+}
+
 // returns the number of bytes produced, or -(1000 + code) ; info[0] = chunks decoded, info[1] = chunks whose start was found by
 // the search, info[2] = markers resolved, info[3] = members seen
 extern "C" long snk_emul_gunzip(const uint8_t *gz, size_t n, size_t chunk_bytes, uint8_t *out, size_t out_cap, long *info, long ends_cap) {
@@ -53,7 +66,7 @@ extern "C" long snk_emul_gunzip(const uint8_t *gz, size_t n, size_t chunk_bytes,
         std::vector<MemberEnd> ends((size_t)ends_cap);
         ck[c].ends_off = 0;
         ck[c].ends_cap = (u32)ends_cap;
-        decode_chunk(comp.data(), n, ck[c], syms.data(), ends.data(), T, S, cl_tab);
+        decode_chunk(comp.data(), n, ck[c], syms.data(), ends.data(), T, S, cl_tab, coop());
         if (ck[c].status != INF_OK) return -(1000 + 10 * (long)ck[c].status + 3);
         ++decoded;
         members += ck[c].n_ends;
@@ -129,7 +142,7 @@ struct EmulBackend : snk::DgBackend {
             ck[c].ends_cap = epc;
             if (start[c] != ~0ull) next = start[c];
         }
-        for (uint32_t c = 0; c < nc; ++c) decode_chunk(comp.data(), nbytes, ck[c], syms.data(), (MemberEnd *)ends, T, S, cl_tab);   // inf_decode_kernel
+        for (uint32_t c = 0; c < nc; ++c) decode_chunk(comp.data(), nbytes, ck[c], syms.data(), (MemberEnd *)ends, T, S, cl_tab, coop());   // inf_decode_kernel
         memcpy(chunks, ck.data(), nc * sizeof(Chunk));
         return true;
     }

@@ -28,7 +28,17 @@ def emul():
     lib.snk_emul_gunzip.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_long), C.c_long]
     lib.snk_emul_gunzip.restype = C.c_long
     lib.snk_emul_probe.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
+    lib.snk_emul_set_coop.argtypes = [C.c_int]
     return lib
+
+
+@pytest.fixture(params=[0, 1], ids=["one_thread_io", "wave_cooperative_io"])
+def io_mode(emul, request):
+    """the decoder's two I/O forms: plain loads / stores of one thread, and the wavefront-cooperative one (LDS input ring, LDS
+    symbol buffer, lane-parallel flushes and match copies; the 64 lanes emulated in turn)"""
+    emul.snk_emul_set_coop(request.param)
+    yield request.param
+    emul.snk_emul_set_coop(0)
 
 
 def _gunzip(lib, blob, chunk, cap, ends_cap=64):
@@ -58,7 +68,7 @@ def _vectors():
     return files
 
 
-def test_chunked_marker_decoding_is_zlibs_bytes(emul):
+def test_chunked_marker_decoding_is_zlibs_bytes(emul, io_mode):
     total_markers = 0
     for name, (blob, raw) in _vectors().items():
         assert zlib.decompress(blob, 47) == raw[:len(zlib.decompress(blob, 47))] or name in ("multi", "many_members")
@@ -85,7 +95,7 @@ def test_block_start_probe_finds_zlibs_blocks_and_little_else(emul):
     assert got == raw and info[1] >= len(blob) // (1 << 16) - 1   # a start was found in (nearly) every 64 KiB chunk
 
 
-def test_damaged_streams_are_errors_or_zlibs_bytes(emul):
+def test_damaged_streams_are_errors_or_zlibs_bytes(emul, io_mode):
     """bit flips anywhere in the deflate data: the decoder refuses exactly what zlib's inflate refuses, and where zlib decodes
     (the damage only changed bytes: CRC-32 / ISIZE, which the caller checks, would catch it) it produces zlib's bytes"""
     raw = _fastq_bytes(3000)
@@ -138,7 +148,7 @@ def dg(emul):
     return emul
 
 
-def test_device_gunzip_orchestration_windows_chains_and_fallbacks(dg):
+def test_device_gunzip_orchestration_windows_chains_and_fallbacks(dg, io_mode):
     """DeviceGunzip: windows of several sizes (a window's last chunk is cut by the window and decoded again by the next), chunks
     whose symbol slots overflow and BGZF-like files with more members per chunk than slots (both: sequential host decoder from the
     last good block), empty and tiny files -- always zlib's bytes"""
