@@ -39,6 +39,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <map>
 #include <vector>
 
 #include "../../include/snk_filter.h"
@@ -487,6 +488,14 @@ public:
 };
 Pool g_pool;
 int g_host_threads = 1;
+// a child of a sharded run (run_sharded in main): its record range per input file, the global index of its first pair
+struct ShardEnv {
+    bool child = false;
+    int g = 0, G = 1;
+    uint64_t first = 0;
+    std::map<string, std::pair<size_t, size_t>> range;     // input path -> [lo, hi) bytes
+    string stats_path;
+} g_shard;
 
 // CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota (a container with 256
 // visible hardware threads and a quota of 16 CPUs only gets slower with more than 16 busy threads)
@@ -815,12 +824,16 @@ void reader_plain_count(const string path, int batch, int workers, Channel<RawCh
     if (fd < 0) die("cannot open file," + path);
     struct stat st;
     fstat(fd, &st);
-    const size_t size = (size_t)st.st_size;
+    size_t size = (size_t)st.st_size;
     const char *base = (const char *)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (base == MAP_FAILED) die("cannot map file," + path);
     madvise((void *)base, size, MADV_SEQUENTIAL);
     const size_t want = (size_t)batch * 4;
     size_t pos = 0;
+    {   // a shard of a sharded run (main: sharded ingest): whole records [lo, hi) of this file
+        auto it = g_shard.range.find(path);
+        if (it != g_shard.range.end()) { pos = it->second.first; size = std::min(size, it->second.second); }
+    }
     double per_line = 100.0;
     std::vector<NlPiece> pieces;
     while (pos < size) {
@@ -1318,6 +1331,72 @@ size_t rmdup_cache_budget() {
     return avail > 0 ? (size_t)(avail * 0.4) : 0;
 }
 
+// ---------------------------------------------------------------- sharded ingest / egress (--devices a,b,...)
+// Plain-text input and several devices: one child process per device takes the g-th contiguous range of RECORDS of the input
+// (byte ranges cut at record boundaries: the parent counts the newlines of both files once, in parallel), runs the ordinary
+// single-device pipeline on it with the global index of its first pair (the virtual reference threads of appendix C are a function
+// of that index), writes its own ordered part files and dumps its statistics blocks; the parent concatenates the parts in rank
+// order -- the trick of the reference's per-thread temporaries, src/peprocess.cpp:2386 -- adds the blocks up and writes the
+// reports.  Readers, writers and PCIe streams scale with the devices instead of feeding all of them from one reader and one writer.
+struct ShardStatsHeader { uint64_t magic; int32_t T, lcap, nq, pad; uint64_t clean_total; };
+const uint64_t SHARD_MAGIC = 0x534E4B5348415244ull;      // "SNKSHARD"
+
+// the newlines of a plain FASTQ file counted once (in parallel, 1 MB pieces), then any record's byte offset
+struct RecordIndex {
+    const char *base = nullptr;
+    size_t size = 0;
+    uint64_t n_records = 0;
+    static constexpr size_t W = (size_t)1 << 30;          // windows of 1 GB: the piece offsets are per window
+    std::vector<uint64_t> wcount;                          // newlines up to the end of window w
+    std::vector<std::vector<NlPiece>> wpieces;
+    void open_and_count(const string &path, int workers) {
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) die("cannot open file," + path);
+        struct stat st;
+        fstat(fd, &st);
+        size = (size_t)st.st_size;
+        base = (const char *)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (base == MAP_FAILED) die("cannot map file," + path);
+        close(fd);
+        uint64_t lines = 0;
+        for (size_t a = 0; a < size; a += W) {
+            std::vector<NlPiece> pieces;
+            lines += count_pieces(base + a, 0, std::min(size, a + W) - a, workers, pieces);
+            wcount.push_back(lines);
+            wpieces.push_back(std::move(pieces));
+        }
+        if (size && base[size - 1] != '\n') ++lines;
+        if (lines % 4) die("truncated fastq record");
+        n_records = lines / 4;
+    }
+    uint64_t offset_of(uint64_t rec) const {               // where record number rec starts
+        const uint64_t want = rec * 4;                     // behind this many newlines
+        if (want == 0) return 0;
+        if (rec >= n_records) return size;
+        size_t w = 0;
+        while (wcount[w] < want) ++w;
+        return (uint64_t)w * W + locate_nl(base + w * W, wpieces[w], (size_t)(want - (w ? wcount[w - 1] : 0)));
+    }
+    void done() { if (base) munmap((void *)base, size); base = nullptr; }
+};
+
+void append_file(int out_fd, const string &part) {
+    const int fd = open(part.c_str(), O_RDONLY);
+    if (fd < 0) die("cannot open such file," + part);
+    std::vector<char> buf((size_t)8 << 20);
+    for (;;) {
+        const ssize_t n = read(fd, buf.data(), buf.size());
+        if (n < 0) die("read error," + part);
+        if (n == 0) break;
+        for (ssize_t w = 0; w < n;) {
+            const ssize_t k = write(out_fd, buf.data() + w, (size_t)(n - w));
+            if (k <= 0) die("write error (disk full?)");
+            w += k;
+        }
+    }
+    close(fd);
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -1328,6 +1407,7 @@ int main(int argc, char **argv) {
     parse_args(argc, argv, o);
     const int mates = o.p.paired ? 2 : 1;
     mkdir(o.out_dir.c_str(), 0755);
+    if (const char *e = getenv("SNK_SHARD")) o.log += string(".shard") + std::to_string(atoi(e));      // (a shard of a sharded run keeps its own log)
     std::ofstream log(o.log.c_str());
     if (!log) die("cannot open such file," + o.log);
     log << local_time() << "\tAnalysis start!" << endl;
@@ -1340,6 +1420,111 @@ int main(int argc, char **argv) {
     const int B = o.batch_pairs, T = o.threads, WK = ht;
     const string inputs[2] = {o.fq1, o.fq2};
     { struct stat st; for (int m = 0; m < mates; ++m) if (stat(inputs[m].c_str(), &st) != 0 || st.st_size == 0) die("cannot open file or empty file," + inputs[m]); }
+    // ---- sharded ingest / egress: am I a shard, or shall I start the shards?
+    if (const char *e = getenv("SNK_SHARD")) {
+        unsigned long long lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0, first = 0;
+        if (sscanf(e, "%d/%d", &g_shard.g, &g_shard.G) != 2 || !getenv("SNK_SHARD_RANGE1") || sscanf(getenv("SNK_SHARD_RANGE1"), "%llu,%llu", &lo1, &hi1) != 2 ||
+            (mates == 2 && (!getenv("SNK_SHARD_RANGE2") || sscanf(getenv("SNK_SHARD_RANGE2"), "%llu,%llu", &lo2, &hi2) != 2)) ||
+            !getenv("SNK_SHARD_FIRST") || sscanf(getenv("SNK_SHARD_FIRST"), "%llu", &first) != 1 || !getenv("SNK_SHARD_STATS") ||
+            g_shard.g < 0 || g_shard.g >= g_shard.G || (size_t)g_shard.G != o.devices.size())
+            die("bad SNK_SHARD environment");
+        g_shard.child = true;
+        g_shard.first = first;
+        g_shard.range[o.fq1] = {(size_t)lo1, (size_t)hi1};
+        if (mates == 2) g_shard.range[o.fq2] = {(size_t)lo2, (size_t)hi2};
+        g_shard.stats_path = getenv("SNK_SHARD_STATS");
+        o.devices = std::vector<int>(1, o.devices[(size_t)g_shard.g]);
+        o.clean1 += ".part" + std::to_string(g_shard.g);
+        if (mates == 2) o.clean2 += ".part" + std::to_string(g_shard.g);
+    }
+    // (opt-in until it has met the hardware: SNK_SHARDED=1; without it several devices are fed batch by batch from one reader)
+    const bool shardable = !g_shard.child && o.devices.size() > 1 && getenv("SNK_SHARDED") && !strcmp(getenv("SNK_SHARDED"), "1") &&
+                           !is_gzip_file(o.fq1) && (mates == 1 || !is_gzip_file(o.fq2)) && !o.streaming && !o.p.rmdup && o.trim_fq[0].empty() &&
+                           o.clean_out_split == 0 && !(o.total_reads > 0) && o.out_file_type != "fasta" && !o.index_remove && o.tile.empty() && o.fov.empty() &&
+                           !getenv("SNK_HOST_TEXT");
+    if (shardable) {
+        const int G = (int)o.devices.size();
+        std::vector<uint64_t> rec((size_t)G + 1), off[2];
+        RecordIndex ri[2];
+        for (int m = 0; m < mates; ++m) ri[m].open_and_count(inputs[m], ht);
+        if (mates == 2 && ri[0].n_records != ri[1].n_records) die("reads number in fq1 and fq2 are different");
+        const uint64_t nrec[2] = {ri[0].n_records, ri[1].n_records};
+        if (nrec[0] >= (uint64_t)G * 4096) {
+            for (int g = 0; g <= G; ++g) rec[(size_t)g] = nrec[0] * (uint64_t)g / (uint64_t)G;
+            for (int m = 0; m < mates; ++m) { off[m].resize((size_t)G + 1); for (int g = 0; g <= G; ++g) off[m][(size_t)g] = ri[m].offset_of(rec[(size_t)g]); ri[m].done(); }
+            log << local_time() << "\tsharded run: " << G << " shards of about " << nrec[0] / (uint64_t)G << (mates == 2 ? " pairs" : " reads") << endl;
+            std::vector<pid_t> kids((size_t)G, 0);
+            for (int g = 0; g < G; ++g) {
+                std::vector<string> env;
+                for (char **e = environ; *e; ++e) env.push_back(*e);
+                env.push_back("SNK_SHARD=" + std::to_string(g) + "/" + std::to_string(G));
+                env.push_back("SNK_SHARD_RANGE1=" + std::to_string(off[0][(size_t)g]) + "," + std::to_string(off[0][(size_t)g + 1]));
+                if (mates == 2) env.push_back("SNK_SHARD_RANGE2=" + std::to_string(off[1][(size_t)g]) + "," + std::to_string(off[1][(size_t)g + 1]));
+                env.push_back("SNK_SHARD_FIRST=" + std::to_string(rec[(size_t)g]));
+                env.push_back("SNK_SHARD_STATS=" + o.out_dir + "/shard." + std::to_string(g) + ".stats");
+                env.push_back("SNK_HOST_THREADS=" + std::to_string(std::max(2, ht / G)));
+                std::vector<char *> envp;
+                for (auto &x : env) envp.push_back(const_cast<char *>(x.c_str()));
+                envp.push_back(nullptr);
+                if (posix_spawn(&kids[(size_t)g], "/proc/self/exe", nullptr, nullptr, argv, envp.data()) != 0) die("cannot start a shard");
+            }
+            int worst = 0;
+            for (int g = 0; g < G; ++g) {
+                int status = 0;
+                if (waitpid(kids[(size_t)g], &status, 0) != kids[(size_t)g] || !WIFEXITED(status)) worst = std::max(worst, 1);
+                else worst = std::max(worst, WEXITSTATUS(status));
+            }
+            if (worst) _exit(worst);                          // (the shard has printed the reference's message)
+            // the parts in rank order (gzip members concatenate legally, as the reference's per-thread temporaries do)
+            const string names[2] = {o.clean1, o.clean2};
+            for (int m = 0; m < mates; ++m) {
+                const string fin = o.out_dir + "/" + names[m];
+                const int fd = open(fin.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+                if (fd < 0) die("cannot write to the file," + fin);
+                for (int g = 0; g < G; ++g) {
+                    const string part = fin + ".part" + std::to_string(g);
+                    append_file(fd, part);
+                    unlink(part.c_str());
+                }
+                close(fd);
+            }
+            // the statistics blocks of the shards, virtual thread by virtual thread
+            const int T_ = o.threads;
+            int lfin = 0, nq_ = 0;
+            std::vector<ShardStatsHeader> hd((size_t)G);
+            std::vector<std::vector<uint64_t>> blob((size_t)G);
+            for (int g = 0; g < G; ++g) {
+                const string sp_ = o.out_dir + "/shard." + std::to_string(g) + ".stats";
+                FILE *f = fopen(sp_.c_str(), "rb");
+                if (!f || fread(&hd[(size_t)g], sizeof(ShardStatsHeader), 1, f) != 1 || hd[(size_t)g].magic != SHARD_MAGIC || hd[(size_t)g].T != T_) die("cannot read such file," + sp_);
+                const size_t words = (size_t)T_ * ((size_t)snk_stats_u64(hd[(size_t)g].lcap, hd[(size_t)g].nq) + SNK_MAX_N);
+                blob[(size_t)g].resize(words);
+                if (fread(blob[(size_t)g].data(), 8, words, f) != words) die("cannot read such file," + sp_);
+                fclose(f);
+                unlink(sp_.c_str());
+                unlink((o.log + ".shard" + std::to_string(g)).c_str());
+                lfin = std::max(lfin, (int)hd[(size_t)g].lcap);
+                nq_ = hd[(size_t)g].nq;
+            }
+            std::vector<std::vector<uint64_t>> sums((size_t)T_, std::vector<uint64_t>((size_t)snk_stats_u64(lfin, nq_), 0)), maxs((size_t)T_, std::vector<uint64_t>(SNK_MAX_N, 0));
+            std::vector<const uint64_t *> sp((size_t)T_), mp((size_t)T_);
+            for (int g = 0; g < G; ++g) {
+                const size_t ns = (size_t)snk_stats_u64(hd[(size_t)g].lcap, hd[(size_t)g].nq);
+                for (int t = 0; t < T_; ++t) {
+                    widen_add(blob[(size_t)g].data() + (size_t)t * ns, hd[(size_t)g].lcap, sums[(size_t)t].data(), lfin, nq_);
+                    const uint64_t *mx = blob[(size_t)g].data() + (size_t)T_ * ns + (size_t)t * SNK_MAX_N;
+                    for (int k = 0; k < SNK_MAX_N; ++k) maxs[(size_t)t][(size_t)k] = std::max(maxs[(size_t)t][(size_t)k], mx[k]);
+                }
+            }
+            for (int t = 0; t < T_; ++t) { sp[(size_t)t] = sums[(size_t)t].data(); mp[(size_t)t] = maxs[(size_t)t].data(); }
+            char ebuf[512];
+            o.p.max_read_len = lfin;
+            if (snk_write_reports(&o.p, T_, sp.data(), mp.data(), o.out_dir.c_str(), ebuf, sizeof ebuf) != 0) { cerr << ebuf << endl; _exit(1); }
+            log << local_time() << "\tAnalysis accomplished!" << endl;
+            log.close();
+            _exit(0);
+        }
+    }
     const int space_num = first_line_space_num(o.fq1);
     char bc_from = 0, bc_to = 0;                          // baseConvert "TtoU" / "T2U" / "TU" (src/peprocess.cpp:1629-1646)
     if (!o.base_convert.empty()) {
@@ -1419,7 +1604,7 @@ int main(int argc, char **argv) {
             for (int i = 0; i < c[m]->n; ++i) { int l; c[m]->line(4 * i + 1, l); mx = std::max(mx, l); }
         return mx;
     };
-    phred_sanity(o, *first[0]);
+    if (!g_shard.child || g_shard.g == 0) phred_sanity(o, *first[0]);       // (the reference looks at the first patch of the file only)
 
     // one context + one set of batch slots per device; one accumulator per virtual reference thread
     //  and device.  A run is a sequence of epochs of constant capacity (normally one).
@@ -2076,7 +2261,7 @@ int main(int argc, char **argv) {
         }
     });
 
-    uint64_t total = 0, batch_no = 0;
+    uint64_t total = g_shard.first, batch_no = 0;         // (a shard: the global index of its first pair)
     RawChunk *c[2] = {first[0], first[1]};
     bool have = true;
     if (dev_text) {
@@ -2426,6 +2611,18 @@ int main(int argc, char **argv) {
         }
         sp[t] = sums[t].data();
         mp[t] = maxs[t].data();
+    }
+    if (g_shard.child) {                                  // a shard: its blocks go to the parent, which writes the reports
+        FILE *f = fopen(g_shard.stats_path.c_str(), "wb");
+        ShardStatsHeader h{SHARD_MAGIC, T, lfin, nq, 0, clean_total};
+        bool ok = f && fwrite(&h, sizeof h, 1, f) == 1;
+        for (int t = 0; t < T && ok; ++t) ok = fwrite(sums[(size_t)t].data(), 8, sums[(size_t)t].size(), f) == sums[(size_t)t].size();
+        for (int t = 0; t < T && ok; ++t) ok = fwrite(maxs[(size_t)t].data(), 8, (size_t)SNK_MAX_N, f) == (size_t)SNK_MAX_N;
+        if (!ok || fclose(f) != 0) die("cannot write to the file," + g_shard.stats_path);
+        log.close();
+        cout.flush();
+        fflush(stdout);
+        _exit(0);
     }
     if (o.total_reads > 0 && !o.total_head) extract_every_kth(o, mates, clean_total);
     char ebuf[512];
