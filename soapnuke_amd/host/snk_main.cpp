@@ -1436,6 +1436,27 @@ int main(int argc, char **argv) {
         o.devices = std::vector<int>(1, o.devices[(size_t)g_shard.g]);
         o.clean1 += ".part" + std::to_string(g_shard.g);
         if (mates == 2) o.clean2 += ".part" + std::to_string(g_shard.g);
+        if (getenv("SNK_SHARD_FAKE")) {
+            // test hook (tests/test_shard_plumbing.py, no GPU): the shard copies its record range to its part files and reports empty
+            // statistics -- what is left is exactly the parent's work: record boundaries, environment, concatenation, merging
+            const string names[2] = {o.clean1, o.clean2};
+            for (int m = 0; m < mates; ++m) {
+                const auto r = g_shard.range[m ? o.fq2 : o.fq1];
+                const int fd = open((m ? o.fq2 : o.fq1).c_str(), O_RDONLY);
+                std::vector<char> buf(r.second - r.first);
+                if (fd < 0 || pread(fd, buf.data(), buf.size(), (off_t)r.first) != (ssize_t)buf.size()) die("fake shard: read error");
+                close(fd);
+                FILE *f = fopen((o.out_dir + "/" + names[m]).c_str(), "wb");
+                if (!f || fwrite(buf.data(), 1, buf.size(), f) != buf.size() || fclose(f) != 0) die("fake shard: write error");
+            }
+            const int lc = 150, nqf = o.p.max_base_quality + 1;
+            ShardStatsHeader h{SHARD_MAGIC, o.threads, lc, nqf, 0, 0};
+            std::vector<uint64_t> z((size_t)o.threads * ((size_t)snk_stats_u64(lc, nqf) + SNK_MAX_N), 0);
+            z[(size_t)SNK_FS_N + SNK_GS_READS] = (uint64_t)(g_shard.first + 1);         // (something to add up: raw1 reads of virtual thread 0)
+            FILE *f = fopen(g_shard.stats_path.c_str(), "wb");
+            if (!f || fwrite(&h, sizeof h, 1, f) != 1 || fwrite(z.data(), 8, z.size(), f) != z.size() || fclose(f) != 0) die("fake shard: stats");
+            _exit(0);
+        }
     }
     // (opt-in until it has met the hardware: SNK_SHARDED=1; without it several devices are fed batch by batch from one reader)
     const bool shardable = !g_shard.child && o.devices.size() > 1 && getenv("SNK_SHARDED") && !strcmp(getenv("SNK_SHARDED"), "1") &&
