@@ -56,14 +56,14 @@ __global__ void __launch_bounds__(64) inf_decode_kernel(const u8 *comp, u64 nbyt
 
 // The same with the whole wavefront at work: all 64 lanes run the decoder in lockstep on the same values (its tables, header
 // workspace and decisions are uniform), and share the I/O -- compressed bytes through an LDS ring refilled 1 KB at a time by all
-// lanes, symbols through an LDS buffer flushed by all lanes, matches copied 64 symbols at a time (snk_inflate_core.cuh, Coop).
-// A lane on its own pays a global-memory round trip per bit-buffer refill and per copied symbol.
+// lanes, matches queued and copied 64 at a time, one per lane (snk_inflate_core.cuh, Coop).  A lane on its own pays a global-memory
+// round trip per bit-buffer refill and per copied symbol: gzip turns the base lines of FASTQ into ~40 short matches per read.
 __global__ void __launch_bounds__(64) inf_decode_coop_kernel(const u8 *comp, u64 nbytes, Chunk *chunks, u16 *syms, MemberEnd *ends) {
     __shared__ WaveSpace W;
     __shared__ __attribute__((aligned(16))) u8 ring[2 * HALF];
-    __shared__ u16 ob[OBCAP];
+    __shared__ u32 qdst[QCAP], qinfo[QCAP];
     Coop co;
-    co.ring = ring; co.ob = ob; co.ring_lo = co.ring_end = 0; co.ob_n = 0;
+    co.ring = ring; co.qdst = qdst; co.qinfo = qinfo; co.ring_lo = co.ring_end = 0; co.qn = 0; co.q_first = 0;
     Chunk ck = chunks[blockIdx.x];
     decode_chunk(comp, nbytes, ck, syms, ends, W.T, W.S, W.cl_tab, &co);
     if (threadIdx.x == 0) chunks[blockIdx.x] = ck;

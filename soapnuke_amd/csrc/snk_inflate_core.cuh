@@ -58,23 +58,26 @@ struct Scratch { u8 lens[320]; u16 count[16], offs[16]; u16 sorted[288]; u8 subm
 // ---------------------------------------------------------------- wave-cooperative I/O (optional)
 // The plain form of the decoder is one thread that loads its input from global memory and stores every symbol there.  On the GPU
 // a chunk is decoded by a whole wavefront whose 64 lanes run the same (uniform) code; with a Coop they share the I/O: the compressed
-// bytes come through a 2 KB ring in LDS that all lanes refill with 16-byte loads, symbols collect in an LDS buffer that all lanes
-// flush with coalesced stores, and matches are copied 64 elements at a time.  SNKI_LANES(lane): the statement runs for this lane on
-// the device and for lanes 0..63 in turn on the host (the emulation), where every lane-parallel step below is written so that its
-// iterations do not depend on each other.
+// bytes come through a 2 KB ring in LDS that all lanes refill with 16-byte loads, and matches are copied 64 at a time, one per lane.
+// SNKI_LANES(lane): the statement runs for this lane on the device and for the 64 lanes in turn on the host (the emulation) -- in
+// DESCENDING order, so that a lane-parallel step whose lanes did depend on each other would show (ascending order is the
+// sequential order, in which everything is right).
 #if defined(__HIPCC__)
 #define SNKI_LANES(lane) for (int lane = (int)(threadIdx.x & 63), once_ = 1; once_; once_ = 0)
 #define SNKI_FENCE() __threadfence_block()
 #else
-#define SNKI_LANES(lane) for (int lane = 0; lane < 64; ++lane)
+#define SNKI_LANES(lane) for (int lane = 63; lane >= 0; --lane)
 #define SNKI_FENCE() ((void)0)
 #endif
-enum { HALF = 1024, OBCAP = 1024 };
+enum { HALF = 1024, QCAP = 64 };
 struct Coop {
     u8 *ring;                 // LDS, 2 * HALF bytes: compressed bytes [ring_lo, ring_end), byte p at ring[p % (2 * HALF)]
     u64 ring_lo, ring_end;    // multiples of HALF, ring_end - ring_lo <= 2 * HALF
-    u16 *ob;                  // LDS, OBCAP symbols not yet in global memory
-    u32 ob_n;
+    // matches wait in a queue and are copied QCAP at a time, one per lane (a copy is a chain of global-memory round trips -- gzip
+    // encodes DNA mostly as 3..5-symbol matches at distances all over the window -- and 64 chains in flight hide them); literals
+    // are stored at once.  A match whose source reaches into the region the queue still has to fill makes the queue run first.
+    u32 *qdst, *qinfo;        // LDS, QCAP words each: destination index; distance | length << 16
+    u32 qn, q_first;          // queued matches; the destination of the oldest of them
 };
 
 // ---------------------------------------------------------------- bit input
@@ -365,57 +368,48 @@ SNKI_DEV bool gzip_header(Bits &b) {
 }
 
 // ---------------------------------------------------------------- the chunk
-// symbol output: straight to global memory, or through a Coop's LDS buffer
+// symbol output: one thread stores and copies in order; a Coop queues the matches (see there)
 struct Out {
     u16 *out;                 // the chunk's symbol slots
-    u32 n;                    // symbols so far
-    u32 flushed;              // ... of which in global memory (Coop)
+    u32 n;                    // symbols so far (queued matches included)
     Coop *co;
 };
-SNKI_DEV void out_flush(Out &o) {
-    if (!o.co || o.co->ob_n == 0) return;
+SNKI_DEV u16 match_sym(const u16 *out, long src) { return src < 0 ? (u16)(256 + WIN + src) : out[src]; }     // in front of the chunk: a marker
+SNKI_DEV void out_flush(Out &o) {                      // runs the queued matches, one per lane
+    if (!o.co || o.co->qn == 0) return;
     Coop &c = *o.co;
+    SNKI_FENCE();                                      // the literals and earlier copies the sources may be (other lanes' stores)
     SNKI_LANES(lane) {
-        for (u32 k = (u32)lane; k < c.ob_n; k += 64) o.out[o.flushed + k] = c.ob[k];
+        if ((u32)lane < c.qn) {
+            const u32 dst = c.qdst[lane], dist = c.qinfo[lane] & 0xFFFFu, len = c.qinfo[lane] >> 16;
+            const long first = (long)dst - (long)(dist ? dist : 65536u);
+            for (u32 i = 0; i < len; ++i) o.out[dst + i] = match_sym(o.out, first + (long)(i % (dist ? dist : 65536u)));
+        }
     }
-    o.flushed += c.ob_n;
-    c.ob_n = 0;
-    SNKI_FENCE();                                      // later matches read these symbols back (other lanes' stores)
+    SNKI_FENCE();
+    c.qn = 0;
 }
 SNKI_DEV void out_put(Out &o, u16 v) {
     if (o.co) {
-        o.co->ob[o.co->ob_n++] = v;
+        SNKI_LANES(lane) { if (lane == 0) o.out[o.n] = v; }
         ++o.n;
-        if (o.co->ob_n == OBCAP) out_flush(o);
     } else {
         o.out[o.n++] = v;
     }
 }
-// a match of len symbols at distance dist; sources in front of the chunk (index < 0) become markers
+// a match of len symbols at distance dist (<= 32768: 0 in the 16-bit field stands for 65536 and never occurs)
 SNKI_DEV void out_match(Out &o, u32 len, u32 dist) {
     const long first = (long)o.n - (long)dist;
     if (o.co) {
         Coop &c = *o.co;
-        if (c.ob_n + len > OBCAP) out_flush(o);
-        const u32 at = c.ob_n;
-        SNKI_LANES(lane) {
-            for (u32 i = (u32)lane; i < len; i += 64) {
-                const long src = first + (long)(i % dist);            // (i % dist: an overlapping match repeats its first dist symbols)
-                u16 v;
-                if (src < 0) v = (u16)(256 + WIN + src);
-                else if ((u32)src >= o.flushed) v = c.ob[(u32)src - o.flushed];
-                else v = o.out[src];
-                c.ob[at + i] = v;
-            }
-        }
-        c.ob_n += len;
+        if (c.qn && first + (long)len > (long)c.q_first) out_flush(o);        // its source reaches into what the queue has yet to write
+        if (c.qn == 0) c.q_first = o.n;
+        SNKI_LANES(lane) { if (lane == 0) { c.qdst[c.qn] = o.n; c.qinfo[c.qn] = dist | (len << 16); } }
+        ++c.qn;
         o.n += len;
-        if (c.ob_n == OBCAP) out_flush(o);
+        if (c.qn == QCAP) out_flush(o);
     } else {
-        for (u32 i = 0; i < len; ++i) {
-            const long src = first + (long)i;
-            o.out[o.n + i] = src < 0 ? (u16)(256 + WIN + src) : o.out[src];
-        }
+        for (u32 i = 0; i < len; ++i) o.out[o.n + i] = match_sym(o.out, first + (long)i);
         o.n += len;
     }
 }
@@ -423,11 +417,9 @@ SNKI_DEV void out_stored(Out &o, const u8 *comp, u64 p, u32 len) {
     if (o.co) {
         out_flush(o);
         SNKI_LANES(lane) {
-            for (u32 i = (u32)lane; i < len; i += 64) o.out[o.flushed + i] = comp[p + i];
+            for (u32 i = (u32)lane; i < len; i += 64) o.out[o.n + i] = comp[p + i];
         }
-        o.flushed += len;
         o.n += len;
-        SNKI_FENCE();
     } else {
         for (u32 i = 0; i < len; ++i) o.out[o.n + i] = comp[p + i];
         o.n += len;
@@ -441,8 +433,8 @@ SNKI_DEV void decode_chunk(const u8 *comp, u64 nbytes, Chunk &ck, u16 *syms_all,
     ck.n_syms = 0; ck.status = INF_OK; ck.end_bit = ck.start_bit; ck.known_from = 0xFFFFFFFFu; ck.n_ends = 0; ck.stream_end = 0;
     if (ck.start_bit == ~0ull) { ck.status = INF_NOT_STARTED; return; }
     Out o;
-    o.out = syms_all + ck.out_off; o.n = 0; o.flushed = 0; o.co = co;
-    if (co) { co->ob_n = 0; co->ring_lo = co->ring_end = 0; }
+    o.out = syms_all + ck.out_off; o.n = 0; o.co = co;
+    if (co) { co->qn = 0; co->q_first = 0; co->ring_lo = co->ring_end = 0; }
     const u32 cap = ck.out_cap;
     u32 known_from = ck.first_of_member ? 0u : 0xFFFFFFFFu;
     Bits b;

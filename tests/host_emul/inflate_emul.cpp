@@ -12,12 +12,12 @@ using namespace snkinf;
 // emulated in turn; snk_emul_set_coop(1) selects it for every decode below
 static int g_coop = 0;
 static uint8_t g_ring[2 * HALF];
-static u16 g_ob[OBCAP];
+static u32 g_qdst[QCAP], g_qinfo[QCAP];
 extern "C" void snk_emul_set_coop(int on) { g_coop = on; }
 static Coop *coop() {
     static Coop c;
     if (!g_coop) return nullptr;
-    c.ring = g_ring; c.ob = g_ob; c.ring_lo = c.ring_end = 0; c.ob_n = 0;
+    c.ring = g_ring; c.qdst = g_qdst; c.qinfo = g_qinfo; c.ring_lo = c.ring_end = 0; c.qn = 0; c.q_first = 0;
     return &c;
 }
 
