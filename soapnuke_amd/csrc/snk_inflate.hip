@@ -62,8 +62,9 @@ __global__ void __launch_bounds__(64) inf_decode_coop_kernel(const u8 *comp, u64
     __shared__ WaveSpace W;
     __shared__ __attribute__((aligned(16))) u8 ring[2 * HALF];
     __shared__ u32 qdst[QCAP], qinfo[QCAP];
+    __shared__ u16 hist[HS];
     Coop co;
-    co.ring = ring; co.qdst = qdst; co.qinfo = qinfo; co.ring_lo = co.ring_end = 0; co.qn = 0; co.q_first = 0;
+    co.ring = ring; co.hist = hist; co.qdst = qdst; co.qinfo = qinfo; co.ring_lo = co.ring_end = 0; co.qn = 0; co.q_first = 0;
     Chunk ck = chunks[blockIdx.x];
     decode_chunk(comp, nbytes, ck, syms, ends, W.T, W.S, W.cl_tab, &co);
     if (threadIdx.x == 0) chunks[blockIdx.x] = ck;

@@ -69,13 +69,18 @@ struct Scratch { u8 lens[320]; u16 count[16], offs[16]; u16 sorted[288]; u8 subm
 #define SNKI_LANES(lane) for (int lane = 63; lane >= 0; --lane)
 #define SNKI_FENCE() ((void)0)
 #endif
-enum { HALF = 1024, QCAP = 64 };
+enum { HALF = 1024, QCAP = 64, HS = 4096, NEAR_MAX = HS - 258, SPAN_MAX = HS - 2 * 258 };
 struct Coop {
     u8 *ring;                 // LDS, 2 * HALF bytes: compressed bytes [ring_lo, ring_end), byte p at ring[p % (2 * HALF)]
     u64 ring_lo, ring_end;    // multiples of HALF, ring_end - ring_lo <= 2 * HALF
-    // matches wait in a queue and are copied QCAP at a time, one per lane (a copy is a chain of global-memory round trips -- gzip
-    // encodes DNA mostly as 3..5-symbol matches at distances all over the window -- and 64 chains in flight hide them); literals
-    // are stored at once.  A match whose source reaches into the region the queue still has to fill makes the queue run first.
+    // gzip turns FASTQ into short matches (tools/inflate_stats.py: 82 matches of 3.8 symbols and 14 literals per read at level 1, 52 of
+    // 5.4 and 46 at level 6) whose copies are chains of memory round trips.  The last HS symbols are kept in LDS: a NEAR match
+    // (distance <= NEAR_MAX: 71 % at level 1, 37 % at level 6) is copied there at once, lane-parallel.  A FAR match waits in a queue
+    // and the queue is copied QCAP matches at a time, one per lane, from global memory -- 64 chains in flight hide the round trips,
+    // and decoding does not wait for them (the Huffman stream does not depend on the output).  The queue runs early when a near
+    // match wants a symbol a queued match has yet to produce (the lanes compare their match with the new source range), and before
+    // it spans SPAN_MAX symbols (a far source then never lies inside it).
+    u16 *hist;                // LDS, HS symbols: symbol i at hist[i % HS] (unknown while a queued match owns it)
     u32 *qdst, *qinfo;        // LDS, QCAP words each: destination index; distance | length << 16
     u32 qn, q_first;          // queued matches; the destination of the oldest of them
 };
@@ -368,46 +373,107 @@ SNKI_DEV bool gzip_header(Bits &b) {
 }
 
 // ---------------------------------------------------------------- the chunk
-// symbol output: one thread stores and copies in order; a Coop queues the matches (see there)
+// symbol output: one thread stores and copies in order; a Coop copies near matches in LDS and queues the far ones (see there)
 struct Out {
     u16 *out;                 // the chunk's symbol slots
     u32 n;                    // symbols so far (queued matches included)
     Coop *co;
 };
-SNKI_DEV u16 match_sym(const u16 *out, long src) { return src < 0 ? (u16)(256 + WIN + src) : out[src]; }     // in front of the chunk: a marker
-SNKI_DEV void out_flush(Out &o) {                      // runs the queued matches, one per lane
+SNKI_DEV u16 marker_of(long src) { return (u16)(256 + WIN + src); }          // src < 0: in front of the chunk
+SNKI_DEV u16 match_sym(const u16 *out, long src) { return src < 0 ? marker_of(src) : out[src]; }
+#if !defined(__HIPCC__)
+struct HostStats { unsigned long long literals, matches, match_syms, flush_conflict, flush_full, dist_lt[8], near; };   // dist_lt[k]: matches nearer than 256 << k
+inline HostStats &host_stats() { static HostStats h; return h; }
+#define SNKI_STAT(x) (host_stats().x)
+#endif
+SNKI_DEV void out_flush(Out &o) {                      // runs the queued (far) matches, one per lane
     if (!o.co || o.co->qn == 0) return;
     Coop &c = *o.co;
-    SNKI_FENCE();                                      // the literals and earlier copies the sources may be (other lanes' stores)
+    SNKI_FENCE();                                      // the literals and earlier copies the sources are (other lanes' stores)
     SNKI_LANES(lane) {
         if ((u32)lane < c.qn) {
             const u32 dst = c.qdst[lane], dist = c.qinfo[lane] & 0xFFFFu, len = c.qinfo[lane] >> 16;
-            const long first = (long)dst - (long)(dist ? dist : 65536u);
-            for (u32 i = 0; i < len; ++i) o.out[dst + i] = match_sym(o.out, first + (long)(i % (dist ? dist : 65536u)));
+            const long first = (long)dst - (long)dist;
+            for (u32 i = 0; i < len; ++i) {
+                const u16 v = match_sym(o.out, first + (long)(i % dist));
+                o.out[dst + i] = v;
+                c.hist[(dst + i) & (HS - 1)] = v;      // (the queue spans less than HS symbols: the slot is still this symbol's)
+            }
         }
     }
     SNKI_FENCE();
     c.qn = 0;
 }
+// does a queued match have to produce a symbol of [a, b) ?
+SNKI_DEV bool queue_owns(const Coop &c, long a, long b) {
+    bool hit = false;
+#if defined(__HIPCC__)
+    const u32 lane = threadIdx.x & 63;
+    bool mine = false;
+    if (lane < c.qn) { const long d = (long)c.qdst[lane], e = d + (long)(c.qinfo[lane] >> 16); mine = d < b && a < e; }
+    hit = __any(mine);
+#else
+    for (u32 k = 0; k < c.qn; ++k) { const long d = (long)c.qdst[k], e = d + (long)(c.qinfo[k] >> 16); hit = hit || (d < b && a < e); }
+#endif
+    return hit;
+}
 SNKI_DEV void out_put(Out &o, u16 v) {
+#if !defined(__HIPCC__)
+    ++SNKI_STAT(literals);
+#endif
     if (o.co) {
-        SNKI_LANES(lane) { if (lane == 0) o.out[o.n] = v; }
+        SNKI_LANES(lane) { if (lane == 0) { o.out[o.n] = v; o.co->hist[o.n & (HS - 1)] = v; } }
         ++o.n;
+        if (o.co->qn && o.n - o.co->q_first > (u32)SPAN_MAX) out_flush(o);     // (the queue never spans more than the history holds)
     } else {
         o.out[o.n++] = v;
     }
 }
-// a match of len symbols at distance dist (<= 32768: 0 in the 16-bit field stands for 65536 and never occurs)
+// a match of len symbols at distance dist (1..32768)
 SNKI_DEV void out_match(Out &o, u32 len, u32 dist) {
     const long first = (long)o.n - (long)dist;
     if (o.co) {
         Coop &c = *o.co;
-        if (c.qn && first + (long)len > (long)c.q_first) out_flush(o);        // its source reaches into what the queue has yet to write
-        if (c.qn == 0) c.q_first = o.n;
-        SNKI_LANES(lane) { if (lane == 0) { c.qdst[c.qn] = o.n; c.qinfo[c.qn] = dist | (len << 16); } }
-        ++c.qn;
-        o.n += len;
-        if (c.qn == QCAP) out_flush(o);
+#if !defined(__HIPCC__)
+        ++SNKI_STAT(matches); SNKI_STAT(match_syms) += len;
+        for (int k = 0; k < 8; ++k) if (dist < (256u << k)) ++SNKI_STAT(dist_lt[k]);
+#endif
+        if (dist <= (u32)NEAR_MAX) {
+            // near: from the LDS history, at once -- unless a queued match still owes one of the source symbols
+            const u32 used = len < dist ? len : dist;                          // (an overlapping match repeats its first dist symbols)
+            if (c.qn && first + (long)used > (long)c.q_first && queue_owns(c, first, first + (long)used)) {
+#if !defined(__HIPCC__)
+                ++SNKI_STAT(flush_conflict);
+#endif
+                out_flush(o);
+            }
+#if !defined(__HIPCC__)
+            ++SNKI_STAT(near);
+#endif
+            SNKI_LANES(lane) {
+                for (u32 i = (u32)lane; i < len; i += 64) {
+                    const long src = first + (long)(i % dist);
+                    const u16 v = src < 0 ? marker_of(src) : c.hist[(u32)src & (HS - 1)];
+                    o.out[o.n + i] = v;
+                    c.hist[(o.n + i) & (HS - 1)] = v;                          // (dist <= HS - len: no source slot is a destination slot)
+                }
+            }
+            o.n += len;
+        } else {
+            // far: queued; its source lies in front of everything queued (distance > NEAR_MAX, span <= SPAN_MAX) -- checked all the same
+            if (c.qn && first + (long)(len < dist ? len : dist) > (long)c.q_first) out_flush(o);
+            if (c.qn == 0) c.q_first = o.n;
+            SNKI_LANES(lane) { if (lane == 0) { c.qdst[c.qn] = o.n; c.qinfo[c.qn] = dist | (len << 16); } }
+            ++c.qn;
+            o.n += len;
+            if (c.qn == QCAP || o.n - c.q_first > (u32)SPAN_MAX) {
+#if !defined(__HIPCC__)
+                ++SNKI_STAT(flush_full);
+#endif
+                out_flush(o);
+            }
+        }
+        if (c.qn && o.n - c.q_first > (u32)SPAN_MAX) out_flush(o);             // (literals and near matches lengthen the span too)
     } else {
         for (u32 i = 0; i < len; ++i) o.out[o.n + i] = match_sym(o.out, first + (long)i);
         o.n += len;
@@ -417,7 +483,10 @@ SNKI_DEV void out_stored(Out &o, const u8 *comp, u64 p, u32 len) {
     if (o.co) {
         out_flush(o);
         SNKI_LANES(lane) {
-            for (u32 i = (u32)lane; i < len; i += 64) o.out[o.n + i] = comp[p + i];
+            for (u32 i = (u32)lane; i < len; i += 64) {
+                o.out[o.n + i] = comp[p + i];
+                if (i + HS >= len) o.co->hist[(o.n + i) & (HS - 1)] = comp[p + i];      // (the last HS of them)
+            }
         }
         o.n += len;
     } else {

@@ -13,11 +13,12 @@ using namespace snkinf;
 static int g_coop = 0;
 static uint8_t g_ring[2 * HALF];
 static u32 g_qdst[QCAP], g_qinfo[QCAP];
+static u16 g_hist[HS];
 extern "C" void snk_emul_set_coop(int on) { g_coop = on; }
 static Coop *coop() {
     static Coop c;
     if (!g_coop) return nullptr;
-    c.ring = g_ring; c.qdst = g_qdst; c.qinfo = g_qinfo; c.ring_lo = c.ring_end = 0; c.qn = 0; c.q_first = 0;
+    c.ring = g_ring; c.hist = g_hist; c.qdst = g_qdst; c.qinfo = g_qinfo; c.ring_lo = c.ring_end = 0; c.qn = 0; c.q_first = 0;
     return &c;
 }
 
@@ -183,4 +184,12 @@ extern "C" long snk_emul_dgunzip(const uint8_t *gz, size_t n, size_t window, uin
     if (info) { info[0] = (long)z.windows(); info[1] = z.fallback_bit() == ~0ull ? -1 : (long)z.fallback_bit(); info[2] = be.decodes; }
     if (z.error()) { if (errbuf && errcap) { strncpy(errbuf, z.error(), errcap - 1); errbuf[errcap - 1] = 0; } return -1; }
     return (long)got;
+}
+
+extern "C" void snk_emul_stats(unsigned long long *out5, int reset) {
+    HostStats &h = host_stats();
+    out5[0] = h.literals; out5[1] = h.matches; out5[2] = h.match_syms; out5[3] = h.flush_conflict; out5[4] = h.flush_full;
+    for (int k = 0; k < 8; ++k) out5[5 + k] = h.dist_lt[k];
+    out5[13] = h.near;
+    if (reset) h = HostStats();
 }
