@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include <zlib.h>
@@ -27,7 +29,7 @@ struct DgBackend {
     virtual ~DgBackend() {}
     virtual bool decode(const uint8_t *comp, uint64_t nbytes, uint64_t first_bit, bool first_of_member, snk_gunzip_chunk *chunks, snk_gunzip_member *ends) = 0;
     virtual bool resolve(const uint32_t *order, uint32_t k, const uint8_t *win_in, uint8_t *text, uint64_t text_bytes, uint8_t *win_out) = 0;
-    virtual uint8_t *text_buffer(size_t bytes) = 0;       // at least `bytes` (pinned memory on the device backend, grown on demand); owned by the backend
+    virtual uint8_t *text_buffer(int slot, size_t bytes) = 0;   // slot 0 / 1: at least `bytes` (pinned memory on the device backend, grown on demand); owned by the backend
     virtual std::string error() = 0;
 };
 
@@ -44,21 +46,49 @@ public:
         // the first member's header (the later ones are followed on the device)
         if (!member_header_at(0, pos_bit_)) { seq_from_start(); return; }
         first_of_member_ = true;
+        producer_ = std::thread([this] { produce(); });
     }
+    ~DeviceGunzip() {
+        { std::lock_guard<std::mutex> l(m_); quit_ = true; }
+        cv_.notify_all();
+        if (producer_.joinable()) producer_.join();
+    }
+    DeviceGunzip(const DeviceGunzip &) = delete;
+    DeviceGunzip &operator=(const DeviceGunzip &) = delete;
     const char *error() const { return err_.empty() ? nullptr : err_.c_str(); }
     bool done() const { return done_; }
     uint64_t windows() const { return windows_; }
     uint64_t fallback_bit() const { return fallback_bit_; }            // ~0: the device decoded everything
 
+    // The windows are made by a producer thread one ahead of the reader (two text slots): the device decodes window k + 1 while
+    // window k is consumed.
     size_t run(uint8_t *out, size_t cap) {
         size_t got = 0;
         while (got < cap && !done_ && err_.empty()) {
             if (seq_) { got += seq_run(out + got, cap - got); continue; }
-            if (t_off_ == t_have_ && !next_window()) continue;
-            const size_t k = std::min(cap - got, (size_t)(t_have_ - t_off_));
-            memcpy(out + got, text_ + t_off_, k);
+            if (!cur_) {                                     // the next full slot, or the end of what the producer makes
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return slot_[cons_].full || finished_; });
+                if (slot_[cons_].full) { cur_ = &slot_[cons_]; t_off_ = 0; }
+                else {                                       // the producer is through: an error, the end, or the hand-over to the host decoder
+                    l.unlock();
+                    if (producer_.joinable()) producer_.join();
+                    if (!perr_.empty()) { err_ = perr_; break; }
+                    if (want_seq_) { start_sequential(); continue; }
+                    done_ = true;
+                    break;
+                }
+            }
+            const size_t k = std::min(cap - got, (size_t)(cur_->have - t_off_));
+            memcpy(out + got, cur_->text + t_off_, k);
             got += k;
             t_off_ += k;
+            if (t_off_ == cur_->have) {
+                { std::lock_guard<std::mutex> l(m_); cur_->full = false; }
+                cv_.notify_all();
+                cur_ = nullptr;
+                cons_ ^= 1;
+            }
         }
         return got;
     }
@@ -73,8 +103,17 @@ private:
     std::vector<snk_gunzip_chunk> chunks_;
     std::vector<snk_gunzip_member> ends_;
     std::vector<uint32_t> order_;
-    uint8_t *text_ = nullptr;
-    uint64_t t_have_ = 0, t_off_ = 0;
+    struct Slot { uint8_t *text = nullptr; uint64_t have = 0; bool full = false; };
+    Slot slot_[2];
+    Slot *cur_ = nullptr;                      // (consumer) the slot being read
+    int cons_ = 0;
+    uint64_t t_off_ = 0;
+    uint8_t *text_ = nullptr;                  // (producer) the slot being filled
+    std::thread producer_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    bool quit_ = false, finished_ = false, want_seq_ = false;
+    std::string perr_;                         // the producer's error, handed over with finished_
     uint64_t pos_bit_ = 0;                     // the next block header of the stream
     bool first_of_member_ = false, stream_done_ = false;
     bool done_ = false, seq_ = false;
@@ -131,18 +170,44 @@ private:
         mlen_ += hi - lo;
     }
     bool end_member(uint32_t want_crc, uint32_t want_isize) {
-        if (member_checkable_ && (mcrc_ != want_crc || (uint32_t)mlen_ != want_isize)) { fail("invalid gzip data (CRC-32 / length of a member)"); return false; }
+        if (member_checkable_ && (mcrc_ != want_crc || (uint32_t)mlen_ != want_isize)) {
+            if (seq_) fail("invalid gzip data (CRC-32 / length of a member)"); else pfail("invalid gzip data (CRC-32 / length of a member)");
+            return false;
+        }
         mcrc_ = 0; mlen_ = 0; member_checkable_ = true;
         return true;
     }
 
-    bool next_window() {
-        if (stream_done_) { done_ = true; return false; }
+    // producer thread: windows into the two slots until the stream ends, an error, or the hand-over to the sequential decoder
+    void produce() {
+        int p = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return !slot_[p].full || quit_; });
+                if (quit_) break;
+            }
+            uint64_t have = 0;
+            const bool ok = !stream_done_ && next_window(p, have);
+            std::lock_guard<std::mutex> l(m_);
+            if (ok) { slot_[p].text = text_; slot_[p].have = have; slot_[p].full = true; }
+            else finished_ = true;
+            cv_.notify_all();
+            if (!ok) break;
+            p ^= 1;
+        }
+        std::lock_guard<std::mutex> l(m_);
+        finished_ = true;
+        cv_.notify_all();
+    }
+    void pfail(const std::string &m) { if (perr_.empty()) perr_ = m; }
+
+    bool next_window(int slot, uint64_t &have) {
         const uint64_t wb = (pos_bit_ >> 3) & ~3ull;
         const uint64_t nbytes = std::min<uint64_t>(g_.window_bytes, n_ - wb);
         const uint64_t first = pos_bit_ - wb * 8;
         const uint32_t nc = (uint32_t)((nbytes + g_.chunk_bytes - 1) / g_.chunk_bytes);
-        if (!be_->decode(in_ + wb, nbytes, first, first_of_member_, chunks_.data(), ends_.data())) { to_sequential(); return false; }
+        if (!be_->decode(in_ + wb, nbytes, first, first_of_member_, chunks_.data(), ends_.data())) { want_seq_ = true; return false; }
         ++windows_;
         // the chain: chunks whose start is where the one before stopped
         order_.clear();
@@ -160,11 +225,11 @@ private:
         }
         // a chunk that ran into the end of the WINDOW (not of the file) reports invalid data and is decoded again by the next
         // window; a window that yields nothing at all cannot make progress
-        if (order_.empty()) { to_sequential(); return false; }
-        text_ = be_->text_buffer((size_t)text_bytes + 64);      // (grown on demand: pinning gigabytes up front costs a second)
-        if (!text_) { to_sequential(); return false; }
+        if (order_.empty()) { want_seq_ = true; return false; }
+        text_ = be_->text_buffer(slot, (size_t)text_bytes + 64);      // (grown on demand: pinning gigabytes up front costs a second)
+        if (!text_) { want_seq_ = true; return false; }
         std::vector<uint8_t> wout(HIST);
-        if (!be_->resolve(order_.data(), (uint32_t)order_.size(), first_of_member_ ? nullptr : win_.data(), text_, text_bytes, wout.data())) { to_sequential(); return false; }
+        if (!be_->resolve(order_.data(), (uint32_t)order_.size(), first_of_member_ ? nullptr : win_.data(), text_, text_bytes, wout.data())) { want_seq_ = true; return false; }
         // members that ended in this window: CRC-32 and ISIZE over the text
         uint64_t at = 0, from = 0;
         for (uint32_t c : order_) {
@@ -179,18 +244,17 @@ private:
         }
         add_text(from, at);
         win_.swap(wout);
-        t_have_ = text_bytes;
-        t_off_ = 0;
+        have = text_bytes;
         pos_bit_ = wb * 8 + expect;
         // where the next window starts: inside a member, unless the last chunk ended exactly behind a member header
         const snk_gunzip_chunk &last = chunks_[order_.back()];
         first_of_member_ = last.known_from != 0xFFFFFFFFu && last.known_from == last.n_syms;
-        if (at_file_end) { stream_done_ = true; if (mlen_ != 0) { fail("device inflate: text behind the last member"); return false; } }
+        if (at_file_end) { stream_done_ = true; if (mlen_ != 0) { pfail("device inflate: text behind the last member"); return false; } }
         return true;
     }
 
     // ---- sequential host decoder from the block header at pos_bit_ on (the rest of the stream)
-    void to_sequential() {
+    void start_sequential() {                  // (the producer has ended: its state -- position, window, CRC so far -- is the reader's now)
         fallback_bit_ = pos_bit_;
         if (getenv("SNK_PGZ_DEBUG")) fprintf(stderr, "device inflate: sequential from bit %llu (%s)\n", (unsigned long long)pos_bit_, be_->error().c_str());
         seq_ = true;

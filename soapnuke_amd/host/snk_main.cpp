@@ -690,15 +690,16 @@ void index_chunk(RawChunk *c, int space_num, int workers) {
 // either the host's parallel decoder or the device one -- same bytes, same errors
 struct HipGunzipBackend : snk::DgBackend {
     snk_gunzip *g = nullptr;
-    uint8_t *pinned = nullptr;
-    size_t pinned_cap = 0;
+    uint8_t *pinned[2] = {nullptr, nullptr};       // two text slots: one served to the parser while the next window is decoded
+    size_t pinned_cap[2] = {0, 0};
     string err;
-    HipGunzipBackend(int device, const snk::DeviceGunzip::Geometry &geo) {
+    int device_ = 0;
+    HipGunzipBackend(int device, const snk::DeviceGunzip::Geometry &geo) : device_(device) {
         g = snk_gunzip_create(device, geo.window_bytes, geo.chunk_bytes, geo.syms_per_chunk, geo.ends_per_chunk);
         if (!g) err = snk_last_error();
     }
     ~HipGunzipBackend() override {
-        if (pinned) (void)hipHostFree(pinned);
+        for (int s = 0; s < 2; ++s) if (pinned[s]) (void)hipHostFree(pinned[s]);
         snk_gunzip_destroy(g);
     }
     bool decode(const uint8_t *comp, uint64_t nbytes, uint64_t first_bit, bool first_of_member, snk_gunzip_chunk *chunks, snk_gunzip_member *ends) override {
@@ -710,16 +711,17 @@ struct HipGunzipBackend : snk::DgBackend {
         if (snk_gunzip_resolve(g, order, k, win_in, text, text_bytes, win_out) != SNK_OK) { err = snk_last_error(); return false; }
         return true;
     }
-    uint8_t *text_buffer(size_t bytes) override {
-        if (bytes > pinned_cap) {
-            if (pinned) (void)hipHostFree(pinned);
-            pinned = nullptr;
-            pinned_cap = 0;
+    uint8_t *text_buffer(int slot, size_t bytes) override {
+        if (bytes > pinned_cap[slot]) {
+            if (pinned[slot]) (void)hipHostFree(pinned[slot]);
+            pinned[slot] = nullptr;
+            pinned_cap[slot] = 0;
             const size_t cap = bytes + bytes / 4;
-            if (hipHostMalloc((void **)&pinned, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); err = "cannot pin the text buffer"; return nullptr; }
-            pinned_cap = cap;
+            (void)hipSetDevice(device_);                 // (called on the decoder's producer thread)
+            if (hipHostMalloc((void **)&pinned[slot], cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); err = "cannot pin the text buffer"; return nullptr; }
+            pinned_cap[slot] = cap;
         }
-        return pinned;
+        return pinned[slot];
     }
     std::string error() override { return err; }
 };

@@ -107,7 +107,7 @@ extern "C" int snk_emul_probe(const uint8_t *gz, size_t n, uint64_t bit) {
 namespace {
 struct EmulBackend : snk::DgBackend {
     uint32_t chunk_bytes, spc, epc;
-    std::vector<uint8_t> comp, text;
+    std::vector<uint8_t> comp, text, text1;
     std::vector<u16> syms;
     std::vector<Chunk> ck;
     std::string err;
@@ -164,7 +164,7 @@ struct EmulBackend : snk::DgBackend {
         memcpy(win_out, w.data(), WIN);
         return true;
     }
-    uint8_t *text_buffer(size_t bytes) override { if (text.size() < bytes) text.assign(bytes, 0); return text.data(); }
+    uint8_t *text_buffer(int slot, size_t bytes) override { auto &t = slot ? text1 : text; if (t.size() < bytes) t.assign(bytes, 0); return t.data(); }
     std::string error() override { return err; }
 };
 }  // namespace
@@ -193,3 +193,35 @@ extern "C" void snk_emul_stats(unsigned long long *out5, int reset) {
     out5[13] = h.near;
     if (reset) h = HostStats();
 }
+
+#ifdef SNK_EMUL_MAIN
+// Stand-alone runner for the sanitizer builds (tests/test_sanitizers.py): file.gz file.raw window chunk_bytes syms_per_chunk
+//   exit 0 + "IDENTICAL", 2 + "ERROR <text>" for a stream the decoder refuses, 1 for a difference.
+#include <fstream>
+#include <iterator>
+static std::vector<uint8_t> slurp(const char *p) {
+    std::ifstream f(p, std::ios::binary);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+int main(int argc, char **argv) {
+    if (argc < 6) { fprintf(stderr, "usage: %s file.gz file.raw window chunk_bytes syms_per_chunk\n", argv[0]); return 64; }
+    const std::vector<uint8_t> gz = slurp(argv[1]), want = slurp(argv[2]);
+    const size_t window = (size_t)atol(argv[3]);
+    const uint32_t chunk = (uint32_t)atol(argv[4]), spc = (uint32_t)atol(argv[5]);
+    {   // a reader that walks away after the first bytes: the producer is inside a window or waiting for a slot
+        EmulBackend be;
+        be.chunk_bytes = chunk; be.spc = spc; be.epc = 16;
+        snk::DeviceGunzip z(gz.data(), gz.size(), &be, snk::DeviceGunzip::Geometry{window, chunk, spc, 16}, 3);
+        uint8_t few[100];
+        (void)z.run(few, sizeof few);
+    }
+    std::vector<uint8_t> out(want.size() + 64);
+    long info[4] = {0, 0, 0, 0};
+    char err[256] = "";
+    const long r = snk_emul_dgunzip(gz.data(), gz.size(), window, chunk, spc, 16, out.data(), want.size() + 32, info, err, sizeof err);
+    if (r < 0) { printf("ERROR %s\n", err); return 2; }
+    if ((size_t)r != want.size() || memcmp(out.data(), want.data(), want.size()) != 0) { printf("DIFFERENT (%ld of %zu bytes)\n", r, want.size()); return 1; }
+    printf("IDENTICAL windows=%ld fallback=%ld decodes=%ld\n", info[0], info[1], info[2]);
+    return 0;
+}
+#endif

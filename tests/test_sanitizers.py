@@ -72,3 +72,22 @@ print('ASAN_RUN_OK')
     r = subprocess.run(["python", "-c", code], capture_output=True,
                        env=dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1 print_stacktrace=1"))
     assert r.returncode == 0 and b"ASAN_RUN_OK" in r.stdout, (r.stdout[-300:], r.stderr[-2500:])
+
+
+def test_device_inflate_orchestration_under_tsan(tmp_path):
+    """The producer thread of host/snk_dgunzip.h (window k + 1 decoded while window k is read; two text slots, the threaded CRC,
+    the hand-over to the sequential decoder, a reader that walks away early) with ThreadSanitizer, CPU backend"""
+    exe = str(tmp_path / "dgz_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-sanitize-recover=all", "-w", "-DSNK_EMUL_MAIN",
+                           "-I" + os.path.join(T.ROOT, "soapnuke_amd", "csrc"), "-x", "c++", "inflate_emul.cpp", "-o", exe, "-lz", "-pthread"], cwd=EMUL)
+    raw = _fastq_bytes(6000)
+    blob = gzip.compress(raw[:500000], 1) + gzip.compress(raw[500000:], 6)
+    open(str(tmp_path / "b.gz"), "wb").write(blob)
+    open(str(tmp_path / "b.raw"), "wb").write(raw)
+    open(str(tmp_path / "d.gz"), "wb").write(blob[:len(blob) * 2 // 3] + b"\x55" * 64)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1")
+    for window, chunk, spc in ((1 << 22, 1 << 16, 1 << 20), (200000, 1 << 16, 1 << 20), (1 << 22, 1 << 16, 90000)):
+        r = subprocess.run([exe, str(tmp_path / "b.gz"), str(tmp_path / "b.raw"), str(window), str(chunk), str(spc)], capture_output=True, env=env)
+        assert r.returncode == 0 and b"IDENTICAL" in r.stdout, (window, spc, r.stdout[-300:], r.stderr[-2500:])
+    r = subprocess.run([exe, str(tmp_path / "d.gz"), str(tmp_path / "b.raw"), "200000", "65536", "1048576"], capture_output=True, env=env)
+    assert r.returncode == 2 and b"ERROR" in r.stdout and b"Sanitizer" not in r.stderr, (r.stdout[-300:], r.stderr[-2500:])
