@@ -479,7 +479,7 @@ __device__ bool gcontam_bits_nb(const DevGContam &G, int d, const u32 (&X)[4][NW
 // conflicts.  NW = plane words (32 positions each); NW == 0: sequential matchers only (reads over 256 nt).
 template <int NW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SNK_CWAVES, SNK_CWAVES))) snk_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, int stride) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, sm)
     const DevParams &P = *Pp;
     const int pe = P.paired ? 1 : 0, tid = threadIdx.x;
     uint8_t *rows = sm;
@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SNK_CW
 // their offset: only the verdict is ever used, so a hit in any block is the hit.  One work-item per pair; reads shorter than a
 // contaminant and contaminants outside the bit paths take the sequential matchers on the read's row, per lane.
 __global__ void __launch_bounds__(256) snk_long_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, const u32 *planes, long ngroups, int nquads) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t sm[];
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, sm)
     const DevParams &P = *Pp;
     const int pe = P.paired ? 1 : 0, tid = threadIdx.x;
     DevContam *lct = reinterpret_cast<DevContam *>(sm);

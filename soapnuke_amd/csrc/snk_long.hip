@@ -93,7 +93,7 @@ __device__ __forceinline__ u64 wave_max64(u64 v) {
 template <int SEG>
 __global__ void __launch_bounds__(256)
 snk_long_prep_kernel(const DevParams *Pp, DevBatch B, int lcap, u32 *planes, long ngroups, int nquads) {
-    extern __shared__ u32 lds[];                                     // nquads * 5 KB: block (quad, plane) at (quad * 5 + plane) * 256, its cells XOR-skewed
+    HIP_DYNAMIC_SHARED(u32, lds)                                      // nquads * 5 KB: block (quad, plane) at (quad * 5 + plane) * 256, its cells XOR-skewed
                                                                      // by quad * 4: the 32 words of a read fall into the 32 banks (8 quads: 40 KB, 4 per CU)
     const DevParams &P = *Pp;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -392,7 +392,7 @@ snk_long_hist_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int
     // Three histograms: a kept read that nothing was cut from counts the same in the raw and the clean statistics -- it is added
     // once, to `both`; the other reads add their raw characters to `raw` and (kept, trimmed) their clean range to `clean`, in a
     // second step that most wavefronts skip.  raw = raw + both, clean = clean + both at the flush.
-    extern __shared__ u32 h[];                       // raw[(5 + nq + 1)][128] | both[...] | clean[...]
+    HIP_DYNAMIC_SHARED(u32, h)                        // raw[(5 + nq + 1)][128] | both[...] | clean[...]
     const int rows = 5 + nq, words = (rows + 1) * HPB;
     u32 *hraw = h, *hcl = h + 2 * words;
     int id = blockIdx.x;

@@ -93,7 +93,7 @@ struct HashArgs {
 // rows staged through LDS one mate at a time (pitch a multiple of 16, 16-byte aligned planes)
 template <bool PAIRED>
 __global__ void __launch_bounds__(256) snk_hash_lds_kernel(const HashArgs A, const int p2, const long tiles) {
-    extern __shared__ uint8_t smem[];
+    HIP_DYNAMIC_SHARED(uint8_t, smem)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;
     uint8_t *rows = smem + (size_t)wave * 64 * p2;              // [row][p2], mate 1 then mate 2
     const int upr = A.pitch >> 4;                               // 16-byte units per row

@@ -76,55 +76,10 @@ using namespace snk;
 
 #include "snk_adapter_bits.cuh"
 
-extern "C" __device__ int __snk_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+#include "snk_gfx950.cuh"      // the hand-placed instructions: LDS reads / adds / waits, the LDS DMA, v_writelane
 
 namespace {
 
-
-// clang exposes readlane but not writelane as a builtin; the LLVM intrinsic is bound above
-// (v_writelane_b32: uniform value -> one lane of a VGPR; per-read scalars and the rare fix-up pass use it).
-__device__ __forceinline__ int wl(int dst, int val, int lane) { return __snk_writelane(val, lane, dst); }
-__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-
-// Fire-and-forget LDS add with a compile-time offset.  Issued as inline asm on purpose: with a
-// global_load_lds (LDS DMA) in flight hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS
-// store/atomic it knows about, which would drain the prefetched chunk at the first histogram add
-// of every chunk.  The histogram words never overlap the staging buffers; the flush waits
-// lgkmcnt(0) explicitly before its barrier.  `addr` is an absolute LDS byte address.
-template <int OFF>
-__device__ __forceinline__ void lds_add_u32(u32 addr, u32 val) {
-    asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(addr), "v"(val), "n"(OFF));
-}
-typedef __attribute__((address_space(3))) u32 *lds_u32_ptr;
-// asynchronous LDS reads of one read's row: its bases and qualities as dwords (lane l: positions 4l..4l+3, for the
-// bit collectors) and its qualities once more as one byte per lane and 64-position strip (lane = position, for the
-// per-position histogram); pair with lds_wait
-template <int S, int E, int NS>                 // strips S .. E-1
-__device__ __forceinline__ void lds_read_qstrips(u32 (&q)[NS], u32 addrq) {
-    if constexpr (S < E) {
-        asm volatile("ds_read_u8 %0, %1 offset:%2" : "=&v"(q[S]) : "v"(addrq), "n"(64 * S));
-        lds_read_qstrips<S + 1, E>(q, addrq);
-    }
-}
-template <int S, int E, int BASE, int NS>              // strips S .. E-1 at immediate offsets BASE + 64 s
-__device__ __forceinline__ void lds_read_qstrips_at(u32 (&q)[NS], u32 addrq) {
-    if constexpr (S < E) {
-        asm volatile("ds_read_u8 %0, %1 offset:%2" : "=&v"(q[S]) : "v"(addrq), "n"(BASE + 64 * S));
-        lds_read_qstrips_at<S + 1, E, BASE>(q, addrq);
-    }
-}
-template <int OFF>
-__device__ __forceinline__ void lds_read_b32_at(u32 &d, u32 addr) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF)); }
-__device__ __forceinline__ void lds_read_b32(u32 &d, u32 addr) { asm volatile("ds_read_b32 %0, %1" : "=&v"(d) : "v"(addr)); }
-// wait until at most N LDS ops are outstanding; the registers of the (asm) reads being waited for
-// are tied to the wait so that no use can be scheduled above it
-template <int N, int NS>
-__device__ __forceinline__ void lds_wait(u32 &c4, u32 &q4, u32 (&q)[NS]) {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
-    asm volatile("" : "+v"(c4), "+v"(q4));
-#pragma unroll
-    for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(q[s]));
-}
 // 4 x 4 byte transpose: out[k] = bytes k of in[0..3] (8 v_perm)
 __device__ __forceinline__ void byte_tr4(u32 i0, u32 i1, u32 i2, u32 i3, u32 (&o)[4]) {
     const u32 t0 = __builtin_amdgcn_perm(i1, i0, 0x05010400u), t1 = __builtin_amdgcn_perm(i1, i0, 0x07030602u);
@@ -212,9 +167,6 @@ struct TileGeom {
 // LDS words behind the four histogram sets: 64 per-lane scratch words, 80 misc counters
 constexpr int SNK_LDS_TAIL = 64 + 80;
 
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
-typedef const __attribute__((address_space(1))) void *glb_ptr_t;
-
 // Static shape of the staged path: row pitch, bytes per staging array and reads per chunk known at compile time (the PE150 / PE250
 // batches of BASELINE configs[1..4]: pitch 160 / 256).  Every LDS read of phase 1 then is `base register + immediate` -- no address
 // arithmetic per read -- and the chunk bookkeeping (which read closes a chunk, which buffer a row sits in) folds away: 3 VALU,
@@ -290,7 +242,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         // slots of positions >= lcap, which are never flushed -> no validity masking of the histogram adds
         const bool fulllen = fixed && len0 == G.lcap && G.lcap >= 4;
         const u32 rawBw = (u32)((m * 2 + 0) * G.SET), rawQw = rawBw + (u32)G.WB;
-        const u32 lds0 = (u32)(uintptr_t)(lds_u32_ptr)lds;                   // absolute LDS address of the histograms
+        const u32 lds0 = SNK_LDS_ADDR(lds);                   // absolute LDS address of the histograms
         const u32 laneB = lds0 + (rawBw + (u32)lane) * 4u;                   // base bin row 0
         // quality rows: the character itself is clamped to [phred-1, phred+nq] -> rows -1 (underflow, the spare
         // sixth base row) .. nq (overflow); the flush reports both
@@ -322,7 +274,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         // after an odd read: the two packed quality sums cross the wave and land in the lanes of their reads
         auto sum_flush = [&](const int r) {
             int hm = FULL ? has_meanq : 0;
-            asm volatile("" : "+s"(hm));
+            SNK_OPAQUE_S(hm);
             if (FULL && hm != 0 && SNK_ABL != 16) {
                 const u32 tot = (u32)wave_sum((int)aS);
                 v_sumq = wl(v_sumq, (int)(tot & 0xFFFFu), r - 1);
@@ -357,7 +309,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     if (has_lqh) aA = (aA >> 1) | ((q4 + KA) & 0x80808080u);
                     if (has_lqt) aT = (aT >> 1) | ((q4 + KT) & 0x80808080u);
                     int hm = has_meanq;                // (the mean-quality filter selects the FULL variant)
-                    asm volatile("" : "+s"(hm));       // a plain scalar compare + branch per read (hoisted, the flag turns into lane masks)
+                    SNK_OPAQUE_S(hm);       // a plain scalar compare + branch per read (hoisted, the flag turns into lane masks)
                     if (hm != 0 && SNK_ABL != 16) {
                         // quality sum of the read (src/read_filter.cpp:299-308): v_sad_u8 adds this lane's four bytes, two reads share
                         // a dword (a read's characters sum to at most 256 * 255 < 2^16), one wave reduction per two reads; the Phred
@@ -379,10 +331,9 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     // reads with an s_nop (it has to assume a dst_sel forwarding hazard), three per read
                     u32 aQa;
                     if (FULLLEN && SNK_ABL != 11) {                // ... and the fire-and-forget add behind them
-                        asm volatile("v_med3_u32 %0, %1, %2, %3\n\tv_lshl_add_u32 %0, %0, %4, %5\n\tds_add_u32 %0, %6 offset:%7"
-                                     : "=&v"(aQa) : "v"(qb), "v"(qlo_v), "s"(qhi), "s"(lgb), "v"(laneQc), "v"((s & 1) ? 0x10000u : 1u), "n"(256 * (s >> 1)));
+                        aQa = clamp_row_addr_add<256 * (s >> 1)>(qb, qlo_v, qhi, lgb, laneQc, (s & 1) ? 0x10000u : 1u);
                     } else {
-                        asm("v_med3_u32 %0, %1, %2, %3\n\tv_lshl_add_u32 %0, %0, %4, %5" : "=&v"(aQa) : "v"(qb), "v"(qlo_v), "s"(qhi), "s"(lgb), "v"(laneQc));
+                        aQa = clamp_row_addr(qb, qlo_v, qhi, lgb, laneQc);
                         if (!FULLLEN) aQa = pos < len_r ? aQa : dumB - 256u * (s >> 1);
                         if (SNK_ABL == 11) { asm volatile("" ::"v"(aQa)); }
                         else lds_add_u32<256 * (s >> 1)>(aQa, (s & 1) ? 0x10000u : 1u);
@@ -436,9 +387,10 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     uint8_t *dst = stg + (k & 1) * 2 * cba;
                     int off = offF;
                     if (!(SS && CNT64) && (k + 1) * rb > cnt) off = min(lane * 16, (cnt - k * rb) * pitch - 16);     // last chunk of the last tile
+                    SNK_WAVE_SYNC();                       // (every lane has its rows of the buffer's previous chunk in registers)
                     if (SNK_ABL != 12 && dlane) {          // same instruction count every chunk (counted vmcnt below)
-                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gs + off), (lds_ptr_t)dst, 16, 0, 0);
-                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gq + off), (lds_ptr_t)(dst + cba), 16, 0, 0);
+                        dma_to_lds16(gs + off, dst);
+                        dma_to_lds16(gq + off, dst + cba);
                     }
                     gs += chunkB;
                     gq += chunkB;
@@ -466,8 +418,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 issue(0);
                 if (nchunks > 1) issue(1);
                 if (SNK_ABL != 14) {
-                    if (nchunks > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (nchunks > 1) vmem_wait<2>();
+                    else vmem_wait<0>();
                 }
                 auto lds_rd = [&](auto OD, u32 &c4, u32 &q4, u32 (&q)[NS], const u32 row) {
                     lds_read_b32(c4, row + lc4);
@@ -475,7 +427,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     const u32 a2 = row + l2;
                     if constexpr (PAIR) {
                         lds_read_qstrips<0, NS - 1>(q, row + l1);
-                        if constexpr (!decltype(OD)::value) asm volatile("ds_read_u8 %0, %1" : "=&v"(q[NS - 1]) : "v"(a2));
+                        if constexpr (!decltype(OD)::value) lds_read_u8(q[NS - 1], a2);
                     } else {
                         lds_read_qstrips<0, NS>(q, row + l1);
                     }
@@ -523,7 +475,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                                 constexpr bool closes = (R2 % RBs) == 0;               // read r+1 is the last of chunk k
                                 const int k = (8 * o) / RBs + R2 / RBs - 1;
                                 if constexpr (closes) {
-                                    if (k + 1 < nchunks && SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                    if (k + 1 < nchunks && SNK_ABL != 14) vmem_wait<0>();
                                 }
                                 constexpr int par = (R2 / RBs) & 1, rowi = R2 % RBs;
                                 lds_rd_s(IntC<par * 2 * (SS ? SH::CBA : 0) + rowi * (SS ? SH::PITCH : 0)>{}, C4[(j + 2) & 3], Q4[(j + 2) & 3], QS[(j + 2) & 3]);
@@ -542,7 +494,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                             const bool closes = j < 7 && ((evm >> ((j + 1) & 7)) & 1u);
                             const int k = ((r + 2) >> lgrb) - 1;
                             if (closes) {                   // row of read r+2 = row 0 of chunk k+1
-                                if (k + 1 < nchunks && SNK_ABL != 14) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                if (k + 1 < nchunks && SNK_ABL != 14) vmem_wait<0>();
                                 row = stgA + (u32)(((k + 1) & 1) * 2 * cba);
                             } else {
                                 row += (u32)pitch;
@@ -636,8 +588,10 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 byte_tr4(V[0], V[1], V[2], V[3], lo);
                 byte_tr4(V[4], V[5], V[6], V[7], hi);
                 v4u *dst = reinterpret_cast<v4u *>(scr + 32 * lane);
+                SNK_WAVE_SYNC();              // (the gathers of the rows written before are done ...
                 dst[0] = v4u{lo[0], hi[0], lo[1], hi[1]};
                 dst[1] = v4u{lo[2], hi[2], lo[3], hi[3]};
+                SNK_WAVE_SYNC();              //  ... and these rows are there for every lane of the wave)
             };
             auto gather = [&](const int s, u32 &w0, u32 &w1) {
                 const v2u v = *reinterpret_cast<const v2u *>(scr + 8 * (64 * s + lane));
@@ -775,10 +729,10 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     for (int j = 0; j < NW; ++j) LQT[j] = ~LQT[j];
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the scratch may be the next mate's DMA target
+            lds_wait_all();      // the scratch may be the next mate's DMA target
         }
         if ((SNK_ABL == 1 || SNK_ABL >= 11)) {
-            if (SNK_ABL == 14) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (SNK_ABL == 14) vmem_wait<0>();
 #pragma unroll
             for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(X[0][j]), "v"(X[1][j]), "v"(X[2][j]), "v"(X[3][j]), "v"(VP[j]), "v"(QP[j]));
             asm volatile("" ::"v"(v_sumq));
@@ -1007,7 +961,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         const u32 pk = (u32)R.len | ((u32)R.clen << 9) | ((u32)R.start << 18) | ((reason != SNK_KEEP ? 1u : 0u) << 27) |
                        ((R.n_n > 0 ? 1u : 0u) << 28);
         const uint8_t *seqt = seq + t0 * (long)B.pitch, *qualt = qual + t0 * (long)B.pitch;
-        const u32 lds0 = (u32)(uintptr_t)(lds_u32_ptr)lds;
+        const u32 lds0 = SNK_LDS_ADDR(lds);
         const u32 remBa = lds0 + ((u32)((m * 2 + 1) * G.SET) + (u32)lane) * 4u, remQa = remBa + (u32)G.WB * 4u;
         const u32 dumR = lds0 + ((u32)(4 * G.SET) + (u32)lane) * 4u;
         const u32 remQc = remQa - ((u32)phred << lgb);      // clamped character -> quality row, as in phase 1
@@ -1049,8 +1003,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                         constexpr int s = decltype(sc)::v;
                         const u32 c = cb[b][s];
-                        u32 qa;
-                        asm("v_med3_u32 %0, %1, %2, %3\n\tv_lshl_add_u32 %0, %0, %4, %5" : "=&v"(qa) : "v"(qb[b][s]), "v"(qlo_v), "s"(qhi), "s"(lgb), "v"(remQc));
+                        const u32 qa = clamp_row_addr(qb[b][s], qlo_v, qhi, lgb, remQc);
                         lds_add_u32<256 * (s >> 1)>(((c & 6u) << (lgb - 1)) + remBa, (s & 1) ? 0x10000u : 1u);
                         lds_add_u32<256 * (s >> 1)>(qa, (s & 1) ? 0x10000u : 1u);
                     });
@@ -1059,8 +1012,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     static_for(std::make_integer_sequence<int, NS>{}, [&](auto sc) {
                         constexpr int s = decltype(sc)::v;
                         const u32 c = cb[b][s];
-                        u32 qa;
-                        asm("v_med3_u32 %0, %1, %2, %3\n\tv_lshl_add_u32 %0, %0, %4, %5" : "=&v"(qa) : "v"(qb[b][s]), "v"(qlo_v), "s"(qhi), "s"(lgb), "v"(remQc));
+                        const u32 qa = clamp_row_addr(qb[b][s], qlo_v, qhi, lgb, remQc);
                         const bool inr = (u32)(64 * s + lane - rm_lo) < span;
                         const u32 aB = inr ? ((c & 6u) << (lgb - 1)) + remBa : dumR - 256u * (s >> 1);
                         const u32 aQ = inr ? qa : dumR - 256u * (s >> 1);
@@ -1097,7 +1049,7 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
                  const int flush_every) {
     // parameters travel by value in the kernarg segment: the compiler keeps them in SGPRs instead
     // of re-loading them from global memory next to every atomic
-    extern __shared__ u32 lds[];
+    HIP_DYNAMIC_SHARED(u32, lds)
     constexpr int NS = (NW + 1) / 2;
     const int lane = threadIdx.x & 63, W = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile index and addresses stay scalar
@@ -1119,7 +1071,7 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
         const int cnt = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
         if (cnt > 0) process_tile<NW, FULL, STAGED, SH>(P, TA, B, st, G, lds, t0, cnt);
         if ((it + 1) % flush_every == 0 || it + 1 == iters) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the asm histogram adds
+            lds_wait_all();      // the asm histogram adds
             __syncthreads();
             // flush: the workgroup's histogram words are added to its own slice of DevStats::part (plain adds: nobody else touches
             // it); snk_tiled_reduce_kernel sums the slices behind this kernel (global raw += raw ; global clean += raw - removed).

@@ -15,6 +15,12 @@ from soapnuke_amd.filter import FilterContext, records_to_numpy
 def main():
     case, var_len = sys.argv[1], sys.argv[2] == "1"
     n = 150_000
+    if len(sys.argv) > 3 and sys.argv[3] == "simt":          # tests/test_simt_kernels.py: the emulated library, a tenth of the reads
+        import pytest
+        import simt_lib
+        mp = pytest.MonkeyPatch()
+        simt_lib.torch_on_host(mp)
+        n = 15_000
     d = synth.make_batch(n, 150, paired=True, seed=77, var_len=var_len)
     p = abi.default_params(paired=True, max_read_len=150, **PE_CASES[case])
     ctx = FilterContext(p, device=0)

@@ -1,0 +1,54 @@
+"""Builds the SIMT-emulated twin of libsnk_filter.so: the same sources (soapnuke_amd/csrc), compiled for the host with
+tests/simt/hip/hip_runtime.h standing in for the HIP runtime.  Test infrastructure only -- see hip/hip_runtime.h."""
+import concurrent.futures as cf
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "soapnuke_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libsnk_filter_simt.so")
+CXX = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")       # clang: the sources use ext_vector_type and address_space attributes
+FLAGS = ["-std=c++17", "-O2", "-g1", "-gdwarf-4", "-fPIC", "-w", "-pthread", "-I" + HERE, "-I" + CSRC, "-fno-strict-aliasing", "-fno-omit-frame-pointer"]
+
+
+def sources():
+    import sys
+    sys.path.insert(0, ROOT)
+    from soapnuke_amd import build
+    return list(build.SOURCES), build._headers()
+
+
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
+        return True
+    srcs, hdrs = sources()
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, s) for s in srcs] + hdrs + [os.path.join(HERE, f) for f in ("simt_runtime.cpp", "simt_gfx950.h", "hip/hip_runtime.h")]
+    return any(os.path.getmtime(f) > t for f in deps)
+
+
+def build(force=False, extra=(), lib=LIB):
+    if not force and not needs_build(lib):
+        return lib
+    os.makedirs(OUT, exist_ok=True)
+    srcs, _ = sources()
+    tag = os.path.basename(lib).replace(".so", "")
+
+    def one(src):
+        path = os.path.join(CSRC, src) if src != "simt_runtime.cpp" else os.path.join(HERE, src)
+        obj = os.path.join(OUT, tag + "_" + src.replace(".", "_") + ".o")
+        r = subprocess.run([CXX] + FLAGS + list(extra) + ["-x", "c++", "-c", path, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{src}:\n{r.stdout[-4000:]}")
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(one, srcs + ["simt_runtime.cpp"]))
+    subprocess.check_call([CXX, "-shared", "-fPIC", "-pthread", "-o", lib] + list(extra) + objs + ["-ldl"])
+    return lib
+
+
+if __name__ == "__main__":
+    print(build(force=True))
