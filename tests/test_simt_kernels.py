@@ -12,9 +12,12 @@ import snk_testlib as T
 from soapnuke_amd import synth
 
 import test_adapter_fuzz_gpu as AF
+import test_contam_fuzz_gpu as CF
 import test_gpu_parity as GP
+import test_long_reads_gpu as LR
+import test_phred_gpu as PH
 
-CAP = 5000          # pairs per batch under the emulator (about 10 k pairs a second here); sizes up to it stay as they are
+CAP = 12000          # pairs per batch under the emulator (about 10 k pairs a second here); sizes up to it stay as they are
 
 
 @pytest.fixture(autouse=True)
@@ -27,7 +30,7 @@ def _emulated(monkeypatch):
 
     monkeypatch.setattr(synth, "make_batch", make_batch)
     monkeypatch.setenv("SNK_RUN_UNVERIFIED", "1")          # (tests guarded until they have run on hardware: this tier is what they wait for)
-    for mod in (GP, AF):
+    for mod in (GP, AF, CF, LR, PH):
         monkeypatch.setattr(mod, "run_hip_device", S.run_device, raising=False)
 
 
@@ -54,3 +57,75 @@ def test_multi_flush_launches_emulated(case, var_len, wgs, every):
 @pytest.fixture
 def snk_lib():
     return S.lib()
+
+
+# ---- the fuzz suites: every k-th context of the GPU tier's lists (the functions themselves are the GPU tier's)
+@pytest.mark.parametrize("i", range(0, AF.N_CONTEXTS, 3))
+def test_adapter_fuzz(i):
+    AF.test_adapter_fuzz(i)
+
+
+def test_phase_a_dimers_reach_the_tiled_kernel(monkeypatch):
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "CAP", 40000)          # (its count of phase-A reads wants the full batch)
+    AF.test_phase_a_dimers_reach_the_tiled_kernel()
+
+
+@pytest.mark.parametrize("mis", [(4, 5), (6, 4), (9, 3)])
+def test_adapter_budgets_above_three(mis):
+    AF.test_adapter_budgets_above_three(mis)
+
+
+@pytest.mark.parametrize("i", range(0, 16, 2))
+def test_long_adapter_lists_and_lower_case_on_the_fast_paths(i):
+    AF.test_long_adapter_lists_and_lower_case_on_the_fast_paths(i)
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_adapters_of_any_length_on_the_tiled_kernel(i):
+    """(written while the GPU was closed: this tier is the first place it runs)"""
+    AF.test_adapters_of_any_length_on_the_tiled_kernel(i)
+
+
+@pytest.mark.parametrize("i", range(0, CF.N_CONTEXTS, 4))
+def test_contam_fuzz(i):
+    CF.test_contam_fuzz(i)
+
+
+@pytest.mark.parametrize("i", range(0, 20, 4))
+def test_contam_fuzz_long_reads(i):
+    CF.test_contam_fuzz_long_reads(i)
+
+
+@pytest.mark.parametrize("i", range(0, 10, 3))
+def test_global_contaminants_outside_the_event_walk_range(i):
+    CF.test_global_contaminants_outside_the_event_walk_range(i)
+
+
+@pytest.mark.parametrize("L,paired,var,name", LR.CASES)
+def test_long_reads(L, paired, var, name):
+    LR.test_long_reads(L, paired, var, name)
+
+
+from test_long_reads_gpu import (test_long_reads_several_adapters_and_budgets, test_long_reads_contaminants_and_duplicates,      # noqa: E402,F401
+                                 test_long_reads_quality_range_error, test_long_reads_plane_store_group_edges_and_regrowth)
+from test_phred_gpu import test_se100_phred_and_max_quality, test_quality_range_errors_follow_the_offset      # noqa: E402,F401
+
+
+@pytest.mark.parametrize("kernel", [1, 0])
+@pytest.mark.parametrize("phred,mbq", [(33, 40), (64, 42), (33, 50)])
+@pytest.mark.parametrize("name", ["C3_full", "hard_lq_trim"])
+def test_pe150_phred_and_max_quality(name, phred, mbq, kernel):
+    PH.test_pe150_phred_and_max_quality(name, phred, mbq, kernel)
+
+
+@pytest.mark.parametrize("L", [250, 1000])
+@pytest.mark.parametrize("phred,mbq", [(64, 42), (33, 45)])
+def test_long_reads_phred_and_max_quality(L, phred, mbq):
+    PH.test_long_reads_phred_and_max_quality(L, phred, mbq)
+
+
+@pytest.mark.parametrize("kernel", [1, 0])
+@pytest.mark.parametrize("i", range(0, 48, 4))
+def test_random_parameter_contexts_on_the_device(i, kernel):
+    PH.test_random_parameter_contexts_on_the_device(i, kernel)
