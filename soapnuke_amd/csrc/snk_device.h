@@ -5,6 +5,14 @@
 #include <stdint.h>
 #include "../../include/snk_filter.h"
 
+// SNK_WAVE_SYNC(): lanes of one wave hand data to each other through LDS or memory at the marked places without a workgroup
+// barrier.  A wave executes in lock-step and its memory operations complete in order, so on the device there is nothing to emit;
+// the CPU test tier (tests/simt), which runs the lanes of a wave one after the other, defines it as the point where they wait
+// for each other.
+#ifndef SNK_WAVE_SYNC
+#define SNK_WAVE_SYNC() ((void)0)
+#endif
+
 #define SNK_DEV_MAX_ADA_LEN 256
 
 // One adapter with everything adapter_pos() (src/read_filter.cpp:707-790) derives

@@ -23,8 +23,6 @@ typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 #define SNK_LDS_ADDR(p) ((uint32_t)(uintptr_t)(snk::lds_u32_ptr)(p))
 // the value lives in a scalar register from here on (the compiler may not fold what it knows about it into the code behind)
 #define SNK_OPAQUE_S(x) asm volatile("" : "+s"(x))
-// lanes of a wave hand data to each other through memory here: the wave executes in lock-step, nothing to emit
-#define SNK_WAVE_SYNC() ((void)0)
 
 // clang exposes readlane but not writelane as a builtin; the LLVM intrinsic is bound above
 // (v_writelane_b32: uniform value -> one lane of a VGPR; per-read scalars and the rare fix-up pass use it).

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(64) inf_decode_kernel(const u8 *comp, u64 nbyt
 // lanes, matches queued and copied 64 at a time, one per lane (snk_inflate_core.cuh, Coop).  A lane on its own pays a global-memory
 // round trip per bit-buffer refill and per copied symbol: gzip turns the base lines of FASTQ into ~40 short matches per read.
 __global__ void __launch_bounds__(64) inf_decode_coop_kernel(const u8 *comp, u64 nbytes, Chunk *chunks, u16 *syms, MemberEnd *ends) {
-    __shared__ WaveSpace W;
+    SNK_WAVE_UNIFORM_SHARED WaveSpace W;
     __shared__ __attribute__((aligned(16))) u8 ring[2 * HALF];
     __shared__ u32 qdst[QCAP], qinfo[QCAP];
     __shared__ u16 hist[HS];

@@ -62,9 +62,21 @@ struct Scratch { u8 lens[320]; u16 count[16], offs[16]; u16 sorted[288]; u8 subm
 // SNKI_LANES(lane): the statement runs for this lane on the device and for the 64 lanes in turn on the host (the emulation) -- in
 // DESCENDING order, so that a lane-parallel step whose lanes did depend on each other would show (ascending order is the
 // sequential order, in which everything is right).
+// Lanes hand data to each other through LDS at the marked places; a wave runs in lock-step and its LDS operations complete in
+// order, so there is nothing to emit on the device (snk_device.h has the same definition for the other kernels; tests/simt, which
+// runs the lanes one after the other, makes it the place where they wait for each other).
+#ifndef SNK_WAVE_SYNC
+#define SNK_WAVE_SYNC() ((void)0)
+#endif
 #if defined(__HIPCC__)
 #define SNKI_LANES(lane) for (int lane = (int)(threadIdx.x & 63), once_ = 1; once_; once_ = 0)
 #define SNKI_FENCE() __threadfence_block()
+// The decoder's tables and header workspace are written by all 64 lanes at once with the same values (the lanes run the same
+// code on the same data): one copy per wave in LDS.  (tests/simt: a copy per lane -- a lane-after-lane emulation would apply a
+// read-modify-write of such a word 64 times.)
+#ifndef SNK_WAVE_UNIFORM_SHARED
+#define SNK_WAVE_UNIFORM_SHARED __shared__
+#endif
 #else
 #define SNKI_LANES(lane) for (int lane = 63; lane >= 0; --lane)
 #define SNKI_FENCE() ((void)0)
@@ -109,12 +121,14 @@ SNKI_DEV u64 ring64(Bits &b, u64 pos) {
         c.ring_lo = c.ring_end = pos & ~(u64)(HALF - 1);                      // a jump (stored block, member header): start over at its half
     while (pos + 12 > c.ring_end) {                                          // (uniform) the next half, 16 bytes per lane
         const u64 from = c.ring_end;
+        SNK_WAVE_SYNC();
         SNKI_LANES(lane) {
             const u32 *src = reinterpret_cast<const u32 *>(b.base + from + (u64)lane * 16);
             u32 *dst = reinterpret_cast<u32 *>(c.ring + (from & (u64)HALF) + (u64)lane * 16);
             const u32 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
             dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
         }
+        SNK_WAVE_SYNC();
         c.ring_end = from + HALF;
         if (c.ring_end - c.ring_lo > 2 * HALF) c.ring_lo = c.ring_end - 2 * HALF;
     }
@@ -410,6 +424,7 @@ SNKI_DEV bool queue_owns(const Coop &c, long a, long b) {
 #if defined(__HIPCC__)
     const u32 lane = threadIdx.x & 63;
     bool mine = false;
+    SNK_WAVE_SYNC();                                   // (lane 0 wrote the queue)
     if (lane < c.qn) { const long d = (long)c.qdst[lane], e = d + (long)(c.qinfo[lane] >> 16); mine = d < b && a < e; }
     hit = __any(mine);
 #else
@@ -450,6 +465,7 @@ SNKI_DEV void out_match(Out &o, u32 len, u32 dist) {
 #if !defined(__HIPCC__)
             ++SNKI_STAT(near);
 #endif
+            SNK_WAVE_SYNC();                           // (the sources: literals stored by lane 0, copies by any lane)
             SNKI_LANES(lane) {
                 for (u32 i = (u32)lane; i < len; i += 64) {
                     const long src = first + (long)(i % dist);

@@ -109,12 +109,14 @@ __global__ void __launch_bounds__(256) snk_hash_lds_kernel(const HashArgs A, con
         const int cnt = rem >= 64 ? 64 : (int)rem;
         auto stage = [&](int m) {                               // coalesced 16-byte loads -> padded LDS rows
             const uint8_t *base = A.seq[m] + t0 * (long)A.pitch;
+            SNK_WAVE_SYNC();                                    // (the rows staged before have been read)
             for (int row0 = 0; row0 < cnt; row0 += rpp) {
                 const int row = row0 + rowoff;
                 if (act && row < cnt)
                     *reinterpret_cast<uint4 *>(rows + (size_t)row * p2 + col * 16) =
                         *reinterpret_cast<const uint4 *>(base + (long)row * A.pitch + col * 16);
             }
+            SNK_WAVE_SYNC();
         };
         // (one wave reads only what it wrote itself: no barrier, LDS ops of a wave are ordered)
         const bool valid = lane < cnt;

@@ -10,7 +10,8 @@ CSRC = os.path.join(ROOT, "soapnuke_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libsnk_filter_simt.so")
 CXX = os.environ.get("SIMT_CXX", "/opt/rocm/lib/llvm/bin/clang++")       # clang: the sources use ext_vector_type and address_space attributes
-FLAGS = ["-std=c++17", "-O2", "-g1", "-gdwarf-4", "-fPIC", "-w", "-pthread", "-I" + HERE, "-I" + CSRC, "-fno-strict-aliasing", "-fno-omit-frame-pointer"]
+FLAGS = ["-std=c++17", "-O2", "-g1", "-gdwarf-4", "-fPIC", "-w", "-pthread", "-I" + HERE, "-I" + CSRC, "-fno-strict-aliasing", "-fno-omit-frame-pointer",
+         "-fconvergent-functions", "-mllvm", "-disable-tail-duplicate", "-mllvm", "-disable-early-taildup", "-mllvm", "-tail-dup-placement=0"]      # every function may hold wave-level operations (what hipcc assumes for device code): no duplication of calls into the arms of lane-dependent branches -- in the middle end by the attribute, in the x86 backend, which does not know it, by switching tail duplication off
 
 
 def sources():
@@ -46,7 +47,7 @@ def build(force=False, extra=(), lib=LIB):
 
     with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(one, srcs + ["simt_runtime.cpp"]))
-    subprocess.check_call([CXX, "-shared", "-fPIC", "-pthread", "-o", lib] + list(extra) + objs + ["-ldl"])
+    subprocess.check_call([CXX, "-shared", "-fPIC", "-pthread", "-Wl,-Bsymbolic", "-o", lib] + list(extra) + objs + ["-ldl"])
     return lib
 
 

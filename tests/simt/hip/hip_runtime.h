@@ -29,6 +29,9 @@
 #include <type_traits>
 
 #define SNK_SIMT_EMUL 1
+#ifndef __HIPCC__
+#define __HIPCC__ 1          // the sources are compiled as HIP device code (their host-emulation branches belong to other harnesses)
+#endif
 #define __device__
 #define __host__
 #define __global__
@@ -38,6 +41,7 @@
 #define __launch_bounds__(...)
 #define __shared__ thread_local
 #define HIP_SYMBOL(x) (x)
+#define SNK_WAVE_UNIFORM_SHARED          /* state that all lanes of a wave write redundantly in lock-step: a copy per lane here */
 uint8_t *simt_dyn_shared();
 #define HIP_DYNAMIC_SHARED(type, var) type *var = (type *)simt_dyn_shared();
 static constexpr int warpSize = 64;
@@ -134,7 +138,7 @@ struct Wave {
     bool uniform = true;                // every waiting lane is at the same place (site0)
     uint64_t site0[3] = {0, 0, 0};
     uint64_t val[64];                   // operands of the waiting lanes
-    uint64_t site[64][3];               // where each waits: instruction pointer, return address of the enclosing function, stack depth
+    uint64_t site[64][3];               // where each waits: call site of the operation, call site of the function around it, stack depth
     const char *kind[64];
     uint64_t snap[2][64];               // operands of the last two completed operations and who took part
     uint64_t snap_mask[2] = {0, 0};
@@ -172,39 +176,13 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &bo
 // A wave-level operation: the lane publishes its operand and waits for the lanes it executes the operation with; returns their
 // operands (indexed by lane) and who they are.  In wave-uniform control flow that is every live lane, and the operation
 // completes when the last one arrives.  Lanes that reach DIFFERENT operations (a vote inside `if (lane-dependent)`, the
-// hardware's EXEC mask) are told apart by where they wait; the scheduler completes such an operation for the lanes that are
-// there once nothing else can run (simt_runtime.cpp: innermost call first, then code order -- the order in which the hardware
-// serialises the sides of a branch does not matter to them, but a side must be done before the lanes meet again behind it).
-__attribute__((always_inline)) static inline const uint64_t *wave_exchange(uint64_t mine, uint64_t &mask, const char *where) {
-    Fiber *f = cur;
-    Wave &w = *f->wave;
-    const int l = f->lane;
-    uint64_t ip, sp;
-    asm volatile("leaq 0(%%rip), %0\n\tmovq %%rsp, %1" : "=r"(ip), "=r"(sp));
-    w.val[l] = mine;
-    w.kind[l] = where;
-    w.site[l][0] = ip;
-    w.site[l][1] = (uint64_t)__builtin_return_address(0);
-    sp = f->stack_top - sp;              // call depth in bytes
-    w.site[l][2] = sp;
-    if (w.arrived == 0) {
-        w.uniform = true;
-        w.site0[0] = ip; w.site0[1] = w.site[l][1]; w.site0[2] = sp;
-    } else if (w.site0[0] != ip || w.site0[1] != w.site[l][1] || w.site0[2] != sp) {
-        w.uniform = false;
-    }
-    w.pend_mask |= 1ull << l;
-    const uint64_t woke = f->wake;
-    if (++w.arrived == w.live && w.uniform) wave_release(w, w.pend_mask);
-    if (f->wake == woke) {
-        f->wait_ptr = &f->wake;
-        f->wait_val = woke;
-        f->where = where;
-        yield_to_scheduler();
-    }
-    mask = w.snap_mask[f->snap_idx];
-    return w.snap[f->snap_idx];
-}
+// hardware's EXEC mask) are told apart by where they wait -- the call site of this function, its caller's call site and the stack
+// depth; the scheduler completes such an operation for the lanes that are there once nothing else can run (simt_runtime.cpp:
+// innermost call first, then code order -- the order in which the hardware serialises the sides of a branch does not matter to
+// them, but a side must be done before the lanes meet again behind it).
+// `convergent` is what the amdgpu target puts on these operations: the optimizer may not duplicate a call into the arms of a
+// lane-dependent branch (jump threading would give the lanes of ONE source-level operation different call sites).
+__attribute__((noinline, convergent)) const uint64_t *wave_exchange(uint64_t mine, uint64_t &mask, const char *where);
 static inline void block_barrier(const char *where) {
     Fiber *f = cur;
     Block &b = *f->blk;
@@ -255,7 +233,11 @@ static inline int __syncthreads_count(int p) {
     return b.vote_res;
 }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+// lanes of a wave that hand data to each other through memory wait for each other here: a wave executes in lock-step on the
+// device, one lane after the other in this emulator.  (__threadfence_block orders a lane's own accesses for the rest of the
+// workgroup -- where the sources use it between lanes of one wave, it is such a point.)
+#define SNK_WAVE_SYNC() do { uint64_t simt_m_; (void)simt::wave_exchange(0, simt_m_, "SNK_WAVE_SYNC"); } while (0)
+__attribute__((always_inline)) static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); SNK_WAVE_SYNC(); }
 static inline int __lane_id() { return simt::cur->lane; }
 
 __attribute__((always_inline)) static inline unsigned long long __ballot(int p) {

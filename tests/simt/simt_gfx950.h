@@ -14,7 +14,6 @@ static inline uint8_t *simt_lds_at(g9_u32 addr) {
 }
 #define SNK_LDS_ADDR(p) ((uint32_t)((const uint8_t *)(p) - (const uint8_t *)simt_dyn_shared()))
 #define SNK_OPAQUE_S(x) ((void)(x))
-#define SNK_WAVE_SYNC() do { uint64_t simt_m_; (void)simt::wave_exchange(0, simt_m_, "SNK_WAVE_SYNC"); } while (0)
 
 static inline int wl(int dst, int val, int lane) { return simt_writelane(val, lane, dst); }
 static inline int rl(int v, int lane) { return simt_readlane(v, lane); }

@@ -94,7 +94,25 @@ bool release_divergent(Worker &wk, int nwaves) {
             if (w.site[l][0] == w.site[best][0] && w.site[l][1] == w.site[best][1] && w.site[l][2] == w.site[best][2]) group |= 1ull << l;
         }
         if (getenv("SIMT_TRACE_DIVERGENCE"))
-            fprintf(stderr, "simt: wave %d: %s completes for lanes %016llx of %016llx\n", wi, w.kind[best], (unsigned long long)group, (unsigned long long)w.live_mask);
+        {
+            fprintf(stderr, "simt: wave %d: %s completes for lanes %016llx of %016llx", wi, w.kind[best], (unsigned long long)group, (unsigned long long)w.live_mask);
+            Dl_info di;
+            if (dladdr((void *)w.site[best][0], &di) && di.dli_fbase) {
+                fprintf(stderr, "; waiting at (site+0x, caller+0x, depth):");
+                uint64_t seen[8][3];
+                int ns = 0;
+                for (uint64_t t = w.pend_mask; t; t &= t - 1) {
+                    const int l = __builtin_ctzll(t);
+                    bool known = false;
+                    for (int k = 0; k < ns; ++k) known = known || (seen[k][0] == w.site[l][0] && seen[k][1] == w.site[l][1] && seen[k][2] == w.site[l][2]);
+                    if (known || ns == 8) continue;
+                    seen[ns][0] = w.site[l][0]; seen[ns][1] = w.site[l][1]; seen[ns][2] = w.site[l][2];
+                    ++ns;
+                    fprintf(stderr, " (%llx, %llx, %llu)", (unsigned long long)(w.site[l][0] - (uint64_t)di.dli_fbase), (unsigned long long)(w.site[l][1] - (uint64_t)di.dli_fbase), (unsigned long long)w.site[l][2]);
+                }
+            }
+            fprintf(stderr, "\n");
+        }
         wave_release(w, group);
         any = true;
     }
@@ -279,6 +297,34 @@ void wave_release(Wave &w, uint64_t group) {
         if (!have) { have = true; w.site0[0] = w.site[l][0]; w.site0[1] = w.site[l][1]; w.site0[2] = w.site[l][2]; }
         else if (w.site0[0] != w.site[l][0] || w.site0[1] != w.site[l][1] || w.site0[2] != w.site[l][2]) w.uniform = false;
     }
+}
+
+__attribute__((noinline, convergent)) const uint64_t *wave_exchange(uint64_t mine, uint64_t &mask, const char *where) {
+    Fiber *f = cur;
+    Wave &w = *f->wave;
+    const int l = f->lane;
+    const uint64_t site[3] = {(uint64_t)__builtin_return_address(0), (uint64_t)__builtin_return_address(1),
+                              f->stack_top - (uint64_t)__builtin_frame_address(0)};
+    w.val[l] = mine;
+    w.kind[l] = where;
+    w.site[l][0] = site[0]; w.site[l][1] = site[1]; w.site[l][2] = site[2];
+    if (w.arrived == 0) {
+        w.uniform = true;
+        w.site0[0] = site[0]; w.site0[1] = site[1]; w.site0[2] = site[2];
+    } else if (w.site0[0] != site[0] || w.site0[1] != site[1] || w.site0[2] != site[2]) {
+        w.uniform = false;
+    }
+    w.pend_mask |= 1ull << l;
+    const uint64_t woke = f->wake;
+    if (++w.arrived == w.live && w.uniform) wave_release(w, w.pend_mask);
+    if (f->wake == woke) {
+        f->wait_ptr = &f->wake;
+        f->wait_val = woke;
+        f->where = where;
+        yield_to_scheduler();
+    }
+    mask = w.snap_mask[f->snap_idx];
+    return w.snap[f->snap_idx];
 }
 
 void yield_to_scheduler() {

@@ -16,6 +16,10 @@ import test_contam_fuzz_gpu as CF
 import test_gpu_parity as GP
 import test_long_reads_gpu as LR
 import test_phred_gpu as PH
+import test_rmdup_gpu as RD
+import test_fastq_gpu as FQ
+import test_gunzip_gpu as GZ
+import test_bittr_gpu as BT
 
 CAP = 12000          # pairs per batch under the emulator (about 10 k pairs a second here); sizes up to it stay as they are
 
@@ -30,7 +34,7 @@ def _emulated(monkeypatch):
 
     monkeypatch.setattr(synth, "make_batch", make_batch)
     monkeypatch.setenv("SNK_RUN_UNVERIFIED", "1")          # (tests guarded until they have run on hardware: this tier is what they wait for)
-    for mod in (GP, AF, CF, LR, PH):
+    for mod in (GP, AF, CF, LR, PH, RD, FQ, GZ, BT):
         monkeypatch.setattr(mod, "run_hip_device", S.run_device, raising=False)
 
 
@@ -129,3 +133,14 @@ def test_long_reads_phred_and_max_quality(L, phred, mbq):
 @pytest.mark.parametrize("i", range(0, 48, 4))
 def test_random_parameter_contexts_on_the_device(i, kernel):
     PH.test_random_parameter_contexts_on_the_device(i, kernel)
+
+
+# ---- duplicate marking (snk_rmdup.hip), device-side FASTQ text (snk_fastq.hip), gzip members (snk_gzip.hip), inflate (snk_inflate.hip),
+# the 64 x 64 bit transpose (snk_bittr.cuh)
+from test_rmdup_gpu import (test_hash_golden, test_hash_vs_oracle, test_hash_odd_tile_counts, test_mark_golden, test_mark_vs_oracle_random,      # noqa: E402,F401
+                            test_mark_with_explicit_indices, test_too_many_reads_is_refused, test_one_pass_table_vs_oracle,
+                            test_one_pass_table_refuses_too_many_reads)
+from test_fastq_gpu import (test_parse_and_format_match_the_restatement, test_parse_reports_bad_input, test_device_gzip_members_round_trip,      # noqa: E402,F401
+                            test_format_selects_other_verdicts_whole)
+from test_gunzip_gpu import test_device_inflate_kernels_produce_zlibs_bytes, test_device_inflate_refuses_what_does_not_fit      # noqa: E402,F401
+from test_bittr_gpu import test_bit_transpose      # noqa: E402,F401
