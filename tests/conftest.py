@@ -18,3 +18,16 @@ def snk_lib():
     """The HIP extension through its C ABI.  No fallback: missing library == failure."""
     from soapnuke_amd import abi
     return abi.load_library()
+
+
+def pytest_collection_modifyitems(config, items):
+    """The emulated tier (tests/test_simt_*.py) re-runs the GPU tier's test functions on the CPU; all of it takes about twelve minutes,
+    so an ordinary run takes each module's CORE selection (a few minutes) and SNK_SIMT_FULL=1 the rest as well
+    (profiles/r04_simt_full.txt holds such a run)."""
+    if os.environ.get("SNK_SIMT_FULL") == "1":
+        return
+    skip = pytest.mark.skip(reason="emulated tier beyond its core selection: SNK_SIMT_FULL=1 runs it")
+    for item in items:
+        core = getattr(item.module, "CORE", None)
+        if core is not None and not any(c in item.name for c in core):
+            item.add_marker(skip)

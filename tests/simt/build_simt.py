@@ -51,5 +51,23 @@ def build(force=False, extra=(), lib=LIB):
     return lib
 
 
+CLI = os.path.join(OUT, "SOAPnuke_simt")
+
+
+def build_cli(force=False):
+    """`SOAPnuke filter` (soapnuke_amd/host) linked against the emulated library: the whole host side -- readers, gzip, shards, rmdup
+    orchestration, reports -- runs on the CPU and can be compared with the reference binary file by file"""
+    lib = build(force)
+    host = os.path.join(ROOT, "soapnuke_amd", "host")
+    srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith((".cpp", ".h"))]
+    if not force and os.path.exists(CLI) and os.path.getmtime(CLI) >= max(os.path.getmtime(f) for f in srcs + [lib]):
+        return CLI
+    cmd = [CXX] + FLAGS + ["-x", "c++", os.path.join(host, "snk_main.cpp"), os.path.join(host, "snk_report.cpp"), "-x", "none",
+                           "-o", CLI, "-L" + OUT, "-lsnk_filter_simt", "-lz", "-ldl", "-Wl,-rpath," + OUT]
+    subprocess.check_call(cmd)
+    return CLI
+
+
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_cli(force=True))

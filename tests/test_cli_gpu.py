@@ -517,8 +517,8 @@ def test_cli_sharded_ingest(paired, gz_out, trim, tmp_path):
     devs = "0,1" if torch.cuda.device_count() >= 2 else "0,0"
     n, L, threads, patch = 40000, 150, 3, 250
     d = synth.make_batch(n, L, paired=paired, seed=64)
-    cli = ["-f", synth.ADAPTER1, "-J", "-l", "10", "-q", "0.1"] + (["-r", synth.ADAPTER2] if paired else [])
-    case = ("shard", paired, L, n, threads, patch, {}, {}, cli, ["trimBadTail=20,30"] if trim else [])     # (trimming: clean lengths vary, the reports depend on the virtual threads)
+    cli = ["-f", synth.ADAPTER1, "-J", "-l", "10", "-q", "0.1"] + (["-r", synth.ADAPTER2] if paired else []) + (["-t", "3,4"] if trim and not paired else [])
+    case = ("shard", paired, L, n, threads, patch, {}, {}, cli, ["trimBadTail=20,30"] if trim and paired else [])     # (trimming: clean lengths vary, the reports depend on the virtual threads)
     work = str(tmp_path)
     ref = R.run_reference_cli(case, d, work, gz_input=True)
     ext = ".fq.gz" if gz_out else ".fq"

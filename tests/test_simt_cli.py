@@ -1,0 +1,40 @@
+"""The end-to-end tests of the GPU tier (tests/test_cli_gpu.py: this repo's `SOAPnuke filter` against the compiled reference binary on
+the same FASTQ files -- reports, clean FASTQ and side files byte-identical) run on the CPU: the CLI of soapnuke_amd/host built
+against the SIMT-emulated library (tests/simt).  Readers, parallel gunzip, device-side FASTQ parse / format / gzip, the filter
+kernels, duplicate marking, shards, report writers: the same code as on the GPU box, every kernel executed by the emulator."""
+import os
+
+import pytest
+
+import simt_lib as S
+import snk_testlib as T
+import test_cli_gpu as CG
+import test_gunzip_gpu as GZ
+
+# what an ordinary run takes (substrings of the test ids); SNK_SIMT_FULL=1: everything (tests/conftest.py)
+CORE = ["test_cli_matches_reference_binary[pe_full_T3]", "test_cli_matches_reference_binary[se_trim_T2]", "test_cli_gz_in_gz_out", "test_cli_rmdup_matches_reference_binary[False-20100]",
+        "test_cli_rmdup_one_pass_variants[small_batches]", "emulated", "test_cli_with_device_inflate", "test_cli_two_device_slots[True]",
+        "test_cli_device_text_growing_names_and_ragged_end[True-True-False]", "test_cli_streaming[True-2-50"]
+pytestmark = pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")
+
+
+@pytest.fixture(autouse=True)
+def _emulated_cli(monkeypatch):
+    cli = S.build_module().build_cli()
+    monkeypatch.setattr(CG, "CLI", cli)
+    monkeypatch.setattr(GZ, "CLI", cli, raising=False)
+    monkeypatch.setenv("SNK_RUN_UNVERIFIED", "1")
+
+
+from test_cli_gpu import *      # noqa: E402,F401,F403  (every test function of the GPU tier's module)
+from test_gunzip_gpu import test_cli_with_device_inflate_matches_the_reference_binary      # noqa: E402,F401
+
+
+# ---- written while the GPU was closed (guarded in the GPU tier until they have run on hardware): this tier is where they run first
+@pytest.mark.parametrize("paired,gz_out,trim", [(True, False, False), (True, True, True), (False, False, True)])
+def test_cli_sharded_ingest_emulated(paired, gz_out, trim, tmp_path):
+    CG.test_cli_sharded_ingest(paired, gz_out, trim, tmp_path)
+
+
+def test_cli_rmdup_table_that_does_not_fit_emulated(tmp_path):
+    CG.test_cli_rmdup_one_pass_variants("table_does_not_fit", tmp_path)
