@@ -61,6 +61,14 @@ int snk_rmdup_mark_device(snk_ctx *ctx, const uint64_t *d_hash, const uint32_t *
 typedef struct snk_rmdup_stream snk_rmdup_stream;
 snk_rmdup_stream *snk_rmdup_stream_create(snk_ctx *ctx, uint64_t expected_pairs);
 int snk_rmdup_stream_mark_device(snk_rmdup_stream *t, const uint64_t *d_hash, uint64_t first_index, int64_t n, uint8_t *d_dup, void *stream);
+/* Single-end runs.  The reference's SE filter reads i of a FULL patch with the duplicate flag of read i - 1 (it records "reads so
+ * far" before it counts the patch's last quality line, src/seprocess.cpp:1086,1159; PE: src/peprocess.cpp:2147); only the partial
+ * patch at the end of the file is aligned (:1112).  This call marks like snk_rmdup_stream_mark_device and writes the flags the
+ * reference's cascade sees: d_dup[i] = true flag of read i - 1 for i < n_shifted (the flag of the last read of the previous call
+ * for i = 0; 0 in the first call), the true flag of read i behind that.  A caller that cuts its batches at multiples of the patch
+ * size passes n_shifted = n for every batch but a last one that ends inside a patch (n / patch * patch there).              */
+int snk_rmdup_stream_mark_se_device(snk_rmdup_stream *t, const uint64_t *d_hash, uint64_t first_index, int64_t n, int64_t n_shifted,
+                                    uint8_t *d_dup, void *stream);
 int snk_rmdup_stream_stats(snk_rmdup_stream *t, uint64_t *n_marked, int32_t *sentinel_seen);     /* synchronises */
 void snk_rmdup_stream_destroy(snk_rmdup_stream *t);
 /* device bytes a one-pass table for `pairs` pairs holds at its largest (resident hashes 8 B per pair + the open-addressing table,

@@ -182,7 +182,7 @@ EXPORTS = [
     "snk_stats_fetch", "snk_error_peek_async", "snk_error_decode", "snk_stats_allreduce", "snk_set_timing", "snk_last_kernel_ms", "snk_reserve",
     # include/snk_rmdup.h
     "snk_rmdup_hash_device", "snk_rmdup_bucket_count_device", "snk_rmdup_mark_device", "snk_rmdup_prime",
-    "snk_rmdup_stream_create", "snk_rmdup_stream_mark_device", "snk_rmdup_stream_stats", "snk_rmdup_stream_destroy", "snk_rmdup_stream_bytes",
+    "snk_rmdup_stream_create", "snk_rmdup_stream_mark_device", "snk_rmdup_stream_mark_se_device", "snk_rmdup_stream_stats", "snk_rmdup_stream_destroy", "snk_rmdup_stream_bytes",
     # include/snk_selftest.h
     "snk_selftest_bit_transpose",
     # include/snk_fastq.h
@@ -235,6 +235,7 @@ def load_library(path=None):
     lib.snk_rmdup_stream_create.argtypes = [vp, C.c_uint64]
     lib.snk_rmdup_stream_create.restype = vp
     lib.snk_rmdup_stream_mark_device.argtypes = [vp, vp, C.c_uint64, C.c_int64, vp, vp]
+    lib.snk_rmdup_stream_mark_se_device.argtypes = [vp, vp, C.c_uint64, C.c_int64, C.c_int64, vp, vp]
     lib.snk_rmdup_stream_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     lib.snk_rmdup_stream_destroy.argtypes = [vp]
     lib.snk_rmdup_stream_destroy.restype = None

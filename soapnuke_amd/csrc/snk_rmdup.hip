@@ -245,6 +245,18 @@ __global__ void __launch_bounds__(256) snk_stream_lookup_kernel(const u64 *__res
     if ((threadIdx.x & 63) == 0 && b) atomicAdd(marked, (u64)__popcll(b));
 }
 
+// Single-end runs of the reference filter read i of a FULL patch with the duplicate flag of read i - 1 (seProcess records "reads
+// so far" before it counts the patch's last quality line: src/seprocess.cpp:1086,1159 against src/peprocess.cpp:2147); only the
+// partial patch at the end of the file is aligned (:1112).  out[i] = i < n_shifted ? (i ? flags[i - 1] : the flag in front of the
+// batch) : flags[i]; the batch's last flag is handed to the next call.
+__global__ void __launch_bounds__(256) snk_se_shift_kernel(const uint8_t *__restrict__ flags, long n, long n_shifted, const uint8_t *carry_in, uint8_t *carry_out,
+                                                           uint8_t *__restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = i < n_shifted ? (i ? flags[i - 1] : *carry_in) : flags[i];
+    if (i == n - 1) *carry_out = flags[i];
+}
+
 }  // namespace
 
 #define RM_OK(call)                                      \
@@ -347,6 +359,11 @@ struct snk_rmdup_stream {
     hipStream_t last = nullptr;
     bool have_ev = false;
     bool dead = false;                               // a failed growth left no table: every later call reports SNK_E_NOMEM
+    // single-end runs (snk_rmdup_stream_mark_se_device): the batch's true flags, and the flag of the read in front of the batch
+    uint8_t *d_true = nullptr;
+    size_t true_cap = 0;
+    uint8_t *d_carry = nullptr;                      // [2]: read by call k at [k & 1], written at [(k + 1) & 1]
+    u64 se_calls = 0;
 };
 
 static u64 *stream_hash_room(snk_rmdup_stream *t, size_t n) {
@@ -405,12 +422,15 @@ void snk_rmdup_stream_destroy(snk_rmdup_stream *t) {
     if (t->keys) (void)hipFree(t->keys);
     if (t->minidx) (void)hipFree(t->minidx);
     if (t->d_marked) (void)hipFree(t->d_marked);
+    if (t->d_true) (void)hipFree(t->d_true);
+    if (t->d_carry) (void)hipFree(t->d_carry);
     for (auto d : t->slabs) (void)hipFree(d);
     if (t->ev) (void)hipEventDestroy(t->ev);
     delete t;
 }
 
-int snk_rmdup_stream_mark_device(snk_rmdup_stream *t, const uint64_t *d_hash, uint64_t first_index, int64_t n, uint8_t *d_dup, void *stream) {
+// the marking itself; the event that orders the next call is recorded by the callers (behind whatever they add)
+static int stream_mark(snk_rmdup_stream *t, const uint64_t *d_hash, uint64_t first_index, int64_t n, uint8_t *d_dup, void *stream) {
     if (!t || !d_hash || !d_dup || n < 0) { snk_set_error("snk_rmdup_stream_mark_device: bad argument"); return SNK_E_PARAM; }
     if (first_index + (uint64_t)n > 4294967295ull) {           // src/peprocess.cpp:3094
         snk_set_error("snk_rmdup_stream_mark_device: reads number is too large to do remove duplication (limit 2^32-1)");
@@ -446,10 +466,47 @@ int snk_rmdup_stream_mark_device(snk_rmdup_stream *t, const uint64_t *d_hash, ui
     hipLaunchKernelGGL(snk_stream_insert_kernel, dim3(grid), dim3(256), 0, st, (const u64 *)c.d, c.base, (long)n, t->keys, t->minidx, t->cap - 1, 64 - t->lg, flag);
     hipLaunchKernelGGL(snk_stream_lookup_kernel, dim3(grid), dim3(256), 0, st, (const u64 *)c.d, c.base, (long)n, (const u64 *)t->keys, (const u32 *)t->minidx,
                        t->cap - 1, 64 - t->lg, d_dup, t->d_marked, flag);
-    if (hipGetLastError() != hipSuccess || hipEventRecord(t->ev, st) != hipSuccess) return fail("snk_rmdup_stream_mark_device: launch failed");
+    if (hipGetLastError() != hipSuccess) return fail("snk_rmdup_stream_mark_device: launch failed");
+    return SNK_OK;
+}
+static int stream_mark_done(snk_rmdup_stream *t, hipStream_t st) {
+    if (hipEventRecord(t->ev, st) != hipSuccess) { snk_set_error("snk_rmdup_stream_mark_device: hipEventRecord failed"); return SNK_E_HIP; }
     t->have_ev = true;
     t->last = st;
     return SNK_OK;
+}
+
+int snk_rmdup_stream_mark_device(snk_rmdup_stream *t, const uint64_t *d_hash, uint64_t first_index, int64_t n, uint8_t *d_dup, void *stream) {
+    const int rc = stream_mark(t, d_hash, first_index, n, d_dup, stream);
+    if (rc != SNK_OK || n == 0) return rc;
+    return stream_mark_done(t, (hipStream_t)stream);
+}
+
+int snk_rmdup_stream_mark_se_device(snk_rmdup_stream *t, const uint64_t *d_hash, uint64_t first_index, int64_t n, int64_t n_shifted, uint8_t *d_dup, void *stream) {
+    if (!t || n < 0 || n_shifted < 0 || n_shifted > n) { snk_set_error("snk_rmdup_stream_mark_se_device: bad argument"); return SNK_E_PARAM; }
+    if (n == 0) return SNK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (!t->d_carry) {
+        if (hipMalloc((void **)&t->d_carry, 16) != hipSuccess) { (void)hipGetLastError(); snk_set_error("snk_rmdup_stream_mark_se_device: out of device memory"); return SNK_E_NOMEM; }
+        if (hipMemset(t->d_carry, 0, 16) != hipSuccess) { snk_set_error("snk_rmdup_stream_mark_se_device: memset failed"); return SNK_E_HIP; }     // (read 0 of the file: no duplicate in front of it)
+    }
+    if ((size_t)n > t->true_cap) {
+        // (the launches that read the old buffer are ordered in front of everything this call issues only on their own stream)
+        if (t->have_ev && hipEventSynchronize(t->ev) != hipSuccess) { snk_set_error("snk_rmdup_stream_mark_se_device: synchronise failed"); return SNK_E_HIP; }
+        if (t->d_true) (void)hipFree(t->d_true);
+        t->d_true = nullptr;
+        t->true_cap = 0;
+        const size_t cap = ((size_t)n + 65535) & ~(size_t)65535;
+        if (hipMalloc((void **)&t->d_true, cap) != hipSuccess) { (void)hipGetLastError(); snk_set_error("snk_rmdup_stream_mark_se_device: out of device memory"); return SNK_E_NOMEM; }
+        t->true_cap = cap;
+    }
+    const int rc = stream_mark(t, d_hash, first_index, n, t->d_true, stream);
+    if (rc != SNK_OK) return rc;
+    const int par = (int)(t->se_calls++ & 1);
+    hipLaunchKernelGGL(snk_se_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)t->d_true, (long)n, (long)n_shifted,
+                       (const uint8_t *)(t->d_carry + par), t->d_carry + (par ^ 1), d_dup);
+    if (hipGetLastError() != hipSuccess) { snk_set_error("snk_rmdup_stream_mark_se_device: launch failed"); return SNK_E_HIP; }
+    return stream_mark_done(t, st);
 }
 
 int snk_rmdup_stream_stats(snk_rmdup_stream *t, uint64_t *n_marked, int32_t *sentinel_seen) {

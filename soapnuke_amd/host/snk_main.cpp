@@ -340,6 +340,12 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
     if (o.clean_out_split > 0 && o.total_reads > 0) die("-w and -L cannot be both assigned");
     if (o.streaming)                                          // one batch = one patch of the reference (src/peprocess.cpp:2137-2148)
         o.batch_pairs = (int)(o.patch_size > 0 ? o.patch_size : o.threads * 20000 / 8);
+    else if (o.p.rmdup && !o.p.paired) {
+        // single-end rmdup in one pass: batches end on patch borders, so that only the file's last batch can hold a partial patch --
+        // the one place where the reference's duplicate flags are not shifted by a read (see the rmdup pre-pass below)
+        const int64_t ps = o.patch_size > 0 ? o.patch_size : (int64_t)o.threads * 20000 / 8;
+        if (ps > 0 && ps <= (1 << 24)) o.batch_pairs = (int)std::max<int64_t>(ps, (int64_t)o.batch_pairs / ps * ps);
+    }
     if (!o.wrong_paras.empty()) {
         string l = o.wrong_paras[0];
         for (size_t i = 1; i < o.wrong_paras.size(); ++i) l += "," + o.wrong_paras[i];
@@ -1219,6 +1225,10 @@ struct Slot {                                           // one batch in flight
     hipEvent_t parsed = nullptr;
     // one-pass rmdup: the batch's hashes, and the raw text of its duplicate pairs for the dupReads side files
     uint64_t *d_hash = nullptr;
+    // ... on a device other than the table's: hashes over to the table's device, flags back (8 + 1 bytes per pair)
+    uint64_t *d_hash0 = nullptr;
+    uint8_t *d_flags0 = nullptr;
+    hipEvent_t hashed = nullptr, marked = nullptr;
     uint8_t *d_dupout[2] = {nullptr, nullptr};
     uint32_t *d_dupoff[2] = {nullptr, nullptr}, *h_dupoff[2] = {nullptr, nullptr};
 };
@@ -1564,9 +1574,12 @@ int main(int argc, char **argv) {
     // newlines, (de)compresses and writes.  The output variants that need per-record work on the names or several outputs
     // per read keep the host formatter (same bytes either way; SNK_HOST_TEXT=1 forces it).
     // rmdup of paired input in device-text mode is one pass (include/snk_rmdup.h, snk_rmdup_stream_*): every batch is hashed and
-    // looked up in a table that stays in HBM; the other rmdup runs keep the reference's two passes (SE: its flags are shifted by
-    // one read inside full patches, see below; several devices: the table lives on one).  SNK_RMDUP_TWO_PASS=1 forces them.
-    bool rmdup_one_pass = o.p.rmdup && mates == 2 && o.devices.size() == 1 && !getenv("SNK_RMDUP_TWO_PASS");
+    // looked up in a table that stays in HBM (single end: with the reference's one-read shift of the flags inside full patches,
+    // snk_rmdup_stream_mark_se_device -- the batches end on patch borders).  With several devices the table lives on the first:
+    // the other devices send their batches' hashes there and get the flags back (9 bytes per pair against the ~700 of the
+    // pair's text), marked in input order on a stream of the table's device.  SNK_RMDUP_TWO_PASS=1 forces the reference's two passes.
+    const int64_t rmdup_patch = o.patch_size > 0 ? o.patch_size : (int64_t)o.threads * 20000 / 8;
+    bool rmdup_one_pass = o.p.rmdup && (mates == 2 || (rmdup_patch > 0 && o.batch_pairs % rmdup_patch == 0)) && !getenv("SNK_RMDUP_TWO_PASS");
     if (rmdup_one_pass) {
         // the one-pass table keeps 8 B per pair of hashes and up to 48 B per pair of table resident in HBM: when twice the
         // estimated number of pairs (file size / bytes of the first record) does not fit, the two passes run instead
@@ -1708,7 +1721,17 @@ int main(int argc, char **argv) {
                     HIPCHK(hipMalloc(&sl.d_tmp, sl.tmp_bytes));
                     if (dev_gz) { sl.ztmp_bytes = snk_fastq_deflate_tmp_bytes(B, GZ_RPM); HIPCHK(hipMalloc(&sl.d_ztmp, sl.ztmp_bytes)); }
                     HIPCHK(hipEventCreateWithFlags(&sl.parsed, hipEventDisableTiming));
-                    if (rmdup_stream) HIPCHK(hipMalloc(&sl.d_hash, (size_t)B * sizeof(uint64_t)));
+                    if (rmdup_stream) {
+                        HIPCHK(hipMalloc(&sl.d_hash, (size_t)B * sizeof(uint64_t)));
+                        if (d.id != devs[0].id) {
+                            HIPCHK(hipEventCreateWithFlags(&sl.hashed, hipEventDisableTiming));
+                            HIPCHK(hipSetDevice(devs[0].id));
+                            HIPCHK(hipMalloc(&sl.d_hash0, (size_t)B * sizeof(uint64_t)));
+                            HIPCHK(hipMalloc(&sl.d_flags0, (size_t)B));
+                            HIPCHK(hipEventCreateWithFlags(&sl.marked, hipEventDisableTiming));
+                            HIPCHK(hipSetDevice(d.id));
+                        }
+                    }
                 }
                 HIPCHK(hipHostMalloc(&sl.h_flags, (size_t)B)); HIPCHK(hipMalloc(&sl.d_flags, (size_t)B));
                 HIPCHK(hipHostMalloc(&sl.h_err, sizeof(uint64_t)));
@@ -1739,7 +1762,16 @@ int main(int argc, char **argv) {
                     HIPCHK(hipHostFree(sl.h_seq[m])); HIPCHK(hipHostFree(sl.h_qual[m])); HIPCHK(hipHostFree(sl.h_len[m])); HIPCHK(hipHostFree(sl.h_rec[m]));
                 }
                 if (dev_text) { HIPCHK(hipFree(sl.d_tmp)); HIPCHK(hipEventDestroy(sl.parsed)); }
-                if (rmdup_stream) HIPCHK(hipFree(sl.d_hash));
+                if (rmdup_stream) {
+                    HIPCHK(hipFree(sl.d_hash));
+                    if (sl.d_hash0) {
+                        HIPCHK(hipEventDestroy(sl.hashed));
+                        HIPCHK(hipSetDevice(devs[0].id));
+                        HIPCHK(hipFree(sl.d_hash0)); HIPCHK(hipFree(sl.d_flags0)); HIPCHK(hipEventDestroy(sl.marked));
+                        HIPCHK(hipSetDevice(d.id));
+                        sl.d_hash0 = nullptr; sl.d_flags0 = nullptr; sl.hashed = sl.marked = nullptr;
+                    }
+                }
                 if (dev_gz) HIPCHK(hipFree(sl.d_ztmp));
                 HIPCHK(hipHostFree(sl.h_flags)); HIPCHK(hipFree(sl.d_flags)); HIPCHK(hipHostFree(sl.h_err));
                 HIPCHK(hipStreamDestroy(sl.stream));
@@ -1835,8 +1867,10 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> dup_host;                        // the same flags on the host (combined with tile/fov bits per batch)
     std::vector<OutFile> dupw[2];
     snk_rmdup_stream *dup_table = nullptr;
+    hipStream_t mark_stream = nullptr;                      // (of the table's device: batches of the other devices are marked there)
     if (rmdup_stream) {
         HIPCHK(hipSetDevice(devs[0].id));
+        if (G > 1) HIPCHK(hipStreamCreate(&mark_stream));
         uint64_t guess = 1u << 20;                          // pairs in the input, from the file sizes and the first batch (the table grows if it was short)
         struct stat st;
         if (stat(inputs[0].c_str(), &st) == 0 && first[0]->n > 0 && first[0]->nbytes > 0) {
@@ -1845,6 +1879,7 @@ int main(int argc, char **argv) {
         }
         dup_table = snk_rmdup_stream_create(devs[0].ctx, std::min<uint64_t>(guess, 4294967295ull));
         if (!dup_table) die(snk_last_error());
+        log << local_time() << "\trmdup: one pass (duplicate table resident on the device" << (mates == 1 ? "; batches of " + std::to_string(B) + " reads end on patch borders)" : ")") << endl;
         for (int m = 0; m < mates; ++m) {                   // dupReads.<thread>.<mate>.gz, src/peprocess.cpp:167-174
             dupw[m].resize(T);
             for (int t = 0; t < T; ++t) dupw[m][t].open(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz", true);
@@ -2348,7 +2383,26 @@ int main(int argc, char **argv) {
                 hb.pitch = pitch;
                 for (int m = 0; m < mates; ++m) { hb.seq[m] = s.d_seq[m]; hb.qual[m] = s.d_qual[m]; hb.len[m] = s.d_len[m]; }
                 if (snk_rmdup_hash_device(dv.ctx, &hb, s.d_hash, s.stream) != SNK_OK) die(snk_last_error());
-                int mrc = snk_rmdup_stream_mark_device(dup_table, s.d_hash, s.first, n, s.d_flags, s.stream);
+                // (single end: every batch but the file's last is whole patches -- a shorter one can only be the last)
+                auto mark = [&](const uint64_t *dh, uint8_t *df, hipStream_t st) {
+                    return mates == 2 ? snk_rmdup_stream_mark_device(dup_table, dh, s.first, n, df, st)
+                                      : snk_rmdup_stream_mark_se_device(dup_table, dh, s.first, n, (int64_t)n / rmdup_patch * rmdup_patch, df, st);
+                };
+                int mrc;
+                if (!s.d_hash0) mrc = mark(s.d_hash, s.d_flags, s.stream);
+                else {                                       // the table is on the first device
+                    HIPCHK(hipEventRecord(s.hashed, s.stream));
+                    HIPCHK(hipSetDevice(devs[0].id));
+                    HIPCHK(hipStreamWaitEvent(mark_stream, s.hashed, 0));
+                    HIPCHK(hipMemcpyAsync(s.d_hash0, s.d_hash, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, mark_stream));
+                    mrc = mark(s.d_hash0, s.d_flags0, mark_stream);
+                    if (mrc == SNK_OK) {
+                        HIPCHK(hipMemcpyAsync(s.d_flags, s.d_flags0, (size_t)n, hipMemcpyDeviceToDevice, mark_stream));
+                        HIPCHK(hipEventRecord(s.marked, mark_stream));
+                    }
+                    HIPCHK(hipSetDevice(dv.id));
+                    if (mrc == SNK_OK) HIPCHK(hipStreamWaitEvent(s.stream, s.marked, 0));
+                }
                 if (mrc == SNK_E_NOMEM)                      // (the estimate below was short by more than a factor of two)
                     die(string(snk_last_error()) + ": run again with SNK_RMDUP_TWO_PASS=1 in the environment (the memory-lean two passes)");
                 if (mrc != SNK_OK) die(snk_last_error());

@@ -152,6 +152,53 @@ def test_cli_rmdup_one_pass_variants(mode, tmp_path):
     assert (b"the one-pass table would need" in log) == (mode == "table_does_not_fit")
 
 
+@T.not_yet_on_hardware
+@pytest.mark.parametrize("n,batch,mode", [(20000, "4096", "one"), (20100, "4096", "one"), (20100, "700", "one"), (19999, "4096", "gz"), (20100, "4096", "two_pass"),
+                                           (20100, "4096", "sentinel_restart"), (20100, "2048", "two_devices")])
+def test_cli_rmdup_single_end_one_pass(n, batch, mode, tmp_path):
+    """Single-end rmdup in one pass (snk_rmdup_stream_mark_se_device): the reference filters read i of a full patch with the duplicate
+    flag of read i - 1 (src/seprocess.cpp:1086,1159) and only the partial patch at the end of the file aligned -- batches cut at
+    patch borders (4096 -> 4000, 700 -> 500 reads with patch = 250), the flag in front of a batch carried on the device, duplicates
+    next to patch and batch borders and inside the last patch.  Same bytes as the reference binary, and as the two passes."""
+    L, threads, patch = 150, 3, 250
+    d = synth.make_batch(n, L, paired=False, seed=63)
+    d["seq"][0][10000:12000] = d["seq"][0][0:2000]              # duplicates whose shifted flags cross batch borders (12000 = 3 x 4000)
+    d["seq"][0][15999:16001] = d["seq"][0][3:5]                 # ... and sit on both sides of one
+    d["seq"][0][4249:4251] = d["seq"][0][7:9]                   # both sides of a patch border
+    d["seq"][0][n - 40:n - 20] = d["seq"][0][700:720]           # inside the last patch (partial for n = 20100 / 19999: aligned flags)
+    d["seq"][0][n - 1] = d["seq"][0][1]                         # the file's last read
+    cli = ["-f", synth.ADAPTER1, "-J"]
+    env = {"SNK_BATCH_PAIRS": batch}
+    if mode == "two_pass":
+        env["SNK_RMDUP_TWO_PASS"] = "1"
+    if mode == "sentinel_restart":
+        env["SNK_RMDUP_SENTINEL_TEST"] = "1"
+    case = ("rmdup_se", False, L, n, threads, patch, {}, {}, cli, ["rmdup"])
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    gz = mode == "gz"
+    ours_case = case
+    if mode == "two_devices":                                   # the table on the first device, batches alternating between the two
+        import torch
+        ours_case = case[:8] + (cli + ["--devices", "0,1" if torch.cuda.device_count() >= 2 else "0,0"],) + case[9:]
+    ours = _run_ours(ours_case, work, gz=gz, env=env)
+    for f in R.REPORT_FILES_SE:
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    assert _cat(os.path.join(ours, "c1.fq" + (".gz" if gz else ""))) == _cat(os.path.join(ref, "c1.fq"))
+    nd = 0
+    for t in range(threads):
+        f = f"dupReads.{t}.1.gz"
+        a = _cat(os.path.join(ours, f))
+        assert a == _cat(os.path.join(ref, f)), f
+        nd += a.count(b"\n") // 4
+    log = open(os.path.join(ours, "log"), "rb").read()
+    assert nd > 2000 and (b"dup number:\t%d" % nd) in log
+    assert (b"restarted" in log) == (mode == "sentinel_restart")
+    assert (b"rmdup: one pass" in log) == (mode in ("one", "gz", "two_devices"))      # (the restarted run writes a new log)
+    if mode in ("one", "gz", "two_devices"):
+        assert (b"batches of %d reads" % (int(batch) // patch * patch)) in log
+
+
 def test_cli_pe_info_outqual_and_crlf(tmp_path):
     """config keys pe_info + outQualSys (output-side transforms) and CRLF input (the first-line white-space rule)."""
     n, L = 3000, 100

@@ -230,3 +230,42 @@ def test_one_pass_table_refuses_too_many_reads():
     assert lib.snk_rmdup_stream_mark_device(t, hb.data_ptr(), 4294967290, 8, db.data_ptr(), None) != 0
     assert b"2^32-1" in lib.snk_last_error()
     lib.snk_rmdup_stream_destroy(t)
+
+
+@T.not_yet_on_hardware
+def test_one_pass_table_single_end_shift():
+    """snk_rmdup_stream_mark_se_device: out[i] = the true flag of read i - 1 inside full patches (across batch borders, from
+    alternating streams, through a regrown scratch), the true flag of read i in the file's partial last patch
+    (src/seprocess.cpp:1086,1112,1159)."""
+    import ctypes as C
+    import torch
+    lib = abi.load_library()
+    rng = np.random.default_rng(22)
+    for n, ps, per_batch in ((100_000, 250, 4000), (60_100, 500, 7500), (999, 1000, 5000), (3000, 1000, 1000)):
+        h = rng.integers(0, max(2, n // 3), n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1)
+        true = T.oracle_markdup(h)
+        full_end = n // ps * ps
+        want = true.copy()
+        want[1:full_end] = true[:max(full_end - 1, 0)]
+        if full_end:
+            want[0] = 0
+        t = lib.snk_rmdup_stream_create(None, 1024)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs, pos, k = [], 0, 0
+        while pos < n:
+            m = min(n - pos, per_batch)
+            st = streams[k % 2]
+            with torch.cuda.stream(st):
+                hb = torch.from_numpy(h[pos:pos + m].view(np.int64).copy()).cuda()
+                db = torch.empty(m, dtype=torch.uint8, device="cuda")
+            assert lib.snk_rmdup_stream_mark_se_device(t, hb.data_ptr(), pos, m, m // ps * ps, db.data_ptr(), st.cuda_stream) == 0, lib.snk_last_error()
+            outs.append((pos, m, db, hb))
+            pos += m
+            k += 1
+        marked, seen = C.c_uint64(0), C.c_int32(0)
+        assert lib.snk_rmdup_stream_stats(t, C.byref(marked), C.byref(seen)) == 0
+        torch.cuda.synchronize()
+        got = np.concatenate([db.cpu().numpy() for _, _, db, _ in outs])
+        lib.snk_rmdup_stream_destroy(t)
+        assert np.array_equal(got, want), (n, ps, np.nonzero(got != want)[0][:8])
+        assert marked.value == int(true.sum())

@@ -38,3 +38,28 @@ def test_cli_sharded_ingest_emulated(paired, gz_out, trim, tmp_path):
 
 def test_cli_rmdup_table_that_does_not_fit_emulated(tmp_path):
     CG.test_cli_rmdup_one_pass_variants("table_does_not_fit", tmp_path)
+
+
+@pytest.mark.parametrize("n,batch,mode", [(20000, "4096", "one"), (20100, "4096", "one"), (20100, "700", "one"), (19999, "4096", "gz"), (20100, "4096", "two_pass"),
+                                           (20100, "4096", "sentinel_restart"), (20100, "2048", "two_devices")])
+def test_cli_rmdup_single_end_one_pass_emulated(n, batch, mode, tmp_path):
+    CG.test_cli_rmdup_single_end_one_pass(n, batch, mode, tmp_path)
+
+
+@pytest.fixture
+def two_emulated_devices(monkeypatch):
+    """--devices 0,1 with the emulator posing as two devices (one address space, so the copies between them are plain copies:
+    what this shows is the orchestration -- which buffers, which stream, which order -- not peer access)"""
+    import torch
+    monkeypatch.setenv("SIMT_DEVICES", "2")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+
+
+@pytest.mark.parametrize("paired", [True, False])
+def test_cli_rmdup_one_pass_across_two_devices_emulated(paired, two_emulated_devices, tmp_path):
+    """the duplicate table on the first device, the second device's batches marked there (hashes over, flags back)"""
+    if paired:
+        CG.test_cli_two_device_slots(True, tmp_path)
+        assert b"rmdup: one pass" in open(os.path.join(str(tmp_path), "ours", "log"), "rb").read()
+    else:
+        CG.test_cli_rmdup_single_end_one_pass(20100, "2048", "two_devices", tmp_path)

@@ -28,7 +28,7 @@ CORE = ["test_pe150_cases", "test_se100_cases[C3_full", "test_pe250_full[0]", "t
         "test_adapter_budgets_above_three", "test_adapters_of_any_length", "test_long_adapter_lists_and_lower_case_on_the_fast_paths[6]",
         "test_contam_fuzz[8]", "test_contam_fuzz[28]", "test_contam_fuzz_long_reads[4]", "test_long_reads[", "test_long_reads_contaminants",
         "test_long_reads_plane_store", "test_random_parameter_contexts_on_the_device[0-", "test_random_parameter_contexts_on_the_device[20-",
-        "test_hash_vs_oracle", "test_hash_odd", "test_mark_vs_oracle", "test_one_pass_table_vs_oracle", "test_parse_and_format", "test_device_gzip_members_round_trip[5000",
+        "test_hash_vs_oracle", "test_hash_odd", "test_mark_vs_oracle", "test_one_pass_table_vs_oracle", "test_one_pass_table_single_end_shift", "test_parse_and_format", "test_device_gzip_members_round_trip[5000",
         "test_device_inflate_kernels_produce_zlibs_bytes[65536]", "test_device_inflate_refuses", "test_bit_transpose[random]"]
 CAP = 12000          # pairs per batch under the emulator (about 10 k pairs a second here); sizes up to it stay as they are
 
@@ -149,6 +149,12 @@ def test_random_parameter_contexts_on_the_device(i, kernel):
 from test_rmdup_gpu import (test_hash_golden, test_hash_vs_oracle, test_hash_odd_tile_counts, test_mark_golden, test_mark_vs_oracle_random,      # noqa: E402,F401
                             test_mark_with_explicit_indices, test_too_many_reads_is_refused, test_one_pass_table_vs_oracle,
                             test_one_pass_table_refuses_too_many_reads)
+
+
+def test_one_pass_table_single_end_shift():
+    RD.test_one_pass_table_single_end_shift()
+
+
 from test_fastq_gpu import (test_parse_and_format_match_the_restatement, test_parse_reports_bad_input, test_device_gzip_members_round_trip,      # noqa: E402,F401
                             test_format_selects_other_verdicts_whole)
 from test_gunzip_gpu import test_device_inflate_kernels_produce_zlibs_bytes, test_device_inflate_refuses_what_does_not_fit      # noqa: E402,F401
