@@ -2696,6 +2696,8 @@ int main(int argc, char **argv) {
         for (int t = 0; t < T && ok; ++t) ok = fwrite(sums[(size_t)t].data(), 8, sums[(size_t)t].size(), f) == sums[(size_t)t].size();
         for (int t = 0; t < T && ok; ++t) ok = fwrite(maxs[(size_t)t].data(), 8, (size_t)SNK_MAX_N, f) == (size_t)SNK_MAX_N;
         if (!ok || fclose(f) != 0) die("cannot write to the file," + g_shard.stats_path);
+        for (auto &t : slot_makers) t.join();              // (a short shard can get here before its last slots exist)
+        slot_makers.clear();
         log.close();
         cout.flush();
         fflush(stdout);

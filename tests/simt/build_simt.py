@@ -54,18 +54,26 @@ def build(force=False, extra=(), lib=LIB):
 CLI = os.path.join(OUT, "SOAPnuke_simt")
 
 
-def build_cli(force=False):
+def build_cli_tsan(force=False):
+    """the CLI's own code (readers, the writer, slot makers, the parallel and the device gunzip orchestration) with ThreadSanitizer,
+    linked against the plain emulated library (whose fibers the sanitizer would not follow)"""
+    return build_cli(force, extra=("-fsanitize=thread",), tag="_tsan", lib_tag="")
+
+
+def build_cli(force=False, extra=(), tag="", lib_tag=None):
     """`SOAPnuke filter` (soapnuke_amd/host) linked against the emulated library: the whole host side -- readers, gzip, shards, rmdup
     orchestration, reports -- runs on the CPU and can be compared with the reference binary file by file"""
-    lib = build(force)
+    lib_tag = tag if lib_tag is None else lib_tag
+    lib = build(force, extra if lib_tag else (), os.path.join(OUT, "libsnk_filter_simt" + lib_tag + ".so"))
+    cli = CLI + tag
     host = os.path.join(ROOT, "soapnuke_amd", "host")
     srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith((".cpp", ".h"))]
-    if not force and os.path.exists(CLI) and os.path.getmtime(CLI) >= max(os.path.getmtime(f) for f in srcs + [lib]):
-        return CLI
-    cmd = [CXX] + FLAGS + ["-x", "c++", os.path.join(host, "snk_main.cpp"), os.path.join(host, "snk_report.cpp"), "-x", "none",
-                           "-o", CLI, "-L" + OUT, "-lsnk_filter_simt", "-lz", "-ldl", "-Wl,-rpath," + OUT]
+    if not force and os.path.exists(cli) and os.path.getmtime(cli) >= max(os.path.getmtime(f) for f in srcs + [lib]):
+        return cli
+    cmd = [CXX] + FLAGS + list(extra) + ["-x", "c++", os.path.join(host, "snk_main.cpp"), os.path.join(host, "snk_report.cpp"), "-x", "none",
+                                         "-o", cli, "-L" + OUT, "-lsnk_filter_simt" + lib_tag, "-lz", "-ldl", "-Wl,-rpath," + OUT]
     subprocess.check_call(cmd)
-    return CLI
+    return cli
 
 
 if __name__ == "__main__":

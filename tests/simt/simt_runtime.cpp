@@ -44,6 +44,15 @@ simt_switch:
 alignas(256) thread_local uint8_t simt_dyn_lds[160 * 1024];
 uint8_t *simt_dyn_shared() { return simt_dyn_lds; }
 
+// AddressSanitizer builds (tests/test_simt_sanitized.py): the runtime is told about every stack switch
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define SIMT_ASAN 1
+extern "C" void __sanitizer_start_switch_fiber(void **fake_stack_save, const void *bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const void **bottom_old, size_t *size_old);
+#endif
+#endif
+
 namespace simt {
 thread_local Fiber *cur = nullptr;
 
@@ -58,6 +67,9 @@ struct Worker {
     Wave waves[MAXT / 64];
     Block blk;
     const std::function<void()> *body = nullptr;
+    const void *sched_bottom = nullptr;        // (AddressSanitizer: the scheduler's own stack)
+    size_t sched_size = 0;
+    void *sched_fake = nullptr;
     Worker() {
         stacks = (char *)mmap(nullptr, STACK * MAXT, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
         if (stacks == MAP_FAILED) { perror("simt: mmap of the fiber stacks"); abort(); }
@@ -121,8 +133,14 @@ bool release_divergent(Worker &wk, int nwaves) {
 
 extern "C" void simt_fiber_main() {
     Fiber *f = cur;
+#ifdef SIMT_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &W->sched_bottom, &W->sched_size);
+#endif
     (*W->body)();
     fiber_exit(f);
+#ifdef SIMT_ASAN
+    __sanitizer_start_switch_fiber(nullptr, W->sched_bottom, W->sched_size);      // (nullptr: this fiber's fake stack is given up)
+#endif
     for (;;) simt_switch(&f->sp, W->sched_sp);       // never resumed
 }
 
@@ -172,7 +190,13 @@ void run_block(Worker &wk, const std::function<void()> &body, dim3 grid, dim3 bl
             }
             ran = true;
             cur = &f;
+#ifdef SIMT_ASAN
+            __sanitizer_start_switch_fiber(&wk.sched_fake, wk.stacks + STACK * (size_t)i, STACK);
+#endif
             simt_switch(&wk.sched_sp, f.sp);
+#ifdef SIMT_ASAN
+            __sanitizer_finish_switch_fiber(wk.sched_fake, nullptr, nullptr);
+#endif
             if (f.done) --left;
         }
         if (!ran && release_divergent(wk, nw)) continue;
@@ -329,7 +353,14 @@ __attribute__((noinline, convergent)) const uint64_t *wave_exchange(uint64_t min
 
 void yield_to_scheduler() {
     Fiber *f = cur;
+#ifdef SIMT_ASAN
+    void *fake = nullptr;
+    __sanitizer_start_switch_fiber(&fake, W->sched_bottom, W->sched_size);
+#endif
     simt_switch(&f->sp, W->sched_sp);
+#ifdef SIMT_ASAN
+    __sanitizer_finish_switch_fiber(fake, &W->sched_bottom, &W->sched_size);
+#endif
 }
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {

@@ -1,0 +1,93 @@
+"""AddressSanitizer over the kernels and the host side at once: the emulated library (tests/simt: the HIP sources compiled for the
+host) and the CLI of soapnuke_amd/host built with -fsanitize=address, end-to-end cases of tests/test_cli_gpu.py run with them
+against the reference binary.  Device memory is the sanitizer's malloc here, so a kernel that reads or writes past a device buffer
+(or past the 160 KB of LDS), a host buffer overrun in the readers / writers, a use after free of a slot -- abort the run.
+(VERDICT r3 #9 asked for sanitizer builds of the CLI; the emulator's fiber switches are announced to the sanitizer,
+tests/simt/simt_runtime.cpp.)"""
+import os
+
+import pytest
+
+import simt_lib as S
+import snk_testlib as T
+import test_cli_gpu as CG
+import test_gunzip_gpu as GZ
+
+# an ordinary run takes one case; SNK_SIMT_FULL=1 all of them (tests/conftest.py)
+CORE = ["test_asan_cli_matches_reference_binary[pe_full_T3]", "test_tsan_cli_host_threads[gz]"]
+pytestmark = pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")
+ASAN_FLAGS = ("-fsanitize=address", "-fno-sanitize-recover=all", "-shared-libasan")
+
+
+@pytest.fixture
+def tsan_cli(monkeypatch):
+    """ThreadSanitizer over the CLI's own threads (the emulated library stays uninstrumented: its fibers are not threads)"""
+    cli = S.build_module().build_cli_tsan()
+    monkeypatch.setattr(CG, "CLI", cli)
+    monkeypatch.setenv("TSAN_OPTIONS", "halt_on_error=1 second_deadlock_stack=1 exitcode=66")
+    monkeypatch.setenv("SNK_RUN_UNVERIFIED", "1")
+
+
+@pytest.fixture(autouse=True)
+def _asan_cli(monkeypatch):
+    import subprocess
+    mod = S.build_module()
+    cli = mod.build_cli(extra=ASAN_FLAGS, tag="_asan")
+    rt = os.path.dirname(subprocess.check_output([mod.CXX, "-print-file-name=libclang_rt.asan-x86_64.so"]).decode().strip())
+    monkeypatch.setattr(CG, "CLI", cli)
+    monkeypatch.setattr(GZ, "CLI", cli, raising=False)
+    monkeypatch.setenv("LD_LIBRARY_PATH", rt + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    monkeypatch.setenv("ASAN_OPTIONS", "detect_leaks=0:abort_on_error=0:detect_stack_use_after_return=0")
+    monkeypatch.setenv("SNK_RUN_UNVERIFIED", "1")
+
+
+@pytest.mark.parametrize("case", CG.R.REPORT_CASES, ids=[c[0] for c in CG.R.REPORT_CASES])
+def test_asan_cli_matches_reference_binary(case, tmp_path):
+    CG.test_cli_matches_reference_binary(case, tmp_path)
+
+
+def test_asan_gz_in_gz_out(tmp_path):
+    CG.test_cli_gz_in_gz_out(tmp_path)
+
+
+def test_asan_long_reads(tmp_path):
+    CG.test_cli_long_reads(600, True, tmp_path)
+
+
+def test_asan_contaminants(tmp_path):
+    CG.test_cli_contaminants_match_reference_binary(True, 150, 12000, tmp_path)
+
+
+@pytest.mark.parametrize("mode", ["small_batches", "two_pass"])
+def test_asan_rmdup(mode, tmp_path):
+    CG.test_cli_rmdup_one_pass_variants(mode, tmp_path)
+
+
+def test_asan_rmdup_single_end(tmp_path):
+    CG.test_cli_rmdup_single_end_one_pass(20100, "700", "one", tmp_path)
+
+
+def test_asan_device_inflate(tmp_path):
+    GZ.test_cli_with_device_inflate_matches_the_reference_binary(tmp_path)
+
+
+def test_asan_sharded_ingest(tmp_path):
+    CG.test_cli_sharded_ingest(True, True, True, tmp_path)
+
+
+def test_asan_streaming(tmp_path):
+    CG.test_cli_streaming(True, 2, 50, ["pe_info", "outQualSys=1"], tmp_path)
+
+
+@pytest.mark.parametrize("which", ["pe_full", "gz", "rmdup_small_batches", "streaming", "sharded"])
+def test_tsan_cli_host_threads(which, tsan_cli, tmp_path):
+    if which == "pe_full":
+        CG.test_cli_matches_reference_binary(CG.R.REPORT_CASES[1], tmp_path)
+    elif which == "gz":
+        CG.test_cli_gz_in_gz_out(tmp_path)
+    elif which == "rmdup_small_batches":
+        CG.test_cli_rmdup_one_pass_variants("small_batches", tmp_path)
+    elif which == "streaming":
+        CG.test_cli_streaming(True, 2, 50, ["pe_info", "outQualSys=1"], tmp_path)
+    else:
+        CG.test_cli_sharded_ingest(True, False, False, tmp_path)
