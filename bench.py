@@ -34,6 +34,9 @@ PAIRS_UNIQUE = 1_000_000
 L = 150
 BYTES_PER_PAIR = 2 * (2 * L + 16)      # bases + qualities read once + 16 B record, per mate
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# tests/test_simt_bench.py runs this file on the CPU emulator to check that every leg produces its keys: the row sizes of
+# other_workloads() shrink by this factor there (1 on the GPU box -- never set it for a measurement)
+TEST_DIVISOR = max(1, int(os.environ.get("SNK_BENCH_TEST_DIVISOR", "1")))
 
 
 WORKLOADS = {
@@ -128,6 +131,7 @@ def end_to_end(n_pairs, threads=16, rmdup_pairs=4_000_000):
             res["modes"]["plain_ours"]["speedup_vs_reference_gz2plain"] = round(b["wall_s"] / a["wall_s"], 2)
     except KeyError:
         pass
+    rmdup_pairs //= TEST_DIVISOR
     if rmdup_pairs > 0:
         tmp = tempfile.mkdtemp(prefix="snkbench_", dir=shm)
         try:
@@ -145,7 +149,8 @@ def rmdup_kernels(n=10_000_000, L=250):
     import torch
     from soapnuke_amd import abi, synth
     from soapnuke_amd.filter import FilterContext
-    uniq = 500_000
+    uniq = max(64, 500_000 // TEST_DIVISOR)
+    n = max(uniq, n // TEST_DIVISOR)
     d = synth.make_batch(uniq, L, paired=True)
     ctx = FilterContext(abi.default_params(paired=True, max_read_len=L, rmdup=1), device=0)
     dev = ctx.upload(d)
@@ -176,10 +181,10 @@ def rmdup_kernels(n=10_000_000, L=250):
     ctx.close()
     del dev, h, hh
     torch.cuda.empty_cache()
-    return [{"workload": f"rmdup hash kernel (std::hash of mate1 ++ mate2), PE{L}, {nn // 1000000} M pairs", "ms": round(ms_h, 3),
+    return [{"workload": f"rmdup hash kernel (std::hash of mate1 ++ mate2), PE{L}, {nn / 1e6:g} M pairs", "ms": round(ms_h, 3),
              "Mreads_per_s": round(2 * nn / ms_h / 1e3, 1), "algorithmic_GBps": round((2 * L + 8) * nn / ms_h / 1e6, 1),
              "frac_of_hbm_peak": round((2 * L + 8) * nn / ms_h / 1e6 / HBM_PEAK_GBS, 4), "error": 0},
-            {"workload": f"rmdup marking kernels (hash table in HBM: insert + look-up), {nn // 1000000} M hashes, 5 % duplicates", "ms": round(ms_m, 3),
+            {"workload": f"rmdup marking kernels (hash table in HBM: insert + look-up), {nn / 1e6:g} M hashes, 5 % duplicates", "ms": round(ms_m, 3),
              "Mreads_per_s": round(2 * nn / ms_m / 1e3, 1), "algorithmic_GBps": round(9 * nn / ms_m / 1e6, 1),
              "frac_of_hbm_peak": round(9 * nn / ms_m / 1e6 / HBM_PEAK_GBS, 4), "error": 0,
              "note": "random access: 8 B hash in + 1 B flag out per pair are the algorithmic bytes, the table traffic is not counted"}]
@@ -227,7 +232,8 @@ def _workload_row(name, L, n, kern, kw, var_len):
     from soapnuke_amd import abi, synth
     from soapnuke_amd.filter import FilterContext
     if True:
-        uniq = 500_000 if L <= 150 else 100_000
+        uniq = max(64, (500_000 if L <= 150 else 100_000) // TEST_DIVISOR)
+        n = max(uniq, n // TEST_DIVISOR)
         d = synth.make_batch(uniq, L, paired=True, var_len=var_len)
         ctx = FilterContext(abi.default_params(paired=True, max_read_len=L, **kw), device=0)
         dev = ctx.upload(d)

@@ -74,6 +74,21 @@ def torch_on_host(monkeypatch):
     monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
     monkeypatch.setattr(torch.cuda, "Stream", lambda *a, **k: stream)
     monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    class Event:                                        # wall-clock stand-in (timing means nothing on the emulator)
+        def __init__(self, enable_timing=False):
+            self.t = 0.0
+
+        def record(self, stream=None):
+            import time
+            self.t = time.perf_counter()
+
+        def synchronize(self):
+            pass
+
+        def elapsed_time(self, other):
+            return max((other.t - self.t) * 1e3, 1e-6)
+
+    monkeypatch.setattr(torch.cuda, "Event", Event)
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a: (16 << 30, 32 << 30))

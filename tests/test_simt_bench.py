@@ -1,0 +1,49 @@
+"""bench.py from its first line to its last on the CPU emulator (tests/simt), at a thousandth of its sizes: what this checks is
+that the ONE JSON line the round-end driver parses is produced with every key of the contract -- the headline block with
+`roofline`, `cpu_baseline`, the `end_to_end` legs (this CLI and the reference binary on the same files, `report_identical`),
+the `pe250_rmdup` leg, every `other_workloads` row without an error -- by the code paths written while the GPU was closed.
+The numbers mean nothing here."""
+import importlib.util
+import json
+import os
+import sys
+
+import pytest
+
+import simt_lib as S
+import snk_testlib as T
+
+CORE = ["test_bench_line"]
+pytestmark = pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")
+
+
+def test_bench_line_has_every_leg(monkeypatch, capsys):
+    S.torch_on_host(monkeypatch)
+    monkeypatch.setenv("SNK_BENCH_TEST_DIVISOR", "1000")
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(T.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sys.path.insert(0, os.path.join(T.ROOT, "tools"))
+    import bench_e2e
+    monkeypatch.setattr(bench_e2e, "OURS", S.build_module().build_cli())
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--pairs", "10000", "--e2e-pairs", "16000"])
+    bench.main()
+    line = [x for x in capsys.readouterr().out.splitlines() if x.startswith("{")][-1]
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "end_to_end", "other_workloads"):
+        assert k in out, k
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["n_gpus"] == 1 and out["config"]["pairs_per_gpu_per_step"] == 10000
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and out["roofline"]["bound"] == "hbm"
+    assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and out["cpu_baseline"]["kind"] == "reference"
+    e2e = out["end_to_end"]
+    assert "error" not in e2e, e2e
+    assert set(e2e["modes"]) == {"plain_ours", "gz", "gz2plain", "gz_c3"}
+    for m in ("gz", "gz2plain", "gz_c3"):
+        leg = e2e["modes"][m]
+        assert leg["ours"]["rc"] == 0 and leg["reference"]["rc"] == 0 and leg["report_identical"] is True, (m, leg)
+    assert e2e["modes"]["plain_ours"]["ours"]["rc"] == 0 and "speedup_vs_reference_gz2plain" in e2e["modes"]["plain_ours"]
+    rm = e2e["pe250_rmdup"]
+    assert "error" not in rm and rm["modes"]["gz"]["report_identical"] is True, rm
+    rows = out["other_workloads"]
+    assert len(rows) == 11 and all(isinstance(r.get("error"), int) and r["error"] == 0 for r in rows), [r for r in rows if r.get("error") != 0]
