@@ -13,7 +13,7 @@ import pytest
 import simt_lib as S
 import snk_testlib as T
 
-CORE = ["test_bench_line"]
+CORE = ["test_bench_line", "test_bounded_memory"]
 pytestmark = pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")
 
 
@@ -47,3 +47,22 @@ def test_bench_line_has_every_leg(monkeypatch, capsys):
     assert "error" not in rm and rm["modes"]["gz"]["report_identical"] is True, rm
     rows = out["other_workloads"]
     assert len(rows) == 11 and all(isinstance(r.get("error"), int) and r["error"] == 0 for r in rows), [r for r in rows if r.get("error") != 0]
+
+
+def test_bounded_memory_big_run_tool(monkeypatch, capsys):
+    """tools/bench_e2e_big.py --bounded (the 628 M-pair run of BASELINE configs[2] under the GPU box's 300 GiB memory cgroup: this CLI
+    timed with holes punched behind its writer, once more into named pipes read by md5 consumers, the reference with a tail reader
+    behind its appends) at 30 000 pairs with the emulated CLI: every stage runs, reports and clean FASTQ compare equal."""
+    sys.path.insert(0, os.path.join(T.ROOT, "tools"))
+    import bench_e2e
+    import bench_e2e_big
+    monkeypatch.setattr(bench_e2e, "OURS", S.build_module().build_cli())
+    monkeypatch.setenv("SNK_BIG_UNIT", "6000")
+    monkeypatch.setattr(sys, "argv", ["bench_e2e_big.py", "30000", "4", "--bounded"])
+    bench_e2e_big.main()
+    out = json.loads([x for x in capsys.readouterr().out.splitlines() if x.startswith("{")][-1])
+    gz = out["gz"]
+    assert gz["ours"]["rc"] == 0 and gz["ours_verify"]["rc"] == 0 and gz["reference"]["rc"] == 0
+    assert gz["ours_verify"]["reports_same_as_timed_run"] is True
+    assert gz["reports_compared"] == 10 and gz["reports_differing"] == [] and gz["clean_fastq_identical"] is True
+    assert out["watchdog_tripped"] is False and "bounded" in out["mode"]

@@ -217,7 +217,7 @@ def main():
     wd.start()
     res["memory_limit_GiB"] = None if wd.limit is None else wd.limit >> 30
     try:
-        u = 1_000_000
+        u = int(os.environ.get("SNK_BIG_UNIT", "1000000"))       # pairs per gzip member (tests/test_simt_bench.py shrinks it)
         d = synth.make_batch(u, L, paired=True)
         if rmdup:                                           # duplicates by sequence (qualities differ), as rmdup sees them
             import numpy as np
