@@ -13,7 +13,7 @@ import pytest
 import simt_lib as S
 import snk_testlib as T
 
-CORE = ["test_bench_line", "test_bounded_memory"]
+CORE = ["test_bench_line", "test_bounded_memory", "test_smoke_entry_point"]
 pytestmark = pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")
 
 
@@ -66,3 +66,13 @@ def test_bounded_memory_big_run_tool(monkeypatch, capsys):
     assert gz["ours_verify"]["reports_same_as_timed_run"] is True
     assert gz["reports_compared"] == 10 and gz["reports_differing"] == [] and gz["clean_fastq_identical"] is True
     assert out["watchdog_tripped"] is False and "bounded" in out["mode"]
+
+
+def test_smoke_entry_point(monkeypatch, capsys):
+    """__graft_entry__.smoke() -- what the driver runs on the GPU box before the bench -- with the emulated library"""
+    S.torch_on_host(monkeypatch)
+    spec = importlib.util.spec_from_file_location("graft_entry_under_test", os.path.join(T.ROOT, "__graft_entry__.py"))
+    entry = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(entry)
+    entry.smoke()
+    assert "smoke OK" in capsys.readouterr().out
