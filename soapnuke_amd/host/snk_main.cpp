@@ -2394,10 +2394,10 @@ int main(int argc, char **argv) {
                     HIPCHK(hipEventRecord(s.hashed, s.stream));
                     HIPCHK(hipSetDevice(devs[0].id));
                     HIPCHK(hipStreamWaitEvent(mark_stream, s.hashed, 0));
-                    HIPCHK(hipMemcpyAsync(s.d_hash0, s.d_hash, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, mark_stream));
+                    HIPCHK(hipMemcpyPeerAsync(s.d_hash0, devs[0].id, s.d_hash, dv.id, (size_t)n * sizeof(uint64_t), mark_stream));
                     mrc = mark(s.d_hash0, s.d_flags0, mark_stream);
                     if (mrc == SNK_OK) {
-                        HIPCHK(hipMemcpyAsync(s.d_flags, s.d_flags0, (size_t)n, hipMemcpyDeviceToDevice, mark_stream));
+                        HIPCHK(hipMemcpyPeerAsync(s.d_flags, dv.id, s.d_flags0, devs[0].id, (size_t)n, mark_stream));
                         HIPCHK(hipEventRecord(s.marked, mark_stream));
                     }
                     HIPCHK(hipSetDevice(dv.id));

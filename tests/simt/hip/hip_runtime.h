@@ -98,6 +98,7 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned flags = 0);
 hipError_t hipHostFree(void *p);
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind);
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr);
+hipError_t hipMemcpyPeerAsync(void *d, int ddev, const void *s, int sdev, size_t n, hipStream_t = nullptr);
 hipError_t hipMemset(void *d, int v, size_t n);
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr);
 hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b);

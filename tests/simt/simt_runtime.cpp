@@ -423,6 +423,7 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
 hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
+hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { return hipMemset(d, v, n); }
 hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
