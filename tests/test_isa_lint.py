@@ -52,3 +52,19 @@ def test_the_shipped_build_is_clean():
         pytest.skip("no kept assembly (soapnuke_amd/build.py writes it)")
     funcs, rep = lint.lint_file(asm)
     assert funcs >= 20 and rep == [], rep[:5]
+
+
+def test_the_headline_instances_have_not_grown():
+    """tools/isa_static.py: spilled registers, scratch bytes and instruction counts of the BASELINE configs[1] / [2] instances of the
+    tiled kernel in the build's assembly against the committed figures (profiles/r04_isa_static.json) -- a change that makes them
+    worse shows here, without a GPU"""
+    import subprocess
+    import sys
+
+    import pytest
+    asm = os.path.join(T.ROOT, "soapnuke_amd", "csrc", "build", "snk_tiled-hip-amdgcn-amd-amdhsa-gfx950.s")
+    if not os.path.exists(asm):
+        pytest.skip("no build directory (the assembly is kept by soapnuke_amd/build.py)")
+    r = subprocess.run([sys.executable, os.path.join(T.ROOT, "tools", "isa_static.py"), "--check", os.path.join(T.ROOT, "profiles", "r04_isa_static.json")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
