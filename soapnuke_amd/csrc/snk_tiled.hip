@@ -126,13 +126,16 @@ __device__ __forceinline__ u32 wave_or(u32 x) {
 // survive the second mate's phases 1 and 2; kept whole it was spilled at the top of every mate iteration: 26 scratch stores per
 // lane and tile-mate, 2.1 GB of scratch writes per 10 M pairs in the FULL variant).  Every count is at most the tile kernel's 256
 // positions (9 bits); inc_ada <=> adacut >= 0; hd_h / hd_t are parameters (trim_finish) and are not stored.
+// ... and of the two mates' states only ONE is carried in registers: the first mate's is parked in its own 16-byte output record
+// (which the pair level fills later anyway: one coalesced 1 KB store per tile and one load instead of six spilled registers stored
+// at the top and reloaded at the bottom of EVERY mate iteration) together with the mate's input-error code.
 struct PackedRS { u64 a; u32 lq; int sumq; };
-__device__ __forceinline__ PackedRS rs_pack(const ReadState &r) {
+__device__ __forceinline__ PackedRS rs_pack(const ReadState &r, int estat) {
     PackedRS p;
     const u32 lo = (u32)r.len | ((u32)r.n_a << 9) | ((u32)r.n_n << 18) | ((u32)r.lowq << 27);                  // lowq: low 5 bits here
     const u32 hi = ((u32)r.lowq >> 5) | ((u32)r.clen << 4) | ((u32)r.start << 13) | ((u32)(r.adacut + 1) << 22) | ((u32)r.polyx << 31);
     p.a = ((u64)hi << 32) | lo;
-    p.lq = ((u32)r.lq_h << 16) | ((u32)r.lq_t & 0xFFFFu);
+    p.lq = ((u32)(r.lq_h + 1) & 0x3FFu) | (((u32)(r.lq_t + 1) & 0x3FFu) << 10) | ((u32)estat << 20);      // -1 .. 256 each; SNK_E_* input errors are 0 .. 4
     p.sumq = r.sumq;
     return p;
 }
@@ -147,12 +150,25 @@ __device__ __forceinline__ void rs_unpack(const DevParams &P, int mate, const Pa
     r.adacut = (int)((hi >> 22) & 511u) - 1;
     r.polyx = (int)(hi >> 31);
     r.inc_ada = r.adacut >= 0 ? 1 : 0;
-    r.lq_h = (int)(short)(p.lq >> 16);
-    r.lq_t = (int)(short)(p.lq & 0xFFFFu);
+    r.lq_h = (int)(p.lq & 0x3FFu) - 1;
+    r.lq_t = (int)((p.lq >> 10) & 0x3FFu) - 1;
     r.sumq = p.sumq;
     const bool hard = P.trim_on && P.has_hard;                         // trim_finish(), snk_common.cuh
     r.hd_h = hard ? P.hard[P.paired ? 2 * mate : 0] : -1;
     r.hd_t = hard ? P.hard[P.paired ? 2 * mate + 1 : 1] : -1;
+}
+
+__device__ __forceinline__ int rs_estat(const PackedRS &p) { return (int)(p.lq >> 20); }
+__device__ __forceinline__ void rs_park(snk_read_result *out, long i, const PackedRS &p) {
+    *reinterpret_cast<uint4 *>(out + i) = make_uint4((u32)p.a, (u32)(p.a >> 32), p.lq, (u32)p.sumq);
+}
+__device__ __forceinline__ PackedRS rs_fetch(const snk_read_result *out, long i) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(out + i);
+    PackedRS p;
+    p.a = ((u64)v.y << 32) | v.x;
+    p.lq = v.z;
+    p.sumq = (int)v.w;
+    return p;
 }
 
 struct TileGeom {
@@ -188,11 +204,9 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
     const bool lanev = lane < cnt;
     const long fb = file_block(G.lcap, nq);
     const long ts_off = SNK_GS_N + (long)G.lcap * 5 + (long)G.lcap * nq;
-    const u64 gidx = B.first_index + (u64)(t0 + lane);
     const int lgb = G.lg + 2;                         // log2(bytes per histogram bin row)
 
-    PackedRS p0 = {0ull, 0u, 0}, p1 = {0ull, 0u, 0};
-    int e0 = 0, e1 = 0;
+    PackedRS pl = {0ull, 0u, 0};                      // the state of the mate the loop ran last (written by every iteration: nothing is carried)
     const bool oobH = (0 - phred) < P.lq_head_q, oobT = (0 - phred) < P.lq_tail_q;
 
     const uint8_t *const seq0 = B.seq[0], *const seq1 = B.seq[1], *const qual0 = B.qual[0], *const qual1 = B.qual[1];
@@ -632,16 +646,13 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             // past a read's end as the 'A' they were replaced by): A = reads covering the position - C - T - G, and
             // the fix-up pass moves the N of the reads that have any.
             if (SNK_ABL != 11) {
-                u32 IN[NW];                     // variable lengths: bit r of lane p = position p lies inside read r
-                if (!fulllen) {
-#pragma unroll
-                    for (int j = 0; j < NW; ++j) IN[j] = lanev ? lowmask32(clen_v - 32 * j) : 0u;
-                }
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     u32 cover = (u32)cnt;
                     if (!fulllen) {
-                        u32 i0 = IN[2 * s], i1 = (2 * s + 1 < NW) ? IN[(2 * s + 1 < NW) ? 2 * s + 1 : 0] : 0u;
+                        // variable lengths: bit r of lane p = position p lies inside read r (made here, strip by strip: five words
+                        // computed ahead of the loop were spilled across the transposes)
+                        u32 i0 = lanev ? lowmask32(clen_v - 64 * s) : 0u, i1 = (2 * s + 1 < NW && lanev) ? lowmask32(clen_v - 64 * s - 32) : 0u;
                         bit_transpose64(i0, i1, lane);
                         cover = __popc(i0) + __popc(i1);
                     }
@@ -869,19 +880,23 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         }
         if (ada_pos >= 0) { R.inc_ada = 1; R.adacut = R.len - ada_pos; }
         if (SNK_ABL != 10 && P.trim_on) trim_finish(P, m, R, hix, tix, polyg);
-        if (m == 0) { p0 = rs_pack(R); e0 = estat; }
-        else { p1 = rs_pack(R); e1 = estat; }
+        pl = rs_pack(R, estat);
+        if (m + 1 < mates && lanev) rs_park(B.out[0], t0 + lane, pl);
     }
 
     if ((SNK_ABL == 1 || SNK_ABL >= 11)) return;
     if (SNK_ABL == 2) {
-        asm volatile("" ::"v"(p0.a), "v"(p0.lq), "v"(p0.sumq), "v"(p1.a), "v"(p1.lq), "v"(p1.sumq));
+        asm volatile("" ::"v"(pl.a), "v"(pl.lq), "v"(pl.sumq));
         return;
     }
     // ---------------------------------------------------------------- pair level
     // (quality-range errors are found by the flush through the overflow bin)
     asm volatile("" : "+v"(lane));
     const int pe = mates - 1;
+    PackedRS p0 = pl, p1 = pl;
+    if (pe && lanev) p0 = rs_fetch(B.out[0], t0 + lane);
+    const int e0 = lanev ? rs_estat(p0) : 0, e1 = lanev ? rs_estat(p1) : 0;
+    const u64 gidx = B.first_index + (u64)(t0 + lane);
     if (lanev && (e0 || (pe && e1))) report_err(st, gidx, e0 ? 0 : 1, e0 ? e0 : e1);
     const bool live = lanev && !(e0 || (pe && e1));
     int v = 0, reason = SNK_KEEP;
@@ -894,6 +909,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         reason = pe ? discard_reason(P, r0, r1, dup, v, cfv & 3, (cfv >> 2) & 3) : discard_reason(P, r0, r0, dup, v, cfv & 3, cfv & 3);
         store_rec(B.out[0], t0 + lane, r0, reason, v);
         if (pe) store_rec(B.out[1], t0 + lane, r1, reason, v);
+    } else if (pe && lanev) {
+        rs_park(B.out[0], t0 + lane, PackedRS{0ull, 0u, 0});      // (a pair with an input error gets no record: not the parked state either)
     }
     // reason counters: one LDS add per (family, tile); the workgroup flushes them (chip-wide atomics on
     // a handful of hot addresses once per tile cost a third of the kernel)
