@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/catchup.sh <stage> ... : what round 4 could not run because the GPU lease was closed, in the order it matters.  On the GPU box
-# (through gpurun), from the repository root.  Stages: tests | bench | prof | inflate | big
+# (through gpurun), from the repository root.  Stages: tests | stress | quick | bench | prof | inflate | rmdup | big8 | big
+# (everything here ran on the CPU emulator of tests/simt before: what is open is speed, and what only the hardware can show)
 set -u
 ROOT=$(pwd); export TMPDIR=/tmp; mkdir -p gpurun_out
 for stage in "$@"; do
@@ -22,6 +23,15 @@ for t in ('r4c','r4c_c3'):
       for lvl in 1 6; do timeout 300 python tools/bench_gunzip.py 4 $lvl 128 2>&1 | tail -3; done
       timeout 300 python tools/bench_gunzip.py 4 1 32 2>&1 | tail -3
       for v in 0 1; do SNK_DEVICE_INFLATE=$v SNK_TIMING=1 timeout 600 python tools/bench_e2e.py 8000000 16 gz 2>&1 | grep -E "ours|Mreads" | head -3; done ;;
+    rmdup)   # one pass against two passes, single end and paired, 4 M reads of 250 positions, 5 % duplicates
+      for v in "" 1; do SNK_RMDUP_TWO_PASS=$v timeout 600 python - <<'PY' 2>&1 | tail -2
+import os, sys, json, tempfile
+sys.path.insert(0, "tools"); import bench_e2e
+tmp = tempfile.mkdtemp(prefix="snk_rm_", dir="/dev/shm")
+r = bench_e2e.measure(tmp, 4_000_000, 16, ["gz"], c3=False, extra_cfg=["rmdup"], L=250, dup_frac=0.05)
+print("two passes" if os.environ.get("SNK_RMDUP_TWO_PASS") else "one pass", json.dumps(r["modes"]["gz"]["ours"]), r["modes"]["gz"].get("report_identical"))
+PY
+      done ;;
     big)
       timeout 5000 python tools/bench_e2e_big.py 628000000 16 2> gpurun_out/big628.err | tail -1 > gpurun_out/big628.json; tail -5 gpurun_out/big628.err; cat gpurun_out/big628.json ;;
     big8)
