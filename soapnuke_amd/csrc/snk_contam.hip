@@ -30,6 +30,7 @@ using namespace snk;
 
 #ifndef SNK_CWAVES
 #define SNK_CWAVES 3         // waves per SIMD the register allocation aims at (168 VGPRs: 3 workgroups of 46 KB LDS per CU; 2 -> 3: 9.0 -> 7.65 ms)
+                             // -- up to 160 positions; the 8-word instance (PE250) spills 293 registers at that cap and none at 248: two waves there
 #endif
 #ifndef SNK_CABL
 #define SNK_CABL 0          // ablation builds (tools/ab_contam.sh): 1 no head section, 2 no middle/tail decisions, 3 no counting screen, 4 no planes
@@ -478,7 +479,7 @@ __device__ bool gcontam_bits_nb(const DevGContam &G, int d, const u32 (&X)[4][NW
 // row stride an odd number of dwords, so the per-lane walks (plane building, the sequential matchers) are free of bank
 // conflicts.  NW = plane words (32 positions each); NW == 0: sequential matchers only (reads over 256 nt).
 template <int NW>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SNK_CWAVES, SNK_CWAVES))) snk_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, int stride) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? SNK_CWAVES : 2, NW <= 5 ? SNK_CWAVES : 2))) snk_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, int stride) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, sm)
     const DevParams &P = *Pp;
     const int pe = P.paired ? 1 : 0, tid = threadIdx.x;

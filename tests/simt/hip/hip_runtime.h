@@ -7,12 +7,13 @@
 //   * a kernel launch runs its workgroups on a pool of OS threads (in workgroup order); a workgroup's threads are fibers
 //     (one stack each) on one OS thread, so `__shared__` storage is `thread_local` and needs no locking;
 //   * a fiber runs until it reaches a wave-level operation (ballot, shuffle, DPP, permlane, readlane, ds_bpermute ...) or
-//     `__syncthreads`; there it publishes its operand and waits until every live lane of its wave (thread of its workgroup)
-//     has arrived -- the operations therefore see all 64 lanes' values exactly as the hardware's lock-step execution does.
-//     A lane that has returned from the kernel no longer takes part (the hardware's EXEC mask for early exits);
-//   * wave operations reached by only a part of the live lanes (divergent control flow around a cross-lane operation) cannot
-//     be ordered this way: the scheduler notices that no fiber can run and aborts with the positions of the stuck lanes.
-//     The product kernels keep their cross-lane operations in wave-uniform control flow, which this checks as a side effect;
+//     `__syncthreads`; there it publishes its operand and waits for the lanes it executes the operation with -- in wave-uniform
+//     control flow every live lane of the wave -- so the operation sees the lanes' values exactly as the hardware's lock-step
+//     execution does.  A lane that has returned from the kernel no longer takes part (the EXEC mask of an early exit);
+//   * lanes that reach DIFFERENT wave operations (a vote inside `if (lane-dependent)`) are told apart by where they wait; when
+//     nothing of the workgroup can run, the operation completes for the lanes that are there (wave_exchange below, and
+//     release_divergent in simt_runtime.cpp) -- the lanes the EXEC mask would have enabled.  Only a workgroup in which no
+//     operation can complete at all (a barrier some threads never reach) aborts, with the call chains of the waiting threads;
 //   * memory: hipMalloc is malloc (filled with 0xEE so that reads of uninitialised device memory show), copies and memsets
 //     are synchronous, streams and events keep their order trivially.  Device atomics are __atomic builtins.
 //   * timing means nothing here.
