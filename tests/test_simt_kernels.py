@@ -22,14 +22,15 @@ import test_gunzip_gpu as GZ
 import test_bittr_gpu as BT
 
 # what an ordinary run takes (substrings of the test ids); SNK_SIMT_FULL=1: everything (tests/conftest.py)
-CORE = ["test_pe150_cases", "test_se100_cases[C3_full", "test_pe250_full[0]", "test_ragged_and_chunked", "test_tiny_batches[0]", "test_error_reporting[0]",
-        "test_lowercase_and_N_reads[0]", "test_pitch_not_multiple_of_16[152-True-C3_full]", "test_capacity_boundaries", "test_contaminant_screening",
-        "test_multi_flush_launches_emulated[5-1-C3_full", "test_adapter_fuzz[0]", "test_adapter_fuzz[9]", "test_adapter_fuzz[27]", "test_adapter_fuzz[45]",
-        "test_adapter_budgets_above_three", "test_adapters_of_any_length", "test_long_adapter_lists_and_lower_case_on_the_fast_paths[6]",
-        "test_contam_fuzz[8]", "test_contam_fuzz[28]", "test_contam_fuzz_long_reads[4]", "test_long_reads[", "test_long_reads_contaminants",
-        "test_long_reads_plane_store", "test_random_parameter_contexts_on_the_device[0-", "test_random_parameter_contexts_on_the_device[20-",
-        "test_hash_vs_oracle", "test_hash_odd", "test_mark_vs_oracle", "test_one_pass_table_vs_oracle", "test_one_pass_table_single_end_shift", "test_parse_and_format", "test_device_gzip_members_round_trip[5000",
-        "test_device_inflate_kernels_produce_zlibs_bytes[65536]", "test_device_inflate_refuses", "test_bit_transpose[random]"]
+CORE = ["test_pe150_cases[C3_full", "test_pe150_cases[C2_adatrim_lowq", "test_pe150_cases[hard_lq_trim-0", "test_pe150_cases[meanq_polyx-0", "test_se100_cases[C3_full-0",
+        "test_pe250_full[0]", "test_ragged_and_chunked[0]", "test_tiny_batches[0]", "test_error_reporting[0]", "test_lowercase_and_N_reads[0]",
+        "test_pitch_not_multiple_of_16[152-True-C3_full]", "test_capacity_boundaries", "test_contaminant_screening",
+        "test_multi_flush_launches_emulated[5-1-C3_full", "test_adapter_fuzz[0]", "test_adapter_fuzz[27]", "test_adapter_budgets_above_three[mis0]",
+        "test_adapters_of_any_length_on_the_tiled_kernel[0]", "test_adapters_of_any_length_on_the_tiled_kernel[5]", "test_adapters_of_any_length_on_the_tiled_kernel[10]",
+        "test_long_adapter_lists_and_lower_case_on_the_fast_paths[6]", "test_contam_fuzz[8]", "test_contam_fuzz_long_reads[4]", "test_long_reads[600", "test_long_reads[1000-True",
+        "test_long_reads_plane_store", "test_random_parameter_contexts_on_the_device[20-", "test_hash_vs_oracle[150-160-True", "test_hash_odd", "test_mark_vs_oracle",
+        "test_one_pass_table_single_end_shift", "test_parse_and_format", "test_device_gzip_members_round_trip[5000", "test_device_inflate_kernels_produce_zlibs_bytes[65536]",
+        "test_bit_transpose[random]"]
 CAP = 12000          # pairs per batch under the emulator (about 10 k pairs a second here); sizes up to it stay as they are
 
 

@@ -13,8 +13,8 @@ import snk_testlib as T
 import test_cli_gpu as CG
 import test_gunzip_gpu as GZ
 
-# an ordinary run takes one case; SNK_SIMT_FULL=1 all of them (tests/conftest.py)
-CORE = ["test_asan_cli_matches_reference_binary[pe_full_T3]", "test_tsan_cli_host_threads[gz]"]
+# the sanitizer builds take minutes to make: only SNK_SIMT_FULL=1 runs these (tests/conftest.py; profiles/r04_simt_full.txt holds such a run)
+CORE = []
 pytestmark = pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")
 ASAN_FLAGS = ("-fsanitize=address", "-fno-sanitize-recover=all", "-shared-libasan")
 
