@@ -13,7 +13,7 @@ import pytest
 import simt_lib as S
 import snk_testlib as T
 
-CORE = ["test_bench_line", "test_bounded_memory", "test_smoke_entry_point"]
+CORE = ["test_bench_line", "test_bounded_memory", "test_smoke_entry_point", "test_bench_with_two_ranks"]
 pytestmark = pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")
 
 
@@ -76,3 +76,30 @@ def test_smoke_entry_point(monkeypatch, capsys):
     spec.loader.exec_module(entry)
     entry.smoke()
     assert "smoke OK" in capsys.readouterr().out
+
+
+def test_bench_with_two_ranks(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment), on the
+    emulated library with gloo in RCCL's place: the stats all-reduce inside the timed region, the MAX of the elapsed time, rank 0's line"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SIMT_THREADS="3",
+                   PYTHONPATH=os.pathsep.join([here, T.ROOT, os.environ.get("PYTHONPATH", "")]))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "simt_bench_rank.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "6000"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    lines = [x for x in outs[0][0].splitlines() if x.startswith("{")]
+    assert len(lines) == 1 and not [x for x in outs[1][0].splitlines() if x.startswith("{")]        # one line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "shard2"
+    assert out["config"]["pairs_per_gpu_per_step"] == 6000 and out["steps"] == 3
+    # whole-job throughput: both ranks' reads over the slower rank's time
+    assert abs(out["value"] - 2.0 * 6000 * 2 * 3 / (out["ms_per_step"] * 3 / 1e3) / 1e6) < 0.02 * out["value"] + 1e-3
+    assert out["config"]["clean_pairs_per_step_per_gpu"] > 0 and "cpu_baseline" not in out
