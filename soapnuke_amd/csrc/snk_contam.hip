@@ -15,8 +15,8 @@
 //               is neither match nor mismatch, so it drops out of both).
 //   global      A hit of the reference's carried scoring window (snk_common.cuh) implies min_match_len consecutive cells
 //               of one lay with <= mismatch_number mismatches (or nearly that at the read end, see gcontam_bits).  The
-//               mismatches of the last cells are kept as a bit-sliced binary counter per offset, sliding along the
-//               contaminant; the offsets with such a stretch are decided exactly by the window walk (gc_walk) on the 64
+//               mismatches of the last cells are kept as a bit-sliced binary counter per offset (biased, so that its top
+//               plane is the verdict), sliding along the contaminant; the offsets with such a stretch are decided exactly by the window walk (gc_walk) on the 64
 //               equality bits of their lay.
 //
 // What the bit paths do not cover (contaminants over 64 characters or with anything but ACGTN, reads shorter than the
@@ -300,27 +300,27 @@ __device__ bool has_contam_bits_nc(const DevContam &C, const DevContam &L, const
     return has_contam_bits<NW, 4, true>(C, L, X, XN, len, active, do_head, do_tail);
 }
 
-// x = ~(plane >> c) for a uniform c in [0, 64): the offsets whose cell at contaminant position c is NOT that letter;
-// zeros shifted in, so anything outside the read counts as a mismatch
+// e = plane >> c for a uniform c in [0, 64): the offsets whose cell at contaminant position c IS that letter; zeros shifted
+// in, so anything outside the read counts as a mismatch
 template <int NQ>
-__device__ __forceinline__ void not_shifted(const u32 (&P)[NQ], int c, u32 (&x)[NQ]) {
+__device__ __forceinline__ void shifted(const u32 (&P)[NQ], int c, u32 (&e)[NQ]) {
     if (c < 32) {
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) x[j] = ~__builtin_amdgcn_alignbit(j + 1 < NQ ? P[j + 1 < NQ ? j + 1 : 0] : 0u, P[j], c);
+        for (int j = 0; j < NQ; ++j) e[j] = __builtin_amdgcn_alignbit(j + 1 < NQ ? P[j + 1 < NQ ? j + 1 : 0] : 0u, P[j], c);
     } else {
 #pragma unroll
         for (int j = 0; j < NQ; ++j)
-            x[j] = ~__builtin_amdgcn_alignbit(j + 2 < NQ ? P[j + 2 < NQ ? j + 2 : 0] : 0u, j + 1 < NQ ? P[j + 1 < NQ ? j + 1 : 0] : 0u, c - 32);
+            e[j] = __builtin_amdgcn_alignbit(j + 2 < NQ ? P[j + 2 < NQ ? j + 2 : 0] : 0u, j + 1 < NQ ? P[j + 1 < NQ ? j + 1 : 0] : 0u, c - 32);
     }
 }
 template <int NQ>
-__device__ __forceinline__ void mism_plane(const u32 (&XP)[5][NQ], int letter, int c, u32 (&x)[NQ]) {
+__device__ __forceinline__ void match_plane(const u32 (&XP)[5][NQ], int letter, int c, u32 (&e)[NQ]) {
     switch (letter) {                                // uniform
-    case 0: not_shifted<NQ>(XP[0], c, x); break;
-    case 1: not_shifted<NQ>(XP[1], c, x); break;
-    case 2: not_shifted<NQ>(XP[2], c, x); break;
-    case 3: not_shifted<NQ>(XP[3], c, x); break;
-    default: not_shifted<NQ>(XP[4], c, x); break;
+    case 0: shifted<NQ>(XP[0], c, e); break;
+    case 1: shifted<NQ>(XP[1], c, e); break;
+    case 2: shifted<NQ>(XP[2], c, e); break;
+    case 3: shifted<NQ>(XP[3], c, e); break;
+    default: shifted<NQ>(XP[4], c, e); break;
     }
 }
 
@@ -332,20 +332,22 @@ __device__ __forceinline__ void mism_plane(const u32 (&XP)[5][NQ], int letter, i
 // window goes on at cell 0 of the next lay.  Hence a hit implies
 //   (W) min_match_len consecutive cells of one lay with at most mismatch_number mismatches, or
 //   (J) the first min_match_len - 1 cells of a lay hanging off the read end with at most mismatch_number mismatches,
-// and so it does with Ls = min(min_match_len, 15 or 31) cells instead.  Both are sliding counts along the lay, kept for
-// every offset at once: bit q of the planes = offset p = q - PAD, the count a bit-sliced binary number (NB planes,
-// 2^NB > Ls) that takes the cell entering the window and gives back the cell leaving it; cells outside the read count as
-// mismatches.  The offsets that pass are decided exactly with the window walk (gc_walk) on the 64 equality bits of their
-// lay: one lay for an offset of the first two sections, the whole last section once one of its offsets passes.
-template <int NW, int NB, int NQ>
+// and so it does with Ls = min(min_match_len, 16 + mismatch_number) cells instead.  Both are sliding counts along the lay, kept
+// for every offset at once: bit q of the planes = offset p = q - PAD, the count a bit-sliced binary number that takes the
+// cell entering the window and gives back the cell leaving it; cells outside the read count as mismatches.  The number kept is
+// count + 15 - mismatch_number in five planes, so that "more than mismatch_number" IS the top plane (no comparison, and
+// nothing that depends on the budget inside the loop): 14 three-input operations per plane word and cell while the window
+// slides, 3 while it fills.  The offsets that pass are decided exactly with the window walk (gc_walk) on the 64 equality bits
+// of their lay: one lay for an offset of the first two sections, the whole last section once one of its offsets passes.
+template <int NW, int NQ>
 // do_head (uniform) / do_tail (per lane) as in has_contam_bits: a block in the middle of a long read has the whole lays only
 // (offsets p >= 0 that end inside the block), the lays hanging off the read's start belong to its first block, the last section to
 // its final one.
 __device__ bool gcontam_bits(const DevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
                              bool do_head = true, bool do_tail = true) {
     constexpr int NP = NW + 2;                       // plane words: read positions + PAD
-    const int cl = G.len, mml = G.min_match_len, mmn = G.mm, PAD = cl - mml;
-    const int Ls = min(mml, (1 << NB) - 1);
+    const int cl = __builtin_amdgcn_readfirstlane(G.len), mml = __builtin_amdgcn_readfirstlane(G.min_match_len), mmn = __builtin_amdgcn_readfirstlane(G.mm), PAD = cl - mml;
+    const int Ls = min(mml, 16 + mmn);
     const u64 cm0 = G.cm[d][0], cm1 = G.cm[d][1], cm2 = G.cm[d][2], cm3 = G.cm[d][3], nm = G.nm[d];
     auto letter = [&](int c) -> int { return ((cm0 >> c) & 1) ? 0 : ((cm1 >> c) & 1) ? 1 : ((cm2 >> c) & 1) ? 2 : ((cm3 >> c) & 1) ? 3 : 4; };
     u32 W[NQ], J[NQ];
@@ -368,47 +370,57 @@ __device__ bool gcontam_bits(const DevGContam &G, int d, const u32 (&X)[4][NW], 
 #pragma unroll
             for (int j = 0; j < NP; ++j) XP[b][j] = r ? __builtin_amdgcn_alignbit(T[j + 1], T[j], 32 - r) : T[j + 1];
         }
-        u32 cnt[NB][NQ];
+        // count + 15 - mmn in five planes: bit 4 is set exactly while the window holds more than mmn mismatches
+        // (Ls <= 16 + mmn, mmn <= 4: the number stays inside 0..31), so "within the budget" is a plane, not a comparison
+        u32 cnt[5][NQ], Wn[NQ];
+        const int bias = 15 - mmn;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            W[j] = J[j] = 0;
+            J[j] = 0;
+            Wn[j] = 0xFFFFFFFFu;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) cnt[b][j] = 0;
+            for (int b = 0; b < 5; ++b) cnt[b][j] = ((bias >> b) & 1) ? 0xFFFFFFFFu : 0u;
         }
-        for (int c = 0; c < cl; ++c) {
-            u32 xin[NP], xout[NP];
-            mism_plane<NP>(XP, letter(c), c, xin);
-            if (c >= Ls) mism_plane<NP>(XP, letter(c - Ls), c - Ls, xout);
-            else {
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) xout[j] = 0;
-            }
-            u32 lt[NQ];
+        // one cell: ein = the offsets whose cell entering the window matches, eout = those whose cell leaving it did
+        auto slide = [&](const u32 (&ein)[NP], const u32 (&eout)[NP]) {
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
-                const u32 dec = ~xin[j] & xout[j];
-                u32 carry = xin[j] ^ xout[j];        // the offsets whose count changes; up where dec is clear, down where set
+                const u32 dec = ein[j] & ~eout[j];
+                u32 carry = ein[j] ^ eout[j];        // the offsets whose count changes; up where dec is clear, down where set
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
+                for (int b = 0; b < 5; ++b) {
                     const u32 t = cnt[b][j];
                     cnt[b][j] = t ^ carry;
                     carry &= t ^ dec;
                 }
-                u32 hi = cnt[3][j];
-                if (NB > 4) hi |= cnt[NB > 4 ? 4 : 0][j];
-                const u32 b0 = cnt[0][j], b1 = cnt[1][j], b2 = cnt[2][j];
-                // count <= mmn
-                lt[j] = mmn <= 0 ? ~(b0 | b1 | b2 | hi) : mmn == 1 ? ~(b1 | b2 | hi) : mmn == 2 ? (~(b2 | hi) & ~(b1 & b0))
-                      : mmn == 3 ? ~(b2 | hi) : (~hi & ~(b2 & (b1 | b0)));
             }
-            if (c >= Ls - 1) {
+        };
+        {
+            u32 ones[NP];
 #pragma unroll
-                for (int j = 0; j < NQ; ++j) W[j] |= lt[j];
-            } else if (c == Ls - 2) {
+            for (int j = 0; j < NP; ++j) ones[j] = 0xFFFFFFFFu;
+            for (int c = 0; c < Ls; ++c) {           // the window fills: nothing leaves
+                u32 ein[NP];
+                match_plane<NP>(XP, letter(c), c, ein);
+                slide(ein, ones);
+                if (c == Ls - 2) {
 #pragma unroll
-                for (int j = 0; j < NQ; ++j) J[j] = lt[j];
+                    for (int j = 0; j < NQ; ++j) J[j] = ~cnt[4][j];
+                }
             }
         }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) Wn[j] = cnt[4][j];
+        for (int c = Ls; c < cl; ++c) {
+            u32 ein[NP], eout[NP];
+            match_plane<NP>(XP, letter(c), c, ein);
+            match_plane<NP>(XP, letter(c - Ls), c - Ls, eout);
+            slide(ein, eout);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) Wn[j] &= cnt[4][j];
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) W[j] = ~Wn[j];
     }
     // offsets that exist: p = -PAD .. len - mml; the lays hanging off the end: p = len - cl + 1 .. len - mml
     bool tail = false;
@@ -459,20 +471,13 @@ __device__ bool gcontam_bits(const DevGContam &G, int d, const u32 (&X)[4][NW], 
     return hit;
 }
 
-template <int NW, int NB>
+template <int NW>
 __device__ bool gcontam_bits_nq(const DevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, int lcap, bool active,
                                 bool do_head = true, bool do_tail = true) {
     const int need = __builtin_amdgcn_readfirstlane((lcap - 2 * G.min_match_len + G.len + 32) >> 5);   // words of offsets -PAD .. lcap - mml
-    if (need <= NW) return gcontam_bits<NW, NB, NW>(G, d, X, XN, len, active, do_head, do_tail);
-    if (need == NW + 1) return gcontam_bits<NW, NB, NW + 1>(G, d, X, XN, len, active, do_head, do_tail);
-    return gcontam_bits<NW, NB, NW + 2>(G, d, X, XN, len, active, do_head, do_tail);
-}
-template <int NW>
-__device__ bool gcontam_bits_nb(const DevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, int lcap, bool active,
-                                bool do_head = true, bool do_tail = true) {
-    const int mml = __builtin_amdgcn_readfirstlane(G.min_match_len), mmn = __builtin_amdgcn_readfirstlane(G.mm);
-    if (mml < 16 || mmn <= 2) return gcontam_bits_nq<NW, 4>(G, d, X, XN, len, lcap, active, do_head, do_tail);
-    return gcontam_bits_nq<NW, 5>(G, d, X, XN, len, lcap, active, do_head, do_tail);
+    if (need <= NW) return gcontam_bits<NW, NW>(G, d, X, XN, len, active, do_head, do_tail);
+    if (need == NW + 1) return gcontam_bits<NW, NW + 1>(G, d, X, XN, len, active, do_head, do_tail);
+    return gcontam_bits<NW, NW + 2>(G, d, X, XN, len, active, do_head, do_tail);
 }
 
 // One work-item per pair.  The workgroup first copies its 256 rows (coalesced) and the contaminant tables into LDS --
@@ -532,7 +537,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 
                     for (int d = 0; d < 2; ++d) {
                         const bool want = exists && !(fm & 2);
                         const bool bits = G.bits_ok != 0, fast = bits && len >= G.len;
-                        if (bits && __any(want && fast) && gcontam_bits_nb<NW>(G, d, X, XN, len, P.lcap, want && fast)) fm |= 2;
+                        if (bits && __any(want && fast) && gcontam_bits_nq<NW>(G, d, X, XN, len, P.lcap, want && fast)) fm |= 2;
                         if (want && !fast && global_contam_hit(row, len, lg[c].seq[d], lg[c].len, lg[c].min_match_len, lg[c].mm)) fm |= 2;
                     }
                 }
@@ -605,7 +610,7 @@ __global__ void __launch_bounds__(256) snk_long_contam_kernel(const DevParams *P
                     const DevGContam &G = P.gct[c];
                     for (int d = 0; d < 2; ++d) {
                         const bool want = here && !(fm & 2) && G.bits_ok != 0;
-                        if (__any(want) && gcontam_bits_nb<PL_NW>(G, d, X, XN, vlen, PL_VLEN + 1, want, p0 == 0, final)) fm |= 2;
+                        if (__any(want) && gcontam_bits_nq<PL_NW>(G, d, X, XN, vlen, PL_VLEN + 1, want, p0 == 0, final)) fm |= 2;
                     }
                 }
                 through |= here && final;
