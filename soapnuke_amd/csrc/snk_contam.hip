@@ -217,20 +217,36 @@ __device__ bool has_contam_bits(const DevContam &C, const DevContam &L, const u3
         const int tm1 = max(C.S, 1) - 1;                              // screened cells of a middle alignment
         const u64 sm = SNK_CABL == 3 ? 0ull : lowmask64(C.scr);       // cells screened for any offset at all
         const int tb = len - edge + 1;                                // tail offsets with r1 >= r: p < tb - r
+        // ... as a thermometer over the offsets, made once: the mask of a cell is this plane shifted down by the cell's rT (uniform,
+        // 0..64) -- one funnel shift per plane word instead of a per-lane mask construction (10 VALU) per word and cell
+        u32 TB[NW + 3];
+#pragma unroll
+        for (int j = 0; j < NW + 3; ++j) TB[j] = j < NW ? lowmask32(tb - 32 * j) : 0u;
         auto steps = [&](u64 m64) {
             for (int h = 0; h < 2; ++h) {
                 u32 m = __builtin_amdgcn_readfirstlane((u32)(m64 >> (32 * h)));
                 while (m) {
                     const int cr = __ffs((int)m) - 1, c = 32 * h + cr;
                     m &= m - 1;
-                    const int rt = C.rT[c];                            // the cell counts for tail alignments with r1 >= rt
-                    const bool inmid = c < tm1;
+                    const int rt = __builtin_amdgcn_readfirstlane(L.rT[c]);   // the cell counts for tail alignments with r1 >= rt (LDS copy: no global round trip per cell)
+                    const u32 im = c < tm1 ? 0xFFFFFFFFu : 0u;               // ... and for the middle alignments or not
+                    const int ws = rt >> 5, bs = rt & 31;
+                    u32 tl[NW];
+                    if (ws == 0) {
+#pragma unroll
+                        for (int j = 0; j < NW; ++j) tl[j] = __builtin_amdgcn_alignbit(TB[j + 1], TB[j], bs);
+                    } else if (ws == 1) {
+#pragma unroll
+                        for (int j = 0; j < NW; ++j) tl[j] = __builtin_amdgcn_alignbit(TB[j + 2], TB[j + 1], bs);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NW; ++j) tl[j] = TB[j + 2 < NW + 3 ? j + 2 : 0];      // rt == 64
+                    }
 #pragma unroll
                     for (int j = 0; j < NW; ++j) {
                         const int jl = j + h, jh = j + h + 1;
                         const u32 lo = jl < NW ? S[jl < NW ? jl : 0] : 0xFFFFFFFFu, hi = jh < NW ? S[jh < NW ? jh : 0] : 0xFFFFFFFFu;
-                        const u32 tl = lowmask32(tb - rt - 32 * j);
-                        const u32 msk = inmid ? (tl | mid[j]) : (tl & ~mid[j]);
+                        const u32 msk = (tl[j] & ~mid[j]) | (mid[j] & im);
                         const u32 x = ~__builtin_amdgcn_alignbit(hi, lo, cr) & msk;
 #pragma unroll
                         for (int k = NC - 1; k >= 1; --k) Cn[k][j] |= Cn[k - 1][j] & x;
