@@ -38,6 +38,12 @@ using namespace snk;
 
 namespace {
 
+// the descriptors as the kernels read them: through the constant address space, so that every field with a uniform index is a
+// scalar load into SGPRs (through a generic reference the compiler took them for per-lane values: flat loads into VGPRs, 64-bit
+// VALU shifts of the letter masks, a global round trip per trip of the head loop, loops run under EXEC masks)
+typedef __attribute__((address_space(4))) DevContam CDevContam;
+typedef __attribute__((address_space(4))) DevGContam CDevGContam;
+
 __device__ __forceinline__ u32 lowmask32(int n) { return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u)); }
 __device__ __forceinline__ u64 lowmask64(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); }
 __device__ __forceinline__ u64 cat64(u32 hi, u32 lo) { return ((u64)hi << 32) | lo; }
@@ -177,7 +183,7 @@ __device__ __forceinline__ bool contam_accept(u64 m, u64 n, int ncells, int T, i
 template <int NW, int NC, bool BIG = false>      // BIG: budgets of 4 and more exist -- NC == 4 planes count to four, such offsets are never screened out
 // do_head (uniform) / do_tail (per lane): the planes start at the read's first character / end at its last one.  A block in the
 // middle of a long read (snk_long_contam_kernel) has neither: only the alignments of the middle section exist there.
-__device__ bool has_contam_bits(const DevContam &C, const DevContam &L, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
+__device__ bool has_contam_bits(const CDevContam &C, const DevContam &L, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
                                 bool do_head = true, bool do_tail = true) {
     const int cl = C.len, edge = C.edge, nC = C.nC;
     const u64 cm0 = C.cm[0], cm1 = C.cm[1], cm2 = C.cm[2], cm3 = C.cm[3], nm = C.nm;
@@ -306,7 +312,7 @@ __device__ bool has_contam_bits(const DevContam &C, const DevContam &L, const u3
 }
 
 template <int NW>
-__device__ bool has_contam_bits_nc(const DevContam &C, const DevContam &L, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
+__device__ bool has_contam_bits_nc(const CDevContam &C, const DevContam &L, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
                                    bool do_head = true, bool do_tail = true) {
     const int b = __builtin_amdgcn_readfirstlane(C.bmax);
     if (b <= 0) return has_contam_bits<NW, 1>(C, L, X, XN, len, active, do_head, do_tail);
@@ -359,7 +365,7 @@ template <int NW, int NQ>
 // do_head (uniform) / do_tail (per lane) as in has_contam_bits: a block in the middle of a long read has the whole lays only
 // (offsets p >= 0 that end inside the block), the lays hanging off the read's start belong to its first block, the last section to
 // its final one.
-__device__ bool gcontam_bits(const DevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
+__device__ bool gcontam_bits(const CDevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
                              bool do_head = true, bool do_tail = true) {
     constexpr int NP = NW + 2;                       // plane words: read positions + PAD
     const int cl = __builtin_amdgcn_readfirstlane(G.len), mml = __builtin_amdgcn_readfirstlane(G.min_match_len), mmn = __builtin_amdgcn_readfirstlane(G.mm), PAD = cl - mml;
@@ -488,7 +494,7 @@ __device__ bool gcontam_bits(const DevGContam &G, int d, const u32 (&X)[4][NW], 
 }
 
 template <int NW>
-__device__ bool gcontam_bits_nq(const DevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, int lcap, bool active,
+__device__ bool gcontam_bits_nq(const CDevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, int lcap, bool active,
                                 bool do_head = true, bool do_tail = true) {
     const int need = __builtin_amdgcn_readfirstlane((lcap - 2 * G.min_match_len + G.len + 32) >> 5);   // words of offsets -PAD .. lcap - mml
     if (need <= NW) return gcontam_bits<NW, NW>(G, d, X, XN, len, active, do_head, do_tail);
@@ -542,14 +548,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 
                 u32 X[4][NW], XN[NW];
                 build_planes<NW>(row, B.pitch, len, X, XN);
                 for (int c = 0; c < n_ct; ++c) {
-                    const DevContam &C = P.ct[m * SNK_MAX_CONTAMS + c];
+                    const CDevContam &C = ((const CDevContam *)(uintptr_t)P.ct)[m * SNK_MAX_CONTAMS + c];
                     const bool want = exists && !(fm & 1);
                     const bool bits = C.bits_ok != 0, fast = bits && len >= C.len;
                     if (bits && __any(want && fast) && has_contam_bits_nc<NW>(C, lct[c], X, XN, len, want && fast)) fm |= 1;
                     if (want && !fast && has_contam_seq(row, len, lct[c]) >= 0) fm |= 1;
                 }
                 for (int c = 0; c < n_gct; ++c) {
-                    const DevGContam &G = P.gct[c];
+                    const CDevGContam &G = ((const CDevGContam *)(uintptr_t)P.gct)[c];
                     for (int d = 0; d < 2; ++d) {
                         const bool want = exists && !(fm & 2);
                         const bool bits = G.bits_ok != 0, fast = bits && len >= G.len;
@@ -618,12 +624,12 @@ __global__ void __launch_bounds__(256) snk_long_contam_kernel(const DevParams *P
                     XN[w] = W[4][w] & in;
                 }
                 for (int c = 0; c < n_ct; ++c) {
-                    const DevContam &C = P.ct[m * SNK_MAX_CONTAMS + c];
+                    const CDevContam &C = ((const CDevContam *)(uintptr_t)P.ct)[m * SNK_MAX_CONTAMS + c];
                     const bool want = here && !(fm & 1) && C.bits_ok != 0;
                     if (__any(want) && has_contam_bits_nc<PL_NW>(C, lct[c], X, XN, vlen, want, p0 == 0, final)) fm |= 1;
                 }
                 for (int c = 0; c < n_gct; ++c) {
-                    const DevGContam &G = P.gct[c];
+                    const CDevGContam &G = ((const CDevGContam *)(uintptr_t)P.gct)[c];
                     for (int d = 0; d < 2; ++d) {
                         const bool want = here && !(fm & 2) && G.bits_ok != 0;
                         if (__any(want) && gcontam_bits_nq<PL_NW>(G, d, X, XN, vlen, PL_VLEN + 1, want, p0 == 0, final)) fm |= 2;
