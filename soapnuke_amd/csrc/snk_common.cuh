@@ -248,7 +248,8 @@ __device__ inline int contam_flags(const DevContam *ct, int n_ct, const DevGCont
 
 // A3 fastq_trim() arithmetic once the per-read scan results are known
 // (src/read_filter.cpp:383-468).  lq_hix/lq_tix/polyg: the three run lengths.
-__device__ __forceinline__ void trim_finish(const DevParams &P, int mate, ReadState &r, int lq_hix,
+template <class PT>       // PT: DevParams, or DevParams in the constant address space (scalar loads of every field: snk_long.hip)
+__device__ __forceinline__ void trim_finish(const PT &P, int mate, ReadState &r, int lq_hix,
                                             int lq_tix, int polyg) {
     const int len = r.len;
     int head_cut = 0, tail_cut = 0;
@@ -276,7 +277,8 @@ __device__ __forceinline__ void trim_finish(const DevParams &P, int mate, ReadSt
 }
 
 // A1 stat_read() and A3 fastq_trim() of one read, sequential (the generic kernel; the per-lane fallback of the long-read kernel)
-__device__ inline void stat_read_dev(const DevParams &P, int mate, const uint8_t *s, const uint8_t *q,
+template <class PT>
+__device__ inline void stat_read_dev(const PT &P, int mate, const uint8_t *s, const uint8_t *q,
                               int len, ReadState &r, int &err) {
     rs_init(r, len);
     err = SNK_OK;
@@ -303,7 +305,8 @@ __device__ inline void stat_read_dev(const DevParams &P, int mate, const uint8_t
     r.polyx = (P.polyX_num != -1 && maxrun >= P.polyX_num) ? 1 : 0;
 }
 
-__device__ inline void fastq_trim_dev(const DevParams &P, int mate, const uint8_t *s, const uint8_t *q,
+template <class PT>
+__device__ inline void fastq_trim_dev(const PT &P, int mate, const uint8_t *s, const uint8_t *q,
                                ReadState &r) {
     if (!P.trim_on) return;                                  // src/read_filter.cpp:354
     const int len = r.len;
@@ -326,7 +329,8 @@ __device__ __forceinline__ int pe_dis(bool a, bool b) { return (a ? 1 : 0) + (b 
 // A6: the cascade (src/sequence.cpp:198-387 PE, :76-178 SE); returns the reason and
 // the pe_dis() code, counters are the caller's business.
 // cfa / cfb: contaminant verdicts of the mates, bit 0 = include_contam, bit 1 = include_global_contam
-__device__ inline int discard_reason(const DevParams &P, const ReadState &a, const ReadState &b, int dup,
+template <class PT>
+__device__ inline int discard_reason(const PT &P, const ReadState &a, const ReadState &b, int dup,
                                      int &vout, int cfa = 0, int cfb = 0) {
     const bool pe = P.paired;
     int v;

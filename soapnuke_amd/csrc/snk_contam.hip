@@ -43,6 +43,7 @@ namespace {
 // VALU shifts of the letter masks, a global round trip per trip of the head loop, loops run under EXEC masks)
 typedef __attribute__((address_space(4))) DevContam CDevContam;
 typedef __attribute__((address_space(4))) DevGContam CDevGContam;
+typedef __attribute__((address_space(4))) DevParams CDevParams;
 
 __device__ __forceinline__ u32 lowmask32(int n) { return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u)); }
 __device__ __forceinline__ u64 lowmask64(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); }
@@ -508,7 +509,7 @@ __device__ bool gcontam_bits_nq(const CDevGContam &G, int d, const u32 (&X)[4][N
 template <int NW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? SNK_CWAVES : 2, NW <= 5 ? SNK_CWAVES : 2))) snk_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, int stride) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, sm)
-    const DevParams &P = *Pp;
+    const CDevParams &P = *(const CDevParams *)(uintptr_t)Pp;
     const int pe = P.paired ? 1 : 0, tid = threadIdx.x;
     uint8_t *rows = sm;
     DevContam *lct = reinterpret_cast<DevContam *>(sm + (((size_t)256 * stride + 15) & ~(size_t)15));
@@ -580,7 +581,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 
 // contaminant and contaminants outside the bit paths take the sequential matchers on the read's row, per lane.
 __global__ void __launch_bounds__(256) snk_long_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, const u32 *planes, long ngroups, int nquads) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, sm)
-    const DevParams &P = *Pp;
+    const CDevParams &P = *(const CDevParams *)(uintptr_t)Pp;
     const int pe = P.paired ? 1 : 0, tid = threadIdx.x;
     DevContam *lct = reinterpret_cast<DevContam *>(sm);
     DevGContam *lg = reinterpret_cast<DevGContam *>(lct + max(P.n_ct[0], P.n_ct[1]));

@@ -188,7 +188,11 @@ snk_long_prep_kernel(const DevParams *Pp, DevBatch B, int lcap, u32 *planes, lon
 #endif
 __global__ void __launch_bounds__(256, SNK_LONG_WPE)
 snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, DevStats st, int lcap, int nq, const u32 *planes, long ngroups, int nquads) {
-    const DevParams &P = *Pp;
+    // the parameter block through the constant address space: every field is a scalar load the compiler may keep across the loop
+    // (through the generic reference they were vector loads with a uniform address -- some sixty of them per pair --, their values
+    // VGPRs, and every branch on a parameter a branch under an EXEC mask)
+    typedef __attribute__((address_space(4))) DevParams CDevParams;
+    const CDevParams &P = *(const CDevParams *)(uintptr_t)Pp;
     const long fb = file_block(lcap, nq);
     const long ts_off = SNK_GS_N + (long)lcap * 5 + (long)lcap * nq;
     const int pe = P.paired ? 1 : 0;
