@@ -26,7 +26,8 @@ namespace {
 // own_hist == 0: the per-position histograms (and the quality-range check that comes with them) are left to
 // snk_long_hist_kernel, which runs behind this kernel on the records it wrote -- one global atomic per base and quality was
 // nine tenths of this kernel's time
-__device__ int hist_read(const DevParams &P, unsigned long long *file, int lcap, int nq,
+template <class PT>
+__device__ int hist_read(const PT &P, unsigned long long *file, int lcap, int nq,
                          const uint8_t *s, const uint8_t *q, int start, int n, int own_hist) {
     unsigned long long *bs = file + SNK_GS_N, *qs = file + SNK_GS_N + (long)lcap * 5;
     int rc = SNK_OK;
@@ -44,7 +45,8 @@ __device__ int hist_read(const DevParams &P, unsigned long long *file, int lcap,
 
 __global__ void __launch_bounds__(256)
 snk_generic_kernel(const DevParams *Pp, DevBatch B, DevStats st, int lcap, int nq, int own_hist) {
-    const DevParams &P = *Pp;
+    typedef __attribute__((address_space(4))) DevParams CDevParams;          // scalar loads of every field (see snk_long_decide_kernel)
+    const CDevParams &P = *(const CDevParams *)(uintptr_t)Pp;
     const long fb = file_block(lcap, nq);
     const long ts_off = SNK_GS_N + (long)lcap * 5 + (long)lcap * nq;
     const int pe = P.paired ? 1 : 0;
