@@ -313,7 +313,7 @@ __device__ bool has_contam_bits(const CDevContam &C, const DevContam &L, const u
 }
 
 template <int NW>
-__device__ bool has_contam_bits_nc(const CDevContam &C, const DevContam &L, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
+__device__ __forceinline__ bool has_contam_bits_nc(const CDevContam &C, const DevContam &L, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, bool active,
                                    bool do_head = true, bool do_tail = true) {
     const int b = __builtin_amdgcn_readfirstlane(C.bmax);
     if (b <= 0) return has_contam_bits<NW, 1>(C, L, X, XN, len, active, do_head, do_tail);
@@ -495,7 +495,7 @@ __device__ bool gcontam_bits(const CDevGContam &G, int d, const u32 (&X)[4][NW],
 }
 
 template <int NW>
-__device__ bool gcontam_bits_nq(const CDevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, int lcap, bool active,
+__device__ __forceinline__ bool gcontam_bits_nq(const CDevGContam &G, int d, const u32 (&X)[4][NW], const u32 (&XN)[NW], int len, int lcap, bool active,
                                 bool do_head = true, bool do_tail = true) {
     const int need = __builtin_amdgcn_readfirstlane((lcap - 2 * G.min_match_len + G.len + 32) >> 5);   // words of offsets -PAD .. lcap - mml
     if (need <= NW) return gcontam_bits<NW, NW>(G, d, X, XN, len, active, do_head, do_tail);
