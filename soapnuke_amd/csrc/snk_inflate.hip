@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(64) inf_decode_kernel(const u8 *comp, u64 nbyt
     __shared__ WaveSpace W;
     if (threadIdx.x == 0) {
         Chunk ck = chunks[blockIdx.x];
-        decode_chunk(comp, nbytes, ck, syms, ends, W.T, W.S, W.cl_tab);
+        decode_chunk(comp, nbytes, ck, syms, ends, W.T, W.S, W.cl_tab, nullptr, false);
         chunks[blockIdx.x] = ck;
     }
 }
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(64) inf_decode_coop_kernel(const u8 *comp, u64
     Coop co;
     co.ring = ring; co.hist = hist; co.qdst = qdst; co.qinfo = qinfo; co.ring_lo = co.ring_end = 0; co.qn = 0; co.q_first = 0;
     Chunk ck = chunks[blockIdx.x];
-    decode_chunk(comp, nbytes, ck, syms, ends, W.T, W.S, W.cl_tab, &co);
+    decode_chunk(comp, nbytes, ck, syms, ends, W.T, W.S, W.cl_tab, &co, true);
     if (threadIdx.x == 0) chunks[blockIdx.x] = ck;
 }
 

@@ -113,6 +113,9 @@ struct Bits {
     u64 bb;
     int bc;                   // valid bits in bb
     Coop *co;                 // null: loads straight from global memory
+    bool coop;                // co != nullptr, kept as a flag: a null test of the pointer is a comparison of the caller's Coop object's
+                              // address, and an object whose address is compared is not promoted to registers (it stayed in scratch memory,
+                              // its LDS pointers generic: scratch loads + flat accesses on every symbol)
 };
 // the same 8 bytes through the ring
 SNKI_DEV u64 ring64(Bits &b, u64 pos) {
@@ -141,10 +144,10 @@ SNKI_DEV u64 ring64(Bits &b, u64 pos) {
 }
 SNKI_DEV u64 fetch64(Bits &b, u64 pos) {            // zeros behind the end of the input (the caller notices with past_end())
     const u64 p = pos < b.nbytes + 8 ? pos : b.nbytes + 8;
-    return b.co ? ring64(b, p) : load64(b.base, p);
+    return b.coop ? ring64(b, p) : load64(b.base, p);
 }
-SNKI_DEV void bits_init(Bits &b, const u8 *base, u64 nbytes, u64 bit, Coop *co = nullptr) {
-    b.base = base; b.nbytes = nbytes; b.pos = bit >> 3; b.bb = 0; b.bc = 0; b.co = co;
+SNKI_DEV void bits_init(Bits &b, const u8 *base, u64 nbytes, u64 bit, Coop *co = nullptr, bool coop = false) {
+    b.base = base; b.nbytes = nbytes; b.pos = bit >> 3; b.bb = 0; b.bc = 0; b.co = co; b.coop = coop;
     const int skip = (int)(bit & 7);
     if (skip) { b.bb = fetch64(b, b.pos); b.pos += 7; b.bc = 56; b.bb &= (1ull << 56) - 1; b.bb >>= skip; b.bc -= skip; }
 }
@@ -382,7 +385,7 @@ SNKI_DEV bool gzip_header(Bits &b) {
     if (flg & 16) { while (p < n && d[p]) ++p; ++p; }
     if (flg & 2) p += 2;
     if (p > n) return false;
-    bits_init(b, d, n, p * 8, b.co);
+    bits_init(b, d, n, p * 8, b.co, b.coop);
     return true;
 }
 
@@ -392,6 +395,7 @@ struct Out {
     u16 *out;                 // the chunk's symbol slots
     u32 n;                    // symbols so far (queued matches included)
     Coop *co;
+    bool coop;                // co != nullptr (see Bits)
 };
 SNKI_DEV u16 marker_of(long src) { return (u16)(256 + WIN + src); }          // src < 0: in front of the chunk
 SNKI_DEV u16 match_sym(const u16 *out, long src) { return src < 0 ? marker_of(src) : out[src]; }
@@ -401,7 +405,7 @@ inline HostStats &host_stats() { static HostStats h; return h; }
 #define SNKI_STAT(x) (host_stats().x)
 #endif
 SNKI_DEV void out_flush(Out &o) {                      // runs the queued (far) matches, one per lane
-    if (!o.co || o.co->qn == 0) return;
+    if (!o.coop || o.co->qn == 0) return;
     Coop &c = *o.co;
     SNKI_FENCE();                                      // the literals and earlier copies the sources are (other lanes' stores)
     SNKI_LANES(lane) {
@@ -436,7 +440,7 @@ SNKI_DEV void out_put(Out &o, u16 v) {
 #if !defined(__HIPCC__)
     ++SNKI_STAT(literals);
 #endif
-    if (o.co) {
+    if (o.coop) {
         SNKI_LANES(lane) { if (lane == 0) { o.out[o.n] = v; o.co->hist[o.n & (HS - 1)] = v; } }
         ++o.n;
         if (o.co->qn && o.n - o.co->q_first > (u32)SPAN_MAX) out_flush(o);     // (the queue never spans more than the history holds)
@@ -447,7 +451,7 @@ SNKI_DEV void out_put(Out &o, u16 v) {
 // a match of len symbols at distance dist (1..32768)
 SNKI_DEV void out_match(Out &o, u32 len, u32 dist) {
     const long first = (long)o.n - (long)dist;
-    if (o.co) {
+    if (o.coop) {
         Coop &c = *o.co;
 #if !defined(__HIPCC__)
         ++SNKI_STAT(matches); SNKI_STAT(match_syms) += len;
@@ -496,7 +500,7 @@ SNKI_DEV void out_match(Out &o, u32 len, u32 dist) {
     }
 }
 SNKI_DEV void out_stored(Out &o, const u8 *comp, u64 p, u32 len) {
-    if (o.co) {
+    if (o.coop) {
         out_flush(o);
         SNKI_LANES(lane) {
             for (u32 i = (u32)lane; i < len; i += 64) {
@@ -513,17 +517,18 @@ SNKI_DEV void out_stored(Out &o, const u8 *comp, u64 p, u32 len) {
 
 // Decodes chunk ck (see its fields) to syms[ck.out_off ...].  One thread -- or, with a Coop, the 64 lanes of a wavefront running
 // it in lockstep on the same values; T and S are the workspace (LDS on the device).
+// (coop says whether there is a Coop: the kernels pass the flag themselves, so that the address of their Coop object is never compared)
 SNKI_DEV void decode_chunk(const u8 *comp, u64 nbytes, Chunk &ck, u16 *syms_all, MemberEnd *ends_all, Tables &T, Scratch &S, u32 *cl_tab,
-                           Coop *co = nullptr) {
+                           Coop *co, bool coop) {
     ck.n_syms = 0; ck.status = INF_OK; ck.end_bit = ck.start_bit; ck.known_from = 0xFFFFFFFFu; ck.n_ends = 0; ck.stream_end = 0;
     if (ck.start_bit == ~0ull) { ck.status = INF_NOT_STARTED; return; }
     Out o;
-    o.out = syms_all + ck.out_off; o.n = 0; o.co = co;
-    if (co) { co->qn = 0; co->q_first = 0; co->ring_lo = co->ring_end = 0; }
+    o.out = syms_all + ck.out_off; o.n = 0; o.co = co; o.coop = coop;
+    if (coop) { co->qn = 0; co->q_first = 0; co->ring_lo = co->ring_end = 0; }
     const u32 cap = ck.out_cap;
     u32 known_from = ck.first_of_member ? 0u : 0xFFFFFFFFu;
     Bits b;
-    bits_init(b, comp, nbytes, ck.start_bit, co);
+    bits_init(b, comp, nbytes, ck.start_bit, co, coop);
     for (;;) {
         // ---- block header
         const u64 at = bitpos(b);
@@ -541,7 +546,7 @@ SNKI_DEV void decode_chunk(const u8 *comp, u64 nbytes, Chunk &ck, u16 *syms_all,
             const u64 p = bitpos(b) >> 3;
             if (p + len > nbytes) { ck.status = INF_BAD; break; }
             out_stored(o, comp, p, len);
-            bits_init(b, comp, nbytes, (p + len) * 8, co);
+            bits_init(b, comp, nbytes, (p + len) * 8, co, coop);
         } else {
             int nlit = 288, ndist = 32;
             if (type == 1) fixed_lengths(S);
@@ -588,7 +593,7 @@ SNKI_DEV void decode_chunk(const u8 *comp, u64 nbytes, Chunk &ck, u16 *syms_all,
             m.sym_index = o.n;
             m.crc = (u32)comp[p] | ((u32)comp[p + 1] << 8) | ((u32)comp[p + 2] << 16) | ((u32)comp[p + 3] << 24);
             m.isize = (u32)comp[p + 4] | ((u32)comp[p + 5] << 8) | ((u32)comp[p + 6] << 16) | ((u32)comp[p + 7] << 24);
-            bits_init(b, comp, nbytes, (p + 8) * 8, co);
+            bits_init(b, comp, nbytes, (p + 8) * 8, co, coop);
             ck.end_bit = (p + 8) * 8;
             if (p + 8 >= nbytes) { ck.stream_end = 1; break; }
             if (!gzip_header(b)) { ck.status = INF_BAD; break; }
@@ -606,6 +611,12 @@ SNKI_DEV u8 resolve_sym(u16 x, const u8 *win) { return x < 256 ? (u8)x : win[x -
 SNKI_DEV u8 chain_byte(u32 n_syms, const u16 *s, const u8 *win, u32 i) {
     const u32 back = (u32)WIN - i;                     // this many bytes from the end of the stream so far
     return back <= n_syms ? resolve_sym(s[n_syms - back], win) : win[i + n_syms];
+}
+
+// for callers that hold a Coop by pointer anyway (the CPU twins of the kernels in tests/host_emul)
+SNKI_DEV void decode_chunk(const u8 *comp, u64 nbytes, Chunk &ck, u16 *syms_all, MemberEnd *ends_all, Tables &T, Scratch &S, u32 *cl_tab,
+                           Coop *co = nullptr) {
+    decode_chunk(comp, nbytes, ck, syms_all, ends_all, T, S, cl_tab, co, co != nullptr);
 }
 
 }  // namespace snkinf
