@@ -23,6 +23,7 @@
 //       at the shifted positions: a step most wavefronts skip), the adds are branch-free.  Flushed once per
 //       workgroup.  It also runs behind the generic kernel (any capacity), which then only decides.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "snk_common.cuh"
 #include "snk_adapter_bits.cuh"
 #include "snk_planes.cuh"
@@ -212,9 +213,11 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
         const uint8_t *s[2] = {nullptr, nullptr}, *q[2] = {nullptr, nullptr};
         const unsigned long long gidx = B.first_index + (unsigned long long)i;
         bool bad = !exists;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            if (m > pe) continue;                                   // (two unrolled copies: r[], s[], q[] indexed by constants stay in registers, the rows keep their global address space)
+        // one copy of the mate's code per mate, the mate a compile-time constant: r[], s[], q[] indexed by constants stay in registers
+        // and the rows keep their global address space (as a loop under `#pragma unroll` it stayed a loop -- its body is too large for
+        // the unroller --, and the dynamically indexed ReadState pair lived in scratch memory: 60 scratch loads and 28 stores per pair)
+        auto mate = [&](auto MC) {
+            constexpr int m = decltype(MC)::value;
             int len = 0;
             if (exists) {
                 len = B.len[m] ? (int)B.len[m][i] : B.fixed_len[m];
@@ -288,7 +291,9 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
                 const int ada_pos = best_pos;
                 if (ada_pos >= 0) { r[m].inc_ada = 1; r[m].adacut = len - ada_pos; }
             }
-        }
+        };
+        mate(std::integral_constant<int, 0>{});
+        if (pe) mate(std::integral_constant<int, 1>{});
         const bool ok = exists && !bad;
         if (ok) {
             fastq_trim_dev(P, 0, s[0], q[0], r[0]);
