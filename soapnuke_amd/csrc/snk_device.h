@@ -10,7 +10,14 @@
 // the CPU test tier (tests/simt), which runs the lanes of a wave one after the other, defines it as the point where they wait
 // for each other.
 #ifndef SNK_WAVE_SYNC
+#if defined(__HIP_DEVICE_COMPILE__)
+// compiler-level ordering only: a wavefront-scope fence pair around a wave barrier emits no instruction on gfx950, but it stops
+// LLVM from moving one lane's LDS / memory load across another lane's store at this point
+#define SNK_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
 #define SNK_WAVE_SYNC() ((void)0)
+#endif
 #endif
 
 #define SNK_DEV_MAX_ADA_LEN 256

@@ -66,7 +66,14 @@ struct Scratch { u8 lens[320]; u16 count[16], offs[16]; u16 sorted[288]; u8 subm
 // order, so there is nothing to emit on the device (snk_device.h has the same definition for the other kernels; tests/simt, which
 // runs the lanes one after the other, makes it the place where they wait for each other).
 #ifndef SNK_WAVE_SYNC
+#if defined(__HIP_DEVICE_COMPILE__)
+// compiler-level ordering only: a wavefront-scope fence pair around a wave barrier emits no instruction on gfx950, but it stops
+// LLVM from moving one lane's LDS / memory load across another lane's store at this point
+#define SNK_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
 #define SNK_WAVE_SYNC() ((void)0)
+#endif
 #endif
 #if defined(__HIPCC__)
 #define SNKI_LANES(lane) for (int lane = (int)(threadIdx.x & 63), once_ = 1; once_; once_ = 0)

@@ -5,10 +5,18 @@
 #pragma once
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include "snk_device.h"
 
 namespace {
+
+// SNK_PROVEN_ONLY=1 in the environment: dispatch only to paths that have passed the GPU parity suite on hardware (the CLI reads the
+// same switch for single-end rmdup in one pass, host/snk_main.cpp)
+inline bool snk_proven_only() {
+    static const bool v = [] { const char *e = getenv("SNK_PROVEN_ONLY"); return e && e[0] == '1' && !e[1]; }();
+    return v;
+}
 
 // float -> int as the x86-64 reference build does it (cvttss2si): NaN/overflow -> INT_MIN
 inline int f2i_x86(float f) {
@@ -53,6 +61,9 @@ inline void build_adapter(DevAdapter &A, const char *seq, int mis, float mr, int
     // phase C then).  Any budget: beyond 3 the screen lets the offset through.  long_ok: the block-wise search of the long-read
     // kernel lets an adapter reach 64 positions past a block.
     A.tile_ok = (al >= 1 && al < SNK_DEV_MAX_ADA_LEN && edge >= 1 && mis >= 0) ? 1 : 0;
+    // SNK_PROVEN_ONLY=1: the envelope the last hardware-green GPUTEST record covers -- 6..64 characters, adaEdge within
+    // the adapter -- ; anything else takes the sequential matcher of the generic kernel as it did then
+    if (snk_proven_only() && !(al >= 6 && al <= 64 && edge <= al)) A.tile_ok = 0;
     A.long_ok = (A.tile_ok && al >= 6 && al <= 64 && edge <= al) ? 1 : 0;
     for (int c = 0; c < al; ++c) {
         int k = 4;

@@ -212,7 +212,7 @@ private:
         // the chain: chunks whose start is where the one before stopped
         order_.clear();
         uint64_t expect = first, text_bytes = 0;
-        bool at_file_end = false;
+        bool at_file_end = false, at_member_seam = false;
         for (uint32_t c = 0; c < nc; ++c) {
             const snk_gunzip_chunk &ck = chunks_[c];
             if (ck.start_bit == ~0ull || ck.start_bit < expect) continue;     // no start found / a start inside a block already decoded
@@ -221,7 +221,10 @@ private:
             order_.push_back(c);
             text_bytes += ck.n_syms;
             expect = ck.end_bit;
-            if (ck.stream_end) { at_file_end = true; break; }
+            // stream_end says "the trailer ended where the input given to the kernel ends": the end of the FILE only when this
+            // window is the file's tail -- otherwise a member (BGZF, concatenated .gz) ended exactly on the window's edge and the
+            // next window starts at a member header (that case used to end the stream silently)
+            if (ck.stream_end) { if (wb + nbytes == n_) at_file_end = true; else at_member_seam = true; break; }
         }
         // a chunk that ran into the end of the WINDOW (not of the file) reports invalid data and is decoded again by the next
         // window; a window that yields nothing at all cannot make progress
@@ -249,6 +252,14 @@ private:
         // where the next window starts: inside a member, unless the last chunk ended exactly behind a member header
         const snk_gunzip_chunk &last = chunks_[order_.back()];
         first_of_member_ = last.known_from != 0xFFFFFFFFu && last.known_from == last.n_syms;
+        if (at_member_seam) {                  // (all of the member's text has been checked above: mlen_ is 0 here)
+            const uint64_t p = pos_bit_ >> 3;
+            uint64_t fb = 0;
+            if (n_ - p < 18) { pfail("truncated gzip member"); return false; }                  // as GzipInflate::member_header()
+            if (in_[p] != 0x1F || in_[p + 1] != 0x8B) stream_done_ = true;                      // trailing garbage: zlib's gzread stops quietly
+            else if (member_header_at(p, fb)) { pos_bit_ = fb; first_of_member_ = true; }
+            else { pfail("invalid gzip data (member header)"); return false; }
+        }
         if (at_file_end) { stream_done_ = true; if (mlen_ != 0) { pfail("device inflate: text behind the last member"); return false; } }
         return true;
     }

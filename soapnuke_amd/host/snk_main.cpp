@@ -1579,7 +1579,8 @@ int main(int argc, char **argv) {
     // the other devices send their batches' hashes there and get the flags back (9 bytes per pair against the ~700 of the
     // pair's text), marked in input order on a stream of the table's device.  SNK_RMDUP_TWO_PASS=1 forces the reference's two passes.
     const int64_t rmdup_patch = o.patch_size > 0 ? o.patch_size : (int64_t)o.threads * 20000 / 8;
-    bool rmdup_one_pass = o.p.rmdup && (mates == 2 || (rmdup_patch > 0 && o.batch_pairs % rmdup_patch == 0)) && !getenv("SNK_RMDUP_TWO_PASS");
+    const bool proven_only = getenv("SNK_PROVEN_ONLY") && !strcmp(getenv("SNK_PROVEN_ONLY"), "1");      // (csrc/snk_tables.h: the hardware-green envelope only)
+    bool rmdup_one_pass = o.p.rmdup && (mates == 2 || (!proven_only && rmdup_patch > 0 && o.batch_pairs % rmdup_patch == 0)) && !getenv("SNK_RMDUP_TWO_PASS");
     if (rmdup_one_pass) {
         // the one-pass table keeps 8 B per pair of hashes and up to 48 B per pair of table resident in HBM: when twice the
         // estimated number of pairs (file size / bytes of the first record) does not fit, the two passes run instead

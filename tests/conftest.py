@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "first_contact: GPU test of code that has not run on hardware yet -- runs by default, sorted last")
 
 
 @pytest.fixture(scope="session")
@@ -24,6 +25,8 @@ def pytest_collection_modifyitems(config, items):
     """The emulated tier (tests/test_simt_*.py) re-runs the GPU tier's test functions on the CPU; all of it takes about twelve minutes,
     so an ordinary run takes each module's CORE selection (a few minutes) and SNK_SIMT_FULL=1 the rest as well
     (profiles/r04_simt_full.txt holds such a run)."""
+    # first-contact tests go behind everything else (stable order otherwise): the driver runs `pytest -m gpu -x`
+    items.sort(key=lambda it: it.get_closest_marker("first_contact") is not None)
     if os.environ.get("SNK_SIMT_FULL") == "1":
         return
     skip = pytest.mark.skip(reason="emulated tier beyond its core selection: SNK_SIMT_FULL=1 runs it")

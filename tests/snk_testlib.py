@@ -15,12 +15,11 @@ if ROOT not in sys.path:
 
 from soapnuke_amd import abi  # noqa: E402
 
-# GPU tests written while the GPU lease was closed (round 4): their logic is pinned on the CPU (tests/test_host_emul.py,
-# tests/test_inflate_emul.py), they have not met the hardware yet -- SNK_RUN_UNVERIFIED=1 runs them; the guard comes off once they
-# have passed there
+# GPU tests whose kernels have not met the hardware yet (written while the GPU lease was closed): they RUN by default; the marker
+# only makes tests/conftest.py sort them behind every established test, so that under `pytest -x` a failure on first contact
+# cannot hide the rest of the suite.  Remove the mark from a test once a GPUTEST record has it green.
 import pytest  # noqa: E402
-not_yet_on_hardware = pytest.mark.skipif(os.environ.get("SNK_RUN_UNVERIFIED") != "1",
-                                         reason="written while the GPU lease was closed: pinned on the CPU emulation, not yet run on hardware (SNK_RUN_UNVERIFIED=1)")
+first_contact = pytest.mark.first_contact
 
 ORACLE_SO = os.path.join(ROOT, "oracle", "libsnk_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libsnkref.so")

@@ -167,7 +167,7 @@ def test_long_adapter_lists_and_lower_case_on_the_fast_paths(i):
 
 
 # ---- round 4: adapters of any length on the tiled kernel (65..200 characters, shorter than 6, adaEdge beyond the adapter)
-@T.not_yet_on_hardware
+@T.first_contact
 @pytest.mark.parametrize("i", range(12))
 def test_adapters_of_any_length_on_the_tiled_kernel(i):
     """the reference takes adapters of any length (src/read_filter.cpp:707-790); the bit paths took 6..64

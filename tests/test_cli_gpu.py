@@ -112,7 +112,7 @@ def test_cli_rmdup_matches_reference_binary(paired, n, tmp_path):
 
 
 @pytest.mark.parametrize("mode", ["one_pass_gz", "two_pass", "sentinel_restart", "small_batches",
-                                  pytest.param("table_does_not_fit", marks=T.not_yet_on_hardware)])
+                                  pytest.param("table_does_not_fit", marks=T.first_contact)])
 def test_cli_rmdup_one_pass_variants(mode, tmp_path):
     """Paired rmdup is one pass in device-text mode (a hash table resident in HBM, include/snk_rmdup.h snk_rmdup_stream_*):
     .gz output, the retained two-pass path (SNK_RMDUP_TWO_PASS=1), the restart a sentinel hash forces, and batches much
@@ -152,7 +152,7 @@ def test_cli_rmdup_one_pass_variants(mode, tmp_path):
     assert (b"the one-pass table would need" in log) == (mode == "table_does_not_fit")
 
 
-@T.not_yet_on_hardware
+@T.first_contact
 @pytest.mark.parametrize("n,batch,mode", [(20000, "4096", "one"), (20100, "4096", "one"), (20100, "700", "one"), (19999, "4096", "gz"), (20100, "4096", "two_pass"),
                                            (20100, "4096", "sentinel_restart"), (20100, "2048", "two_devices")])
 def test_cli_rmdup_single_end_one_pass(n, batch, mode, tmp_path):
@@ -553,7 +553,7 @@ def test_cli_two_device_slots(rmdup, tmp_path):
     _compare_dirs(os.path.join(work, "ours"), ref, True)
 
 
-@T.not_yet_on_hardware
+@T.first_contact
 @pytest.mark.parametrize("paired,gz_out,trim", [(True, False, False), (True, True, True), (False, False, True)])
 def test_cli_sharded_ingest(paired, gz_out, trim, tmp_path):
     """SURVEY 8e / VERDICT r3 #5: plain input, several devices, SNK_SHARDED=1 -- one child process per device takes a contiguous

@@ -15,7 +15,7 @@ import snk_testlib as T
 from soapnuke_amd import abi
 from test_inflate_emul import _vectors
 
-pytestmark = [pytest.mark.gpu, T.not_yet_on_hardware]
+pytestmark = [pytest.mark.gpu, T.first_contact]
 
 
 class Chunk(C.Structure):

@@ -176,3 +176,34 @@ def test_device_gunzip_checks_crc_and_length(dg):
     for cut in (30, len(blob) // 2, len(blob) - 3):             # truncated files: an error, like zlib's gzread
         r, got, info, err = _dgunzip(dg, bytes(gzip.compress(raw, 6)[:cut]), 1 << 22, 1 << 16, 1 << 20, len(raw) + 100)
         assert r == -1, (cut, r, err)
+
+
+def test_device_gunzip_member_ending_on_a_window_edge(dg):
+    """a member whose trailer ends exactly where a window ends is not the end of the file -- the chunk's
+    `stream_end` only says "the input given to the kernel ends here".  Windows swept around the seams of a three-member file (every
+    offset of the 4-byte window alignment), BGZF-like small members, trailing garbage behind a seam on the edge (zlib's gzread stops
+    quietly), and a truncated member header there (an error)."""
+    raw = [_fastq_bytes(2500 + 300 * k) for k in range(3)]
+    members = [gzip.compress(r, 6) for r in raw]
+    blob, want = b"".join(members), b"".join(raw)
+    seams = [len(members[0]), len(members[0]) + len(members[1])]
+    exact = 0
+    for seam in seams:
+        for window in range(seam - 12, seam + 13):
+            for chunk in (1 << 16, 1 << 20):
+                r, got, info, err = _dgunzip(dg, blob, window, chunk, 1 << 21, len(want) + 1000)
+                assert r == len(want) and got == want, (seam, window, chunk, r, info, err)
+                exact += window == seam
+    assert exact == 4
+    # small members (BGZF-like) and windows that are multiples of the member size: many seams on edges
+    small = [gzip.compress(want[k:k + 4096], 1) for k in range(0, 65536, 4096)]
+    sblob, swant = b"".join(small), want[:65536]
+    for window in sorted({len(small[0]), len(small[0]) + len(small[1]), sum(len(m) for m in small[:5]), 4096, 10000}):
+        r, got, info, err = _dgunzip(dg, sblob, window, 1 << 12, 1 << 17, len(swant) + 1000, 8)
+        assert r == len(swant) and got == swant, (window, r, info, err)
+    # trailing garbage right behind a member that ends on the window's edge: the text of the members, no error
+    r, got, info, err = _dgunzip(dg, members[0] + b"\0" * 64, len(members[0]), 1 << 16, 1 << 21, len(raw[0]) + 1000)
+    assert r == len(raw[0]) and got == raw[0], (r, info, err)
+    # ... and fewer than 18 bytes there: truncated member (as the sequential decoder says)
+    r, got, info, err = _dgunzip(dg, members[0] + members[1][:9], len(members[0]), 1 << 16, 1 << 21, len(want))
+    assert r == -1 and "truncated" in err, (r, err)

@@ -232,7 +232,7 @@ def test_one_pass_table_refuses_too_many_reads():
     lib.snk_rmdup_stream_destroy(t)
 
 
-@T.not_yet_on_hardware
+@T.first_contact
 def test_one_pass_table_single_end_shift():
     """snk_rmdup_stream_mark_se_device: out[i] = the true flag of read i - 1 inside full patches (across batch borders, from
     alternating streams, through a regrown scratch), the true flag of read i in the file's partial last patch

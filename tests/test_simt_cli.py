@@ -23,7 +23,6 @@ def _emulated_cli(monkeypatch):
     cli = S.build_module().build_cli()
     monkeypatch.setattr(CG, "CLI", cli)
     monkeypatch.setattr(GZ, "CLI", cli, raising=False)
-    monkeypatch.setenv("SNK_RUN_UNVERIFIED", "1")
 
 
 from test_cli_gpu import *      # noqa: E402,F401,F403  (every test function of the GPU tier's module)

@@ -43,7 +43,6 @@ def _emulated(monkeypatch):
         return real_make(int(n) if int(n) <= CAP else CAP + int(n) % 61, *a, **k)
 
     monkeypatch.setattr(synth, "make_batch", make_batch)
-    monkeypatch.setenv("SNK_RUN_UNVERIFIED", "1")          # (tests guarded until they have run on hardware: this tier is what they wait for)
     for mod in (GP, AF, CF, LR, PH, RD, FQ, GZ, BT):
         monkeypatch.setattr(mod, "run_hip_device", S.run_device, raising=False)
 

@@ -25,7 +25,6 @@ def tsan_cli(monkeypatch):
     cli = S.build_module().build_cli_tsan()
     monkeypatch.setattr(CG, "CLI", cli)
     monkeypatch.setenv("TSAN_OPTIONS", "halt_on_error=1 second_deadlock_stack=1 exitcode=66")
-    monkeypatch.setenv("SNK_RUN_UNVERIFIED", "1")
 
 
 @pytest.fixture(autouse=True)
@@ -38,7 +37,6 @@ def _asan_cli(monkeypatch):
     monkeypatch.setattr(GZ, "CLI", cli, raising=False)
     monkeypatch.setenv("LD_LIBRARY_PATH", rt + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
     monkeypatch.setenv("ASAN_OPTIONS", "detect_leaks=0:abort_on_error=0:detect_stack_use_after_return=0")
-    monkeypatch.setenv("SNK_RUN_UNVERIFIED", "1")
 
 
 @pytest.mark.parametrize("case", CG.R.REPORT_CASES, ids=[c[0] for c in CG.R.REPORT_CASES])

@@ -7,7 +7,7 @@ ROOT=$(pwd); export TMPDIR=/tmp; mkdir -p gpurun_out
 for stage in "$@"; do
   case $stage in
     tests)   # the whole GPU suite, the guarded tests included
-      SNK_RUN_UNVERIFIED=1 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/catchup_tests.txt ;;
+      timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/catchup_tests.txt ;;
     stress)
       timeout 300 python tools/stress_parity.py 30 2>&1 | tail -12 | cut -c1-400 | tee gpurun_out/catchup_stress.txt ;;
     bench)
