@@ -8,7 +8,7 @@
  * that the chunks chain (every chunk ends where the next one starts), and a chain + resolve kernel pair replaces the
  * markers and leaves the window's text in HBM / copies it to the host.  host/snk_dgunzip.h drives the calls, verifies
  * every member's CRC-32 / ISIZE and falls back to the host decoder (host/snk_inflate.h) for whatever does not fit, so
- * the bytes are always zlib's bytes or an error.  The decoding itself is csrc/snk_inflate_core.cuh, which also compiles
+ * the bytes are always zlib's bytes or an error.  The decoding itself is csrc/snk_inflate_core.hip.h, which also compiles
  * for the host (tests/test_inflate_emul.py: against zlib, no GPU needed).
  *
  * Plain C, plain pointers and sizes.  All calls are synchronous on the library's own stream.
@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-/* one chunk of a window, as csrc/snk_inflate_core.cuh snkinf::Chunk (same layout, 80 bytes) */
+/* one chunk of a window, as csrc/snk_inflate_core.hip.h snkinf::Chunk (same layout, 80 bytes) */
 typedef struct snk_gunzip_chunk {
     uint64_t start_bit, stop_bit, out_off;
     uint32_t out_cap, first_of_member, n_syms, status;

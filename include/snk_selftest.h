@@ -8,7 +8,7 @@
 extern "C" {
 #endif
 
-/* 64 x 64 bit-matrix transpose across the lanes of a wave (csrc/snk_bittr.cuh, the lane = position ->
+/* 64 x 64 bit-matrix transpose across the lanes of a wave (csrc/snk_bittr.hip.h, the lane = position ->
  * lane = read hand-over of the tiled kernel).  in: n_matrices x 64 lanes x 2 words (host memory, lane p =
  * bits r); out: n_matrices x 64 x 2 words (lane r = bits p); out_lo: n_matrices x 64 words, the
  * half-work variant (bits p < 32).  Returns 0, or a negative SNK error code (snk_last_error()). */

@@ -46,6 +46,7 @@ namespace {
 struct ParamHolder {
     snk_params p;
     std::vector<std::string> keep;
+    std::vector<const char *> ptrs[2];      // snk_params.adapter_list points here: owned by the holder, one per calling thread
 };
 
 void fill_params(ParamHolder &H, const C_global_parameter &gp, int max_len) {
@@ -92,11 +93,10 @@ void fill_params(ParamHolder &H, const C_global_parameter &gp, int max_len) {
     P.n_adapters[0] = (int)gp.ada1s.size();
     P.n_adapters[1] = (int)gp.ada2s.size();
     // lists of any length go through snk_params.adapter_list
-    static std::vector<const char *> ptrs[2];
-    ptrs[0].clear(); ptrs[1].clear();
-    for (size_t i = 0; i < gp.ada1s.size(); ++i) { H.keep.push_back(gp.ada1s[i]); ptrs[0].push_back(H.keep.back().c_str()); }
-    for (size_t i = 0; i < gp.ada2s.size(); ++i) { H.keep.push_back(gp.ada2s[i]); ptrs[1].push_back(H.keep.back().c_str()); }
-    for (int m = 0; m < 2; ++m) P.adapter_list[m] = ptrs[m].empty() ? nullptr : ptrs[m].data();
+    H.ptrs[0].clear(); H.ptrs[1].clear();
+    for (size_t i = 0; i < gp.ada1s.size(); ++i) { H.keep.push_back(gp.ada1s[i]); H.ptrs[0].push_back(H.keep.back().c_str()); }
+    for (size_t i = 0; i < gp.ada2s.size(); ++i) { H.keep.push_back(gp.ada2s[i]); H.ptrs[1].push_back(H.keep.back().c_str()); }
+    for (int m = 0; m < 2; ++m) P.adapter_list[m] = H.ptrs[m].empty() ? nullptr : H.ptrs[m].data();
     auto str = [&](const std::string &s) -> const char * {
         if (s.empty()) return nullptr;
         H.keep.push_back(s);

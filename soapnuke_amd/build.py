@@ -7,11 +7,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsnk_filter.so")
 SOURCES = ["snk_filter.cpp", "snk_generic.hip", "snk_tiled.hip", "snk_rmdup.hip", "snk_contam.hip", "snk_long.hip", "snk_fastq.hip", "snk_gzip.hip", "snk_inflate.hip"]
 def _headers():
-    """every header a kernel source can include: csrc/*.cuh|*.h and include/*.h (a missing entry once let a stale
+    """every header a kernel source can include: csrc/*.hip.h|*.h and include/*.h (a missing entry once let a stale
     library survive a plane-store layout change)"""
     import glob
     inc = os.path.join(HERE, "..", "include")
-    return sorted(glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(inc, "*.h")))
+    return sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(inc, "*.h")))
 
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

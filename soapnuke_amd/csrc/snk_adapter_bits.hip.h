@@ -1,9 +1,9 @@
-// snk_adapter_bits.cuh -- the bit-sliced adapter search (A2 adapter_pos, src/read_filter.cpp:707-790) on the bit planes of
+// snk_adapter_bits.hip.h -- the bit-sliced adapter search (A2 adapter_pos, src/read_filter.cpp:707-790) on the bit planes of
 // one read per lane: screening of all candidate offsets at once with unary mismatch counters, exact closed-form decision
 // of the survivors in the reference's order.  Shared by the wave-tiled kernel (snk_tiled.hip: planes of a whole read,
 // NW <= 8 words) and the long-read kernel (snk_long.hip: planes of a 320-position block of the read).
 #pragma once
-#include "snk_common.cuh"
+#include "snk_common.hip.h"
 
 #ifndef SNK_ABL
 #define SNK_ABL 0

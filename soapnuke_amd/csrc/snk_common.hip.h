@@ -1,4 +1,4 @@
-// snk_common.cuh -- device code shared by the generic and the wave-tiled kernels:
+// snk_common.hip.h -- device code shared by the generic and the wave-tiled kernels:
 // the per-read state, the sequential adapter matcher (also the in-kernel fallback
 // for reads shorter than the adapter), the discard cascade and the trimming-
 // position bookkeeping.  Reference rows: SURVEY.md 8(a) A2/A3/A6/A8.

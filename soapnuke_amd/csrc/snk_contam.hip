@@ -13,18 +13,18 @@
 //               exactly, one per lane and trip: 64 match bits of the alignment, then a walk over its at most budget+1
 //               first mismatches -- the run between two mismatches is a popcount of the match bits (an 'N' in the read
 //               is neither match nor mismatch, so it drops out of both).
-//   global      A hit of the reference's carried scoring window (snk_common.cuh) implies min_match_len consecutive cells
+//   global      A hit of the reference's carried scoring window (snk_common.hip.h) implies min_match_len consecutive cells
 //               of one lay with <= mismatch_number mismatches (or nearly that at the read end, see gcontam_bits).  The
 //               mismatches of the last cells are kept as a bit-sliced binary counter per offset (biased, so that its top
 //               plane is the verdict), sliding along the contaminant; the offsets with such a stretch are decided exactly by the window walk (gc_walk) on the 64
 //               equality bits of their lay.
 //
 // What the bit paths do not cover (contaminants over 64 characters or with anything but ACGTN, reads shorter than the
-// contaminant) goes to the sequential matchers of snk_common.cuh, per lane.  Reads over 256 nt: the same bit paths block by
+// contaminant) goes to the sequential matchers of snk_common.hip.h, per lane.  Reads over 256 nt: the same bit paths block by
 // block on the plane store of the long-read path (snk_long_contam_kernel below).
 #include <hip/hip_runtime.h>
-#include "snk_common.cuh"
-#include "snk_planes.cuh"
+#include "snk_common.hip.h"
+#include "snk_planes.hip.h"
 
 using namespace snk;
 
@@ -348,7 +348,7 @@ __device__ __forceinline__ void match_plane(const u32 (&XP)[5][NQ], int letter, 
 }
 
 // global_contam_pos() verdict of one strand for the lanes with `active` (len >= contaminant length).
-// What a hit takes (snk_common.cuh has the walk): a window opens on a matching cell and is dead once it holds more than
+// What a hit takes (snk_common.hip.h has the walk): a window opens on a matching cell and is dead once it holds more than
 // mismatch_number mismatches; in the first two sections it only opens with min_match_len cells of the lay in front of it,
 // so it either hits when it spans exactly min_match_len cells or is dead by then -- every lay starts from a dead window,
 // the lays are independent.  In the last section a window may open on one of the last cells, the lay is abandoned and the
@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 
 }
 
 // Reads of 257..1024 positions: the same bit paths on BLOCKS of a read, from the plane store the long-read prep kernel wrote
-// (snk_planes.cuh): planes of 320 positions serve the 256 alignment offsets of a block and the 64 positions a contaminant reaches
+// (snk_planes.hip.h): planes of 320 positions serve the 256 alignment offsets of a block and the 64 positions a contaminant reaches
 // past them.  Contaminant alignments that hang off the read's start belong to its first block, those hanging off its end to its
 // final block (which is cut so that it ends with the read and holds at least 64 positions), whole alignments to the block of
 // their offset: only the verdict is ever used, so a hit in any block is the hit.  One work-item per pair; reads shorter than a

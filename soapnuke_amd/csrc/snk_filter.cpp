@@ -176,7 +176,7 @@ std::string build_contams(const snk_params &P, std::vector<DevContam> &ct, int n
             G.mm = atoi(mms[i].c_str());
             // the event walk and the bit-parallel screen of the kernels cover 0 <= mismatches <= 4 < ... < match length; outside
             // it the reference's score arithmetic degenerates (a window that is "dead" can pass the hit test) and the kernels
-            // walk the lays cell by cell (gc_lay_cells, snk_common.cuh)
+            // walk the lays cell by cell (gc_lay_cells, snk_common.hip.h)
             const bool in_range = G.mm >= 0 && G.mm <= 4 && G.min_match_len > G.mm;
             if (G.min_match_len < 0 || G.min_match_len > cl) return "global contaminant: match ratio must be in [0, 1]";
             memcpy(G.seq[0], seqs[i].data(), cl);

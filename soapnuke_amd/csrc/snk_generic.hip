@@ -17,7 +17,7 @@
 //   A6 pe/se_discard  src/sequence.cpp:76-178,198-387
 //   A8 stat_*_fqs     src/peprocess.cpp:1076-1423, src/seprocess.cpp:632-869
 #include <hip/hip_runtime.h>
-#include "snk_common.cuh"
+#include "snk_common.hip.h"
 
 using namespace snk;
 

@@ -1,4 +1,4 @@
-// snk_gfx950.cuh -- the instructions the tiled kernel places by hand (snk_tiled.hip, phase 1 / phase 3): LDS reads and adds with
+// snk_gfx950.hip.h -- the instructions the tiled kernel places by hand (snk_tiled.hip, phase 1 / phase 3): LDS reads and adds with
 // immediate offsets and counted waits, the fused clamp + row-address + histogram-add statement, the LDS DMA, v_writelane.
 // They are inline asm on purpose (see the notes at each wrapper); everything here is gfx950 ISA.
 //

@@ -1,5 +1,5 @@
 // snk_inflate.hip -- the device inflate (include/snk_gunzip.h): block-start search, marker-mode chunk decoding, window chain and
-// marker resolution on gfx950.  The decoding is csrc/snk_inflate_core.cuh (one thread per chunk: DEFLATE is a sequential bit
+// marker resolution on gfx950.  The decoding is csrc/snk_inflate_core.hip.h (one thread per chunk: DEFLATE is a sequential bit
 // stream; the parallelism is the thousands of chunks of a window -- one wavefront each, its Huffman tables in LDS, 11 per CU).
 // Replaces the reference's gzgets() reading loop, src/peprocess.cpp:2063-2113.
 #include <hip/hip_runtime.h>
@@ -7,7 +7,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
-#include "snk_inflate_core.cuh"
+#include "snk_inflate_core.hip.h"
 #include "../../include/snk_gunzip.h"
 #include "../../include/snk_filter.h"
 
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(64) inf_decode_kernel(const u8 *comp, u64 nbyt
 
 // The same with the whole wavefront at work: all 64 lanes run the decoder in lockstep on the same values (its tables, header
 // workspace and decisions are uniform), and share the I/O -- compressed bytes through an LDS ring refilled 1 KB at a time by all
-// lanes, matches queued and copied 64 at a time, one per lane (snk_inflate_core.cuh, Coop).  A lane on its own pays a global-memory
+// lanes, matches queued and copied 64 at a time, one per lane (snk_inflate_core.hip.h, Coop).  A lane on its own pays a global-memory
 // round trip per bit-buffer refill and per copied symbol: gzip turns the base lines of FASTQ into ~40 short matches per read.
 __global__ void __launch_bounds__(64) inf_decode_coop_kernel(const u8 *comp, u64 nbytes, Chunk *chunks, u16 *syms, MemberEnd *ends) {
     SNK_WAVE_UNIFORM_SHARED WaveSpace W;

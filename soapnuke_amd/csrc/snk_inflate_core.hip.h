@@ -1,4 +1,4 @@
-// snk_inflate_core.cuh -- DEFLATE (RFC 1951) decoding of one chunk of a gzip stream with an UNKNOWN 32 KiB window, as plain
+// snk_inflate_core.hip.h -- DEFLATE (RFC 1951) decoding of one chunk of a gzip stream with an UNKNOWN 32 KiB window, as plain
 // single-thread code that compiles for gfx950 (snk_inflate.hip: one wavefront per chunk, the tables in LDS) and for the host
 // (tests/host_emul/: the same functions against zlib's bytes, no GPU needed).
 //

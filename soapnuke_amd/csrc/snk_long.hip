@@ -7,11 +7,11 @@
 //       count, quality sum) in the read's record and the read's five bit planes (A C G T N over the positions) in the
 //       batch's plane store, laid out so that 64 consecutive reads fetch a quad of plane words as one contiguous kilobyte.
 //   snk_long_decide_kernel   lane = read (one work-item per pair), on the plane store.  The adapter search (A2,
-//       src/read_filter.cpp:707-790) is the bit-sliced one of the tiled kernel (snk_adapter_bits.cuh) on BLOCKS of the
+//       src/read_filter.cpp:707-790) is the bit-sliced one of the tiled kernel (snk_adapter_bits.hip.h) on BLOCKS of the
 //       read: planes of 320 positions (10 words) serve the 256 candidate offsets of a block plus the 64 positions an
 //       adapter can reach past them; a block in the middle of a read has phase B offsets only, phase A belongs to the first
 //       block, phase C to the last one, which ends with the read.  The A / N counts of A1 are popcounts of the same planes;
-//       a position that is neither ACGT nor N sends the read to the sequential functions of snk_common.cuh in its lane
+//       a position that is neither ACGT nor N sends the read to the sequential functions of snk_common.hip.h in its lane
 //       (lower case, other letters; also reads shorter than 64), which walk the row; so does poly-X when it is asked
 //       for.  Trimming (A3), the discard cascade (A6), the reason counters (one atomic per counter and wavefront:
 //       agg_inc) and the trimming-position counters follow as in the generic kernel.
@@ -24,9 +24,9 @@
 //       workgroup.  It also runs behind the generic kernel (any capacity), which then only decides.
 #include <hip/hip_runtime.h>
 #include <type_traits>
-#include "snk_common.cuh"
-#include "snk_adapter_bits.cuh"
-#include "snk_planes.cuh"
+#include "snk_common.hip.h"
+#include "snk_adapter_bits.hip.h"
+#include "snk_planes.hip.h"
 
 using namespace snk;
 

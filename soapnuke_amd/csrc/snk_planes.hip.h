@@ -1,10 +1,10 @@
-// snk_planes.cuh -- the plane store of a batch of long reads (257..1024 positions): snk_long_prep_kernel (snk_long.hip) writes
+// snk_planes.hip.h -- the plane store of a batch of long reads (257..1024 positions): snk_long_prep_kernel (snk_long.hip) writes
 // it, the decide kernel (snk_long.hip) and the block-wise contaminant kernel (snk_contam.hip) read it.  For every group of 64
 // consecutive reads of a mate: nquads quads of 4 plane words (32 positions each; nquads = the capacity in 128-position units,
 // at most 8) x 5 planes (A C G T N) x 64 reads x 16 bytes, so that the 64 lanes of a wavefront -- 64 consecutive reads -- fetch
 // one quad of one plane as one contiguous kilobyte.
 #pragma once
-#include "snk_common.cuh"
+#include "snk_common.hip.h"
 
 namespace snk {
 namespace {

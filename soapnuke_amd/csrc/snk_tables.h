@@ -1,6 +1,6 @@
 // snk_tables.h -- host-side tables of one adapter: everything adapter_pos() (src/read_filter.cpp:707-790) derives from
 // (adptLen, adaMis, adaMR, adaEdge) with the reference's own int -> float -> int arithmetic, and the compact descriptor the
-// bit-sliced search reads (snk_adapter_bits.cuh).  Plain C++ (no HIP): shared by the C ABI (snk_filter.cpp) and by the host
+// bit-sliced search reads (snk_adapter_bits.hip.h).  Plain C++ (no HIP): shared by the C ABI (snk_filter.cpp) and by the host
 // emulation of the search that fuzzes it against the oracle without a GPU (tests/host_emul/).
 #pragma once
 #include <limits.h>

@@ -13,7 +13,7 @@
 //  hand-over  The parked dwords hold, per byte, the bits of 8 (codes: 4) reads at one position.  Byte transposes + wide
 //           LDS writes/reads give every lane = position its 64 read bits per plane; their popcounts ARE the raw base
 //           histogram of the position (one LDS add per letter, strip and tile), and 64 x 64 bit-matrix transposes
-//           (snk_bittr.cuh: v_permlane32/16_swap + DPP) turn them into the per-read bit planes of phase 2.
+//           (snk_bittr.hip.h: v_permlane32/16_swap + DPP) turn them into the per-read bit planes of phase 2.
 //  phase 2  lane = READ.  Each lane now holds its read as bit planes (one bit per
 //           position).  Adapter search (src/read_filter.cpp:707-790) runs bit-sliced over
 //           all candidate offsets at once: for the first S-1 adapter characters (S =
@@ -39,8 +39,8 @@
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
-#include "snk_common.cuh"
-#include "snk_bittr.cuh"
+#include "snk_common.hip.h"
+#include "snk_bittr.hip.h"
 
 using namespace snk;
 
@@ -74,9 +74,9 @@ using namespace snk;
 #define SNK_TILE_OF(w) ((long)(w) * gridDim.x + blockIdx.x)
 #endif
 
-#include "snk_adapter_bits.cuh"
+#include "snk_adapter_bits.hip.h"
 
-#include "snk_gfx950.cuh"      // the hand-placed instructions: LDS reads / adds / waits, the LDS DMA, v_writelane
+#include "snk_gfx950.hip.h"      // the hand-placed instructions: LDS reads / adds / waits, the LDS DMA, v_writelane
 
 namespace {
 
@@ -153,7 +153,7 @@ __device__ __forceinline__ void rs_unpack(const DevParams &P, int mate, const Pa
     r.lq_h = (int)(p.lq & 0x3FFu) - 1;
     r.lq_t = (int)((p.lq >> 10) & 0x3FFu) - 1;
     r.sumq = p.sumq;
-    const bool hard = P.trim_on && P.has_hard;                         // trim_finish(), snk_common.cuh
+    const bool hard = P.trim_on && P.has_hard;                         // trim_finish(), snk_common.hip.h
     r.hd_h = hard ? P.hard[P.paired ? 2 * mate : 0] : -1;
     r.hd_t = hard ? P.hard[P.paired ? 2 * mate + 1 : 1] : -1;
 }
@@ -591,7 +591,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         {
             // Parked dwords go to the wave's LDS scratch, one 256-byte row each: byte p of row g = the bits of position
             // p for reads 8g..8g+7 (code planes: reads 4g..4g+3, two bits each).  A lane = position gathers its byte of
-            // 8 rows into 64 read bits, and the 64 x 64 bit transposes (snk_bittr.cuh) turn them into per-read planes.
+            // 8 rows into 64 read bits, and the 64 x 64 bit transposes (snk_bittr.hip.h) turn them into per-read planes.
             const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
             // Hand-over scratch of the wave (2 KB): 8 bytes per position.  The owner of positions 4l..4l+3 turns its 8 parked
             // dwords (byte k = 8 read bits of position 4l+k) into four 8-byte rows by two 4 x 4 byte transposes and stores

@@ -4,9 +4,11 @@
 // the compressed file into windows, checks that the chunks of a window CHAIN (every chunk ends exactly where the next one starts;
 // block starts the chain steps over are false positives), verifies CRC-32 and ISIZE of every member on the resolved text, and
 // falls back to the sequential host decoder (snk_inflate.h) from the last good block on for whatever the device path refuses --
-// a chunk that overflowed its symbol slots, invalid data, a window without a single complete chunk.  The bytes are always
-// zlib's bytes or an error.  The device calls sit behind DgBackend so that tests/host_emul/ can run this very class on the CPU
-// with the same chunk decoder (csrc/snk_inflate_core.cuh) -- tests/test_inflate_emul.py.
+// a chunk that overflowed its symbol slots, invalid data, a window without a single complete chunk -- for ONE SPELL: the host
+// decoder stops in front of the first block header a chunk's length further on and the device windows resume there (a spell
+// that the device refuses again right away is twice as long; ADVICE r4: one poly-N region used to put the rest of a 100 GB file
+// on one core).  The bytes are always zlib's bytes or an error.  The device calls sit behind DgBackend so that tests/host_emul/ can run this very class on the CPU
+// with the same chunk decoder (csrc/snk_inflate_core.hip.h) -- tests/test_inflate_emul.py.
 // Reference: the gzgets() reading loop, src/peprocess.cpp:2063-2113.
 #ifndef SNK_DGUNZIP_H
 #define SNK_DGUNZIP_H
@@ -58,7 +60,9 @@ public:
     const char *error() const { return err_.empty() ? nullptr : err_.c_str(); }
     bool done() const { return done_; }
     uint64_t windows() const { return windows_; }
-    uint64_t fallback_bit() const { return fallback_bit_; }            // ~0: the device decoded everything
+    uint64_t fallback_bit() const { return fallback_bit_; }            // ~0: the device decoded everything; else where the first host spell began
+    uint64_t host_spells() const { return spells_; }                   // how often the host decoder took over ...
+    uint64_t resumes() const { return resumes_; }                      // ... and how often the device windows resumed behind it
 
     // The windows are made by a producer thread one ahead of the reader (two text slots): the device decodes window k + 1 while
     // window k is consumed.
@@ -122,6 +126,7 @@ private:
     uint64_t mlen_ = 0;
     bool member_checkable_ = true;
     uint64_t windows_ = 0, fallback_bit_ = ~0ull;
+    uint64_t spells_ = 0, resumes_ = 0, spell_bits_ = 0, windows_at_spell_ = ~0ull;
     // sequential fallback
     GzipInflate sq_;
     std::vector<uint8_t> sbuf_;
@@ -266,12 +271,17 @@ private:
 
     // ---- sequential host decoder from the block header at pos_bit_ on (the rest of the stream)
     void start_sequential() {                  // (the producer has ended: its state -- position, window, CRC so far -- is the reader's now)
-        fallback_bit_ = pos_bit_;
+        if (fallback_bit_ == ~0ull) fallback_bit_ = pos_bit_;
+        // one spell: up to the first block header a chunk further on; twice as far when the device made no window since the last spell
+        spell_bits_ = (spells_ && windows_ == windows_at_spell_) ? std::min<uint64_t>(spell_bits_ * 2, 1ull << 40) : (uint64_t)g_.chunk_bytes * 8;
+        windows_at_spell_ = windows_;
+        ++spells_;
         if (getenv("SNK_PGZ_DEBUG")) fprintf(stderr, "device inflate: sequential from bit %llu (%s)\n", (unsigned long long)pos_bit_, be_->error().c_str());
         seq_ = true;
         sq_.init(in_, n_);
         sq_.set_verify_crc(false);
         sq_.start_at_block(pos_bit_);
+        if (!getenv("SNK_DGZ_NO_RESUME")) sq_.set_stop_bit(pos_bit_ + spell_bits_);
         if (first_of_member_) { mcrc_ = 0; mlen_ = 0; }
         sbuf_.assign(HIST + ((size_t)1 << 22), 0);
         memcpy(sbuf_.data(), win_.data(), HIST);
@@ -285,8 +295,27 @@ private:
         sbuf_.assign(HIST + ((size_t)1 << 22), 0);
         s_have_ = s_off_ = 0;
     }
+    // the host spell is over (sq_ stopped in front of a block header, everything it made has been handed out): the device windows
+    // go on from there -- position, the 32 KiB behind it and the member's CRC / length so far are the producer's again
+    void resume_device() {
+        pos_bit_ = sq_.bitpos();
+        memcpy(win_.data(), sbuf_.data() + s_have_, HIST);
+        first_of_member_ = sq_.at_member_start();
+        s_have_ = s_off_ = 0;
+        seq_ = false;
+        ++resumes_;
+        if (getenv("SNK_PGZ_DEBUG")) fprintf(stderr, "device inflate: windows resume at bit %llu\n", (unsigned long long)pos_bit_);
+        {
+            std::lock_guard<std::mutex> l(m_);
+            finished_ = false; want_seq_ = false;
+            slot_[0].full = slot_[1].full = false;
+        }
+        cur_ = nullptr; cons_ = 0;
+        producer_ = std::thread([this] { produce(); });
+    }
     size_t seq_run(uint8_t *out, size_t cap) {
         if (s_off_ == s_have_) {
+            if (sq_.stopped() && fallback_bit_ != 0) { resume_device(); return 0; }
             if (s_have_) memmove(sbuf_.data(), sbuf_.data() + s_have_, HIST);      // keep the window in front
             uint8_t *p = sbuf_.data() + HIST;
             s_have_ = sq_.run(p, sbuf_.size() - HIST);

@@ -62,6 +62,8 @@ public:
     // run() returns (stopped() true) in front of the first block header at or past this bit offset
     void set_stop_bit(uint64_t b) { stop_bit_ = b; stopped_ = false; }
     bool stopped() const { return stopped_; }
+    // (with stopped()) the block header run() stopped in front of is the first of its member: nothing of the member is out yet
+    bool at_member_start() const { return state_ == BLOCK_HEADER && member_out_ == 0; }
     uint64_t bitpos() const { return (uint64_t)(in_ - base_) * 8 - (uint64_t)bitcnt_; }
     void set_strict(bool v) { strict_ = v; }
     const char *error() const { return err_; }

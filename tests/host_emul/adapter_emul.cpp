@@ -1,9 +1,9 @@
-// One lane of the bit-sliced adapter search (soapnuke_amd/csrc/snk_adapter_bits.cuh) on the host: planes of a read built the way
+// One lane of the bit-sliced adapter search (soapnuke_amd/csrc/snk_adapter_bits.hip.h) on the host: planes of a read built the way
 // the kernels hand them over (exact-letter planes, ones beyond the read), adapter_tile<NW, FULL> called as snk_tiled.hip calls it,
 // result = adapter_pos().  Exported for tests/test_host_emul.py, which fuzzes it against the oracle and the compiled reference.
 #include <hip/hip_runtime.h>
 #include "snk_tables.h"
-#include "snk_adapter_bits.cuh"
+#include "snk_adapter_bits.hip.h"
 
 using namespace snk;
 

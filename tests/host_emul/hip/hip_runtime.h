@@ -1,5 +1,5 @@
-// Host stand-in for <hip/hip_runtime.h>: lets the device headers that hold pure per-lane logic (snk_common.cuh,
-// snk_adapter_bits.cuh) compile with g++ as ONE lane of a wavefront, so that the bit-sliced adapter search can be fuzzed against
+// Host stand-in for <hip/hip_runtime.h>: lets the device headers that hold pure per-lane logic (snk_common.hip.h,
+// snk_adapter_bits.hip.h) compile with g++ as ONE lane of a wavefront, so that the bit-sliced adapter search can be fuzzed against
 // the oracle without a GPU (tests/test_host_emul.py).  Wave votes see that one lane; nothing here is product code.
 #pragma once
 #include <stdint.h>

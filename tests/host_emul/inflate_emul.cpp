@@ -1,10 +1,10 @@
-// The chunk decoder of the device inflate (soapnuke_amd/csrc/snk_inflate_core.cuh) on the host: a gzip file is cut into chunks the
+// The chunk decoder of the device inflate (soapnuke_amd/csrc/snk_inflate_core.hip.h) on the host: a gzip file is cut into chunks the
 // way host/snk_dgunzip.h does it -- block starts found by probe_header(), every chunk decoded with an unknown window to 16-bit
 // symbols, windows chained, markers resolved -- and the bytes are handed back for comparison with zlib (tests/test_inflate_emul.py).
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
-#include "snk_inflate_core.cuh"
+#include "snk_inflate_core.hip.h"
 
 using namespace snkinf;
 
@@ -169,7 +169,7 @@ struct EmulBackend : snk::DgBackend {
 };
 }  // namespace
 
-// info: windows, fallback bit (-1: none), backend decode calls
+// info: windows, fallback bit (-1: none), backend decode calls, resumes << 16 | host spells
 extern "C" long snk_emul_dgunzip(const uint8_t *gz, size_t n, size_t window, uint32_t chunk_bytes, uint32_t spc, uint32_t epc, uint8_t *out, size_t out_cap,
                                  long *info, char *errbuf, size_t errcap) {
     EmulBackend be;
@@ -181,7 +181,7 @@ extern "C" long snk_emul_dgunzip(const uint8_t *gz, size_t n, size_t window, uin
         if (got == out_cap) break;
         got += z.run(out + got, std::min<size_t>(out_cap - got, 777777));
     }
-    if (info) { info[0] = (long)z.windows(); info[1] = z.fallback_bit() == ~0ull ? -1 : (long)z.fallback_bit(); info[2] = be.decodes; }
+    if (info) { info[0] = (long)z.windows(); info[1] = z.fallback_bit() == ~0ull ? -1 : (long)z.fallback_bit(); info[2] = be.decodes; info[3] = (long)((z.resumes() << 16) | z.host_spells()); }
     if (z.error()) { if (errbuf && errcap) { strncpy(errbuf, z.error(), errcap - 1); errbuf[errcap - 1] = 0; } return -1; }
     return (long)got;
 }

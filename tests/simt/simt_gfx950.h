@@ -1,4 +1,4 @@
-// SIMT emulator: C++ bodies of the hand-placed gfx950 instructions of soapnuke_amd/csrc/snk_gfx950.cuh (same names, same
+// SIMT emulator: C++ bodies of the hand-placed gfx950 instructions of soapnuke_amd/csrc/snk_gfx950.hip.h (same names, same
 // meaning).  LDS addresses are byte offsets into the dynamic shared memory of the kernel (HIP_DYNAMIC_SHARED, address 0 = its first byte).
 // Asynchrony is not modelled: a read or DMA completes where it is issued, waits that order lanes against each other
 // (a DMA chunk written by 64 lanes and read by others) are wave-level synchronisation points.  Test infrastructure only.

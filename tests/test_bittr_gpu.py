@@ -1,5 +1,5 @@
 """The lane = position -> lane = read hand-over primitive of the tiled kernel on its own:
-64 x 64 bit-matrix transposes across a wave (csrc/snk_bittr.cuh) against numpy, through the
+64 x 64 bit-matrix transposes across a wave (csrc/snk_bittr.hip.h) against numpy, through the
 shipped library (include/snk_selftest.h)."""
 import ctypes as C
 

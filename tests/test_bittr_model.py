@@ -1,4 +1,4 @@
-"""CPU model of the 64 x 64 bit-matrix transpose of soapnuke_amd/csrc/snk_bittr.cuh: the same six
+"""CPU model of the 64 x 64 bit-matrix transpose of soapnuke_amd/csrc/snk_bittr.hip.h: the same six
 butterfly stages (lane-index bit k <-> bit-index bit k) with the lane exchanges written as numpy
 permutations.  It documents the network and pins its masks / rotations without a GPU; the device code
 itself is checked by tests/test_bittr_gpu.py."""

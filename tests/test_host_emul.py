@@ -1,4 +1,4 @@
-"""The bit-sliced adapter search of the kernels (soapnuke_amd/csrc/snk_adapter_bits.cuh) compiled for the HOST as one lane of a
+"""The bit-sliced adapter search of the kernels (soapnuke_amd/csrc/snk_adapter_bits.hip.h) compiled for the HOST as one lane of a
 wavefront (tests/host_emul/: a stand-in <hip/hip_runtime.h>) and fuzzed against the oracle's adapter_pos() -- no GPU needed.
 Covers what round 4 added to the fast paths: adapters of 1..255 characters (the screen sees the first 64; survivors of longer
 ones are decided character by character), adapters shorter than 6, adaEdge beyond the adapter's length, budgets of any size."""
@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libsnk_emul.so")
 @pytest.fixture(scope="module")
 def emul():
     srcs = [os.path.join(HERE, "adapter_emul.cpp"), os.path.join(HERE, "hip", "hip_runtime.h")] + [
-        os.path.join(T.ROOT, "soapnuke_amd", "csrc", f) for f in ("snk_adapter_bits.cuh", "snk_common.cuh", "snk_tables.h", "snk_device.h")]
+        os.path.join(T.ROOT, "soapnuke_amd", "csrc", f) for f in ("snk_adapter_bits.hip.h", "snk_common.hip.h", "snk_tables.h", "snk_device.h")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-fPIC", "-shared", "-I.", "-I" + os.path.join(T.ROOT, "soapnuke_amd", "csrc"),
                                "-x", "c++", "adapter_emul.cpp", "-o", LIB], cwd=HERE)

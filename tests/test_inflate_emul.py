@@ -1,4 +1,4 @@
-"""The chunk decoder of the DEVICE inflate (soapnuke_amd/csrc/snk_inflate_core.cuh: block-start probe, marker-mode DEFLATE decoding,
+"""The chunk decoder of the DEVICE inflate (soapnuke_amd/csrc/snk_inflate_core.hip.h: block-start probe, marker-mode DEFLATE decoding,
 gzip framing) compiled for the host and run chunk by chunk the way the device path runs it -- against zlib's bytes on every kind of
 stream the reader can meet (the vectors of tests/test_inflate.py), and errors on damaged ones.  No GPU needed."""
 import ctypes as C
@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libsnk_inflate_emul.so")
 
 @pytest.fixture(scope="module")
 def emul():
-    srcs = [os.path.join(HERE, "inflate_emul.cpp"), os.path.join(T.ROOT, "soapnuke_amd", "csrc", "snk_inflate_core.cuh"),
+    srcs = [os.path.join(HERE, "inflate_emul.cpp"), os.path.join(T.ROOT, "soapnuke_amd", "csrc", "snk_inflate_core.hip.h"),
             os.path.join(T.ROOT, "soapnuke_amd", "host", "snk_dgunzip.h"), os.path.join(T.ROOT, "soapnuke_amd", "host", "snk_inflate.h")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-w", "-fPIC", "-shared", "-I" + os.path.join(T.ROOT, "soapnuke_amd", "csrc"),
@@ -207,3 +207,34 @@ def test_device_gunzip_member_ending_on_a_window_edge(dg):
     # ... and fewer than 18 bytes there: truncated member (as the sequential decoder says)
     r, got, info, err = _dgunzip(dg, members[0] + members[1][:9], len(members[0]), 1 << 16, 1 << 21, len(want))
     assert r == -1 and "truncated" in err, (r, err)
+
+
+def test_device_gunzip_resumes_behind_a_host_spell(dg):
+    """a region the device path refuses -- here 3 MB of one letter, whose chunk would need more symbol slots than
+    it has -- is decoded by the host for ONE spell; the device windows resume at the next block header instead of leaving the rest
+    of the file to one core.  Bytes are zlib's, CRC / ISIZE of the member that contains the region are still checked (one member:
+    the CRC runs through device text, host text, device text), and a member boundary inside a spell hands over cleanly."""
+    rng = np.random.default_rng(77)
+
+    def fastq_like(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n)) + b"\n" + bytes(rng.integers(35, 75, n, dtype=np.uint8)) + b"\n"
+    head, tail = b"".join(fastq_like(150) for _ in range(4000)), b"".join(fastq_like(150) for _ in range(9000))
+    poly = b"N" * 3_000_000
+    for level in (1, 6):
+        want = head + poly + tail
+        blob = gzip.compress(want, level)
+        spc = 400_000                                    # symbol slots per chunk: the poly region's chunk overflows them
+        r, got, info, err = _dgunzip(dg, blob, 1 << 20, 1 << 14, spc, len(want) + 1000)
+        assert r == len(want) and got == want, (level, r, info, err)
+        spells, resumes = info[3] & 0xFFFF, info[3] >> 16
+        assert info[1] != -1 and spells >= 1 and resumes >= 1, (level, info)          # the host took over, and gave back
+        # a damaged trailer behind all of that is still caught (the CRC ran through both engines)
+        bad = bytearray(blob)
+        bad[-6] ^= 0x40
+        r, got, info, err = _dgunzip(dg, bytes(bad), 1 << 20, 1 << 14, spc, len(want) + 1000)
+        assert r == -1 and "CRC" in err, (level, r, err)
+        # two members, the seam inside the host's spell
+        want2 = head + poly
+        blob2 = gzip.compress(want2, level) + gzip.compress(tail, level)
+        r, got, info, err = _dgunzip(dg, blob2, 1 << 20, 1 << 14, spc, len(want) + 1000)
+        assert r == len(want) and got == want, (level, r, info, err)

@@ -43,7 +43,7 @@ def test_parallel_gunzip_under_sanitizers(san, env, tmp_path):
 
 
 def test_device_inflate_orchestration_under_asan_ubsan(tmp_path):
-    """host/snk_dgunzip.h + csrc/snk_inflate_core.cuh (CPU backend) with AddressSanitizer + UBSan: windows, chains, the threaded CRC,
+    """host/snk_dgunzip.h + csrc/snk_inflate_core.hip.h (CPU backend) with AddressSanitizer + UBSan: windows, chains, the threaded CRC,
     the fallback to the sequential decoder"""
     import ctypes as C
     lib_path = str(tmp_path / "libemul_asan.so")

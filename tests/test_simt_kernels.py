@@ -145,7 +145,7 @@ def test_random_parameter_contexts_on_the_device(i, kernel):
 
 
 # ---- duplicate marking (snk_rmdup.hip), device-side FASTQ text (snk_fastq.hip), gzip members (snk_gzip.hip), inflate (snk_inflate.hip),
-# the 64 x 64 bit transpose (snk_bittr.cuh)
+# the 64 x 64 bit transpose (snk_bittr.hip.h)
 from test_rmdup_gpu import (test_hash_golden, test_hash_vs_oracle, test_hash_odd_tile_counts, test_mark_golden, test_mark_vs_oracle_random,      # noqa: E402,F401
                             test_mark_with_explicit_indices, test_too_many_reads_is_refused, test_one_pass_table_vs_oracle,
                             test_one_pass_table_refuses_too_many_reads)

@@ -2,7 +2,7 @@
 
 LLVM spills scalar registers into LANES of vector registers it sets aside: a spill is `v_writelane_b32 vS, sN, lane`, a reload
 `v_readlane_b32 sN, vS, lane`.  A spill carrier is a VGPR that nothing but those two instructions ever touches (the kernel's own
-cross-lane reads -- `rl()` / `wl()` of snk_common.cuh -- go through registers that vector instructions also use).  Per kernel
+cross-lane reads -- `rl()` / `wl()` of snk_common.hip.h -- go through registers that vector instructions also use).  Per kernel
 instance: the carriers, the static count of spill stores / reloads, and WHERE they sit -- per basic block with the block's loop
 depth (blocks between a label and the farthest backward branch to it), so that the reloads inside the phase-1 octet loop (executed
 8 x per tile-mate) can be told from the ones executed once per tile or once per launch.

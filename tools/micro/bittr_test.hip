@@ -1,10 +1,10 @@
-// Checks snk::bit_transpose64 (csrc/snk_bittr.cuh) against a host transpose on random matrices.
+// Checks snk::bit_transpose64 (csrc/snk_bittr.hip.h) against a host transpose on random matrices.
 // hipcc --offload-arch=gfx950 -O3 -I soapnuke_amd/csrc tools/micro/bittr_test.hip -o tools/micro/bittr_test
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
 #include <vector>
-#include "snk_bittr.cuh"
+#include "snk_bittr.hip.h"
 
 __global__ void k(const uint32_t *in, uint32_t *out, uint32_t *out_lo) {
     const int lane = threadIdx.x & 63, m = blockIdx.x;
