@@ -2,7 +2,11 @@
 parameters, this repo's CLI and the compiled reference binary on the same files in /dev/shm, ALL ten report files and the
 md5 of the decompressed clean FASTQ compared.
 
-    python tools/bench_e2e_big.py [pairs=256000000] [threads=16] [--len 250] [--rmdup] [--dup 0.05] [--bounded] [--stored]
+    python tools/bench_e2e_big.py [pairs=256000000] [threads=16] [--len 250] [--rmdup] [--dup 0.05] [--bounded] [--stored] [--ours=PATH]
+
+--ours=PATH: another build of this repo's CLI (the emulated one, tests/simt/_build/SOAPnuke_simt, for a rehearsal without a GPU).
+SNK_BIG_MEM_LIMIT_MB / SNK_BIG_HEADROOM_MB: hold the run against a limit of its own (see Watchdog) -- the rehearsal of the 300 GiB
+box at a small size: `--bounded` has to stay under a limit that the stored mode breaks.
 
 --len 250 --rmdup: BASELINE configs[4]'s shape (PE250, configs[1] parameters + config key `rmdup`; --dup: fraction of pairs that
 repeat an earlier pair of the same million), where the dupReads.<thread>.<mate>.gz side files are compared as well.
@@ -94,8 +98,10 @@ class GzMd5:
 class Puncher(threading.Thread):
     """keeps a growing output file from occupying memory: everything but the last `margin` bytes is punched out"""
 
-    def __init__(self, path, margin=1 << 30):
+    def __init__(self, path, margin=None):
         super().__init__(daemon=True)
+        if margin is None:                                   # (SNK_BIG_PUNCH_MARGIN_MB: the rehearsal at a small size)
+            margin = int(os.environ.get("SNK_BIG_PUNCH_MARGIN_MB", "1024")) << 20
         self.path, self.margin, self.stop, self.size = path, margin, threading.Event(), 0
 
     def run(self):
@@ -154,21 +160,34 @@ class TailMd5(threading.Thread):
 class Watchdog(threading.Thread):
     """aborts (kills the running child, sets .tripped) before the memory cgroup's limit is reached"""
 
-    def __init__(self, headroom=16 << 30):
+    def __init__(self, headroom=16 << 30, where="/dev/shm"):
         super().__init__(daemon=True)
         self.headroom, self.child, self.tripped, self.peak, self.stop = headroom, None, False, 0, threading.Event()
-        self.limit = None
+        self.limit, self.where, self.meter = None, where, "cgroup memory.current"
         try:
             v = open("/sys/fs/cgroup/memory.max").read().strip()
             self.limit = None if v == "max" else int(v)
         except OSError:
             pass
+        # SNK_BIG_MEM_LIMIT_MB / SNK_BIG_HEADROOM_MB: a limit of the run's own (a rehearsal of the 300 GiB box at a small size, or a box
+        # whose cgroup files are not visible): what is held against it is the cgroup's figure where there is one, else the bytes the
+        # tmpfs holds (which is what the cgroup charges for this tool: its files ARE its memory)
+        if os.environ.get("SNK_BIG_MEM_LIMIT_MB"):
+            self.limit = int(os.environ["SNK_BIG_MEM_LIMIT_MB"]) << 20
+            self.headroom = int(os.environ.get("SNK_BIG_HEADROOM_MB", "0")) << 20
+            self.meter = "bytes held by " + where
+        if not os.path.exists("/sys/fs/cgroup/memory.current"):
+            self.meter = "bytes held by " + where
+        self.base = self.current()
 
     def current(self):
-        try:
-            return int(open("/sys/fs/cgroup/memory.current").read())
-        except (OSError, ValueError):
-            return 0
+        if self.meter.startswith("cgroup"):
+            try:
+                return int(open("/sys/fs/cgroup/memory.current").read())
+            except (OSError, ValueError):
+                pass
+        st = os.statvfs(self.where)
+        return (st.f_blocks - st.f_bfree) * st.f_frsize - getattr(self, "base", 0)
 
     def run(self):
         while not self.stop.is_set():
@@ -198,6 +217,9 @@ def run_tool(exe, inputs, out_dir, T, wd):
 def main():
     argv = [a for a in sys.argv[1:] if not a.startswith("--")]
     opt = sys.argv[1:]
+    for a in opt:
+        if a.startswith("--ours="):
+            bench_e2e.OURS = a[len("--ours="):]
     L = int(opt[opt.index("--len") + 1]) if "--len" in opt else 150
     rmdup = "--rmdup" in opt
     dupf = float(opt[opt.index("--dup") + 1]) if "--dup" in opt else 0.05
@@ -215,7 +237,8 @@ def main():
            "mode": "bounded memory: outputs never stored whole (see the module docstring)" if bounded else "outputs stored in /dev/shm"}
     wd = Watchdog()
     wd.start()
-    res["memory_limit_GiB"] = None if wd.limit is None else wd.limit >> 30
+    res["memory_limit_GiB"] = None if wd.limit is None else round(wd.limit / (1 << 30), 3)
+    res["memory_meter"] = wd.meter
     try:
         u = int(os.environ.get("SNK_BIG_UNIT", "1000000"))       # pairs per gzip member (tests/test_simt_bench.py shrinks it)
         d = synth.make_batch(u, L, paired=True)
@@ -379,6 +402,7 @@ def main():
         wd.stop.set()
         res["watchdog_tripped"] = wd.tripped
         res["cgroup_peak_GiB"] = round(wd.peak / (1 << 30), 1)
+        res["memory_peak_MiB"] = wd.peak >> 20
         subprocess.call(["rm", "-rf", tmp])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"e2e_big_{n}{'_L%d_rmdup' % L if rmdup else ''}.json"), "w") as fh:
