@@ -76,6 +76,19 @@ void snk_rmdup_stream_destroy(snk_rmdup_stream *t);
  * memory returns SNK_E_NOMEM and leaves the table unusable (later calls repeat the code): fall back to the two passes then.  */
 uint64_t snk_rmdup_stream_bytes(uint64_t pairs);
 
+/* ---- multi-GPU exchange helpers (round 5; SURVEY 8e: "all-to-all keyed by hash % G").  The reference's rmdup::markDup needs the
+ * GLOBAL input order (src/rmdup.cpp:70-123), so with the input sharded over G devices every hash travels to its owner
+ * (hash % G) together with its global index, the owner marks with explicit indices (snk_rmdup_mark_device) and the flags travel
+ * back.  snk_rmdup_partition_device() groups the n hashes of a shard by owner: d_send_hash / d_send_index hold the elements of
+ * owner 0, then of owner 1, ... (the order inside a group is unspecified; the global index first_index + i rides along as
+ * uint32 -- the reference's own limit), h_counts[world] (host memory) receives the group sizes and d_slot[i] the place of
+ * element i in that order; the call synchronises `stream`.  snk_rmdup_flags_home_device(): d_dup[i] = d_back[d_slot[i]], where
+ * d_back are the owners' flags in send order.  The exchange itself (RCCL ncclSend / ncclRecv groups, or a host wire) is the
+ * caller's: soapnuke_amd/host/snk_wire.h for the CLI's shards, soapnuke_amd/shard.py over torch.distributed.              */
+int snk_rmdup_partition_device(snk_ctx *ctx, const uint64_t *d_hash, int64_t n, uint64_t first_index, int32_t world,
+                               uint64_t *d_send_hash, uint32_t *d_send_index, uint32_t *d_slot, uint64_t *h_counts, void *stream);
+int snk_rmdup_flags_home_device(snk_ctx *ctx, const uint8_t *d_back, const uint32_t *d_slot, int64_t n, uint8_t *d_dup, void *stream);
+
 /* rmdup::getPrime(n) (host helper; 0 for n == 0 where the reference exits with "code error") */
 uint32_t snk_rmdup_prime(uint64_t n);
 

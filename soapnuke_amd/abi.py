@@ -183,6 +183,7 @@ EXPORTS = [
     # include/snk_rmdup.h
     "snk_rmdup_hash_device", "snk_rmdup_bucket_count_device", "snk_rmdup_mark_device", "snk_rmdup_prime",
     "snk_rmdup_stream_create", "snk_rmdup_stream_mark_device", "snk_rmdup_stream_mark_se_device", "snk_rmdup_stream_stats", "snk_rmdup_stream_destroy", "snk_rmdup_stream_bytes",
+    "snk_rmdup_partition_device", "snk_rmdup_flags_home_device",
     # include/snk_selftest.h
     "snk_selftest_bit_transpose",
     # include/snk_fastq.h
@@ -239,6 +240,8 @@ def load_library(path=None):
     lib.snk_rmdup_stream_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     lib.snk_rmdup_stream_destroy.argtypes = [vp]
     lib.snk_rmdup_stream_destroy.restype = None
+    lib.snk_rmdup_partition_device.argtypes = [vp, vp, C.c_int64, C.c_uint64, C.c_int32, vp, vp, vp, vp, vp]
+    lib.snk_rmdup_flags_home_device.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
     lib.snk_selftest_bit_transpose.argtypes = [i32, vp, i32, vp, vp]
     lib.snk_fastq_tmp_bytes.argtypes = [C.c_uint64, C.c_int64]
     lib.snk_fastq_tmp_bytes.restype = C.c_size_t

@@ -257,6 +257,53 @@ __global__ void __launch_bounds__(256) snk_se_shift_kernel(const uint8_t *__rest
     if (i == n - 1) *carry_out = flags[i];
 }
 
+
+// ---- the multi-GPU exchange (all-to-all keyed by owner = hash % world, include/snk_rmdup.h).  Grouping a shard's
+// hashes by owner: one pass counts (a ballot per owner value present in the wave, one atomic per wave and owner), the host turns
+// the counts into group bases, the second pass hands out the places -- again one atomic per wave and owner, the lanes of a wave
+// take consecutive places in lane order.  The order inside a group does not matter (the global index travels with the hash).
+__global__ void __launch_bounds__(256) snk_owner_count_kernel(const u64 *__restrict__ hash, long n, u32 world, u64 *counts) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n;
+    const u32 own = in ? (u32)(hash[i] % world) : 0u;
+    u64 todo = __ballot(in);
+    while (todo) {                                               // wave-uniform: one trip per owner value among the live lanes
+        const int lead = __ffsll(todo) - 1;
+        const u32 o = (u32)__shfl((int)own, lead);
+        const u64 same = __ballot(in && own == o);
+        if ((int)(threadIdx.x & 63) == lead) atomicAdd(&counts[o], (u64)__popcll(same));
+        todo &= ~same;
+    }
+}
+__global__ void __launch_bounds__(256) snk_owner_scatter_kernel(const u64 *__restrict__ hash, long n, u32 world, u64 first_index, u64 *cursor /* [world]: next free place per owner */,
+                                                                u64 *__restrict__ send_hash, u32 *__restrict__ send_index, u32 *__restrict__ slot) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n;
+    const u64 h = in ? hash[i] : 0ull;
+    const u32 own = in ? (u32)(h % world) : 0u;
+    const int lane = (int)(threadIdx.x & 63);
+    u64 todo = __ballot(in);
+    while (todo) {
+        const int lead = __ffsll(todo) - 1;
+        const u32 o = (u32)__shfl((int)own, lead);
+        const u64 same = __ballot(in && own == o);
+        u64 base = 0;
+        if (lane == lead) base = atomicAdd(&cursor[o], (u64)__popcll(same));
+        const u32 blo = (u32)__shfl((int)(u32)base, lead), bhi = (u32)__shfl((int)(u32)(base >> 32), lead);
+        if (in && own == o) {
+            const u64 at = (((u64)bhi << 32) | blo) + (u64)__popcll(same & ((1ull << lane) - 1ull));
+            send_hash[at] = h;
+            send_index[at] = (u32)(first_index + (u64)i);
+            slot[i] = (u32)at;
+        }
+        todo &= ~same;
+    }
+}
+__global__ void __launch_bounds__(256) snk_flags_home_kernel(const uint8_t *__restrict__ back, const u32 *__restrict__ slot, long n, uint8_t *__restrict__ dup) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dup[i] = back[slot[i]];
+}
+
 }  // namespace
 
 #define RM_OK(call)                                      \
@@ -517,6 +564,42 @@ int snk_rmdup_stream_stats(snk_rmdup_stream *t, uint64_t *n_marked, int32_t *sen
     if (n_marked) *n_marked = h[0];
     if (sentinel_seen) *sentinel_seen = (int32_t)(h[1] & 1u);
     if (h[1] & 2u) { snk_set_error("snk_rmdup_stream_stats: a hash was not found in the table (internal error)"); return SNK_E_HIP; }
+    return SNK_OK;
+}
+
+// ---- multi-GPU exchange helpers (include/snk_rmdup.h)
+int snk_rmdup_partition_device(snk_ctx *, const uint64_t *d_hash, int64_t n, uint64_t first_index, int32_t world, uint64_t *d_send_hash, uint32_t *d_send_index,
+                               uint32_t *d_slot, uint64_t *h_counts, void *stream) {
+    if (!d_hash || !d_send_hash || !d_send_index || !d_slot || !h_counts || n < 0 || world < 1 || world > 4096 || first_index + (uint64_t)n > 4294967296ull) {
+        snk_set_error("snk_rmdup_partition_device: bad argument");
+        return SNK_E_PARAM;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int g = 0; g < world; ++g) h_counts[g] = 0;
+    if (n == 0) return SNK_OK;
+    u64 *d_cnt = nullptr;
+    auto fail = [&](const char *what) { if (d_cnt) (void)hipFree(d_cnt); snk_set_error(what); return SNK_E_HIP; };
+    if (hipMalloc((void **)&d_cnt, (size_t)world * 2 * sizeof(u64)) != hipSuccess) { (void)hipGetLastError(); snk_set_error("snk_rmdup_partition_device: out of device memory"); return SNK_E_NOMEM; }
+    if (hipMemsetAsync(d_cnt, 0, (size_t)world * 2 * sizeof(u64), st) != hipSuccess) return fail("snk_rmdup_partition_device: memset failed");
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(snk_owner_count_kernel, dim3(grid), dim3(256), 0, st, (const u64 *)d_hash, (long)n, (u32)world, d_cnt);
+    if (hipMemcpyAsync(h_counts, d_cnt, (size_t)world * sizeof(u64), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail("snk_rmdup_partition_device: count pass failed");
+    std::vector<u64> base((size_t)world, 0);
+    for (int g = 1; g < world; ++g) base[(size_t)g] = base[(size_t)g - 1] + h_counts[g - 1];
+    if (hipMemcpyAsync(d_cnt + world, base.data(), (size_t)world * sizeof(u64), hipMemcpyHostToDevice, st) != hipSuccess) return fail("snk_rmdup_partition_device: copy failed");
+    hipLaunchKernelGGL(snk_owner_scatter_kernel, dim3(grid), dim3(256), 0, st, (const u64 *)d_hash, (long)n, (u32)world, (u64)first_index, d_cnt + world,
+                       (u64 *)d_send_hash, d_send_index, d_slot);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail("snk_rmdup_partition_device: scatter pass failed");
+    (void)hipFree(d_cnt);
+    return SNK_OK;
+}
+
+int snk_rmdup_flags_home_device(snk_ctx *, const uint8_t *d_back, const uint32_t *d_slot, int64_t n, uint8_t *d_dup, void *stream) {
+    if (!d_back || !d_slot || !d_dup || n < 0) { snk_set_error("snk_rmdup_flags_home_device: bad argument"); return SNK_E_PARAM; }
+    if (n == 0) return SNK_OK;
+    hipLaunchKernelGGL(snk_flags_home_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_back, d_slot, (long)n, d_dup);
+    if (hipGetLastError() != hipSuccess) { snk_set_error("snk_rmdup_flags_home_device: launch failed"); return SNK_E_HIP; }
     return SNK_OK;
 }
 

@@ -39,12 +39,23 @@ class DeviceGunzip {
 public:
     enum { HIST = 32768 };
     struct Geometry { uint64_t window_bytes; uint32_t chunk_bytes, syms_per_chunk, ends_per_chunk; };
-    DeviceGunzip(const uint8_t *in, size_t n, DgBackend *be, const Geometry &g, int crc_threads)
+    // start_bit / start_win: from the deflate block header at that bit offset on, the 32 KiB of text in front of it given (a shard
+    // of a sharded run; the member the start lies in is not checked again -- the parent's scout pass has, host/snk_main.cpp)
+    DeviceGunzip(const uint8_t *in, size_t n, DgBackend *be, const Geometry &g, int crc_threads, uint64_t start_bit = ~0ull, const uint8_t *start_win = nullptr)
         : in_(in), n_(n), be_(be), g_(g), crc_threads_(crc_threads < 1 ? 1 : crc_threads) {
         win_.assign(HIST, 0);
         const uint32_t maxc = (uint32_t)((g_.window_bytes + g_.chunk_bytes - 1) / g_.chunk_bytes);
         chunks_.resize(maxc);
         ends_.resize((size_t)maxc * g_.ends_per_chunk);
+        if (start_bit != ~0ull && start_win && (start_bit >> 3) < n_) {
+            pos_bit_ = start_bit;
+            memcpy(win_.data(), start_win, HIST);
+            first_of_member_ = false;
+            member_checkable_ = false;
+            mid_start_ = true;
+            producer_ = std::thread([this] { produce(); });
+            return;
+        }
         // the first member's header (the later ones are followed on the device)
         if (!member_header_at(0, pos_bit_)) { seq_from_start(); return; }
         first_of_member_ = true;
@@ -124,7 +135,7 @@ private:
     std::string err_;
     uint32_t mcrc_ = 0;                        // CRC-32 / length of the current member so far
     uint64_t mlen_ = 0;
-    bool member_checkable_ = true;
+    bool member_checkable_ = true, mid_start_ = false;
     uint64_t windows_ = 0, fallback_bit_ = ~0ull;
     uint64_t spells_ = 0, resumes_ = 0, spell_bits_ = 0, windows_at_spell_ = ~0ull;
     // sequential fallback

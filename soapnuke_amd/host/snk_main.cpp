@@ -46,6 +46,7 @@
 #include "snk_inflate.h"
 #include "snk_pgunzip.h"
 #include "snk_dgunzip.h"
+#include "snk_wire.h"
 #include "snk_deflate.h"
 #include "snk_report.h"
 #include "../../include/snk_rmdup.h"
@@ -501,7 +502,28 @@ struct ShardEnv {
     uint64_t first = 0;
     std::map<string, std::pair<size_t, size_t>> range;     // input path -> [lo, hi) bytes
     string stats_path;
+    // .gz input: where this shard's decoder starts (a block header + the 32 KiB of text in front of it, from the parent's scout
+    // pass; bit == ~0: the stream's own header), what to drop behind that and how many records to hand on
+    struct Gz { uint64_t bit = ~0ull, skip_bytes = 0, skip_records = 0, nrec = ~0ull; std::vector<uint8_t> win; };
+    std::map<string, Gz> gz;
+    uint64_t total = 0;                                     // records of the whole input (rmdup: rmdup::getPrime and the SE patch rule want it)
+    string wire_kind, wire_addr;                            // "rccl" (addr = the communicator id in hex) | "host" (addr = socket name) | "file"
+    std::unique_ptr<snk::ShardWire> wire;
+    bool wire_tried = false;
 } g_shard;
+
+// the collectives between the shards (host/snk_wire.h), made on first use; null: this run merges through files only
+snk::ShardWire *shard_wire() {
+    if (!g_shard.child || g_shard.wire_tried) return g_shard.wire.get();
+    g_shard.wire_tried = true;
+    string why;
+    if (g_shard.wire_kind == "rccl") g_shard.wire.reset(snk::RcclWire::connect(g_shard.g, g_shard.G, g_shard.wire_addr, why));
+    else if (g_shard.wire_kind == "host") g_shard.wire.reset(snk::HostWire::connect(g_shard.g, g_shard.G, g_shard.wire_addr, why));
+    else return nullptr;
+    // (every shard takes the same branch: a shard that cannot join leaves the others waiting for it -- the parent ends them)
+    if (!g_shard.wire) { cerr << "Error:shard " << g_shard.g << " cannot join the " << g_shard.wire_kind << " wire (" << why << "); SNK_SHARD_WIRE=host or =file selects another one" << endl; _exit(1); }
+    return g_shard.wire.get();
+}
 
 // CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota (a container with 256
 // visible hardware threads and a quota of 16 CPUs only gets slower with more than 16 busy threads)
@@ -736,7 +758,21 @@ struct GzSource {
     std::unique_ptr<snk::ParallelGunzip> host;
     std::unique_ptr<HipGunzipBackend> be;
     std::unique_ptr<snk::DeviceGunzip> dev;
-    GzSource(const uint8_t *zin, size_t n, int workers) {
+    // a shard of a sharded run (g_shard.gz): the decoder starts at the shard's block, the first skip_b bytes and skip_nl lines
+    // behind that belong to the shard in front, take_nl lines are this shard's
+    bool limited = false, limit_done = false;
+    uint64_t skip_b = 0, skip_nl = 0, take_nl = ~0ull;
+    GzSource(const uint8_t *zin, size_t n, int workers, const string &path = string()) {
+        uint64_t start_bit = ~0ull;
+        const uint8_t *start_win = nullptr;
+        auto it = g_shard.gz.find(path);
+        if (it != g_shard.gz.end()) {
+            limited = true;
+            skip_b = it->second.skip_bytes;
+            skip_nl = it->second.skip_records * 4;
+            take_nl = it->second.nrec == ~0ull ? ~0ull : it->second.nrec * 4;
+            if (it->second.bit != ~0ull) { start_bit = it->second.bit; start_win = it->second.win.data(); }
+        }
         if (const char *e = getenv("SNK_DEVICE_INFLATE")) {
             if (atoi(e) != 0) {
                 snk::DeviceGunzip::Geometry geo;
@@ -748,19 +784,46 @@ struct GzSource {
                 int device = 0;
                 (void)hipGetDevice(&device);
                 be.reset(new HipGunzipBackend(device, geo));
-                if (be->g) dev.reset(new snk::DeviceGunzip(zin, n, be.get(), geo, std::max(1, workers)));
+                if (be->g) dev.reset(new snk::DeviceGunzip(zin, n, be.get(), geo, std::max(1, workers), start_bit, start_win));
                 else cerr << "Warning:device inflate is not available (" << be->err << "), decoding on the host" << endl;
             }
         }
         if (!dev) {
             size_t pg_chunk = (size_t)2 << 20;
             if (const char *e = getenv("SNK_GZ_CHUNK")) { const long v = atol(e); if (v >= 65536) pg_chunk = (size_t)v; }
-            host.reset(new snk::ParallelGunzip(zin, n, workers, pg_chunk));
+            host.reset(new snk::ParallelGunzip(zin, n, workers, pg_chunk, start_bit, start_win));
         }
     }
-    size_t run(uint8_t *out, size_t cap) { return dev ? dev->run(out, cap) : host->run(out, cap); }
+    size_t raw_run(uint8_t *out, size_t cap) { return dev ? dev->run(out, cap) : host->run(out, cap); }
+    size_t run(uint8_t *out, size_t cap) {
+        if (!limited) return raw_run(out, cap);
+        while (!limit_done) {
+            const size_t got = raw_run(out, cap);
+            if (got == 0) return 0;                          // the end of the stream, or an error
+            size_t from = 0;
+            if (skip_b) { const size_t k = (size_t)std::min<uint64_t>(skip_b, got); from = k; skip_b -= k; }
+            while (skip_nl && from < got) {
+                const void *q = memchr(out + from, '\n', got - from);
+                if (!q) { from = got; break; }
+                from = (size_t)((const uint8_t *)q - out) + 1;
+                --skip_nl;
+            }
+            if (from == got) continue;
+            size_t end = got;
+            if (take_nl != ~0ull)
+                for (size_t q = from; q < got;) {
+                    const void *nl = memchr(out + q, '\n', got - q);
+                    if (!nl) break;
+                    q = (size_t)((const uint8_t *)nl - out) + 1;
+                    if (--take_nl == 0) { end = q; limit_done = true; break; }
+                }
+            if (from) memmove(out, out + from, end - from);
+            if (end > from) return end - from;
+        }
+        return 0;
+    }
     const char *error() const { return dev ? dev->error() : host->error(); }
-    bool done() const { return dev ? dev->done() : host->done(); }
+    bool done() const { return limit_done || (dev ? dev->done() : host->done()); }
 };
 
 void reader_gz_count(const string path, int batch, int workers, Channel<RawChunk *> *out) {
@@ -771,7 +834,7 @@ void reader_gz_count(const string path, int batch, int workers, Channel<RawChunk
     const uint8_t *zin = (const uint8_t *)mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (zin == MAP_FAILED) die("cannot map file," + path);
     madvise((void *)zin, (size_t)st.st_size, MADV_SEQUENTIAL);
-    GzSource z(zin, (size_t)st.st_size, workers);
+    GzSource z(zin, (size_t)st.st_size, workers, path);
     const size_t H = snk::GzipInflate::HIST, block = (size_t)1 << 24;
     RawChunk *cur = RawChunk::get();
     const size_t cap0 = H + (size_t)batch * 400 + 2 * block;
@@ -887,7 +950,8 @@ void reader_gz(const string path, int batch, int space_num, int workers, Channel
     // per reading thread (src/peprocess.cpp:2089-2113).
     size_t pg_chunk = (size_t)2 << 20;
     if (const char *e = getenv("SNK_GZ_CHUNK")) { const long v = atol(e); if (v >= 65536) pg_chunk = (size_t)v; }
-    snk::ParallelGunzip z(zin, (size_t)st.st_size, workers, pg_chunk);
+    (void)pg_chunk;
+    GzSource z(zin, (size_t)st.st_size, workers, path);     // (the host's parallel decoder, or the device one with SNK_DEVICE_INFLATE=1; a shard: its part)
     auto crc_drain = [] {};
     const size_t H = snk::GzipInflate::HIST, block = (size_t)1 << 24;
     RawChunk *cur = RawChunk::get();
@@ -960,12 +1024,16 @@ void reader_plain(const string path, int batch, int space_num, int workers, Chan
     if (fd < 0) die("cannot open file," + path);
     struct stat st;
     fstat(fd, &st);
-    const size_t size = (size_t)st.st_size;
+    size_t size = (size_t)st.st_size;
     const char *base = (const char *)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (base == MAP_FAILED) die("cannot map file," + path);
     madvise((void *)base, size, MADV_SEQUENTIAL);
     const size_t want = (size_t)batch * 4;
     size_t pos = 0;
+    {   // a shard of a sharded run: whole records [lo, hi) of this file (as reader_plain_count)
+        auto it = g_shard.range.find(path);
+        if (it != g_shard.range.end()) { pos = it->second.first; size = std::min(size, it->second.second); }
+    }
     double per_line = 100.0;
     while (pos < size) {
         std::vector<std::vector<uint32_t>> found;
@@ -1350,7 +1418,7 @@ size_t rmdup_cache_budget() {
 // of that index), writes its own ordered part files and dumps its statistics blocks; the parent concatenates the parts in rank
 // order -- the trick of the reference's per-thread temporaries, src/peprocess.cpp:2386 -- adds the blocks up and writes the
 // reports.  Readers, writers and PCIe streams scale with the devices instead of feeding all of them from one reader and one writer.
-struct ShardStatsHeader { uint64_t magic; int32_t T, lcap, nq, pad; uint64_t clean_total; };
+struct ShardStatsHeader { uint64_t magic; int32_t T, lcap, nq, pad; uint64_t clean_total, dup_written; };     // pad: 0 = a shard's own blocks, 1 / 2 = all-reduced over RCCL / the host wire
 const uint64_t SHARD_MAGIC = 0x534E4B5348415244ull;      // "SNKSHARD"
 
 // the newlines of a plain FASTQ file counted once (in parallel, 1 MB pieces), then any record's byte offset
@@ -1391,6 +1459,92 @@ struct RecordIndex {
     }
     void done() { if (base) munmap((void *)base, size); base = nullptr; }
 };
+
+// ---- .gz input of a sharded run: the parent's scout pass.  A DEFLATE stream can only be entered at a block header with the 32 KiB
+// of text in front of it known, and a shard has to know the global number of its first record (the virtual reference threads and
+// the duplicate marking are functions of it) -- so the parent decodes every input once on the host's cores (snk_pgunzip.h: all
+// member CRCs are verified here), counts its lines and notes, for every shard border, the first chunk of the parallel decoder's
+// chain that starts at or behind g/G of the compressed bytes: bit offset of its block header, the window, the number of the
+// first whole record behind it and the bytes in front of that record.  The two files of a pair are cut at the same RECORD: the
+// shard of the file whose place lies earlier drops the records in between (about the difference of the two compression ratios).
+struct GzCut { uint64_t bit = 0, text_off = 0, rec = 0, skip_bytes = 0, nl_left = 0; bool have_win = false, resolved = false; std::vector<uint8_t> win; };
+struct GzScout { uint64_t n_records = 0; std::vector<GzCut> cuts; string why; };
+
+bool scout_gz(const string &path, int workers, int G, GzScout &out) {
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) die("cannot open file," + path);
+    struct stat st;
+    fstat(fd, &st);
+    const size_t n = (size_t)st.st_size;
+    const uint8_t *zin = (const uint8_t *)mmap(NULL, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (zin == MAP_FAILED) die("cannot map file," + path);
+    madvise((void *)zin, n, MADV_SEQUENTIAL);
+    const size_t H = snk::GzipInflate::HIST, block = (size_t)1 << 24;
+    {
+        size_t pg_chunk = (size_t)2 << 20;
+        if (const char *e = getenv("SNK_GZ_CHUNK")) { const long v = atol(e); if (v >= 65536) pg_chunk = (size_t)v; }
+        snk::ParallelGunzip z(zin, n, workers, pg_chunk);
+        int next_t = 1;
+        bool crowded = false;
+        z.on_chunk = [&](uint64_t bit, uint64_t text_off) {
+            if (bit == 0 || next_t >= G || (bit >> 3) < (uint64_t)n * (uint64_t)next_t / (uint64_t)G) return;
+            ++next_t;
+            if (next_t < G && (bit >> 3) >= (uint64_t)n * (uint64_t)next_t / (uint64_t)G) crowded = true;      // one chunk serves one border
+            GzCut c;
+            c.bit = bit;
+            c.text_off = text_off;
+            out.cuts.push_back(std::move(c));
+        };
+        std::vector<uint8_t> buf(H + block, 0);
+        uint8_t *data = buf.data() + H;
+        uint64_t total = 0, nl_total = 0;
+        uint8_t last = '\n';
+        std::vector<NlPiece> pieces;
+        for (;;) {
+            const size_t got = z.run(data, block);
+            if (z.error()) die(string("read error in input fastq (") + z.error() + ")," + path);
+            if (got == 0 && z.done()) break;
+            for (GzCut &c : out.cuts) {
+                if (c.resolved) continue;
+                size_t from = 0;
+                if (!c.have_win) {                            // the chunk began inside this block: the window, the lines in front of it
+                    const size_t k = (size_t)(c.text_off - total);
+                    c.win.assign(buf.data() + k, buf.data() + k + H);
+                    c.have_win = true;
+                    uint64_t nl = nl_total;
+                    for (size_t q = 0; q < k;) { const void *e = memchr(data + q, '\n', k - q); if (!e) break; q = (size_t)((const uint8_t *)e - data) + 1; ++nl; }
+                    const uint8_t prev = k ? data[k - 1] : buf[H - 1];
+                    if (prev == '\n' && nl % 4 == 0) { c.rec = nl / 4; c.skip_bytes = 0; c.resolved = true; continue; }
+                    c.rec = nl / 4 + 1;                       // the record that starts behind line 4 * rec
+                    c.nl_left = 4 * c.rec - nl;
+                    from = k;
+                }
+                for (size_t q = from; q < got && c.nl_left;) {
+                    const void *e = memchr(data + q, '\n', got - q);
+                    if (!e) break;
+                    q = (size_t)((const uint8_t *)e - data) + 1;
+                    if (--c.nl_left == 0) { c.skip_bytes = total + q - c.text_off; c.resolved = true; }
+                }
+            }
+            pieces.clear();
+            nl_total += count_pieces((const char *)data, 0, got, workers, pieces);
+            last = data[got - 1];
+            total += got;
+            // the last 32 KiB stay in front of the next block
+            if (got >= H) memcpy(buf.data(), data + got - H, H);
+            else { memmove(buf.data(), buf.data() + got, H); }
+        }
+        const uint64_t lines = nl_total + ((total > 0 && last != '\n') ? 1 : 0);
+        if (lines % 4) die("truncated fastq record");
+        out.n_records = lines / 4;
+        if (crowded) out.why = "the input is too small for that many shards";
+    }
+    munmap((void *)zin, n);
+    close(fd);
+    if (out.why.empty() && (int)out.cuts.size() != G - 1) out.why = "the stream offers too few places to start from (few deflate blocks, or a stream the parallel decoder walks sequentially)";
+    for (const GzCut &c : out.cuts) if (out.why.empty() && (!c.resolved || c.rec >= out.n_records)) out.why = "a border fell behind the last record";
+    return out.why.empty();
+}
 
 void append_file(int out_fd, const string &part) {
     const int fd = open(part.c_str(), O_RDONLY);
@@ -1442,9 +1596,29 @@ int main(int argc, char **argv) {
             die("bad SNK_SHARD environment");
         g_shard.child = true;
         g_shard.first = first;
-        g_shard.range[o.fq1] = {(size_t)lo1, (size_t)hi1};
-        if (mates == 2) g_shard.range[o.fq2] = {(size_t)lo2, (size_t)hi2};
+        if (hi1 > lo1) g_shard.range[o.fq1] = {(size_t)lo1, (size_t)hi1};
+        if (mates == 2 && hi2 > lo2) g_shard.range[o.fq2] = {(size_t)lo2, (size_t)hi2};
+        for (int m = 0; m < mates; ++m)                      // .gz input: "bit,skip_bytes,skip_records,records,window file" (bit -1: the stream's header)
+            if (const char *v = getenv(m ? "SNK_SHARD_GZ2" : "SNK_SHARD_GZ1")) {
+                ShardEnv::Gz z;
+                long long bit = -1;
+                unsigned long long sb = 0, sr = 0, nr = 0;
+                char wp[4096] = "";
+                if (sscanf(v, "%lld,%llu,%llu,%llu,%4095s", &bit, &sb, &sr, &nr, wp) < 4) die("bad SNK_SHARD environment");
+                z.skip_bytes = sb; z.skip_records = sr; z.nrec = nr;
+                if (bit >= 0) {
+                    z.bit = (uint64_t)bit;
+                    z.win.resize(snk::GzipInflate::HIST);
+                    FILE *f = fopen(wp, "rb");
+                    if (!f || fread(z.win.data(), 1, z.win.size(), f) != z.win.size()) die(string("cannot read such file,") + wp);
+                    fclose(f);
+                }
+                g_shard.gz[m ? o.fq2 : o.fq1] = std::move(z);
+            }
         g_shard.stats_path = getenv("SNK_SHARD_STATS");
+        if (const char *v = getenv("SNK_SHARD_TOTAL")) g_shard.total = strtoull(v, nullptr, 10);
+        g_shard.wire_kind = getenv("SNK_SHARD_WIRE_KIND") ? getenv("SNK_SHARD_WIRE_KIND") : "file";
+        g_shard.wire_addr = getenv("SNK_SHARD_WIRE_ADDR") ? getenv("SNK_SHARD_WIRE_ADDR") : "";
         o.devices = std::vector<int>(1, o.devices[(size_t)g_shard.g]);
         o.clean1 += ".part" + std::to_string(g_shard.g);
         if (mates == 2) o.clean2 += ".part" + std::to_string(g_shard.g);
@@ -1462,7 +1636,7 @@ int main(int argc, char **argv) {
                 if (!f || fwrite(buf.data(), 1, buf.size(), f) != buf.size() || fclose(f) != 0) die("fake shard: write error");
             }
             const int lc = 150, nqf = o.p.max_base_quality + 1;
-            ShardStatsHeader h{SHARD_MAGIC, o.threads, lc, nqf, 0, 0};
+            ShardStatsHeader h{SHARD_MAGIC, o.threads, lc, nqf, 0, 0, 0};
             std::vector<uint64_t> z((size_t)o.threads * ((size_t)snk_stats_u64(lc, nqf) + SNK_MAX_N), 0);
             z[(size_t)SNK_FS_N + SNK_GS_READS] = (uint64_t)(g_shard.first + 1);         // (something to add up: raw1 reads of virtual thread 0)
             FILE *f = fopen(g_shard.stats_path.c_str(), "wb");
@@ -1472,20 +1646,72 @@ int main(int argc, char **argv) {
     }
     // (opt-in until it has met the hardware: SNK_SHARDED=1; without it several devices are fed batch by batch from one reader)
     const bool shardable = !g_shard.child && o.devices.size() > 1 && getenv("SNK_SHARDED") && !strcmp(getenv("SNK_SHARDED"), "1") &&
-                           !is_gzip_file(o.fq1) && (mates == 1 || !is_gzip_file(o.fq2)) && !o.streaming && !o.p.rmdup && o.trim_fq[0].empty() &&
+                           (mates == 1 || is_gzip_file(o.fq1) == is_gzip_file(o.fq2)) && !o.streaming && o.trim_fq[0].empty() &&
                            o.clean_out_split == 0 && !(o.total_reads > 0) && o.out_file_type != "fasta" && !o.index_remove && o.tile.empty() && o.fov.empty() &&
                            !getenv("SNK_HOST_TEXT");
     if (shardable) {
         const int G = (int)o.devices.size();
         std::vector<uint64_t> rec((size_t)G + 1), off[2];
-        RecordIndex ri[2];
-        for (int m = 0; m < mates; ++m) ri[m].open_and_count(inputs[m], ht);
-        if (mates == 2 && ri[0].n_records != ri[1].n_records) die("reads number in fq1 and fq2 are different");
-        const uint64_t nrec[2] = {ri[0].n_records, ri[1].n_records};
-        if (nrec[0] >= (uint64_t)G * 4096) {
-            for (int g = 0; g <= G; ++g) rec[(size_t)g] = nrec[0] * (uint64_t)g / (uint64_t)G;
-            for (int m = 0; m < mates; ++m) { off[m].resize((size_t)G + 1); for (int g = 0; g <= G; ++g) off[m][(size_t)g] = ri[m].offset_of(rec[(size_t)g]); ri[m].done(); }
+        uint64_t nrec[2] = {0, 0};
+        const bool gz_in = is_gzip_file(o.fq1);
+        GzScout sc[2];
+        bool plan = false;
+        if (!gz_in) {
+            RecordIndex ri[2];
+            for (int m = 0; m < mates; ++m) ri[m].open_and_count(inputs[m], ht);
+            if (mates == 2 && ri[0].n_records != ri[1].n_records) die("reads number in fq1 and fq2 are different");
+            nrec[0] = ri[0].n_records; nrec[1] = ri[1].n_records;
+            if (nrec[0] >= (uint64_t)G * 4096) {
+                plan = true;
+                for (int g = 0; g <= G; ++g) rec[(size_t)g] = nrec[0] * (uint64_t)g / (uint64_t)G;
+                for (int m = 0; m < mates; ++m) { off[m].resize((size_t)G + 1); for (int g = 0; g <= G; ++g) off[m][(size_t)g] = ri[m].offset_of(rec[(size_t)g]); }
+            }
+            for (int m = 0; m < mates; ++m) ri[m].done();
+        } else {
+            // .gz: the scout pass over both files at once (scout_gz above); the border records are the later of the two files' places
+            const long long t_sc = StageClock::now();
+            bool ok[2] = {true, true};
+            {
+                std::vector<std::thread> th;
+                for (int m = 0; m < mates; ++m) th.emplace_back([&, m] { ok[m] = scout_gz(inputs[m], std::max(1, ht / mates), G, sc[m]); });
+                for (auto &t : th) t.join();
+            }
+            nrec[0] = sc[0].n_records; nrec[1] = sc[1].n_records;
+            if (mates == 2 && nrec[0] != nrec[1]) die("reads number in fq1 and fq2 are different");
+            plan = ok[0] && ok[1] && nrec[0] >= (uint64_t)G * 4096;
+            if (plan) {
+                rec[0] = 0; rec[(size_t)G] = nrec[0];
+                for (int g = 1; g < G; ++g) {
+                    rec[(size_t)g] = sc[0].cuts[(size_t)g - 1].rec;
+                    if (mates == 2) rec[(size_t)g] = std::max(rec[(size_t)g], sc[1].cuts[(size_t)g - 1].rec);
+                }
+                for (int g = 0; g < G; ++g) if (rec[(size_t)g] >= rec[(size_t)g + 1]) plan = false;
+            }
+            log << local_time() << "\tscout pass over the .gz input: " << nrec[0] << (mates == 2 ? " pairs, " : " reads, ") << (double)(StageClock::now() - t_sc) * 1e-9 << " s"
+                << (plan ? "" : "; not sharded (" + (!ok[0] ? sc[0].why : !ok[1] ? sc[1].why : string("the borders do not leave every shard a record")) + ")") << endl;
+            for (int m = 0; m < mates; ++m) { off[m].assign((size_t)G + 1, 0); }
+        }
+        if (plan) {
             log << local_time() << "\tsharded run: " << G << " shards of about " << nrec[0] / (uint64_t)G << (mates == 2 ? " pairs" : " reads") << endl;
+            // the wire between the shards (host/snk_wire.h): RCCL when the device list is G different GPUs, else -- the same device
+            // twice: a one-GPU test configuration -- a host wire; SNK_SHARD_WIRE=rccl|host|file overrides ("file": no wire, the
+            // parent adds up the dumped blocks, as round 4 did; rmdup needs a wire)
+            string wire_kind, wire_addr, wire_why;
+            if (getenv("SNK_SHARD_FAKE")) wire_kind = "file";      // (tests/test_shard_plumbing.py: the shards are stand-ins)
+            else if (const char *e = getenv("SNK_SHARD_WIRE")) wire_kind = e;
+            else {
+                bool distinct = true;
+                for (int a = 0; a < G; ++a) for (int b = a + 1; b < G; ++b) if (o.devices[(size_t)a] == o.devices[(size_t)b]) distinct = false;
+                wire_kind = distinct ? "rccl" : "host";
+            }
+            if (wire_kind != "rccl" && wire_kind != "host" && wire_kind != "file") die("SNK_SHARD_WIRE: rccl, host or file");
+            if (wire_kind == "rccl") {
+                wire_addr = snk::RcclWire::make_id(wire_why);
+                if (wire_addr.empty()) { cerr << "Warning:RCCL is not available (" << wire_why << "): the shards talk over the host wire" << endl; wire_kind = "host"; }
+            }
+            if (wire_kind == "host") wire_addr = "snk-shard-" + std::to_string((long)getpid()) + "-" + std::to_string((long long)StageClock::now());
+            if (wire_kind == "file" && o.p.rmdup) die("rmdup over several shards exchanges the hashes: SNK_SHARD_WIRE=file cannot");
+            log << local_time() << "\tshards talk over: " << (wire_kind == "rccl" ? "RCCL" : wire_kind == "host" ? "host wire" : "files") << endl;
             std::vector<pid_t> kids((size_t)G, 0);
             for (int g = 0; g < G; ++g) {
                 std::vector<string> env;
@@ -1493,25 +1719,53 @@ int main(int argc, char **argv) {
                 env.push_back("SNK_SHARD=" + std::to_string(g) + "/" + std::to_string(G));
                 env.push_back("SNK_SHARD_RANGE1=" + std::to_string(off[0][(size_t)g]) + "," + std::to_string(off[0][(size_t)g + 1]));
                 if (mates == 2) env.push_back("SNK_SHARD_RANGE2=" + std::to_string(off[1][(size_t)g]) + "," + std::to_string(off[1][(size_t)g + 1]));
+                if (gz_in)
+                    for (int m = 0; m < mates; ++m) {
+                        // shard g of file m: from the stream's header (g = 0) or from the scout's place for border g; the records between
+                        // that place and the border record belong to the shard in front
+                        string v = "-1,0,0," + std::to_string(rec[(size_t)g + 1] - rec[(size_t)g]) + ",-";
+                        if (g > 0) {
+                            const GzCut &c = sc[m].cuts[(size_t)g - 1];
+                            const string wp = o.out_dir + "/shard." + std::to_string(g) + "." + std::to_string(m) + ".win";
+                            FILE *f = fopen(wp.c_str(), "wb");
+                            if (!f || fwrite(c.win.data(), 1, c.win.size(), f) != c.win.size() || fclose(f) != 0) die("cannot write to the file," + wp);
+                            v = std::to_string(c.bit) + "," + std::to_string(c.skip_bytes) + "," + std::to_string(rec[(size_t)g] - c.rec) + "," +
+                                std::to_string(rec[(size_t)g + 1] - rec[(size_t)g]) + "," + wp;
+                        }
+                        env.push_back(string(m ? "SNK_SHARD_GZ2=" : "SNK_SHARD_GZ1=") + v);
+                    }
                 env.push_back("SNK_SHARD_FIRST=" + std::to_string(rec[(size_t)g]));
+                env.push_back("SNK_SHARD_TOTAL=" + std::to_string(nrec[0]));
                 env.push_back("SNK_SHARD_STATS=" + o.out_dir + "/shard." + std::to_string(g) + ".stats");
+                env.push_back("SNK_SHARD_WIRE_KIND=" + wire_kind);
+                env.push_back("SNK_SHARD_WIRE_ADDR=" + wire_addr);
                 env.push_back("SNK_HOST_THREADS=" + std::to_string(std::max(2, ht / G)));
                 std::vector<char *> envp;
                 for (auto &x : env) envp.push_back(const_cast<char *>(x.c_str()));
                 envp.push_back(nullptr);
                 if (posix_spawn(&kids[(size_t)g], "/proc/self/exe", nullptr, nullptr, argv, envp.data()) != 0) die("cannot start a shard");
             }
+            // a shard that fails takes the others with it (they may be waiting for it inside a collective)
             int worst = 0;
-            for (int g = 0; g < G; ++g) {
+            for (int left = G; left > 0;) {
                 int status = 0;
-                if (waitpid(kids[(size_t)g], &status, 0) != kids[(size_t)g] || !WIFEXITED(status)) worst = std::max(worst, 1);
-                else worst = std::max(worst, WEXITSTATUS(status));
+                const pid_t w = waitpid(-1, &status, 0);
+                if (w < 0) { worst = std::max(worst, 1); break; }
+                int g = -1;
+                for (int k = 0; k < G; ++k) if (kids[(size_t)k] == w) g = k;
+                if (g < 0) continue;
+                kids[(size_t)g] = 0;
+                --left;
+                const int rc = WIFEXITED(status) ? WEXITSTATUS(status) : 1;
+                if (rc) {
+                    worst = std::max(worst, rc);
+                    for (int k = 0; k < G; ++k) if (kids[(size_t)k] > 0) kill(kids[(size_t)k], SIGKILL);
+                }
             }
+            if (gz_in) for (int g = 1; g < G; ++g) for (int m = 0; m < mates; ++m) unlink((o.out_dir + "/shard." + std::to_string(g) + "." + std::to_string(m) + ".win").c_str());
             if (worst) _exit(worst);                          // (the shard has printed the reference's message)
             // the parts in rank order (gzip members concatenate legally, as the reference's per-thread temporaries do)
-            const string names[2] = {o.clean1, o.clean2};
-            for (int m = 0; m < mates; ++m) {
-                const string fin = o.out_dir + "/" + names[m];
+            auto join_parts = [&](const string &fin) {
                 const int fd = open(fin.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
                 if (fd < 0) die("cannot write to the file," + fin);
                 for (int g = 0; g < G; ++g) {
@@ -1520,10 +1774,18 @@ int main(int argc, char **argv) {
                     unlink(part.c_str());
                 }
                 close(fd);
+            };
+            const string names[2] = {o.clean1, o.clean2};
+            for (int m = 0; m < mates; ++m) join_parts(o.out_dir + "/" + names[m]);
+            if (o.p.rmdup) {                                  // dupReads.<thread>.<mate>.gz: every shard wrote its share of every virtual thread's file
+                for (int m = 0; m < mates; ++m)
+                    for (int t = 0; t < o.threads; ++t) join_parts(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz");
+                cout << "totalReadsNum:\t" << nrec[0] << endl;
             }
             // the statistics blocks of the shards, virtual thread by virtual thread
             const int T_ = o.threads;
             int lfin = 0, nq_ = 0;
+            uint64_t dup_written = 0;
             std::vector<ShardStatsHeader> hd((size_t)G);
             std::vector<std::vector<uint64_t>> blob((size_t)G);
             for (int g = 0; g < G; ++g) {
@@ -1538,7 +1800,9 @@ int main(int argc, char **argv) {
                 unlink((o.log + ".shard" + std::to_string(g)).c_str());
                 lfin = std::max(lfin, (int)hd[(size_t)g].lcap);
                 nq_ = hd[(size_t)g].nq;
+                dup_written += hd[(size_t)g].dup_written;
             }
+            if (o.p.rmdup) log << "dup number:\t" << dup_written << endl;
             std::vector<std::vector<uint64_t>> sums((size_t)T_, std::vector<uint64_t>((size_t)snk_stats_u64(lfin, nq_), 0)), maxs((size_t)T_, std::vector<uint64_t>(SNK_MAX_N, 0));
             std::vector<const uint64_t *> sp((size_t)T_), mp((size_t)T_);
             for (int g = 0; g < G; ++g) {
@@ -1550,9 +1814,28 @@ int main(int argc, char **argv) {
                 }
             }
             for (int t = 0; t < T_; ++t) { sp[(size_t)t] = sums[(size_t)t].data(); mp[(size_t)t] = maxs[(size_t)t].data(); }
+            // rank 0 holds the blocks as the wire's all-reduce left them (the path's one collective), has written the
+            // reports from them and left them here: the sum over the dumped blocks above is the check, and the fallback
+            bool merged_ok = false;
+            const string mpath = o.out_dir + "/shard.merged.stats";
+            if (FILE *f = fopen(mpath.c_str(), "rb")) {
+                ShardStatsHeader mh;
+                std::vector<uint64_t> mb((size_t)T_ * ((size_t)snk_stats_u64(lfin, nq_) + SNK_MAX_N));
+                if (fread(&mh, sizeof mh, 1, f) == 1 && mh.magic == SHARD_MAGIC && mh.T == T_ && mh.lcap == lfin && mh.nq == nq_ && fread(mb.data(), 8, mb.size(), f) == mb.size()) {
+                    merged_ok = true;
+                    const size_t ns = (size_t)snk_stats_u64(lfin, nq_);
+                    for (int t = 0; t < T_ && merged_ok; ++t)
+                        merged_ok = memcmp(mb.data() + (size_t)t * ns, sums[(size_t)t].data(), ns * 8) == 0 &&
+                                    memcmp(mb.data() + (size_t)T_ * ns + (size_t)t * SNK_MAX_N, maxs[(size_t)t].data(), SNK_MAX_N * 8) == 0;
+                    if (merged_ok) log << local_time() << "\tstatistics merged over " << (mh.pad == 1 ? "RCCL" : "the host wire") << " (" << G << " shards)" << endl;
+                    else cerr << "Warning:the all-reduce of the statistics over the shards disagrees with the sum of their dumped blocks; using that sum" << endl;
+                }
+                fclose(f);
+                unlink(mpath.c_str());
+            } else if (wire_kind != "file") cerr << "Warning:the shards did not all-reduce their statistics; merging their dumped blocks on the host" << endl;
             char ebuf[512];
             o.p.max_read_len = lfin;
-            if (snk_write_reports(&o.p, T_, sp.data(), mp.data(), o.out_dir.c_str(), ebuf, sizeof ebuf) != 0) { cerr << ebuf << endl; _exit(1); }
+            if (!merged_ok && snk_write_reports(&o.p, T_, sp.data(), mp.data(), o.out_dir.c_str(), ebuf, sizeof ebuf) != 0) { cerr << ebuf << endl; _exit(1); }
             log << local_time() << "\tAnalysis accomplished!" << endl;
             log.close();
             _exit(0);
@@ -1580,7 +1863,8 @@ int main(int argc, char **argv) {
     // pair's text), marked in input order on a stream of the table's device.  SNK_RMDUP_TWO_PASS=1 forces the reference's two passes.
     const int64_t rmdup_patch = o.patch_size > 0 ? o.patch_size : (int64_t)o.threads * 20000 / 8;
     const bool proven_only = getenv("SNK_PROVEN_ONLY") && !strcmp(getenv("SNK_PROVEN_ONLY"), "1");      // (csrc/snk_tables.h: the hardware-green envelope only)
-    bool rmdup_one_pass = o.p.rmdup && (mates == 2 || (!proven_only && rmdup_patch > 0 && o.batch_pairs % rmdup_patch == 0)) && !getenv("SNK_RMDUP_TWO_PASS");
+    // (a shard of a sharded run: "seen at an earlier index" spans the shards -- two passes with the hash exchange in between)
+    bool rmdup_one_pass = o.p.rmdup && !g_shard.child && (mates == 2 || (!proven_only && rmdup_patch > 0 && o.batch_pairs % rmdup_patch == 0)) && !getenv("SNK_RMDUP_TWO_PASS");
     if (rmdup_one_pass) {
         // the one-pass table keeps 8 B per pair of hashes and up to 48 B per pair of table resident in HBM: when twice the
         // estimated number of pairs (file size / bytes of the first record) does not fit, the two passes run instead
@@ -1944,10 +2228,11 @@ int main(int argc, char **argv) {
             have = next_chunks(c);
         }
         join_readers();
-        if (nall > 4294967295ull) die("reads number is too large to do remove duplication," + std::to_string(nall));
+        const uint64_t nglobal = g_shard.child ? g_shard.total : nall, gfirst = g_shard.child ? g_shard.first : 0;
+        if (nglobal > 4294967295ull) die("reads number is too large to do remove duplication," + std::to_string(nglobal));
         uint64_t *d_hash_all;
-        HIPCHK(hipMalloc(&d_hash_all, (size_t)nall * sizeof(uint64_t)));
-        HIPCHK(hipMalloc(&d_dup_all, (size_t)nall));
+        HIPCHK(hipMalloc(&d_hash_all, std::max<size_t>((size_t)nall, 1) * sizeof(uint64_t)));
+        HIPCHK(hipMalloc(&d_dup_all, std::max<size_t>((size_t)nall, 1)));
         uint64_t off = 0;
         for (size_t k = 0; k < chunks.size(); ++k) {
             HIPCHK(hipMemcpyAsync(d_hash_all + off, chunks[k], (size_t)chunk_n[k] * sizeof(uint64_t), hipMemcpyDeviceToDevice, 0));
@@ -1955,12 +2240,72 @@ int main(int argc, char **argv) {
         }
         HIPCHK(hipStreamSynchronize(0));
         for (uint64_t *ch : chunks) HIPCHK(hipFree(ch));
-        cout << "totalReadsNum:\t" << nall << endl;
-        if (snk_rmdup_mark_device(ctx, d_hash_all, nullptr, (int64_t)nall, nall, -1, d_dup_all, nullptr) != SNK_OK) die(snk_last_error());
-        HIPCHK(hipStreamSynchronize(0));
+        uint8_t prev_flag = 0;                              // SE: the true flag of the read in front of this shard
+        if (!g_shard.child) {
+            cout << "totalReadsNum:\t" << nall << endl;
+            if (snk_rmdup_mark_device(ctx, d_hash_all, nullptr, (int64_t)nall, nall, -1, d_dup_all, nullptr) != SNK_OK) die(snk_last_error());
+            HIPCHK(hipStreamSynchronize(0));
+        } else {
+            // The exchange of the sharded run (include/snk_rmdup.h "multi-GPU exchange helpers"): the population of the
+            // sentinel's bucket summed over the shards, every hash to its owner (hash % G) with its global index, marked there
+            // with explicit indices, the flags home again.  9 + 4 bytes per pair over the wire against the ~700 of its text.
+            snk::ShardWire *w = shard_wire();
+            if (!w) die("rmdup over several shards needs a wire between them");
+            const int W = w->world;
+            auto wire_ok = [&](bool ok) { if (!ok) die("rmdup exchange between the shards failed (" + w->err + ")"); };
+            uint64_t *d_cnt = nullptr;
+            HIPCHK(hipMalloc(&d_cnt, 8));
+            if (snk_rmdup_bucket_count_device(ctx, d_hash_all, (int64_t)nall, nglobal, d_cnt, nullptr) != SNK_OK) die(snk_last_error());
+            HIPCHK(hipStreamSynchronize(0));
+            wire_ok(w->allreduce_u64(d_cnt, 1, snk::WIRE_SUM));
+            uint64_t sentinel_total = 0;
+            HIPCHK(hipMemcpy(&sentinel_total, d_cnt, 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipFree(d_cnt));
+            uint64_t *d_sh = nullptr, *d_rh = nullptr;
+            uint32_t *d_si = nullptr, *d_slot = nullptr, *d_ri = nullptr;
+            uint8_t *d_rf = nullptr, *d_back = nullptr;
+            const size_t n1 = std::max<size_t>((size_t)nall, 1);
+            HIPCHK(hipMalloc(&d_sh, n1 * 8));
+            HIPCHK(hipMalloc(&d_si, n1 * 4));
+            HIPCHK(hipMalloc(&d_slot, n1 * 4));
+            std::vector<uint64_t> sc((size_t)W, 0), rc((size_t)W, 0);
+            if (snk_rmdup_partition_device(ctx, d_hash_all, (int64_t)nall, gfirst, W, d_sh, d_si, d_slot, sc.data(), nullptr) != SNK_OK) die(snk_last_error());
+            wire_ok(w->exchange_counts(sc.data(), rc.data()));
+            uint64_t nrecv = 0;
+            for (uint64_t v : rc) nrecv += v;
+            if (getenv("SNK_SHARD_DEBUG")) { fprintf(stderr, "shard %d: n %llu total %llu first %llu send", w->rank, (unsigned long long)nall, (unsigned long long)nglobal, (unsigned long long)gfirst); for (uint64_t v : sc) fprintf(stderr, " %llu", (unsigned long long)v); fprintf(stderr, " recv"); for (uint64_t v : rc) fprintf(stderr, " %llu", (unsigned long long)v); fprintf(stderr, " sentinel %llu\n", (unsigned long long)sentinel_total); }
+            const size_t r1 = std::max<size_t>((size_t)nrecv, 1);
+            HIPCHK(hipMalloc(&d_rh, r1 * 8));
+            HIPCHK(hipMalloc(&d_ri, r1 * 4));
+            HIPCHK(hipMalloc(&d_rf, r1));
+            HIPCHK(hipMalloc(&d_back, n1));
+            wire_ok(w->alltoallv(d_sh, sc.data(), d_rh, rc.data(), 8));
+            wire_ok(w->alltoallv(d_si, sc.data(), d_ri, rc.data(), 4));
+            HIPCHK(hipFree(d_sh));
+            HIPCHK(hipFree(d_si));
+            if (nrecv && snk_rmdup_mark_device(ctx, d_rh, d_ri, (int64_t)nrecv, nglobal, (int64_t)sentinel_total, d_rf, nullptr) != SNK_OK) die(snk_last_error());
+            HIPCHK(hipStreamSynchronize(0));
+            wire_ok(w->alltoallv(d_rf, rc.data(), d_back, sc.data(), 1));
+            if (snk_rmdup_flags_home_device(ctx, d_back, d_slot, (int64_t)nall, d_dup_all, nullptr) != SNK_OK) die(snk_last_error());
+            HIPCHK(hipStreamSynchronize(0));
+            HIPCHK(hipFree(d_rh)); HIPCHK(hipFree(d_ri)); HIPCHK(hipFree(d_rf)); HIPCHK(hipFree(d_back)); HIPCHK(hipFree(d_slot));
+            if (mates == 1) {
+                // SE: read i of a full patch is filtered with the flag of read i - 1 (below): the first read of a shard needs the
+                // last flag of the shard in front -- every shard puts its last true flag into its own word of a G-word block
+                uint64_t *d_last = nullptr;
+                HIPCHK(hipMalloc(&d_last, (size_t)W * 8));
+                std::vector<uint64_t> last((size_t)W, 0);
+                if (nall) { uint8_t f = 0; HIPCHK(hipMemcpy(&f, d_dup_all + nall - 1, 1, hipMemcpyDeviceToHost)); last[(size_t)w->rank] = f; }
+                HIPCHK(hipMemcpy(d_last, last.data(), (size_t)W * 8, hipMemcpyHostToDevice));
+                wire_ok(w->allreduce_u64(d_last, (size_t)W, snk::WIRE_SUM));
+                HIPCHK(hipMemcpy(last.data(), d_last, (size_t)W * 8, hipMemcpyDeviceToHost));
+                HIPCHK(hipFree(d_last));
+                if (w->rank > 0) prev_flag = (uint8_t)last[(size_t)w->rank - 1];       // (no shard is empty: the parent only shards inputs of G x 4096 records and more)
+            }
+        }
         HIPCHK(hipFree(d_hash_all));
         std::vector<uint8_t> flags((size_t)nall);
-        HIPCHK(hipMemcpy(flags.data(), d_dup_all, (size_t)nall, hipMemcpyDeviceToHost));
+        if (nall) HIPCHK(hipMemcpy(flags.data(), d_dup_all, (size_t)nall, hipMemcpyDeviceToHost));
         uint64_t ndup = 0;
         for (uint8_t f : flags) ndup += f;
         log << "duplicate reads number:\t" << ndup << endl;
@@ -1970,17 +2315,18 @@ int main(int argc, char **argv) {
             // full patch read i is filtered with the flag of read i-1 (read 0: the byte in front of the
             // array, 0 in practice); only the partial patch at the end of the file (:1112) is aligned.
             // Reproduced here, on the host, so that outputs stay identical; the C ABI flags are the true ones.
+            // (indices are global: a shard shifts its own stretch of the input and takes read first - 1's flag from its neighbour)
             const uint64_t ps = o.patch_size > 0 ? (uint64_t)o.patch_size : (uint64_t)T * 20000 / 8;
-            const uint64_t full_end = nall / ps * ps;
+            const uint64_t full_end = nglobal / ps * ps;
             std::vector<uint8_t> eff(flags);
-            for (uint64_t i = 0; i < full_end; ++i) eff[i] = i ? flags[i - 1] : 0;
-            HIPCHK(hipMemcpy(d_dup_all, eff.data(), (size_t)nall, hipMemcpyHostToDevice));
+            for (uint64_t i = 0; i < nall && gfirst + i < full_end; ++i) eff[i] = i ? flags[i - 1] : (gfirst ? prev_flag : 0);
+            if (nall) HIPCHK(hipMemcpy(d_dup_all, eff.data(), (size_t)nall, hipMemcpyHostToDevice));
             flags.swap(eff);
         }
         dup_host.swap(flags);
         for (int m = 0; m < mates; ++m) {                   // dupReads.<thread>.<mate>.gz, src/peprocess.cpp:167-174 (SE: .1.gz only)
             dupw[m].resize(T);
-            for (int t = 0; t < T; ++t) dupw[m][t].open(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz", true);
+            for (int t = 0; t < T; ++t) dupw[m][t].open(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz" + (g_shard.child ? ".part" + std::to_string(g_shard.g) : string()), true);
         }
         for (auto &t : slot_makers) t.join();
         slot_makers.clear();
@@ -2558,7 +2904,7 @@ int main(int argc, char **argv) {
         if (host_flags) {                                   // tile / fov of fq1's read name (src/read_filter.cpp:86-150, src/sequence.cpp:213-231) + the duplicate bit
             parallel_for(WK, n, [&](int, int lo, int hi) {
                 for (int i = lo; i < hi; ++i) {
-                    uint8_t f = rmdup_on ? (uint8_t)(dup_host[total + (uint64_t)i] & 1) : 0;
+                    uint8_t f = rmdup_on ? (uint8_t)(dup_host[total - g_shard.first + (uint64_t)i] & 1) : 0;
                     if (name_verdicts) {
                         int li;
                         const char *id = s.raw[0]->line(4 * i, li);
@@ -2690,14 +3036,68 @@ int main(int argc, char **argv) {
         sp[t] = sums[t].data();
         mp[t] = maxs[t].data();
     }
-    if (g_shard.child) {                                  // a shard: its blocks go to the parent, which writes the reports
-        FILE *f = fopen(g_shard.stats_path.c_str(), "wb");
-        ShardStatsHeader h{SHARD_MAGIC, T, lfin, nq, 0, clean_total};
-        bool ok = f && fwrite(&h, sizeof h, 1, f) == 1;
-        for (int t = 0; t < T && ok; ++t) ok = fwrite(sums[(size_t)t].data(), 8, sums[(size_t)t].size(), f) == sums[(size_t)t].size();
-        for (int t = 0; t < T && ok; ++t) ok = fwrite(maxs[(size_t)t].data(), 8, (size_t)SNK_MAX_N, f) == (size_t)SNK_MAX_N;
-        if (!ok || fclose(f) != 0) die("cannot write to the file," + g_shard.stats_path);
-        for (auto &t : slot_makers) t.join();              // (a short shard can get here before its last slots exist)
+    if (g_shard.child) {
+        // a shard: its blocks are dumped for the parent (the check and the fallback), then all-reduced over the wire -- the path's
+        // one collective (the reference: merge_stat once its threads have joined, src/peprocess.cpp:1994); rank 0
+        // writes the reports from the reduced blocks and leaves them for the parent's comparison
+        auto dump = [&](const string &path, int lc, int kind, const std::vector<const uint64_t *> &S, const std::vector<const uint64_t *> &M) {
+            FILE *f = fopen(path.c_str(), "wb");
+            ShardStatsHeader h{SHARD_MAGIC, T, lc, nq, kind, clean_total, ndup_written};
+            bool ok = f && fwrite(&h, sizeof h, 1, f) == 1;
+            const size_t ns = (size_t)snk_stats_u64(lc, nq);
+            for (int t = 0; t < T && ok; ++t) ok = fwrite(S[(size_t)t], 8, ns, f) == ns;
+            for (int t = 0; t < T && ok; ++t) ok = fwrite(M[(size_t)t], 8, (size_t)SNK_MAX_N, f) == (size_t)SNK_MAX_N;
+            if (!ok || fclose(f) != 0) die("cannot write to the file," + path);
+        };
+        dump(g_shard.stats_path, lfin, 0, sp, mp);
+        if (snk::ShardWire *w = shard_wire()) {
+            for (auto &t : slot_makers) t.join();          // (a short shard can get here before its last slots exist)
+            slot_makers.clear();
+            HIPCHK(hipSetDevice(devs[0].id));
+            // the shards agree on the geometry first (a longer read may have shown up in one of them only)
+            uint64_t *d_geo = nullptr;
+            HIPCHK(hipMalloc(&d_geo, 8));
+            uint64_t geo = (uint64_t)lfin;
+            HIPCHK(hipMemcpy(d_geo, &geo, 8, hipMemcpyHostToDevice));
+            if (!w->allreduce_u64(d_geo, 1, snk::WIRE_MAX)) die("shard all-reduce failed (" + w->err + ")");
+            HIPCHK(hipMemcpy(&geo, d_geo, 8, hipMemcpyDeviceToHost));
+            HIPCHK(hipFree(d_geo));
+            const int lall = (int)geo;
+            const size_t ns = (size_t)snk_stats_u64(lall, nq);
+            std::vector<uint64_t> wide((size_t)T * ns, 0), wmax((size_t)T * SNK_MAX_N, 0);
+            for (int t = 0; t < T; ++t) {
+                widen_add(sums[(size_t)t].data(), lfin, wide.data() + (size_t)t * ns, lall, nq);
+                memcpy(wmax.data() + (size_t)t * SNK_MAX_N, maxs[(size_t)t].data(), SNK_MAX_N * 8);
+            }
+            uint64_t *d_s = nullptr, *d_m = nullptr;
+            HIPCHK(hipMalloc(&d_s, wide.size() * 8));
+            HIPCHK(hipMalloc(&d_m, wmax.size() * 8));
+            HIPCHK(hipMemcpy(d_s, wide.data(), wide.size() * 8, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d_m, wmax.data(), wmax.size() * 8, hipMemcpyHostToDevice));
+            if (void *comm = w->nccl_comm()) {
+                // over RCCL: the C ABI's own collective, block by block (every shard walks t in the same order)
+                snk_params pw = o.p;
+                pw.max_read_len = lall;
+                snk_ctx *cx = snk_create(&pw, devs[0].id);
+                if (!cx) die(snk_last_error());
+                for (int t = 0; t < T; ++t)
+                    if (snk_bind_stats(cx, d_s + (size_t)t * ns, d_m + (size_t)t * SNK_MAX_N) != SNK_OK || snk_stats_allreduce(cx, comm, nullptr) != SNK_OK) die(snk_last_error());
+                HIPCHK(hipDeviceSynchronize());
+                snk_destroy(cx);
+            } else if (!w->allreduce_u64(d_s, wide.size(), snk::WIRE_SUM) || !w->allreduce_u64(d_m, wmax.size(), snk::WIRE_MAX)) die("shard all-reduce failed (" + w->err + ")");
+            if (g_shard.g == 0) {
+                HIPCHK(hipMemcpy(wide.data(), d_s, wide.size() * 8, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(wmax.data(), d_m, wmax.size() * 8, hipMemcpyDeviceToHost));
+                std::vector<const uint64_t *> S((size_t)T), M((size_t)T);
+                for (int t = 0; t < T; ++t) { S[(size_t)t] = wide.data() + (size_t)t * ns; M[(size_t)t] = wmax.data() + (size_t)t * SNK_MAX_N; }
+                char ebuf[512];
+                o.p.max_read_len = lall;
+                if (snk_write_reports(&o.p, T, S.data(), M.data(), o.out_dir.c_str(), ebuf, sizeof ebuf) != 0) { cerr << ebuf << endl; cout.flush(); fflush(stdout); _exit(1); }
+                dump(o.out_dir + "/shard.merged.stats", lall, w->nccl_comm() ? 1 : 2, S, M);
+            }
+            g_shard.wire.reset();
+        }
+        for (auto &t : slot_makers) t.join();
         slot_makers.clear();
         log.close();
         cout.flush();

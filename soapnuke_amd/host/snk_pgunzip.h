@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -198,21 +199,37 @@ private:
 class ParallelGunzip {
 public:
     enum { HIST = GzipInflate::HIST };
-    ParallelGunzip(const uint8_t *in, size_t n, int threads, size_t chunk_bytes = (size_t)2 << 20)
+    // start_bit / start_win: decode from the deflate block header at that bit offset on, the 32 KiB of text in front of it
+    // given (a shard of a sharded run, host/snk_main.cpp: the parent's scout pass has decoded the stream once, verified every
+    // member's CRC-32 and noted such places); the member the start lies in cannot be checked again and is not
+    ParallelGunzip(const uint8_t *in, size_t n, int threads, size_t chunk_bytes = (size_t)2 << 20, uint64_t start_bit = ~0ull, const uint8_t *start_win = nullptr)
         : in_(in), n_(n), cb_(chunk_bytes < 65536 ? 65536 : chunk_bytes) {
         nchunks_ = (n_ + cb_ - 1) / cb_;
         if (nchunks_ == 0) nchunks_ = 1;
         chunks_.reset(new Chunk[nchunks_]);
         win_.assign(HIST, 0);
+        if (start_bit != ~0ull && start_win && (start_bit >> 3) < n_) {
+            mid_ = partial_ = true;
+            start_bit_ = start_bit;
+            first_ = (size_t)(start_bit >> 3) / cb_;
+            win0_.assign(start_win, start_win + HIST);
+            next_task_ = consumed_ = first_;
+        }
         threads = threads < 1 ? 1 : threads;
         lookahead_ = (size_t)threads + threads / 2 + 2;
-        if (nchunks_ > 2 && threads > 1) {
+        if (nchunks_ - first_ > 2 && threads > 1) {
             for (int t = 0; t < threads; ++t) pool_.emplace_back([this] { worker(); });
             chain_thread_ = std::thread([this] { chain(); });
+        } else if (mid_) {
+            win_ = win0_;
+            seq_from(start_bit_, false);
         } else {
             seq_from(0, true);                              // small input or one thread: plain sequential decoding
         }
     }
+    // called from run() whenever the text of a chunk of the chain begins: the chunk's first block header (bit offset; 0 = the
+    // gzip header of the stream) and the number of bytes run() has handed out before it -- a place a later decoder can start from
+    std::function<void(uint64_t bit, uint64_t text_off)> on_chunk;
     ~ParallelGunzip() {
         { std::lock_guard<std::mutex> l(m_); quit_ = true; }
         cv_.notify_all();
@@ -232,6 +249,7 @@ public:
             const size_t n = std::min(cap - got, c.out_len - cur_off_);
             memcpy(out + got, c.buf.data() + HIST + cur_off_, n);
             got += n;
+            handed_out_ += n;
             cur_off_ += n;
             if (cur_off_ == c.out_len) release_current();
         }
@@ -257,6 +275,10 @@ private:
 
     const uint8_t *in_;
     size_t n_, cb_, nchunks_ = 0, lookahead_ = 4;
+    bool mid_ = false, partial_ = false;                   // started inside the stream / inside a member whose front was not seen
+    uint64_t start_bit_ = 0, handed_out_ = 0;
+    size_t first_ = 0;                                     // the chunk the stream (or the part asked for) begins in
+    std::vector<uint8_t> win0_;
     std::unique_ptr<Chunk[]> chunks_;
     std::vector<std::thread> pool_;
     std::thread chain_thread_;
@@ -328,7 +350,7 @@ private:
         if (s == 2) return c.start_bit;
         int zero = 0;
         if (s == 0 && c.searched.compare_exchange_strong(zero, 1)) {
-            c.start_bit = i == 0 ? 0 : find_block((uint64_t)i * cb_ * 8, std::min<uint64_t>((uint64_t)(i + 1) * cb_ * 8, (uint64_t)n_ * 8));
+            c.start_bit = i == first_ ? (mid_ ? start_bit_ : 0) : find_block((uint64_t)i * cb_ * 8, std::min<uint64_t>((uint64_t)(i + 1) * cb_ * 8, (uint64_t)n_ * 8));
             c.searched.store(2, std::memory_order_release);
             return c.start_bit;
         }
@@ -396,12 +418,12 @@ private:
         bool gave_up = false;
         uint64_t stop = next_stop(j, s0 + 1, gave_up);
         if (gave_up) return;                                // no block start near: the chain breaks here, the consumer decodes sequentially
-        bool byte_mode = i == 0;                            // chunk 0 starts at the gzip header: nothing unknown
-        if (i > 0) {
+        bool byte_mode = i == first_;                       // the first chunk starts at the gzip header, or with its window given: nothing unknown
+        if (i > first_) {
             z.start_at_block(s0);
             take(c.M);
             if (c.M.size() < cb_ * 3 + 65536) c.M.resize(cb_ * 3 + 65536);
-        }
+        } else if (mid_) z.start_at_block(s0);
         // ---- marker phase
         while (!byte_mode) {
             const MarkerInflate::Why w = z.run_markers(c.M, c.mlen, stop, cap_syms);
@@ -420,6 +442,7 @@ private:
         size_t cap = mlen + std::max<size_t>(cb_ * 4, (size_t)1 << 20);
         take(c.buf);
         if (c.buf.size() < cap + HIST) c.buf.resize(cap + HIST); else cap = c.buf.size() - HIST;
+        if (i == first_ && mid_) memcpy(c.buf.data(), win0_.data(), HIST);       // (the decoder's contract: the 32 KiB in front of `out` are the stream's)
         uint8_t *base = c.buf.data() + HIST;
         size_t pos = mlen, piece_from = mlen;
         uint32_t crc = 0;
@@ -511,13 +534,14 @@ private:
     }
     void chain() {
         std::vector<uint8_t> win(HIST, 0), nxt(HIST);
-        size_t cur = 0;
-        uint64_t expect = 0;
+        size_t cur = first_;
+        uint64_t expect = mid_ ? start_bit_ : 0;
+        if (mid_) win = win0_;
         for (;;) {
             wait_done(cur);
             { std::lock_guard<std::mutex> l(m_); if (quit_) return; }
             Chunk &c = chunks_[cur];
-            if (!c.ok) { break_chain(expect, cur == 0, win); return; }
+            if (!c.ok) { break_chain(expect, cur == first_ && !mid_, win); return; }
             // the window behind this chunk: its last 32 KiB (with the tail of the old window when it is shorter)
             {
                 const size_t n = c.out_len, take = std::min<size_t>(n, HIST);
@@ -589,6 +613,7 @@ private:
         mlen_ += len;
     }
     bool end_member(uint32_t want_crc, uint32_t want_isize) {
+        if (partial_) { partial_ = false; mcrc_ = 0; mlen_ = 0; return true; }      // the member the start lay in: its front was not seen
         if (mcrc_ != want_crc) { fail("gzip CRC mismatch"); return false; }
         if ((uint32_t)mlen_ != want_isize) { fail("gzip length mismatch"); return false; }
         mcrc_ = 0;
@@ -631,6 +656,7 @@ private:
         cv_.notify_all();
         cur_ = i;
         Chunk &c = chunks_[i];
+        if (on_chunk) on_chunk(c.start_bit, handed_out_);
         add_piece(c.crc_front, c.mlen);
         for (const Piece &p : c.pieces) {
             add_piece(p.crc, p.len);

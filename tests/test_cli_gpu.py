@@ -585,6 +585,54 @@ def test_cli_sharded_ingest(paired, gz_out, trim, tmp_path):
     assert not [x for x in os.listdir(ours) if ".part" in x or x.startswith("shard.")]       # nothing of the shards is left behind
 
 
+@T.first_contact
+@pytest.mark.parametrize("paired,n,gz_in", [(True, 40000, False), (False, 40100, False), (True, 40000, True), (False, 40100, True)])
+def test_cli_sharded_rmdup_and_wire(paired, n, gz_in, tmp_path):
+    """the sharded run with the collectives `north_star` names.  The shards form one communicator (RCCL between
+    different GPUs; a host wire when the device list names one GPU twice -- all this box has -- or SNK_SHARD_WIRE=host says so),
+    all-reduce their per-thread statistics blocks over it (rank 0 writes the reports, the parent checks them against the sum of
+    the dumped blocks) and, with `rmdup`, send every hash to its owner (hash % G) with its global index and get the flag back:
+    duplicates ACROSS the shard border, third copies, the SE flag shift across the border, dupReads side files -- all as the
+    reference binary has them.  gz_in: `.gz` input -- the parent's scout pass decodes both files once, counts the records and notes a
+    block header + window per border; every shard's decoder starts there (the two files of a pair at different places, cut at
+    the same record)."""
+    import torch
+    devs = "0,1" if torch.cuda.device_count() >= 2 else "0,0"
+    L, threads, patch = 150, 3, 250
+    d = synth.make_batch(n, L, paired=paired, seed=65)
+    h = n // 2
+    for m in range(2 if paired else 1):
+        d["seq"][m][h + 1000:h + 3000] = d["seq"][m][0:2000]          # second copies in the other shard
+        d["seq"][m][h - 600:h - 100] = d["seq"][m][0:500]             # third copies, back in the first
+        d["seq"][m][h - 3:h + 3] = d["seq"][m][100:106]               # duplicates on both sides of the border
+        d["seq"][m][n - 40:n - 20] = d["seq"][m][700:720]             # ... and inside the last (partial) patch
+    cli = ["-f", synth.ADAPTER1, "-J"] + (["-r", synth.ADAPTER2] if paired else [])
+    case = ("shardrm", paired, L, n, threads, patch, {}, {}, cli, ["rmdup"])
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ext = ".fq.gz" if gz_in else ".fq"
+    cmd = [CLI, "filter", "-1", os.path.join(work, "r1" + ext), "-C", "c1.fq", "-o", os.path.join(work, "ours"), "-T", str(threads), "--devices", devs,
+           "-c", os.path.join(work, "cfg")]
+    if paired:
+        cmd += ["-2", os.path.join(work, "r2" + ext), "-D", "c2.fq"]
+    r = subprocess.run(cmd + cli, capture_output=True, env=dict(os.environ, SNK_SHARDED="1", SNK_BATCH_PAIRS="4096", SNK_GZ_CHUNK="262144"))
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-800:])
+    ours = os.path.join(work, "ours")
+    log = open(os.path.join(ours, "log"), "rb").read()
+    assert b"sharded run: 2 shards" in log and b"statistics merged over" in log and b"Warning" not in r.stderr, (log[-600:], r.stderr[-400:])
+    _compare_dirs(ours, ref, paired)
+    ndup = 0
+    for t in range(threads):
+        for m in range(2 if paired else 1):
+            f = f"dupReads.{t}.{m + 1}.gz"
+            a, b = _cat(os.path.join(ours, f)), _cat(os.path.join(ref, f))
+            assert a == b, f
+            ndup += a.count(b"\n") // 4
+    assert ndup > 2500 and (b"dup number:\t%d" % (ndup // (2 if paired else 1))) in log
+    assert (b"totalReadsNum:\t%d" % n) in r.stdout
+    assert not [x for x in os.listdir(ours) if ".part" in x or x.startswith("shard.")]
+
+
 @pytest.mark.parametrize("paired", [True, False])
 def test_cli_longer_read_after_first_batch(paired, tmp_path):
     """The reference takes any read up to 1000 nt at any position; here the capacity comes from the first batch and is

@@ -269,3 +269,72 @@ def test_one_pass_table_single_end_shift():
         lib.snk_rmdup_stream_destroy(t)
         assert np.array_equal(got, want), (n, ps, np.nonzero(got != want)[0][:8])
         assert marked.value == int(true.sum())
+
+
+@T.first_contact
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_exchange_helpers_against_the_oracle(world):
+    """include/snk_rmdup.h "multi-GPU exchange helpers": every rank's shard grouped by owner = hash % world
+    (snk_rmdup_partition_device), the groups handed to their owners (here: by hand, what ncclSend / ncclRecv or the host wire do
+    in the CLI, host/snk_wire.h), marked there with explicit global indices and the summed sentinel population
+    (snk_rmdup_mark_device), the flags brought home (snk_rmdup_flags_home_device): the flags are rmdup::markDup's of the whole
+    input (src/rmdup.cpp:14-149), sentinel quirk included."""
+    import ctypes as C
+    import torch
+    from soapnuke_amd.filter import FilterContext
+    lib = abi.load_library()
+    rng = np.random.default_rng(40 + world)
+    n = 50_000
+    h = rng.integers(0, n // 2, n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(7)
+    h[rng.choice(n, 5, replace=False)] = np.uint64(0xFFFFFFFFFFFFFFFF)              # the sentinel value, several times
+    want = T.oracle_markdup(h)
+    bounds = [n * r // world for r in range(world + 1)]
+    shards, counts, sent = [], [], 0
+    p = abi.default_params(paired=True, max_read_len=150, rmdup=1)
+    ctx = FilterContext(p, device=0)
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        m = hi - lo
+        hd = torch.from_numpy(h[lo:hi].view(np.int64).copy()).cuda()
+        sh = torch.empty(max(m, 1), dtype=torch.int64, device="cuda")
+        si = torch.empty(max(m, 1), dtype=torch.int32, device="cuda")
+        slot = torch.empty(max(m, 1), dtype=torch.int32, device="cuda")
+        cnt = (C.c_uint64 * world)()
+        assert lib.snk_rmdup_partition_device(ctx.ctx, hd.data_ptr(), m, lo, world, sh.data_ptr(), si.data_ptr(), slot.data_ptr(), cnt, None) == 0, lib.snk_last_error()
+        cnt = list(cnt)
+        assert sum(cnt) == m
+        own = (h[lo:hi] % np.uint64(world)).astype(np.int64)
+        assert cnt == np.bincount(own, minlength=world).tolist()
+        shn, sin_, sl = sh.cpu().numpy().view(np.uint64)[:m], si.cpu().numpy().view(np.uint32)[:m], slot.cpu().numpy().view(np.uint32)[:m]
+        assert np.array_equal(shn[sl], h[lo:hi]) and np.array_equal(sin_[sl], (lo + np.arange(m)).astype(np.uint32))      # every element sits where its slot says
+        assert np.array_equal(np.sort(sl), np.arange(m))
+        assert np.array_equal((shn % np.uint64(world)).astype(np.int64), np.repeat(np.arange(world), cnt))               # grouped by owner, in owner order
+        c1 = torch.zeros(1, dtype=torch.int64, device="cuda")
+        assert lib.snk_rmdup_bucket_count_device(ctx.ctx, hd.data_ptr(), m, n, c1.data_ptr(), None) == 0
+        sent += int(c1.item())
+        shards.append((hd, sh, si, slot, m))
+        counts.append(cnt)
+    flags_home = []
+    owner_flags = []
+    for o in range(world):                                                        # what owner o receives, in source-rank order
+        rh = torch.cat([shards[r][1][sum(counts[r][:o]):sum(counts[r][:o + 1])] for r in range(world)])
+        ri = torch.cat([shards[r][2][sum(counts[r][:o]):sum(counts[r][:o + 1])] for r in range(world)])
+        k = rh.numel()
+        rf = torch.zeros(max(k, 1), dtype=torch.uint8, device="cuda")
+        if k:
+            assert lib.snk_rmdup_mark_device(ctx.ctx, rh.contiguous().data_ptr(), ri.contiguous().data_ptr(), k, n, sent, rf.data_ptr(), None) == 0, lib.snk_last_error()
+        torch.cuda.synchronize()
+        owner_flags.append(rf)
+    for r in range(world):
+        hd, sh, si, slot, m = shards[r]
+        pieces = []
+        for o in range(world):
+            before = sum(counts[q][o] for q in range(r))
+            pieces.append(owner_flags[o][before:before + counts[r][o]])
+        back = torch.cat(pieces) if m else torch.zeros(1, dtype=torch.uint8, device="cuda")
+        dup = torch.empty(max(m, 1), dtype=torch.uint8, device="cuda")
+        assert lib.snk_rmdup_flags_home_device(ctx.ctx, back.contiguous().data_ptr(), slot.data_ptr(), m, dup.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        flags_home.append(dup.cpu().numpy()[:m])
+    ctx.close()
+    assert np.array_equal(np.concatenate(flags_home), want)

@@ -29,7 +29,7 @@ CORE = ["test_pe150_cases[C3_full", "test_pe150_cases[C2_adatrim_lowq", "test_pe
         "test_adapters_of_any_length_on_the_tiled_kernel[0]", "test_adapters_of_any_length_on_the_tiled_kernel[5]", "test_adapters_of_any_length_on_the_tiled_kernel[10]",
         "test_long_adapter_lists_and_lower_case_on_the_fast_paths[6]", "test_contam_fuzz[8]", "test_contam_fuzz_long_reads[4]", "test_long_reads[600", "test_long_reads[1000-True",
         "test_long_reads_plane_store", "test_random_parameter_contexts_on_the_device[20-", "test_hash_vs_oracle[150-160-True", "test_hash_odd", "test_mark_vs_oracle",
-        "test_one_pass_table_single_end_shift", "test_parse_and_format", "test_device_gzip_members_round_trip[5000", "test_device_inflate_kernels_produce_zlibs_bytes[65536]",
+        "test_one_pass_table_single_end_shift", "test_exchange_helpers_against_the_oracle[3]", "test_parse_and_format", "test_device_gzip_members_round_trip[5000", "test_device_inflate_kernels_produce_zlibs_bytes[65536]",
         "test_bit_transpose[random]"]
 CAP = 12000          # pairs per batch under the emulator (about 10 k pairs a second here); sizes up to it stay as they are
 
@@ -153,6 +153,11 @@ from test_rmdup_gpu import (test_hash_golden, test_hash_vs_oracle, test_hash_odd
 
 def test_one_pass_table_single_end_shift():
     RD.test_one_pass_table_single_end_shift()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_exchange_helpers_against_the_oracle(world):
+    RD.test_exchange_helpers_against_the_oracle(world)
 
 
 from test_fastq_gpu import (test_parse_and_format_match_the_restatement, test_parse_reports_bad_input, test_device_gzip_members_round_trip,      # noqa: E402,F401
