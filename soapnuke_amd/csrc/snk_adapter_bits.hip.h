@@ -181,7 +181,7 @@ __device__ __forceinline__ void screen_step2_bin(const u32 (&Pl)[NW], int cr1, i
 // NC = largest budget + 1 counter planes, at most 4: offsets whose own budget is 4 or more are not screened out by the count.
 template <int NW, bool FULL, int NC, class AD>
 __device__ __forceinline__ void screen_planes(const AD &A, const u32 (&NX)[4][NW], const u32 (&NXN)[NW], int len, bool done,
-                                              u32 (&aliveB)[NW], u32 (&aliveC)[NW]) {
+                                              u32 (&aliveB)[NW], u32 (&aliveC)[NW], int nofs) {
     const int al = A.len, S = max(A.S, 1), edge = A.edge, mis = A.mis;
     u32 C[NC][NW], BY[NW];
 #pragma unroll
@@ -253,7 +253,9 @@ __device__ __forceinline__ void screen_planes(const AD &A, const u32 (&NX)[4][NW
         // candidates: phase B offsets 0 .. len - al (budget adaMis), phase C offsets len - al + 1 .. len - edge (budget of
         // r1 = len - edge - p: at least k for r1 >= rk_k); adaEdge may exceed the adapter (then there is no phase C at all)
         const u32 bm = lowmask32(len - al + 1 - 32 * j);                    // phase B region
-        const u32 valid = bm | lowmask32(len - edge + 1 - 32 * j);
+        // (nofs: the offsets this call owns -- a block in the middle of a long read owns its first 256, the planes behind them
+        // only serve as the characters an alignment reaches)
+        const u32 valid = (bm | lowmask32(len - edge + 1 - 32 * j)) & lowmask32(nofs - 32 * j);
         auto thermo = [&](const int rk, const int k) { return (mis >= k ? bm : 0u) | (~bm & lowmask32(len - edge - rk + 1 - 32 * j)); };
         const u32 t1 = thermo(rk1, 1);
         u32 rej = C[0][j] & ~t1;
@@ -274,16 +276,21 @@ __device__ __forceinline__ void screen_planes(const AD &A, const u32 (&NX)[4][NW
 
 // Adapter search for the lanes with `todo`; returns the position or -1.
 // X[k] bit p = read[p] == "ACGT"[k] (exact), ones beyond the read; XN likewise for 'N'.
-// doA / doC (per lane): the planes start at the read's first character / end at its last one.  A block in the middle of
-// a long read (snk_long.hip) has neither: only the offsets of phase B exist there.
+// doA (per lane): the planes start at the read's first character (phase A exists, and `len` is the whole read).
+// Blocks of a long read (snk_long.hip): `len` is what is LEFT of the read from the block's first position on (it may reach far
+// past the planes), `nofs` the number of offsets the block owns (256, all of them in the read's last block) -- which of them are
+// phase B and which phase C follows from len as in a whole read; the screen looks at 64 characters at most and an exact decision
+// either fits the 64 match bits (adapters up to 64 characters: 255 + 63 < the planes' 320 positions) or walks the row.
+// *hit_c: the position returned is a phase C one (a later block's phase C hit takes precedence: descending offsets, :765-788).
 template <int NW, bool FULL, class AD>
 __device__ int adapter_tile(const AD &A, const DevAdapter &AG, const u32 (&X)[4][NW], const u32 (&XN)[NW],
-                            int len, bool todo, const uint8_t *sptr, bool doA = true, bool doC = true, bool seq_lane = false) {
+                            int len, bool todo, const uint8_t *sptr, bool doA = true, bool doC = true, bool seq_lane = false,
+                            int nofs = 32 * NW, bool *hit_c = nullptr) {
     const int al = A.len, S = max(A.S, 1), edge = A.edge, mis = A.mis;
     int result = -1;
     bool done = !todo;
     // seq_lane: a read with characters the planes do not hold against an adapter with lower-case characters
-    if (!done && (len < al || seq_lane)) {           // shorter than the adapter: negative offsets, rare -> sequential
+    if (!done && ((len < al && doA) || seq_lane)) {  // a READ shorter than the adapter: negative offsets, rare -> sequential
         result = adapter_pos_seq(sptr, len, AG);
         done = true;
     }
@@ -308,9 +315,9 @@ __device__ int adapter_tile(const AD &A, const DevAdapter &AG, const u32 (&X)[4]
     // ---------------- phases B+C screening: candidates p = 0 .. len-edge, bit-sliced
     u32 aliveB[NW], aliveC[NW];
     if (SNK_ABL != 7 && __any(!done)) {
-        if (A.maxb <= 1) screen_planes<NW, FULL, 2>(A, X, XN, len, done, aliveB, aliveC);
-        else if (A.maxb == 2) screen_planes<NW, FULL, 3>(A, X, XN, len, done, aliveB, aliveC);
-        else screen_planes<NW, FULL, 4>(A, X, XN, len, done, aliveB, aliveC);
+        if (A.maxb <= 1) screen_planes<NW, FULL, 2>(A, X, XN, len, done, aliveB, aliveC, nofs);
+        else if (A.maxb == 2) screen_planes<NW, FULL, 3>(A, X, XN, len, done, aliveB, aliveC, nofs);
+        else screen_planes<NW, FULL, 4>(A, X, XN, len, done, aliveB, aliveC, nofs);
     } else {
 #pragma unroll
         for (int j = 0; j < NW; ++j) aliveB[j] = aliveC[j] = 0;
@@ -330,7 +337,7 @@ __device__ int adapter_tile(const AD &A, const DevAdapter &AG, const u32 (&X)[4]
     while (SNK_ABL != 6 && __any(!done && (pa != 0 || any_bit(aliveB) || any_bit(aliveC)))) {
         if (!done) {
             int p = 0, sh = 0, n = 0, budget = 0, res = 0;
-            bool have = true, skip_eval = false, skip_ok = false;
+            bool have = true, skip_eval = false, skip_ok = false, from_c = false;
             if (pa) {
                 sh = __ffs((int)pa) - 1;
                 pa &= pa - 1;
@@ -349,6 +356,7 @@ __device__ int adapter_tile(const AD &A, const DevAdapter &AG, const u32 (&X)[4]
                 clear_bit(aliveC, p);
                 n = len - p;                                         // compared length, edge <= n < al
                 res = p;
+                from_c = true;
                 if (n < S && n <= 64 && A.maxb <= 3) { skip_eval = true; skip_ok = !A.negC; }  // no run possible and every cell screened: survived <=> mis <= budget (exact counters)
                 else budget = AG.budgetC[n - edge];
             } else {
@@ -368,7 +376,7 @@ __device__ int adapter_tile(const AD &A, const DevAdapter &AG, const u32 (&X)[4]
                         ok = accept_exact(m, n, S, budget);
                     }
                 }
-                if (ok) { result = res; done = true; }
+                if (ok) { result = res; done = true; if (hit_c) *hit_c = from_c; }
             }
         }
     }

@@ -444,7 +444,8 @@ __device__ inline void ts_update(CT *ts, int hd_h, int lq_h, int hd_t, int lq_t,
     }
 }
 
-__device__ __forceinline__ void report_err(const DevStats &st, u64 index, int mate, int code) {
+template <class ST>      // ST: DevStats, or DevStats in the constant address space
+__device__ __forceinline__ void report_err(const ST &st, u64 index, int mate, int code) {
     // within one pair the reference meets stat_read() errors of either mate before the
     // quality-range check of the raw-stats pass: class bit 5 orders them that way
     atomicMin(st.err, (index << 8) | ((u64)(code == SNK_E_QUAL_RANGE) << 5) | ((u64)mate << 4) | (u64)code);

@@ -23,11 +23,25 @@ typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 #define SNK_LDS_ADDR(p) ((uint32_t)(uintptr_t)(snk::lds_u32_ptr)(p))
 // the value lives in a scalar register from here on (the compiler may not fold what it knows about it into the code behind)
 #define SNK_OPAQUE_S(x) asm volatile("" : "+s"(x))
+// The kernel's own argument block (its single by-value struct argument A sits at offset 0 of the kernarg segment) as a pointer
+// into the constant address space; SNK_FRESH_ARGS: the same pointer as a value the compiler cannot see through -- what is
+// loaded and derived through it is loaded and derived THERE, not hoisted to the kernel's entry and carried (spilled) across loops
+#define SNK_KERNARG_PTR(T, A) ((const T *)__builtin_amdgcn_kernarg_segment_ptr())
+#define SNK_FRESH_ARGS(p) asm volatile("" : "+s"(p))
 
 // clang exposes readlane but not writelane as a builtin; the LLVM intrinsic is bound above
 // (v_writelane_b32: uniform value -> one lane of a VGPR; per-read scalars and the rare fix-up pass use it).
 __device__ __forceinline__ int wl(int dst, int val, int lane) { return __snk_writelane(val, lane, dst); }
 __device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// 1 when any lane of a wave mask is set, else 0 -- on the scalar unit (s_cmp_lg_u64 + s_cselect_b32).  Written out because the
+// compiler turns every C spelling of it (`m != 0`, min(popcount(m), 1), (m | -m) >> 63) into a boolean that it then moves through a
+// vector select and a v_readfirstlane: two VALU instructions per read in phase 1's loop for a value that never leaves the scalar side.
+__device__ __forceinline__ g9_u32 mask_nonzero(unsigned long long m) {
+    g9_u32 f;
+    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(f) : "s"(m) : "scc");
+    return f;
+}
 
 // Fire-and-forget LDS add with a compile-time offset.  Issued as inline asm on purpose: with a
 // global_load_lds (LDS DMA) in flight hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS

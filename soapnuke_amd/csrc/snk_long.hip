@@ -235,6 +235,7 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
             const int n_ada = P.n_ada[m];
             int cntA = 0, cntN = 0;
             int best_a = 0x7fffffff, best_pos = -1;                  // the adapter earliest in the list with a hit so far, and where
+            bool best_c = false;                                     // ... a phase C hit: the same adapter's phase C hit in a later block comes first in the reference's order
             u32 other = 0;
             bool through = false;                                    // this lane has seen its final block
             for (int p0 = 0; __any(longish && !through); p0 += LBLK) {
@@ -246,12 +247,19 @@ snk_long_decide_kernel(const DevParams *Pp, const TileAdapters TA, DevBatch B, D
                 if (n_ada > 0) {
                     // the first adapter of the list with a hit decides, whatever block its hit is in (src/read_filter.cpp:175-188):
                     // only adapters in front of the best one so far are still searched
+                    // (an adapter of up to 64 characters has its phase C offsets in the read's last block only; a longer one may have
+                    // them in the last TWO: phase C is walked by descending offset, src/read_filter.cpp:765-788, so a phase C hit
+                    // of the best adapter in a later block replaces its phase C hit of the block before)
                     for (int a = 0; a < n_ada; ++a) {
-                        const bool todo = here && a < best_a;
+                        const bool todo = here && (a < best_a || (a == best_a && best_c));
                         if (__any(todo)) {
                             const CTileAdapter &Acur = ((const CTileAdapter *)(uintptr_t)P.tile_ada)[m * P.ada_stride + a];
-                            const int rel = adapter_tile<LNW, true>(Acur, P.ada[m * P.ada_stride + a], X, XN, vlen, todo, s[m] + p0, p0 == 0, final);
-                            if (todo && rel >= 0) { best_a = a; best_pos = p0 + rel; }
+                            bool hc = false;
+                            // the block as adapter_tile sees it: `rem` characters are left of the read (the planes show 320 of them), the
+                            // block owns its first 256 offsets, the last block all of its own
+                            const int rel = adapter_tile<LNW, true>(Acur, P.ada[m * P.ada_stride + a], X, XN, here ? rem : 0, todo, s[m] + p0, p0 == 0, true, false,
+                                                                    final ? 32 * LNW : LBLK, &hc);
+                            if (todo && rel >= 0) { best_a = a; best_pos = p0 + rel; best_c = hc; }
                         }
                     }
                 }

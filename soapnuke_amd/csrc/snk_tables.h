@@ -64,7 +64,9 @@ inline void build_adapter(DevAdapter &A, const char *seq, int mis, float mr, int
     // SNK_PROVEN_ONLY=1: the envelope the last hardware-green GPUTEST record covers -- 6..64 characters, adaEdge within
     // the adapter -- ; anything else takes the sequential matcher of the generic kernel as it did then
     if (snk_proven_only() && !(al >= 6 && al <= 64 && edge <= al)) A.tile_ok = 0;
-    A.long_ok = (A.tile_ok && al >= 6 && al <= 64 && edge <= al) ? 1 : 0;
+    // (round 5: the blocks of the long-read kernel take what the tiled kernel takes -- a block is told how much of the read is left
+    // and which offsets are its own, csrc/snk_adapter_bits.hip.h; SNK_PROVEN_ONLY=1 keeps the envelope of the last hardware-green run)
+    A.long_ok = (A.tile_ok && (!snk_proven_only() || (al >= 6 && al <= 64 && edge <= al))) ? 1 : 0;
     for (int c = 0; c < al; ++c) {
         int k = 4;
         switch (seq[c]) { case 'A': k = 0; break; case 'C': k = 1; break; case 'G': k = 2; break; case 'T': k = 3; break; case 'N': k = 5; break; default: break; }

@@ -37,6 +37,7 @@
 // flight.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include <utility>
 #include "snk_common.hip.h"
@@ -139,7 +140,8 @@ __device__ __forceinline__ PackedRS rs_pack(const ReadState &r, int estat) {
     p.sumq = r.sumq;
     return p;
 }
-__device__ __forceinline__ void rs_unpack(const DevParams &P, int mate, const PackedRS &p, ReadState &r) {
+template <class PT>
+__device__ __forceinline__ void rs_unpack(const PT &P, int mate, const PackedRS &p, ReadState &r) {
     const u32 lo = (u32)p.a, hi = (u32)(p.a >> 32);
     r.len = (int)(lo & 511u);
     r.n_a = (int)((lo >> 9) & 511u);
@@ -190,23 +192,35 @@ constexpr int SNK_LDS_TAIL = 64 + 80;
 template <int PITCH_, int CBA_, int RB_> struct TileShape { static constexpr int PITCH = PITCH_, CBA = CBA_, RB = RB_; };
 typedef TileShape<0, 0, 0> ShapeRT;
 
+// The kernel's argument block: ONE struct by value, so that it sits at offset 0 of the kernarg segment and the kernel can look at
+// it through a constant-address-space pointer of its own (SNK_KERNARG_PTR).  Round 5: the four structs used to be four by-value
+// arguments; everything loaded from them and everything derived from that is loop-invariant, so the compiler loaded and derived all
+// of it at the kernel's entry and carried it through the tile loop -- 230 scalar registers spilled into VGPR lanes, 600 v_readlane
+// reloads in the code (tools/isa_spills.py).  Now each region of a tile (phases 1-2 of the mates, the pair level with phase 3,
+// the flush) takes a FRESH look (SNK_FRESH_ARGS: the pointer passes through an empty asm): its scalar loads and address arithmetic
+// happen where they are used, on the scalar unit (which has slots to spare: the kernel is bound by VALU issue), and die there.
+struct TiledArgs { DevParams P; DevBatch B; DevStats st; TileGeom G; int iters, flush_every; };
+typedef __attribute__((address_space(4))) TiledArgs CTiledArgs;
+
 // One tile = up to 64 pairs starting at t0, processed by one wave.
 // The mate loops are deliberately NOT unrolled (one copy of phases 1-3 in the instruction cache);
 // per-mate results are handed over in the two ReadState values r0 / r1.
 template <int NW, bool FULL, bool STAGED, class SH>
-__device__ void process_tile(const DevParams &P, const TileAdapters &TA, const DevBatch &B, const DevStats &st, const TileGeom &G,
-                             u32 *lds, long t0, int cnt) {
+__device__ void process_tile(const CTiledArgs *ka, u32 *lds, long t0, int cnt) {
     constexpr int NS = (NW + 1) / 2;
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));   // keep per-lane address math local to the tile (no hoisting out of the tile loop)
+    const bool lanev = lane < cnt;
+    PackedRS pl = {0ull, 0u, 0};                      // the state of the mate the loop ran last (written by every iteration: nothing is carried)
+    {   // ------------------------------------------------------------ phases 1 and 2 of the mates: their own look at the arguments
+    const CTiledArgs *ka1 = ka;
+    SNK_FRESH_ARGS(ka1);
+    const auto &P = ka1->P;
+    const auto &B = ka1->B;
+    const auto &G = ka1->G;
     const int mates = P.paired ? 2 : 1;
     const int phred = P.phred, nq = G.nq, lowQ = P.low_qual;
-    const bool lanev = lane < cnt;
-    const long fb = file_block(G.lcap, nq);
-    const long ts_off = SNK_GS_N + (long)G.lcap * 5 + (long)G.lcap * nq;
     const int lgb = G.lg + 2;                         // log2(bytes per histogram bin row)
-
-    PackedRS pl = {0ull, 0u, 0};                      // the state of the mate the loop ran last (written by every iteration: nothing is carried)
     const bool oobH = (0 - phred) < P.lq_head_q, oobT = (0 - phred) < P.lq_tail_q;
 
     const uint8_t *const seq0 = B.seq[0], *const seq1 = B.seq[1], *const qual0 = B.qual[0], *const qual1 = B.qual[1];
@@ -234,7 +248,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         //   aQ   quality >= lowQual + 1 (bit 7 of quality + 128 - threshold; no carry between valid bytes, which are
         //        < 128): aQ = aQ >> 1 | bit 7, parked every 8 reads
         //   aA / aT (FULL)  quality >= head / tail threshold of the low-quality-end trim, like aQ
-        //   badv one bit per READ: some character of this lane's dword is not exactly the letter its code stands for
+        //   sbad one bit per READ, a SCALAR: some lane's dword of the read holds a character that is not exactly the letter its code stands for
         //        (v_perm picks that letter for the four bytes at once), shifted in through the carry
         // The parked dwords (PC: 16, PQ / PA / PT: 8) cross over to lane = read in the hand-over below.  Bytes past the
         // read's end are forced to 'A' first, so they raise no flag and count as code 00 (subtracted at the hand-over).
@@ -242,7 +256,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         // (16-element vectors: the compiler parks into them with s_set_gpr_idx; 8-element ones get a v_cndmask chain)
         v16u PQA = PC;                     // [0,8): aQ, [8,16): aA
         v8u PTT = {0, 0, 0, 0, 0, 0, 0, 0}; // aT
-        u32 aC = 0, aQ = 0, aA = 0, aT = 0, badv = 0, bad0 = 0;
+        u32 aC = 0, aQ = 0, aA = 0, aT = 0;
+        u64 sbad = 0;                      // read r of the tile: bit (reads walked so far - 1 - r)
         u32 aS = 0;                        // FULL, mean-quality filter: byte sums of this lane's four qualities, reads 2k (low half) and 2k+1
         const bool has_px = FULL && __builtin_amdgcn_readfirstlane(P.polyX_num) != -1;
         const bool has_lq = FULL && SNK_ABL != 17 && __builtin_amdgcn_readfirstlane(P.has_lq) != 0;
@@ -314,14 +329,18 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 else aC = (t << (2 * jq - 1)) | aC;                            // v_lshl_or
                 const u32 ex = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, t);   // the letter each code stands for
                 const u32 df = (ex ^ c4) & vm;                                 // one v_bitop3
-                // badv = 2 * badv + (some byte is not the letter of its code): v_min_u32 + v_lshl_or_b32 (a v_cmp / v_addc_co pair
-                // through VCC costs the same two instructions, but VALU-writes-VCC -> VALU-reads-VCC wants two wait states on gfx950
-                // that hand-written asm would have to pad)
-                badv = (badv << 1) | min(df, 1u);
+                // one bit per read, wave-wide: the vector compare leaves the lanes with such a byte as a scalar mask (one VALU
+                // instruction), "any lane" and the shift into the tile's flag word are scalar-unit work.  (Per-lane flag words --
+                // compare + select + shift-or, three VALU instructions per read, and two wave-wide OR reductions per tile-mate at the
+                // hand-over -- were what this replaced in round 5.)
+                sbad = (sbad << 1) | (u64)mask_nonzero(__ballot(df != 0u));
                 aQ = (aQ >> 1) | ((q4 + KQ) & 0x80808080u);                   // v_add, v_lshrrev, v_and_or
                 if (FULL) {
-                    if (has_lqh) aA = (aA >> 1) | ((q4 + KA) & 0x80808080u);
-                    if (has_lqt) aT = (aT >> 1) | ((q4 + KT) & 0x80808080u);
+                    // Real scalar branches (the empty asm keeps the compiler from turning them back into selects: left to itself it
+                    // computes both collectors for every read and SELECTS -- configs[2] trims tails only: four of its VALU
+                    // instructions per read were the head collector it does not have and two selects)
+                    if (has_lqh) { aA = (aA >> 1) | ((q4 + KA) & 0x80808080u); asm volatile("" : "+v"(aA)); }
+                    if (has_lqt) { aT = (aT >> 1) | ((q4 + KT) & 0x80808080u); asm volatile("" : "+v"(aT)); }
                     int hm = has_meanq;                // (the mean-quality filter selects the FULL variant)
                     SNK_OPAQUE_S(hm);       // a plain scalar compare + branch per read (hoisted, the flag turns into lane masks)
                     if (hm != 0 && SNK_ABL != 16) {
@@ -331,6 +350,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                         const u32 qm = q4 & vm;
                         if (!odd) aS = __builtin_amdgcn_sad_u8(qm, 0u, 0u);
                         else aS = __builtin_amdgcn_sad_hi_u8(qm, 0u, aS);
+                        asm volatile("" : "+v"(aS));       // (a branch, not a select)
                     }
                 }
             }
@@ -358,7 +378,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         };
         // a read that does not exist (last tile of a batch): keep the collectors aligned
         auto skip_read = [&](auto JC, const int r) {
-            aQ >>= 1; badv <<= 1;
+            aQ >>= 1; sbad <<= 1;
             if (FULL) {
                 aA >>= 1; aT >>= 1;
                 if (decltype(JC)::v & 1) sum_flush(r);          // (read r - 1 may exist)
@@ -375,7 +395,6 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
             if (FULL) {
                 if (has_lq) { PQA[8 + o] = aA; PTT[o] = aT; aA = aT = 0; }
             }
-            if (o == 3) { bad0 = badv; badv = 0; }
         };
         auto run_phase1 = [&](auto FL, auto C64) {
             constexpr bool CNT64 = decltype(C64)::value;      // a whole tile: no per-read existence test
@@ -403,8 +422,8 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                     if (!(SS && CNT64) && (k + 1) * rb > cnt) off = min(lane * 16, (cnt - k * rb) * pitch - 16);     // last chunk of the last tile
                     SNK_WAVE_SYNC();                       // (every lane has its rows of the buffer's previous chunk in registers)
                     if (SNK_ABL != 12 && dlane) {          // same instruction count every chunk (counted vmcnt below)
-                        dma_to_lds16(gs + off, dst);
-                        dma_to_lds16(gq + off, dst + cba);
+                        dma_to_lds16(gs + (u32)off, dst);      // (scalar base + zero-extended lane offset: the saddr form, no 64-bit add per lane)
+                        dma_to_lds16(gq + (u32)off, dst + cba);
                     }
                     gs += chunkB;
                     gq += chunkB;
@@ -576,11 +595,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         } else {
             run_phase1(std::false_type{}, std::false_type{});
         }
-        if (cnt < 64) {                           // fewer than 8 octets: move the read flags to where 64 reads would have put them
-            const int nocts = (cnt + 7) >> 3;
-            if (nocts < 4) { bad0 = badv << (8 * (4 - nocts)); badv = 0; }
-            else if (nocts > 4 && nocts < 8) badv <<= 8 * (8 - nocts);
-        }
+        const int walked = cnt == 64 ? 64 : 8 * ((cnt + 7) >> 3);       // reads phase 1 walked (whole octets): read r sits at bit walked - 1 - r of sbad
         __builtin_amdgcn_s_setprio((SNK_PRIO / 100) % 10);            // hand-over, planes, fix-up
         // ------------------------------------------------------------ hand-over: lane = 4 positions -> lane = read
         ReadState R;
@@ -656,14 +671,17 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                         bit_transpose64(i0, i1, lane);
                         cover = __popc(i0) + __popc(i1);
                     }
-                    u32 nC = 0, nT = 0, nG = 0;
+                    // C = code 01, T = 10, G = 11 of a bit pair: with P = all set bits, PL = set low bits and G = pairs with both set,
+                    // C = PL - G and T = (P - PL) - G: three popcounts and three logic operations per word (round 4: nine)
+                    u32 pP = 0, pL = 0, nG = 0;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        const u32 x = cw[s][w], l = x & 0x55555555u, h = (x >> 1) & 0x55555555u;
-                        nC += __popc(l & ~h);
-                        nT += __popc(h & ~l);
-                        nG += __popc(l & h);
+                        const u32 x = cw[s][w];
+                        pP += __popc(x);
+                        pL += __popc(x & 0x55555555u);
+                        nG += __popc(x & (x >> 1) & 0x55555555u);
                     }
+                    u32 nC = pL - nG, nT = pP - pL - nG;
                     if (!fulllen && nomask && 64 * s + lane >= lenF) nC = nT = nG = 0;   // (fixed-length tile: duplicates past the end)
                     const u32 nA = cover - nC - nT - nG;
                     const u32 sh = (s & 1) ? 16u : 0u;
@@ -715,10 +733,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
                 X[3][j] = HP[j] & ~LP[j];
             }
             // reads with a character that is not exactly A/C/G/T: flag word bit 31 - (r & 31), OR over the lanes
-            {
-                const u32 f0 = wave_or(bad0), f1 = wave_or(badv);
-                badread = (((lane < 32 ? f0 : f1) >> (31 - (lane & 31))) & 1u) != 0;
-            }
+            badread = lane < walked && ((sbad >> (walked - 1 - lane)) & 1ull) != 0;
             if (FULL) {
                 if (has_px) {
                     // "same character as the previous position" (polyX) from the planes: same code bits and both exact
@@ -883,6 +898,7 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
         pl = rs_pack(R, estat);
         if (m + 1 < mates && lanev) rs_park(B.out[0], t0 + lane, pl);
     }
+    }
 
     if ((SNK_ABL == 1 || SNK_ABL >= 11)) return;
     if (SNK_ABL == 2) {
@@ -892,6 +908,16 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
     // ---------------------------------------------------------------- pair level
     // (quality-range errors are found by the flush through the overflow bin)
     asm volatile("" : "+v"(lane));
+    const CTiledArgs *ka2 = ka;                       // (its own look at the arguments, as the flush: see TiledArgs)
+    SNK_FRESH_ARGS(ka2);
+    const auto &P = ka2->P;
+    const auto &B = ka2->B;
+    const auto &st = ka2->st;
+    const auto &G = ka2->G;
+    const int mates = P.paired ? 2 : 1;
+    const int phred = P.phred, nq = G.nq;
+    const int lgb = G.lg + 2;
+    const long fb = file_block(G.lcap, nq);
     const int pe = mates - 1;
     PackedRS p0 = pl, p1 = pl;
     if (pe && lanev) p0 = rs_fetch(B.out[0], t0 + lane);
@@ -1062,34 +1088,44 @@ __device__ void process_tile(const DevParams &P, const TileAdapters &TA, const D
 
 template <int NW, bool FULL, bool STAGED, int MAXW = 16, class SH = ShapeRT>
 __global__ void __launch_bounds__(MAXW * 64)
-snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, const DevStats st, const TileGeom G, const int iters,
-                 const int flush_every) {
-    // parameters travel by value in the kernarg segment: the compiler keeps them in SGPRs instead
-    // of re-loading them from global memory next to every atomic
+snk_tiled_kernel(const TiledArgs A) {
+    // the arguments travel by value in the kernarg segment and are looked at through a constant-address-space pointer, region by
+    // region (TiledArgs above): scalar loads where a value is used, nothing carried across the tile loop but this pointer
     HIP_DYNAMIC_SHARED(u32, lds)
     constexpr int NS = (NW + 1) / 2;
+    const CTiledArgs *const ka = SNK_KERNARG_PTR(CTiledArgs, A);
     const int lane = threadIdx.x & 63, W = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile index and addresses stay scalar
-    const int mates = P.paired ? 2 : 1;
-    const int nwords = 4 * G.SET + SNK_LDS_TAIL;    // histograms, per-lane scratch words, misc counters
-    for (int i = threadIdx.x; i < nwords; i += blockDim.x) lds[i] = 0;
+    const int iters = ka->iters, flush_every = ka->flush_every;
+    {
+        const int nwords = 4 * ka->G.SET + SNK_LDS_TAIL;    // histograms, per-lane scratch words, misc counters
+        for (int i = threadIdx.x; i < nwords; i += blockDim.x) lds[i] = 0;
+    }
     __syncthreads();
     // LDS histogram word of (bin b, position p = 64*s + l) = b*Lh + 64*(s>>1) + l, half-word s&1:
     // every address/increment of a strip is lane + compile-time constants (no per-lane tables), and
     // the 64 lanes of one ds_add hit 64 consecutive dwords (conflict-free).
     const int Wc = W;
     const long GW = (long)gridDim.x * W;
-    const long fb = file_block(G.lcap, G.nq);
+    const long n_pairs = ka->B.n;
     int flush_lo = 0;
     for (int it = 0; it < iters; ++it) {
         const long tile = (long)it * GW + SNK_TILE_OF(wave);
         const long t0 = tile * 64;
-        long rem = B.n - t0;
+        long rem = n_pairs - t0;
         const int cnt = rem >= 64 ? 64 : (rem > 0 ? (int)rem : 0);
-        if (cnt > 0) process_tile<NW, FULL, STAGED, SH>(P, TA, B, st, G, lds, t0, cnt);
+        if (cnt > 0) process_tile<NW, FULL, STAGED, SH>(ka, lds, t0, cnt);
         if ((it + 1) % flush_every == 0 || it + 1 == iters) {
             lds_wait_all();      // the asm histogram adds
             __syncthreads();
+            const CTiledArgs *kf = ka;               // the flush's own look at the arguments
+            SNK_FRESH_ARGS(kf);
+            const auto &P = kf->P;
+            const auto &B = kf->B;
+            const auto &st = kf->st;
+            const auto &G = kf->G;
+            const int mates = P.paired ? 2 : 1;
+            const long fb = file_block(G.lcap, G.nq);
             // flush: the workgroup's histogram words are added to its own slice of DevStats::part (plain adds: nobody else touches
             // it); snk_tiled_reduce_kernel sums the slices behind this kernel (global raw += raw ; global clean += raw - removed).
             // One 64-bit atomic per word and workgroup on the same 28 k counters (6 M atomics per launch, 256 deep per address)
@@ -1169,6 +1205,12 @@ snk_tiled_kernel(const DevParams P, const TileAdapters TA, const DevBatch B, con
     // orders the workgroup.
     __threadfence();
     __syncthreads();
+    const CTiledArgs *kd = ka;
+    SNK_FRESH_ARGS(kd);
+    const auto &P = kd->P;
+    const auto &st = kd->st;
+    const auto &G = kd->G;
+    const long fb = file_block(G.lcap, G.nq);
     if (lds[4 * G.SET + 64 + 68]) {
         u32 *wts = st.tsw + (size_t)blockIdx.x * (4 * SNK_TS_N);
         const long ts_off = SNK_GS_N + (long)G.lcap * 5 + (long)G.lcap * G.nq;
@@ -1245,7 +1287,11 @@ void go(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const De
             (void)hipGetLastError();
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), shmem, (hipStream_t)stream, hp, ta, b, st, G, iters, flush_every);
+    TiledArgs A;
+    memset(&A, 0, sizeof A);
+    A.P = hp; A.B = b; A.st = st; A.G = G; A.iters = iters; A.flush_every = flush_every;
+    (void)ta;                                    // (the descriptors are read from DevParams::tile_ada: lists of any length)
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(threads), shmem, (hipStream_t)stream, A);
     const int mates = hp.paired ? 2 : 1, per = (G.SET + 15) / 16;
     hipLaunchKernelGGL(snk_tiled_reduce_kernel, dim3((unsigned)(mates * per)), dim3(256), 0, (hipStream_t)stream, st, G, (int)wgs, mates);
 }

@@ -14,7 +14,10 @@ static inline uint8_t *simt_lds_at(g9_u32 addr) {
 }
 #define SNK_LDS_ADDR(p) ((uint32_t)((const uint8_t *)(p) - (const uint8_t *)simt_dyn_shared()))
 #define SNK_OPAQUE_S(x) ((void)(x))
+#define SNK_KERNARG_PTR(T, A) ((const T *)(uintptr_t)&(A))      // (the emulator hands the argument struct to every thread by value)
+#define SNK_FRESH_ARGS(p) ((void)(p))
 
+static inline uint32_t mask_nonzero(unsigned long long m) { return m != 0ull ? 1u : 0u; }
 static inline int wl(int dst, int val, int lane) { return simt_writelane(val, lane, dst); }
 static inline int rl(int v, int lane) { return simt_readlane(v, lane); }
 

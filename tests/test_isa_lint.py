@@ -45,6 +45,32 @@ def test_uses_behind_the_wait_are_fine(tmp_path):
     assert rep == []
 
 
+def test_a_scalar_load_between_a_row_read_and_its_counted_wait_is_reported(tmp_path):
+    """scalar loads share lgkmcnt and return OUT of order: one issued behind an asm ds_read can satisfy that read's counted wait in
+    its place (round 5: the kernel's parameters became on-demand scalar loads); one issued in front of the read cannot"""
+    body = HEAD + """	ds_read_b32 v80, v61 offset:0xa0
+	s_load_dword s4, s[0:1], 0x10
+	s_waitcnt lgkmcnt(1)
+	v_mov_b32_e32 v89, v80
+	s_endpgm
+"""
+    p = tmp_path / "k.s"
+    p.write_text(body)
+    funcs, rep = lint.lint_file(str(p))
+    assert funcs == 1 and len(rep) == 1 and "v_mov_b32_e32 v89, v80" in rep[0]
+    p.write_text(HEAD + """	s_load_dword s4, s[0:1], 0x10
+	ds_read_b32 v80, v61 offset:0xa0
+	ds_read_b32 v81, v61 offset:0xa4
+	s_waitcnt lgkmcnt(1)
+	v_mov_b32_e32 v89, v80
+	s_waitcnt lgkmcnt(0)
+	v_mov_b32_e32 v90, v81
+	s_endpgm
+""")
+    funcs, rep = lint.lint_file(str(p))
+    assert funcs == 1 and rep == [], rep
+
+
 def test_the_shipped_build_is_clean():
     asm = os.path.join(T.ROOT, "soapnuke_amd", "csrc", "build", "snk_tiled-hip-amdgcn-amd-amdhsa-gfx950.s")
     if not os.path.exists(asm):
@@ -56,8 +82,9 @@ def test_the_shipped_build_is_clean():
 
 def test_the_headline_instances_have_not_grown():
     """tools/isa_static.py: spilled registers, scratch bytes and instruction counts of the BASELINE configs[1] / [2] instances of the
-    tiled kernel in the build's assembly against the committed figures (profiles/r04_isa_static.json) -- a change that makes them
-    worse shows here, without a GPU"""
+    tiled kernel in the build's assembly against the committed figures (profiles/r05_isa_static.json: no spilled VGPR and 78 spilled
+    scalar registers in the configs[1] instance, 6 and 98 in the configs[2] one; round 4: 2 / 232 and 15 / 234) -- a change that makes
+    them worse shows here, without a GPU"""
     import subprocess
     import sys
 
@@ -65,6 +92,6 @@ def test_the_headline_instances_have_not_grown():
     asm = os.path.join(T.ROOT, "soapnuke_amd", "csrc", "build", "snk_tiled-hip-amdgcn-amd-amdhsa-gfx950.s")
     if not os.path.exists(asm):
         pytest.skip("no build directory (the assembly is kept by soapnuke_amd/build.py)")
-    r = subprocess.run([sys.executable, os.path.join(T.ROOT, "tools", "isa_static.py"), "--check", os.path.join(T.ROOT, "profiles", "r04_isa_static.json")],
+    r = subprocess.run([sys.executable, os.path.join(T.ROOT, "tools", "isa_static.py"), "--check", os.path.join(T.ROOT, "profiles", "r05_isa_static.json")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout

@@ -28,7 +28,7 @@ CORE = ["test_pe150_cases[C3_full", "test_pe150_cases[C2_adatrim_lowq", "test_pe
         "test_multi_flush_launches_emulated[5-1-C3_full", "test_adapter_fuzz[0]", "test_adapter_fuzz[27]", "test_adapter_budgets_above_three[mis0]",
         "test_adapters_of_any_length_on_the_tiled_kernel[0]", "test_adapters_of_any_length_on_the_tiled_kernel[5]", "test_adapters_of_any_length_on_the_tiled_kernel[10]",
         "test_long_adapter_lists_and_lower_case_on_the_fast_paths[6]", "test_contam_fuzz[8]", "test_contam_fuzz_long_reads[4]", "test_long_reads[600", "test_long_reads[1000-True",
-        "test_long_reads_plane_store", "test_random_parameter_contexts_on_the_device[20-", "test_hash_vs_oracle[150-160-True", "test_hash_odd", "test_mark_vs_oracle",
+        "test_long_reads_plane_store", "test_long_reads_adapters_of_any_length[600-200", "test_long_reads_adapters_of_any_length[600-3-", "test_random_parameter_contexts_on_the_device[20-", "test_hash_vs_oracle[150-160-True", "test_hash_odd", "test_mark_vs_oracle",
         "test_one_pass_table_single_end_shift", "test_exchange_helpers_against_the_oracle[3]", "test_parse_and_format", "test_device_gzip_members_round_trip[5000", "test_device_inflate_kernels_produce_zlibs_bytes[65536]",
         "test_bit_transpose[random]"]
 CAP = 12000          # pairs per batch under the emulator (about 10 k pairs a second here); sizes up to it stay as they are
@@ -118,6 +118,12 @@ def test_global_contaminants_outside_the_event_walk_range(i):
 @pytest.mark.parametrize("L,paired,var,name", LR.CASES)
 def test_long_reads(L, paired, var, name):
     LR.test_long_reads(L, paired, var, name)
+
+
+@pytest.mark.parametrize("L,alen,edge,mr", [(600, 100, 6, 0.5), (600, 3, 2, 0.7), (600, 200, 6, 0.5), (1000, 255, 10, 0.3), (600, 40, 60, 0.5), (640, 5, 6, 1.0),
+                                            (1000, 130, 3, 0.5)])
+def test_long_reads_adapters_of_any_length(L, alen, edge, mr):
+    LR.test_long_reads_adapters_of_any_length(L, alen, edge, mr)
 
 
 from test_long_reads_gpu import (test_long_reads_several_adapters_and_budgets, test_long_reads_contaminants_and_duplicates,      # noqa: E402,F401

@@ -45,9 +45,24 @@ def lint_function(name, lines, report, passes=2):
             if op == "s_waitcnt":
                 m = LGKM.search(ins)
                 if m:
+                    # at most `keep` of the outstanding LDS + SMEM operations may still be in flight.  LDS operations return in
+                    # order; scalar loads do NOT, so in the worst case the completed ones are all the scalar loads first: of the
+                    # LDS operations only (completed - scalar loads in flight) oldest ones are certain (a compiler-made s_load
+                    # between an asm ds_read and its counted wait would satisfy the wait in its place)
                     keep = int(m.group(1))
-                    if len(queue) > keep:
-                        queue = queue[len(queue) - keep:] if keep else []
+                    if keep == 0:
+                        queue = []
+                    else:
+                        done = len(queue) - keep
+                        n_smem = sum(1 for q in queue if q[3] == "smem")
+                        sure = max(0, done - n_smem)
+                        out = []
+                        for q in queue:
+                            if q[3] == "lds" and sure > 0:
+                                sure -= 1
+                                continue
+                            out.append(q)
+                        queue = out
                 elif "lgkmcnt" not in ins and re.fullmatch(r"s_waitcnt\s+\S+", ins) and "vmcnt" not in ins and "expcnt" not in ins:
                     queue = []      # a numeric immediate: treat as a full wait
                 continue
@@ -55,10 +70,10 @@ def lint_function(name, lines, report, passes=2):
                 queue = []
                 continue
             used = vregs(ins[len(op):])
-            pending = set().union(*[q[0] for q in queue]) if queue else set()
+            pending = set().union(*[q[0] for q in queue if q[3] == "lds"]) if queue else set()
             hit = used & pending
             if hit and walk == passes - 1 or (hit and walk == 0 and passes == 1):
-                src = [q for q in queue if q[0] & hit][0]
+                src = [q for q in queue if q[3] == "lds" and q[0] & hit][0]
                 report.append(f"{name}: line {no}: `{ins}` touches v{sorted(hit)} before the wait that covers `{src[2]}` (line {src[1]})")
                 found += 1
             if op.startswith("ds_"):
@@ -67,9 +82,9 @@ def lint_function(name, lines, report, passes=2):
                 returns = op.startswith(("ds_read", "ds_bpermute", "ds_permute", "ds_swizzle", "ds_consume", "ds_append")) or "_rtn" in op
                 if returns and ops:
                     dest = vregs(ops[0])
-                queue.append((dest, no, ins))
-            elif op.startswith("s_load") or op.startswith("s_buffer_load"):
-                queue = queue       # SMEM shares the counter: it only makes a counted wait stricter (see the module docstring)
+                queue.append((dest, no, ins, "lds"))
+            elif op.startswith("s_load") or op.startswith("s_buffer_load") or op.startswith("s_dcache") or op.startswith("s_memtime") or op.startswith("s_memrealtime"):
+                queue.append((set(), no, ins, "smem"))      # shares the counter and returns out of order (see s_waitcnt above)
     return found
 
 

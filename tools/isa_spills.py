@@ -91,11 +91,12 @@ def analyse(body):
     all_rd = sum(len(x) for x in rd.values())
     sp_wl = sum(len(wl.get(v, [])) for v in carriers)
     sp_rd = sum(len(rd.get(v, [])) for v in carriers)
-    # the hottest loop: the innermost loop with the most LDS reads (the phase-1 octet loop)
+    # the hottest loop: the phase-1 octet loop of whole tiles of full-length reads = the SMALLEST loop that holds the LDS reads of
+    # eight rows (the three shapes of phase 1 are three copies; any loop around them holds those reads too)
     hot = None
     for lo, hi in loops:
         n_lds = sum(1 for k in range(lo, hi + 1) if ins[k][1].startswith("ds_read"))
-        if hot is None or n_lds > hot[2]:
+        if n_lds >= 24 and (hot is None or hi - lo < hot[1] - hot[0]):
             hot = (lo, hi, n_lds)
     hot_sp = {"store": 0, "reload": 0, "valu": 0}
     if hot:
@@ -129,7 +130,7 @@ def main():
               f"v_writelane {r['writelane_all']} (spill stores {r['spill_stores']}, own {r['own_writelane']}); carrier VGPRs {r['carriers']}")
         print("  by loop depth (0 = executed once per launch ... deeper = more often): " +
               "; ".join(f"depth {d}: {v['store']} stores / {v['reload']} reloads" for d, v in r["by_loop_depth"].items()))
-        print(f"  phase-1 octet loop: {r['octet_loop']['valu']} VALU of which spill stores {r['octet_loop']['store']} / reloads {r['octet_loop']['reload']}")
+        print(f"  phase-1 octet loop (8 reads, the full-length shape): {r['octet_loop']['valu']} VALU of which spill stores {r['octet_loop']['store']} / reloads {r['octet_loop']['reload']}")
 
 
 if __name__ == "__main__":

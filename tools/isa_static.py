@@ -93,6 +93,12 @@ def main():
             for f in ("vgpr_spill_count", "private_segment_fixed_size", "vgpr_count"):
                 if a[f] > b[f]:
                     bad.append(f"{k}: {f} {b[f]} -> {a[f]}")
+            # scalar registers spilled into VGPR lanes: every reload is a v_readlane in a VALU slot (round 5: 232 -> 78); a handful
+            # more is allocation noise, the old level is a regression
+            if a.get("sgpr_spill_count", 0) > max(120, b.get("sgpr_spill_count", 0) + 16):
+                bad.append(f"{k}: sgpr_spill_count {b.get('sgpr_spill_count')} -> {a.get('sgpr_spill_count')}")
+            if a.get("insts_valu", 0) > b.get("insts_valu", 0) * 1.02:
+                bad.append(f"{k}: {b.get('insts_valu')} -> {a.get('insts_valu')} VALU instructions")
             if a["insts_total"] > b["insts_total"] * 1.02:
                 bad.append(f"{k}: {b['insts_total']} -> {a['insts_total']} instructions")
         print("\n".join(bad) if bad else "isa_static: the headline instances are within the committed figures")
