@@ -18,7 +18,10 @@ namespace {
 // a TileAdapter read through the constant address space (uniform address: scalar loads, hoisted like kernel arguments)
 typedef __attribute__((address_space(4))) TileAdapter CTileAdapter;
 
-__device__ __forceinline__ u32 lowmask32(int n) { return n <= 0 ? 0u : (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u)); }
+// the n lowest bits (n <= 0: none, n >= 32: all): clamp, 64-bit shift, low word - 1 (1 << 32 leaves 0 there, 0 - 1 = all ones):
+// v_med3_i32 + v_lshlrev_b64 + v_add_u32 where two compares, two selects, a shift and an add stood (round 5: the region masks of the
+// adapter screen are ~35 of these per adapter and tile-mate)
+__device__ __forceinline__ u32 lowmask32(int n) { return (u32)(1ull << min(max(n, 0), 32)) - 1u; }
 __device__ __forceinline__ u64 lowmask64(int n) { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); }
 
 // Exact outcome of one alignment of the reference's scan (src/read_filter.cpp:726-741 and
@@ -242,36 +245,43 @@ __device__ __forceinline__ void screen_planes(const AD &A, const u32 (&NX)[4][NW
     }
     // budgets as thermometer planes T_k = [budget >= k]; reject = mis count > budget
     const int rk1 = A.rk[1], rk2 = A.rk[2], rk3 = A.rk[3], rk4 = A.rk[0];     // (rk[0]: budgets >= 4, nC when there is none)
+    // (a scalar copy of this for waves whose live lanes all hold reads of one length -- the masks are functions of the length alone --
+    // was tried in round 5: ~3 VALU per read less on such tiles, but the second copy cost the kernel 6 / 12 more spilled VGPRs; the
+    // cheaper lowmask32() above halves the masks' cost for every tile instead)
+    auto tail = [&](const auto L) {
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
-        if constexpr (NC == 3 && SNK_SCREEN_BIN) {             // binary counter -> "at least 1 / 2 / 3 mismatches"
-            const u32 c0 = C[0][j], c1 = C[1][j];
-            C[0][j] = c0 | c1;
-            C[1][j] = c1;
-            C[2][j] = c0 & c1;
+        for (int j = 0; j < NW; ++j) {
+            u32 c0p = C[0][j], c1p = C[1][j], c2p = NC >= 3 ? C[NC >= 3 ? 2 : 0][j] : 0u;
+            if constexpr (NC == 3 && SNK_SCREEN_BIN) {         // binary counter -> "at least 1 / 2 / 3 mismatches"
+                const u32 c0 = c0p, c1 = c1p;
+                c0p = c0 | c1;
+                c1p = c1;
+                c2p = c0 & c1;
+            }
+            // candidates: phase B offsets 0 .. len - al (budget adaMis), phase C offsets len - al + 1 .. len - edge (budget of
+            // r1 = len - edge - p: at least k for r1 >= rk_k); adaEdge may exceed the adapter (then there is no phase C at all)
+            const u32 bm = lowmask32(L - al + 1 - 32 * j);                    // phase B region
+            // (nofs: the offsets this call owns -- a block in the middle of a long read owns its first 256, the planes behind them
+            // only serve as the characters an alignment reaches)
+            const u32 valid = (bm | lowmask32(L - edge + 1 - 32 * j)) & lowmask32(nofs - 32 * j);
+            auto thermo = [&](const int rk, const int k) { return (mis >= k ? bm : 0u) | (~bm & lowmask32(L - edge - rk + 1 - 32 * j)); };
+            const u32 t1 = thermo(rk1, 1);
+            u32 rej = c0p & ~t1;
+            if (NC >= 3) rej |= c1p & ~thermo(rk2, 2);
+            if (NC >= 4) rej |= c2p & ~thermo(rk3, 3);
+            if (NC >= 4) {
+                // four or more mismatches: out, except where the budget itself is 4 or more -- the counters stop at four, those
+                // offsets all go to the exact decision
+                rej |= C[NC >= 4 ? 3 : 0][j] & ~thermo(rk4, 4);
+            } else {
+                rej |= NC == 3 ? c2p : c1p;                                    // more mismatches than any budget of this adapter
+            }
+            const u32 alive = done ? 0u : (valid & ~rej);
+            aliveB[j] = alive & bm;
+            aliveC[j] = alive & ~bm;
         }
-        // candidates: phase B offsets 0 .. len - al (budget adaMis), phase C offsets len - al + 1 .. len - edge (budget of
-        // r1 = len - edge - p: at least k for r1 >= rk_k); adaEdge may exceed the adapter (then there is no phase C at all)
-        const u32 bm = lowmask32(len - al + 1 - 32 * j);                    // phase B region
-        // (nofs: the offsets this call owns -- a block in the middle of a long read owns its first 256, the planes behind them
-        // only serve as the characters an alignment reaches)
-        const u32 valid = (bm | lowmask32(len - edge + 1 - 32 * j)) & lowmask32(nofs - 32 * j);
-        auto thermo = [&](const int rk, const int k) { return (mis >= k ? bm : 0u) | (~bm & lowmask32(len - edge - rk + 1 - 32 * j)); };
-        const u32 t1 = thermo(rk1, 1);
-        u32 rej = C[0][j] & ~t1;
-        if (NC >= 3) rej |= C[1][j] & ~thermo(rk2, 2);
-        if (NC >= 4) rej |= C[NC >= 4 ? 2 : 0][j] & ~thermo(rk3, 3);
-        if (NC >= 4) {
-            // four or more mismatches: out, except where the budget itself is 4 or more -- the counters stop at four, those
-            // offsets all go to the exact decision
-            rej |= C[NC >= 4 ? 3 : 0][j] & ~thermo(rk4, 4);
-        } else {
-            rej |= C[NC - 1][j];                                             // more mismatches than any budget of this adapter
-        }
-        const u32 alive = done ? 0u : (valid & ~rej);
-        aliveB[j] = alive & bm;
-        aliveC[j] = alive & ~bm;
-    }
+    };
+    tail(len);
 }
 
 // Adapter search for the lanes with `todo`; returns the position or -1.

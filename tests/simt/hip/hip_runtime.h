@@ -357,6 +357,7 @@ static inline simt_u32x2 simt_permlane16_swap(unsigned vdst, unsigned vsrc, bool
 #define __builtin_amdgcn_readlane(x, l) simt_readlane((int)(x), (l))
 #define __builtin_amdgcn_ds_bpermute(a, v) simt_ds_bpermute((a), (v))
 #define __builtin_amdgcn_update_dpp(o, s, c, r, b, bc) simt_update_dpp((int)(o), (int)(s), (c), (r), (b), (bc))
+#define __builtin_amdgcn_mov_dpp(s, c, r, b, bc) simt_update_dpp(0, (int)(s), (c), (r), (b), (bc))
 #define __builtin_amdgcn_permlane32_swap(a, b, f, c) simt_permlane32_swap((a), (b), (f), (c))
 #define __builtin_amdgcn_permlane16_swap(a, b, f, c) simt_permlane16_swap((a), (b), (f), (c))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

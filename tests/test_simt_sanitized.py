@@ -73,11 +73,22 @@ def test_asan_sharded_ingest(tmp_path):
     CG.test_cli_sharded_ingest(True, True, True, tmp_path)
 
 
+@pytest.mark.parametrize("paired,n,gz_in", [(True, 40000, True), (False, 40100, False)])
+def test_asan_sharded_rmdup_and_wire(paired, n, gz_in, monkeypatch, tmp_path):
+    """round 5: the shards' wire (host wire here), the statistics all-reduce, the hash exchange with its partition / flags-home
+    kernels, the scout pass and the mid-stream start of the decoders"""
+    monkeypatch.setenv("SIMT_DEVICES", "2")
+    monkeypatch.setenv("SNK_SHARD_WIRE", "host")
+    import torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    CG.test_cli_sharded_rmdup_and_wire(paired, n, gz_in, tmp_path)
+
+
 def test_asan_streaming(tmp_path):
     CG.test_cli_streaming(True, 2, 50, ["pe_info", "outQualSys=1"], tmp_path)
 
 
-@pytest.mark.parametrize("which", ["pe_full", "gz", "rmdup_small_batches", "streaming", "sharded"])
+@pytest.mark.parametrize("which", ["pe_full", "gz", "rmdup_small_batches", "streaming", "sharded", "sharded_rmdup_gz"])
 def test_tsan_cli_host_threads(which, tsan_cli, tmp_path):
     if which == "pe_full":
         CG.test_cli_matches_reference_binary(CG.R.REPORT_CASES[1], tmp_path)
@@ -87,5 +98,17 @@ def test_tsan_cli_host_threads(which, tsan_cli, tmp_path):
         CG.test_cli_rmdup_one_pass_variants("small_batches", tmp_path)
     elif which == "streaming":
         CG.test_cli_streaming(True, 2, 50, ["pe_info", "outQualSys=1"], tmp_path)
+    elif which == "sharded_rmdup_gz":          # the scout's two decoder threads, the shards' readers started mid-stream, the wire
+        import torch
+        os.environ["SIMT_DEVICES"] = "2"
+        os.environ["SNK_SHARD_WIRE"] = "host"
+        try:
+            real = torch.cuda.device_count
+            torch.cuda.device_count = lambda: 2
+            CG.test_cli_sharded_rmdup_and_wire(True, 40000, True, tmp_path)
+        finally:
+            torch.cuda.device_count = real
+            os.environ.pop("SIMT_DEVICES", None)
+            os.environ.pop("SNK_SHARD_WIRE", None)
     else:
         CG.test_cli_sharded_ingest(True, False, False, tmp_path)
