@@ -206,7 +206,7 @@ typedef __attribute__((address_space(4))) TiledArgs CTiledArgs;
 // The mate loops are deliberately NOT unrolled (one copy of phases 1-3 in the instruction cache);
 // per-mate results are handed over in the two ReadState values r0 / r1.
 template <int NW, bool FULL, bool STAGED, class SH>
-__device__ void process_tile(const CTiledArgs *ka, u32 *lds, long t0, int cnt) {
+__device__ __forceinline__ void process_tile(const CTiledArgs *ka, u32 *lds, long t0, int cnt) {      // (one call site per kernel instance; as a call its uniform arguments would arrive in VGPRs)
     constexpr int NS = (NW + 1) / 2;
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));   // keep per-lane address math local to the tile (no hoisting out of the tile loop)
