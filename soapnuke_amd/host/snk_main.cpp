@@ -1656,6 +1656,7 @@ int main(int argc, char **argv) {
         const bool gz_in = is_gzip_file(o.fq1);
         GzScout sc[2];
         bool plan = false;
+        const long long t_plan = StageClock::now();
         if (!gz_in) {
             RecordIndex ri[2];
             for (int m = 0; m < mates; ++m) ri[m].open_and_count(inputs[m], ht);
@@ -1667,6 +1668,7 @@ int main(int argc, char **argv) {
                 for (int m = 0; m < mates; ++m) { off[m].resize((size_t)G + 1); for (int g = 0; g <= G; ++g) off[m][(size_t)g] = ri[m].offset_of(rec[(size_t)g]); }
             }
             for (int m = 0; m < mates; ++m) ri[m].done();
+            log << local_time() << "\trecord count of the plain input: " << nrec[0] << (mates == 2 ? " pairs, " : " reads, ") << (double)(StageClock::now() - t_plan) * 1e-9 << " s" << endl;
         } else {
             // .gz: the scout pass over both files at once (scout_gz above); the border records are the later of the two files' places
             const long long t_sc = StageClock::now();
@@ -1690,6 +1692,11 @@ int main(int argc, char **argv) {
             log << local_time() << "\tscout pass over the .gz input: " << nrec[0] << (mates == 2 ? " pairs, " : " reads, ") << (double)(StageClock::now() - t_sc) * 1e-9 << " s"
                 << (plan ? "" : "; not sharded (" + (!ok[0] ? sc[0].why : !ok[1] ? sc[1].why : string("the borders do not leave every shard a record")) + ")") << endl;
             for (int m = 0; m < mates; ++m) { off[m].assign((size_t)G + 1, 0); }
+        }
+        if (getenv("SNK_SHARD_PLAN_ONLY")) {               // (measuring the parent's pass in front of the run: the log has its time)
+            for (int g = 0; plan && g <= G; ++g) log << "border " << g << ": record " << rec[(size_t)g] << endl;
+            log.close();
+            _exit(0);
         }
         if (plan) {
             log << local_time() << "\tsharded run: " << G << " shards of about " << nrec[0] / (uint64_t)G << (mates == 2 ? " pairs" : " reads") << endl;
