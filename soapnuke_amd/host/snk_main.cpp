@@ -72,6 +72,7 @@ struct Options {
     string seq_type = "0";
     string contam[2], ct_match_r, global_contams, g_mrs, g_mms;     // kept here: snk_params points into them
     string trim_fq[2];                                               // trimFq1 / trimFq2 (gz): trimmed, not filtered
+    int trim_fq_gz[2] = {-1, -1};                                    // (a shard: its part's name no longer ends like the file's)
     string tile, fov;                                                // reads of these tiles / fovs are dropped (by name)
     string base_convert;
     // limits on the clean output (src/process_argv.cpp:426-443,1476-1552)
@@ -290,6 +291,12 @@ void parse_args(int argc, char **argv, Options &o) {         // src/process_argv
         }
     }
     if (const char *e = getenv("SNK_BATCH_PAIRS")) { const int v = atoi(e); if (v >= 64 && v <= (1 << 24)) o.batch_pairs = v; }   // pairs per pipeline slot (tuning / tests)
+    if (o.devices.empty())                                   // no --devices: SNK_DEVICES (the same list; a wrapper's or a test's default), else device 0
+        if (const char *e = getenv("SNK_DEVICES"))
+            for (const string &x : split(e, ',')) {
+                if (x.empty() || x.find_first_not_of("0123456789") != string::npos) die("SNK_DEVICES takes a comma separated list of HIP device numbers");
+                o.devices.push_back(atoi(x.c_str()));
+            }
     if (o.devices.empty()) o.devices.push_back(0);
     if (o.devices.size() > 16) die("--devices: at most 16 devices");
     if (argc != optind + 1) die("please check the options");
@@ -834,7 +841,10 @@ void reader_gz_count(const string path, int batch, int workers, Channel<RawChunk
     const uint8_t *zin = (const uint8_t *)mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (zin == MAP_FAILED) die("cannot map file," + path);
     madvise((void *)zin, (size_t)st.st_size, MADV_SEQUENTIAL);
-    GzSource z(zin, (size_t)st.st_size, workers, path);
+    // (owned by a pointer: a shard stops reading at its last record while the decoder's threads are still ahead of it in the
+    // mapping -- they have to be gone before the mapping is)
+    std::unique_ptr<GzSource> zp(new GzSource(zin, (size_t)st.st_size, workers, path));
+    GzSource &z = *zp;
     const size_t H = snk::GzipInflate::HIST, block = (size_t)1 << 24;
     RawChunk *cur = RawChunk::get();
     const size_t cap0 = H + (size_t)batch * 400 + 2 * block;
@@ -885,6 +895,7 @@ void reader_gz_count(const string path, int batch, int workers, Channel<RawChunk
         fill += got;
         if (fill > 0xF0000000ull) die("batch larger than 4 GB: lower the batch size");
     }
+    zp.reset();
     munmap((void *)zin, (size_t)st.st_size);
     close(fd);
     out->close();
@@ -951,7 +962,8 @@ void reader_gz(const string path, int batch, int space_num, int workers, Channel
     size_t pg_chunk = (size_t)2 << 20;
     if (const char *e = getenv("SNK_GZ_CHUNK")) { const long v = atol(e); if (v >= 65536) pg_chunk = (size_t)v; }
     (void)pg_chunk;
-    GzSource z(zin, (size_t)st.st_size, workers, path);     // (the host's parallel decoder, or the device one with SNK_DEVICE_INFLATE=1; a shard: its part)
+    std::unique_ptr<GzSource> zp(new GzSource(zin, (size_t)st.st_size, workers, path));     // (the host's parallel decoder, or the device one with SNK_DEVICE_INFLATE=1; a shard: its part)
+    GzSource &z = *zp;
     auto crc_drain = [] {};
     const size_t H = snk::GzipInflate::HIST, block = (size_t)1 << 24;
     RawChunk *cur = RawChunk::get();
@@ -1012,6 +1024,7 @@ void reader_gz(const string path, int batch, int space_num, int workers, Channel
         fill += got;
         if (fill > 0xF0000000ull) die("batch larger than 4 GB: lower the batch size");
     }
+    zp.reset();
     munmap((void *)zin, (size_t)st.st_size);
     close(fd);
     out->close();
@@ -1622,6 +1635,8 @@ int main(int argc, char **argv) {
         o.devices = std::vector<int>(1, o.devices[(size_t)g_shard.g]);
         o.clean1 += ".part" + std::to_string(g_shard.g);
         if (mates == 2) o.clean2 += ".part" + std::to_string(g_shard.g);
+        for (int m = 0; m < mates; ++m)
+            if (!o.trim_fq[m].empty()) { o.trim_fq_gz[m] = ends_with_gz(o.trim_fq[m]); o.trim_fq[m] += ".part" + std::to_string(g_shard.g); }
         if (getenv("SNK_SHARD_FAKE")) {
             // test hook (tests/test_shard_plumbing.py, no GPU): the shard copies its record range to its part files and reports empty
             // statistics -- what is left is exactly the parent's work: record boundaries, environment, concatenation, merging
@@ -1645,14 +1660,17 @@ int main(int argc, char **argv) {
         }
     }
     // (opt-in until it has met the hardware: SNK_SHARDED=1; without it several devices are fed batch by batch from one reader)
+    // What keeps a run from being sharded: outputs that count reads across the whole input (-j streaming, -w / cleanOutSplit,
+    // totalReadsNum) -- everything else, the host formatter's variants included (trimFq1/2, fasta, index removal, tile / fov), is a
+    // per-read matter and runs in the shards as it does in one process.
     const bool shardable = !g_shard.child && o.devices.size() > 1 && getenv("SNK_SHARDED") && !strcmp(getenv("SNK_SHARDED"), "1") &&
-                           (mates == 1 || is_gzip_file(o.fq1) == is_gzip_file(o.fq2)) && !o.streaming && o.trim_fq[0].empty() &&
-                           o.clean_out_split == 0 && !(o.total_reads > 0) && o.out_file_type != "fasta" && !o.index_remove && o.tile.empty() && o.fov.empty() &&
-                           !getenv("SNK_HOST_TEXT");
+                           (mates == 1 || is_gzip_file(o.fq1) == is_gzip_file(o.fq2)) && !o.streaming && o.clean_out_split == 0 && !(o.total_reads > 0);
     if (shardable) {
         const int G = (int)o.devices.size();
         std::vector<uint64_t> rec((size_t)G + 1), off[2];
         uint64_t nrec[2] = {0, 0};
+        // (an input of fewer records per shard than this is not worth the processes; SNK_SHARD_MIN_RECORDS: the tests' small inputs)
+        const uint64_t min_rec = getenv("SNK_SHARD_MIN_RECORDS") ? std::max<uint64_t>(1, strtoull(getenv("SNK_SHARD_MIN_RECORDS"), nullptr, 10)) : 4096;
         const bool gz_in = is_gzip_file(o.fq1);
         GzScout sc[2];
         bool plan = false;
@@ -1662,7 +1680,7 @@ int main(int argc, char **argv) {
             for (int m = 0; m < mates; ++m) ri[m].open_and_count(inputs[m], ht);
             if (mates == 2 && ri[0].n_records != ri[1].n_records) die("reads number in fq1 and fq2 are different");
             nrec[0] = ri[0].n_records; nrec[1] = ri[1].n_records;
-            if (nrec[0] >= (uint64_t)G * 4096) {
+            if (nrec[0] >= (uint64_t)G * min_rec) {
                 plan = true;
                 for (int g = 0; g <= G; ++g) rec[(size_t)g] = nrec[0] * (uint64_t)g / (uint64_t)G;
                 for (int m = 0; m < mates; ++m) { off[m].resize((size_t)G + 1); for (int g = 0; g <= G; ++g) off[m][(size_t)g] = ri[m].offset_of(rec[(size_t)g]); }
@@ -1680,7 +1698,7 @@ int main(int argc, char **argv) {
             }
             nrec[0] = sc[0].n_records; nrec[1] = sc[1].n_records;
             if (mates == 2 && nrec[0] != nrec[1]) die("reads number in fq1 and fq2 are different");
-            plan = ok[0] && ok[1] && nrec[0] >= (uint64_t)G * 4096;
+            plan = ok[0] && ok[1] && nrec[0] >= (uint64_t)G * min_rec;
             if (plan) {
                 rec[0] = 0; rec[(size_t)G] = nrec[0];
                 for (int g = 1; g < G; ++g) {
@@ -1784,6 +1802,7 @@ int main(int argc, char **argv) {
             };
             const string names[2] = {o.clean1, o.clean2};
             for (int m = 0; m < mates; ++m) join_parts(o.out_dir + "/" + names[m]);
+            if (!o.trim_fq[0].empty()) for (int m = 0; m < mates; ++m) join_parts(o.out_dir + "/" + o.trim_fq[m]);
             if (o.p.rmdup) {                                  // dupReads.<thread>.<mate>.gz: every shard wrote its share of every virtual thread's file
                 for (int m = 0; m < mates; ++m)
                     for (int t = 0; t < o.threads; ++t) join_parts(o.out_dir + "/dupReads." + std::to_string(t) + "." + std::to_string(m + 1) + ".gz");
@@ -2373,7 +2392,7 @@ int main(int argc, char **argv) {
     OutFile trimw[2];
     if (trim_out) {
         if (mates == 2 && o.trim_fq[1].empty()) die("trimFq2 is required with trimFq1");
-        for (int m = 0; m < mates; ++m) trimw[m].open(o.out_dir + "/" + o.trim_fq[m], ends_with_gz(o.trim_fq[m]));
+        for (int m = 0; m < mates; ++m) trimw[m].open(o.out_dir + "/" + o.trim_fq[m], o.trim_fq_gz[m] >= 0 ? o.trim_fq_gz[m] != 0 : ends_with_gz(o.trim_fq[m]));
     }
     Channel<Slot *> to_write((size_t)NSLOT * (size_t)G + 1);
     const bool rmdup_on = !dup_host.empty();

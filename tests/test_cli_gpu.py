@@ -633,6 +633,44 @@ def test_cli_sharded_rmdup_and_wire(paired, n, gz_in, tmp_path):
     assert not [x for x in os.listdir(ours) if ".part" in x or x.startswith("shard.")]
 
 
+SHARDED_VARIANTS = ["trim_pe", "trim_se", "tile", "fov", "index", "base_convert", "pe_info_crlf", "contam", "long", "reports_0", "reports_3", "gz_gz"]
+
+
+@T.first_contact
+@pytest.mark.parametrize("which", SHARDED_VARIANTS)
+def test_cli_variants_as_sharded_runs(which, monkeypatch, tmp_path):
+    """round 5: what keeps a run from being sharded is only what counts reads across the whole input (-j, -w, totalReadsNum); the host
+    formatter's variants -- trimFq1/2 (their parts joined like the clean files'), index removal, tile / fov, baseConvert, pe_info +
+    outQualSys, contaminants, long reads, .gz in and out -- run in the shards.  This module's own tests as sharded runs: two shards
+    on device 0 (listed twice: the host wire carries the collectives), whatever the size of the input."""
+    for k, v in (("SNK_DEVICES", "0,0"), ("SNK_SHARDED", "1"), ("SNK_SHARD_MIN_RECORDS", "300"), ("SNK_GZ_CHUNK", "65536")):
+        monkeypatch.setenv(k, v)
+    if which == "trim_pe":
+        test_cli_trim_outputs(True, tmp_path)
+    elif which == "trim_se":
+        test_cli_trim_outputs(False, tmp_path)
+    elif which == "tile":
+        test_cli_tile_and_fov_filters("tile_new", "tile=1103,1101", tmp_path)
+    elif which == "fov":
+        test_cli_tile_and_fov_filters("fov", "fov=C001R002,C004R001", tmp_path)
+    elif which == "index":
+        test_cli_index_removal("1", tmp_path)
+    elif which == "base_convert":
+        test_cli_base_convert("T2C", tmp_path)
+    elif which == "pe_info_crlf":
+        test_cli_pe_info_outqual_and_crlf(tmp_path)
+    elif which == "contam":
+        test_cli_contaminants_match_reference_binary(True, 150, 6000, tmp_path)
+    elif which == "long":
+        test_cli_long_reads(600, True, tmp_path)
+    elif which.startswith("reports_"):
+        test_cli_matches_reference_binary(R.REPORT_CASES[int(which[-1])], tmp_path)
+    else:
+        test_cli_gz_in_gz_out(tmp_path)
+    logs = [os.path.join(dp, f) for dp, _, fs in os.walk(str(tmp_path)) for f in fs if f == "log"]
+    assert any(b"sharded run: 2 shards" in open(x, "rb").read() for x in logs), "the run was not sharded"
+
+
 @pytest.mark.parametrize("paired", [True, False])
 def test_cli_longer_read_after_first_batch(paired, tmp_path):
     """The reference takes any read up to 1000 nt at any position; here the capacity comes from the first batch and is

@@ -103,9 +103,11 @@ def _context(i):
     mode = rng.random()
     if mode < 0.15:
         ours_cli = ["--devices", "0,0"]
-    elif mode < 0.3 and not gz_in and not rmdup:
-        ours_cli = ["--devices", "0,0"]
+    elif mode < 0.4:                                          # sharded run: two shards (a host wire between them: the device is listed twice),
+        ours_cli = ["--devices", "0,0"]                      # plain or .gz input (scout pass), with or without rmdup (hash exchange)
         env["SNK_SHARDED"] = "1"
+        env["SNK_SHARD_MIN_RECORDS"] = "700"                 # (the parent shards inputs of 4096 records per shard and more: these are smaller)
+        env["SNK_GZ_CHUNK"] = "65536"
         env.setdefault("SNK_BATCH_PAIRS", "1536")
     return dict(paired=paired, L=L, n=n, d=d, cli=cli, cfg=cfg, threads=threads, patch=patch, rmdup=rmdup, env=env, ours_cli=ours_cli, gz_in=gz_in, gz_out=gz_out)
 
