@@ -13,7 +13,7 @@ import test_gunzip_gpu as GZ
 
 # what an ordinary run takes (substrings of the test ids); SNK_SIMT_FULL=1: everything (tests/conftest.py)
 CORE = ["test_cli_matches_reference_binary[pe_full_T3]", "test_cli_gz_in_gz_out", "test_cli_rmdup_one_pass_variants[small_batches]",
-        "test_cli_sharded_ingest_emulated[True-True-True]", "test_cli_sharded_rmdup_and_wire_emulated[True-40000-True]", "test_cli_sharded_rmdup_and_wire_emulated[False-40100-False]", "test_cli_variants_as_sharded_runs_emulated[trim_pe]", "test_cli_variants_as_sharded_runs_emulated[tile]", "test_cli_rmdup_single_end_one_pass_emulated[20100-700-one]",
+        "test_cli_sharded_ingest_emulated[True-True-True]", "test_cli_sharded_rmdup_and_wire_emulated[True-40000-True]", "test_cli_sharded_rmdup_and_wire_emulated[False-40100-False]", "test_cli_variants_as_sharded_runs[trim_pe]", "test_cli_variants_as_sharded_runs[tile]", "test_cli_variants_as_sharded_runs[gz_gz]", "test_cli_rmdup_single_end_one_pass_emulated[20100-700-one]",
         "test_cli_rmdup_one_pass_across_two_devices_emulated[False", "test_cli_streaming[True-2-50"]
 pytestmark = pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")
 
@@ -40,11 +40,6 @@ def test_cli_sharded_rmdup_and_wire_emulated(paired, n, gz_in, two_emulated_devi
     """two shards on two emulated devices; the emulator has no RCCL: the host wire carries the collectives"""
     monkeypatch.setenv("SNK_SHARD_WIRE", "host")
     CG.test_cli_sharded_rmdup_and_wire(paired, n, gz_in, tmp_path)
-
-
-@pytest.mark.parametrize("which", CG.SHARDED_VARIANTS)
-def test_cli_variants_as_sharded_runs_emulated(which, monkeypatch, tmp_path):
-    CG.test_cli_variants_as_sharded_runs(which, monkeypatch, tmp_path)
 
 
 def test_cli_rmdup_table_that_does_not_fit_emulated(tmp_path):
