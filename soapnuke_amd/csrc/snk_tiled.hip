@@ -64,7 +64,12 @@ using namespace snk;
 #endif
 // wave priorities of phase 1 / hand-over / adapter search + pair level / phase 3, as a 4-digit number (tools/ab.sh experiments)
 #ifndef SNK_PAIR
-#define SNK_PAIR 0      // 1: two reads share the LDS ops of their short last quality strip (129..160 positions): 7 instead of 8 LDS ops per read, yet 4 % SLOWER (2.99 vs 2.87 ms, profiles/r02_pair_ab.txt) -- off
+// Two reads share the LDS ops of their short last quality strip (129..160 positions: 7 instead of 8 LDS ops and one clamp + address
+// pair less per read).  1 (default): on the static-shape loop only, where the shared strip costs no address select -- a second base
+// register, the row an immediate (round 5; the variant round 4's budget asked for: octet loop 124 -> 116 VALU, 64 -> 56 LDS ops);
+// 2: on the run-time-shape loop too, whose address selects made it 4 % SLOWER when it was measured (2.99 vs 2.87 ms,
+// profiles/r02_pair_ab.txt); 0: off.  tools/ab.sh builds the other two for an A/B.
+#define SNK_PAIR 1
 #endif
 #ifndef SNK_PRIO
 #define SNK_PRIO 3210
@@ -438,7 +443,7 @@ __device__ __forceinline__ void process_tile(const CTiledArgs *ka, u32 *lds, lon
                 // DMA: when the row of the last read of chunk k has been ISSUED (two reads before it is used), the next
                 // row to fetch is row 0 of chunk k+1, whose DMA is waited for there; one step later that last row sits in
                 // registers, and the DMA of chunk k+2 goes into the buffer of chunk k.
-                constexpr bool PAIR = SNK_PAIR && NW == 5 && FULLLEN && CNT64 && !SS;
+                constexpr bool PAIR = (SNK_PAIR == 2 || (SNK_PAIR == 1 && SS)) && NW == 5 && FULLLEN && CNT64;
                 constexpr int ROWOPS = 2 + NS;
                 constexpr int K = (SNK_ABL == 11 ? 0 : NS) + ROWOPS;
                 // PAIR: an even read's row fetch has all NS strips (the last one shared with the odd read behind it), an odd
@@ -468,20 +473,28 @@ __device__ __forceinline__ void process_tile(const CTiledArgs *ka, u32 *lds, lon
                 // static shape: two base registers for the whole tile (dword view / byte view of the wave's staging area), the row
                 // is an immediate: buffer parity * 2 * CBA + row in chunk * PITCH (+ CBA for the qualities, + 64 s for strip s)
                 u32 vC = stgA + lc4, vQ = stgA + (u32)lane;
-                asm volatile("" : "+v"(vC), "+v"(vQ));
-                auto lds_rd_s = [&](auto OFFC, u32 &c4, u32 &q4, u32 (&q)[NS]) {
+                // PAIR: the shared last strip -- lanes 0-31 this row's positions 64 (NS - 1) + lane, lanes 32-63 the same positions of the
+                // NEXT row (an even read and the odd one behind it sit in one chunk: RB is even)
+                u32 vQ2 = vQ + ((PAIR && lane >= 32) ? (u32)((SS ? SH::PITCH : 0) - 32) : 0u);
+                asm volatile("" : "+v"(vC), "+v"(vQ), "+v"(vQ2));
+                auto lds_rd_s = [&](auto OFFC, auto OD, u32 &c4, u32 &q4, u32 (&q)[NS]) {
                     constexpr int O = decltype(OFFC)::v;
                     constexpr int CB = SS ? SH::CBA : 0;
                     lds_read_b32_at<O>(c4, vC);
                     lds_read_b32_at<O + CB>(q4, vC);
-                    lds_read_qstrips_at<0, NS, O + CB>(q, vQ);
+                    if constexpr (PAIR) {
+                        lds_read_qstrips_at<0, NS - 1, O + CB>(q, vQ);
+                        if constexpr (!decltype(OD)::value) lds_read_qstrips_at<NS - 1, NS, O + CB>(q, vQ2);
+                    } else {
+                        lds_read_qstrips_at<0, NS, O + CB>(q, vQ);
+                    }
                 };
                 u32 C4[4], Q4[4], QS[4][NS];                // register set of read r: r & 3
                 u32 row = stgA;                             // LDS address of the newest prefetched row (scalar)
                 const int rbm = rb - 1, lgrb = 31 - __builtin_clz((unsigned)rb);     // rb is a power of two >= 2 (launch())
                 if constexpr (SS) {
-                    lds_rd_s(IntC<0>{}, C4[0], Q4[0], QS[0]);
-                    lds_rd_s(IntC<(SS ? SH::PITCH : 0)>{}, C4[1], Q4[1], QS[1]);
+                    lds_rd_s(IntC<0>{}, std::false_type{}, C4[0], Q4[0], QS[0]);
+                    lds_rd_s(IntC<(SS ? SH::PITCH : 0)>{}, std::true_type{}, C4[1], Q4[1], QS[1]);
                 } else {
                     lds_rd(std::false_type{}, C4[0], Q4[0], QS[0], row);
                     row += (u32)pitch;                      // (row 1 is in chunk 0: rb >= 2)
@@ -511,13 +524,15 @@ __device__ __forceinline__ void process_tile(const CTiledArgs *ka, u32 *lds, lon
                                     if (k + 1 < nchunks && SNK_ABL != 14) vmem_wait<0>();
                                 }
                                 constexpr int par = (R2 / RBs) & 1, rowi = R2 % RBs;
-                                lds_rd_s(IntC<par * 2 * (SS ? SH::CBA : 0) + rowi * (SS ? SH::PITCH : 0)>{}, C4[(j + 2) & 3], Q4[(j + 2) & 3], QS[(j + 2) & 3]);
-                                do_read(FL, IntC<j>{}, std::false_type{}, r, C4[j & 3], Q4[j & 3], QS[j & 3], 0u);
+                                lds_rd_s(IntC<par * 2 * (SS ? SH::CBA : 0) + rowi * (SS ? SH::PITCH : 0)>{}, std::integral_constant<bool, (j & 1) != 0>{},
+                                         C4[(j + 2) & 3], Q4[(j + 2) & 3], QS[(j + 2) & 3]);
+                                do_read(FL, IntC<j>{}, std::integral_constant<bool, PAIR>{}, r, C4[j & 3], Q4[j & 3], QS[j & 3], 0u);
+                                // behind the row of read r+1: the row of read r+2 and the adds of read r (both of this read's parity)
                                 if constexpr (j == 7) {
-                                    lds_wait<K - ROWOPS>(C4[0], Q4[0], QS[0]);       // loop edge: rows of reads r+1 and r+2 both in
-                                    lds_wait<K - ROWOPS>(C4[1], Q4[1], QS[1]);
+                                    lds_wait<PAIR ? ADDO : K - ROWOPS>(C4[0], Q4[0], QS[0]);       // loop edge: rows of reads r+1 and r+2 both in
+                                    lds_wait<PAIR ? ADDO : K - ROWOPS>(C4[1], Q4[1], QS[1]);
                                 } else {
-                                    lds_wait<K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
+                                    lds_wait<PAIR ? ((j & 1) ? ROWO + ADDO : ROWE + ADDE) : K>(C4[(j + 1) & 3], Q4[(j + 1) & 3], QS[(j + 1) & 3]);
                                 }
                                 if constexpr (closes) {
                                     if (k + 2 < nchunks) issue(k + 2);                 // every row of chunk k sits in registers now
@@ -1350,9 +1365,12 @@ int launch(const DevParams &hp, const TileAdapters &ta, const DevBatch &b, const
     const int iters = (int)((tiles + GW - 1) / GW);
     int flush_every = 65535 / (W * 64);
     if (hook_flush > 0 && hook_flush < flush_every) flush_every = hook_flush;
-    G.pairq = (SNK_PAIR && NW == 5 && G.rb) ? 1 : 0;
     // the shapes of BASELINE's configurations get their own instances (TileShape): PE150 at pitch 160, PE250 at pitch 256
     static const bool no_static = getenv("SNK_TILED_RUNTIME_SHAPE") != nullptr;       // (A/B and tests: the run-time shape for every batch)
+    // the flush books the slots of positions 160..191 under 128..159 exactly when the instance that runs pairs its strips (otherwise
+    // those slots hold the spill-over of lanes past the read's end)
+    const bool static160 = NW == 5 && G.rb && !no_static && b.pitch == 160 && G.cba == 768 && G.rb == 4;
+    G.pairq = (NW == 5 && G.rb && (SNK_PAIR == 2 || (SNK_PAIR == 1 && static160))) ? 1 : 0;
     bool launched = false;
     if constexpr (NW == 5) {
         if (G.rb && !no_static && b.pitch == 160 && G.cba == 768 && G.rb == 4) {

@@ -14,6 +14,12 @@ FLAGS = ["-std=c++17", "-O2", "-g1", "-gdwarf-4", "-fPIC", "-w", "-pthread", "-I
          "-fconvergent-functions", "-mllvm", "-disable-tail-duplicate", "-mllvm", "-disable-early-taildup", "-mllvm", "-tail-dup-placement=0"]      # every function may hold wave-level operations (what hipcc assumes for device code): no duplication of calls into the arms of lane-dependent branches -- in the middle end by the attribute, in the x86 backend, which does not know it, by switching tail duplication off
 
 
+# SIMT_EXTRA_CXXFLAGS / SIMT_TAG: a variant of the emulated library (a -D switch of the kernels, e.g. -DSNK_PAIR=1) under its own name
+if os.environ.get("SIMT_EXTRA_CXXFLAGS"):
+    FLAGS = FLAGS + os.environ["SIMT_EXTRA_CXXFLAGS"].split()
+    LIB = os.path.join(OUT, "libsnk_filter_simt_" + os.environ.get("SIMT_TAG", "variant") + ".so")
+
+
 def sources():
     import sys
     sys.path.insert(0, ROOT)
@@ -21,7 +27,8 @@ def sources():
     return list(build.SOURCES), build._headers()
 
 
-def needs_build(lib=LIB):
+def needs_build(lib=None):
+    lib = lib or LIB
     if not os.path.exists(lib):
         return True
     srcs, hdrs = sources()
@@ -30,7 +37,8 @@ def needs_build(lib=LIB):
     return any(os.path.getmtime(f) > t for f in deps)
 
 
-def build(force=False, extra=(), lib=LIB):
+def build(force=False, extra=(), lib=None):
+    lib = lib or LIB
     if not force and not needs_build(lib):
         return lib
     os.makedirs(OUT, exist_ok=True)

@@ -170,3 +170,18 @@ from test_fastq_gpu import (test_parse_and_format_match_the_restatement, test_pa
                             test_format_selects_other_verdicts_whole)
 from test_gunzip_gpu import test_device_inflate_kernels_produce_zlibs_bytes, test_device_inflate_refuses_what_does_not_fit      # noqa: E402,F401
 from test_bittr_gpu import test_bit_transpose      # noqa: E402,F401
+
+
+@pytest.mark.parametrize("pair", ["0", "2"])
+def test_the_other_strip_pairing_builds_emulated(pair):
+    """SNK_PAIR: the shipped build pairs the last quality strips of two reads on the static-shape loop (1); 0 (no pairing) and 2 (also
+    on the run-time-shape loop) are the A/B builds of tools/ab.sh -- each as its own emulated library, on the cases that walk phase 1's
+    whole-tile loops and the flush's remapped slots"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SIMT_EXTRA_CXXFLAGS="-DSNK_PAIR=" + pair, SIMT_TAG="pair" + pair, SNK_SIMT_FULL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_pe150_cases and (C2_adatrim or C3_full) or test_se100_cases and C3_full or test_multi_flush_launches_emulated or test_pitch_not_multiple"],
+                       capture_output=True, text=True, env=env, cwd=T.ROOT)
+    assert r.returncode == 0, r.stdout[-1500:]
