@@ -85,7 +85,10 @@ def build_host(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=HOST)
     if force or not os.path.exists(CLI) or os.path.getmtime(CLI) < newest:
-        cmd = [HIPCC, "-O2", "-std=c++17", "-o", CLI, "snk_main.cpp", "snk_report.cpp", "-L" + HERE, "-lsnk_filter", "-lz", "-pthread",
+        # -march=x86-64-v3 (AVX2, BMI2: every host an MI355X sits in has them; main() checks and says so otherwise): the host inflate
+        # core -- the larger half of the CLI's CPU time on .gz input -- decodes 371 instead of 323 MB/s per thread with it
+        # (tools/micro/inflate_test.cpp, gzip -1 FASTQ, this container)
+        cmd = [HIPCC, "-O2", "-march=x86-64-v3", "-std=c++17", "-o", CLI, "snk_main.cpp", "snk_report.cpp", "-L" + HERE, "-lsnk_filter", "-lz", "-pthread",
                "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))

@@ -1582,6 +1582,10 @@ int main(int argc, char **argv) {
     const long long t_main0 = StageClock::now();
     auto since_start = [&](const char *what) { if (g_clk.on) fprintf(stderr, "[timing] t+%.3f s  %s\n", (double)(StageClock::now() - t_main0) * 1e-9, what); };
     if (argc < 2) { usage(); return 1; }
+#if defined(__AVX2__) && defined(__x86_64__)
+    // (built for x86-64-v3, soapnuke_amd/build.py)
+    if (!__builtin_cpu_supports("avx2") || !__builtin_cpu_supports("bmi2")) { cerr << "Error:this build of SOAPnuke needs a CPU with AVX2 and BMI2 (x86-64-v3)" << endl; return 1; }
+#endif
     Options o;
     parse_args(argc, argv, o);
     const int mates = o.p.paired ? 2 : 1;
