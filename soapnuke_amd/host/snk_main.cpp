@@ -519,16 +519,32 @@ struct ShardEnv {
     bool wire_tried = false;
 } g_shard;
 
-// the collectives between the shards (host/snk_wire.h), made on first use; null: this run merges through files only
+// the collectives between the shards (host/snk_wire.h), made on first use; null: this run merges through files only.  The host
+// wire always comes up first (a socket); for the RCCL wire it is the bootstrap -- rank 0 makes the communicator id, everybody joins,
+// everybody learns whether everybody could -- and the fallback: one shard that cannot join (no RCCL, a device RCCL refuses) puts ALL of
+// them on the host wire, with a warning from rank 0, instead of leaving the others inside ncclCommInitRank.
 snk::ShardWire *shard_wire() {
     if (!g_shard.child || g_shard.wire_tried) return g_shard.wire.get();
     g_shard.wire_tried = true;
+    if (g_shard.wire_kind != "rccl" && g_shard.wire_kind != "host") return nullptr;
     string why;
-    if (g_shard.wire_kind == "rccl") g_shard.wire.reset(snk::RcclWire::connect(g_shard.g, g_shard.G, g_shard.wire_addr, why));
-    else if (g_shard.wire_kind == "host") g_shard.wire.reset(snk::HostWire::connect(g_shard.g, g_shard.G, g_shard.wire_addr, why));
-    else return nullptr;
-    // (every shard takes the same branch: a shard that cannot join leaves the others waiting for it -- the parent ends them)
-    if (!g_shard.wire) { cerr << "Error:shard " << g_shard.g << " cannot join the " << g_shard.wire_kind << " wire (" << why << "); SNK_SHARD_WIRE=host or =file selects another one" << endl; _exit(1); }
+    std::unique_ptr<snk::HostWire> hw(snk::HostWire::connect(g_shard.g, g_shard.G, g_shard.wire_addr, why));
+    if (!hw) { cerr << "Error:shard " << g_shard.g << " cannot join the host wire (" << why << ")" << endl; _exit(1); }
+    if (g_shard.wire_kind == "rccl") {
+        char id[257];
+        memset(id, 0, sizeof id);
+        string why0;
+        if (g_shard.g == 0) { const string s = snk::RcclWire::make_id(why0); if (s.size() == 256) memcpy(id, s.data(), 256); }
+        if (!hw->bcast_bytes(id, 256)) { cerr << "Error:shard " << g_shard.g << ": " << hw->err << endl; _exit(1); }
+        std::unique_ptr<snk::RcclWire> rw;
+        if (id[0]) rw.reset(snk::RcclWire::connect(g_shard.g, g_shard.G, string(id, 256), why));
+        else why = why0.empty() ? "rank 0 could not make a communicator id" : why0;
+        int64_t ok = rw ? 1 : 0;
+        if (!hw->min_of_all(ok)) { cerr << "Error:shard " << g_shard.g << ": " << hw->err << endl; _exit(1); }
+        if (ok) { g_shard.wire = std::move(rw); return g_shard.wire.get(); }
+        if (!rw || g_shard.g == 0) cerr << "Warning:shard " << g_shard.g << ": no RCCL communicator over the shards (" << (rw ? "another shard could not join" : why) << "): the host wire carries the collectives" << endl;
+    }
+    g_shard.wire = std::move(hw);
     return g_shard.wire.get();
 }
 
@@ -1734,13 +1750,9 @@ int main(int argc, char **argv) {
                 wire_kind = distinct ? "rccl" : "host";
             }
             if (wire_kind != "rccl" && wire_kind != "host" && wire_kind != "file") die("SNK_SHARD_WIRE: rccl, host or file");
-            if (wire_kind == "rccl") {
-                wire_addr = snk::RcclWire::make_id(wire_why);
-                if (wire_addr.empty()) { cerr << "Warning:RCCL is not available (" << wire_why << "): the shards talk over the host wire" << endl; wire_kind = "host"; }
-            }
-            if (wire_kind == "host") wire_addr = "snk-shard-" + std::to_string((long)getpid()) + "-" + std::to_string((long long)StageClock::now());
+            if (wire_kind != "file") wire_addr = "snk-shard-" + std::to_string((long)getpid()) + "-" + std::to_string((long long)StageClock::now());
             if (wire_kind == "file" && o.p.rmdup) die("rmdup over several shards exchanges the hashes: SNK_SHARD_WIRE=file cannot");
-            log << local_time() << "\tshards talk over: " << (wire_kind == "rccl" ? "RCCL" : wire_kind == "host" ? "host wire" : "files") << endl;
+            log << local_time() << "\tshards talk over: " << (wire_kind == "rccl" ? "RCCL (bootstrap and fallback: host wire)" : wire_kind == "host" ? "host wire" : "files") << endl;
             std::vector<pid_t> kids((size_t)G, 0);
             for (int g = 0; g < G; ++g) {
                 std::vector<string> env;

@@ -7,12 +7,13 @@
 // the duplicate flag travels back (rmdup::markDup needs the global input order, src/rmdup.cpp:70-123).  Both run on DEVICE
 // memory through this interface, with two engines behind it:
 //
-//   RcclWire   one RCCL communicator over the shards' GPUs (ncclGetUniqueId in the parent, the id through the environment,
-//              ncclCommInitRank per shard): ncclAllReduce for (1) -- issued through the C ABI's snk_stats_allreduce() with this
-//              communicator -- and grouped ncclSend / ncclRecv pairs for (2), over xGMI.
+//   RcclWire   one RCCL communicator over the shards' GPUs (rank 0 calls ncclGetUniqueId and hands the id to the others over the
+//              host wire, every shard calls ncclCommInitRank): ncclAllReduce for (1) -- issued through the C ABI's
+//              snk_stats_allreduce() with this communicator -- and grouped ncclSend / ncclRecv pairs for (2), over xGMI.
 //   HostWire   the same calls over an abstract Unix-domain socket through rank 0 (buffers staged through host memory): what a
 //              run uses when RCCL cannot span the device list -- the same device twice, as the one-GPU test configurations
-//              have it, or no RCCL at all as on the CPU emulator of tests/simt -- and what SNK_SHARD_WIRE=host selects.
+//              have it, or no RCCL at all as on the CPU emulator of tests/simt --, what SNK_SHARD_WIRE=host selects, the RCCL
+//              wire's bootstrap, and what the shards agree to fall back to when one of them cannot join the communicator.
 //
 // RCCL is resolved with dlopen: the CLI has no link-time dependency on it.
 #ifndef SNK_WIRE_H
@@ -104,7 +105,7 @@ class RcclWire : public ShardWire {
     void *comm_ = nullptr;
 
 public:
-    // the parent: a fresh id as 256 hex digits ("" + why when RCCL is not there)
+    // rank 0: a fresh id as 256 hex digits ("" + why when RCCL is not there)
     static std::string make_id(std::string &why) {
         Api &a = api();
         if (!a.load()) { why = a.why; return ""; }
@@ -232,6 +233,29 @@ public:
     }
     ~HostWire() override { for (int f : fd_) if (f >= 0) close(f); }
     const char *name() const override { return "host wire"; }
+
+    // host memory: rank 0's n bytes to everybody / the smallest of everybody's numbers to everybody (the bootstrap of the RCCL wire)
+    bool bcast_bytes(void *buf, size_t n) {
+        if (world == 1) return true;
+        if (rank == 0) { for (int p = 1; p < world; ++p) if (!put_msg(fd_[(size_t)p], buf, n)) { err = "host wire: a shard went away"; return false; } return true; }
+        std::vector<char> in;
+        if (!get_msg(fd_[0], in) || in.size() != n) { err = "host wire: rank 0 went away"; return false; }
+        memcpy(buf, in.data(), n);
+        return true;
+    }
+    bool min_of_all(int64_t &v) {
+        if (world == 1) return true;
+        if (rank == 0) {
+            std::vector<char> in;
+            for (int p = 1; p < world; ++p) {
+                if (!get_msg(fd_[(size_t)p], in) || in.size() != 8) { err = "host wire: a shard went away"; return false; }
+                int64_t x;
+                memcpy(&x, in.data(), 8);
+                v = std::min(v, x);
+            }
+        } else if (!put_msg(fd_[0], &v, 8)) { err = "host wire: rank 0 went away"; return false; }
+        return bcast_bytes(&v, 8);
+    }
 
     bool allreduce_u64(uint64_t *d_buf, size_t n, WireOp op) override {
         if (n == 0 || world == 1) return true;

@@ -42,6 +42,34 @@ def test_cli_sharded_rmdup_and_wire_emulated(paired, n, gz_in, two_emulated_devi
     CG.test_cli_sharded_rmdup_and_wire(paired, n, gz_in, tmp_path)
 
 
+def test_cli_shards_fall_back_to_the_host_wire_together_emulated(two_emulated_devices, tmp_path):
+    """two different (emulated) devices: the parent asks for the RCCL wire; no shard can join a communicator here (no GPU: rank 0 gets
+    no id from ncclGetUniqueId) -- they learn that from each other over the host wire, which then carries the collectives: a warning,
+    not a hang, and the reference's bytes"""
+    import filecmp
+    import subprocess
+    n, L = 20000, 150
+    d = CG.synth.make_batch(n, L, paired=True, seed=66)
+    for m in range(2):
+        d["seq"][m][n // 2 + 100:n // 2 + 600] = d["seq"][m][0:500]
+    cli = ["-f", CG.synth.ADAPTER1, "-r", CG.synth.ADAPTER2, "-J"]
+    case = ("fallback", True, L, n, 2, 250, {}, {}, cli, ["rmdup"])
+    work = str(tmp_path)
+    ref = CG.R.run_reference_cli(case, d, work, gz_input=True)
+    cmd = [CG.CLI, "filter", "-1", os.path.join(work, "r1.fq"), "-2", os.path.join(work, "r2.fq"), "-C", "c1.fq", "-D", "c2.fq", "-o", os.path.join(work, "ours"),
+           "-T", "2", "--devices", "0,1", "-c", os.path.join(work, "cfg")] + cli
+    env = dict(os.environ, SNK_SHARDED="1", SNK_SHARD_MIN_RECORDS="1000")
+    env.pop("SNK_SHARD_WIRE", None)
+    r = subprocess.run(cmd, capture_output=True, env=env, timeout=300)
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-800:])
+    assert b"the host wire carries the collectives" in r.stderr
+    log = open(os.path.join(work, "ours", "log"), "rb").read()
+    assert b"shards talk over: RCCL" in log and b"statistics merged over the host wire (2 shards)" in log
+    CG._compare_dirs(os.path.join(work, "ours"), ref, True)
+    for f in ("dupReads.0.1.gz", "dupReads.1.2.gz"):
+        assert CG._cat(os.path.join(work, "ours", f)) == CG._cat(os.path.join(ref, f)), f
+
+
 def test_cli_rmdup_table_that_does_not_fit_emulated(tmp_path):
     CG.test_cli_rmdup_one_pass_variants("table_does_not_fit", tmp_path)
 
