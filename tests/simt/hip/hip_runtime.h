@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <functional>
 #include <tuple>
+#include <vector>
 #include <type_traits>
 
 #define SNK_SIMT_EMUL 1
@@ -214,10 +215,34 @@ template <class T> static inline T from_bits(uint64_t u) {
 #define blockDim (simt::cur->blk->bdim)
 #define gridDim (simt::cur->blk->gdim)
 
+// SIMT_DUMP_DIR (tools/gfx950_interp.py, tests/test_isa_interp.py): the launch as the device would get it -- the kernel's address
+// (resolved to its symbol by the reader), grid, the kernarg segment (every parameter at its natural alignment) and all device
+// memory before and after the launch -- so that the kernel's gfx950 assembly can be run on the same state and compared.
+namespace simt {
+bool dump_wanted();
+int dump_pre(const void *kernel, dim3 grid, dim3 block, size_t shmem, const void *kernarg, size_t kernarg_bytes);
+void dump_post(int id);
+}  // namespace simt
+
 template <class... P, class... A>
 static inline void hipLaunchKernelGGL(void (*kernel)(P...), dim3 grid, dim3 block, size_t shmem, hipStream_t, A... args) {
     std::tuple<typename std::decay<P>::type...> params(static_cast<typename std::decay<P>::type>(args)...);
+    int dump_id = -1;
+    if (simt::dump_wanted()) {
+        std::vector<char> ka;
+        size_t off = 0;
+        auto pack = [&](const auto &p) {
+            const size_t a = alignof(typename std::decay<decltype(p)>::type);
+            off = (off + a - 1) / a * a;
+            ka.resize(off + sizeof(p));
+            memcpy(ka.data() + off, &p, sizeof(p));
+            off += sizeof(p);
+        };
+        std::apply([&](const auto &...p) { (pack(p), ...); }, params);
+        dump_id = simt::dump_pre((const void *)kernel, grid, block, shmem, ka.data(), ka.size());
+    }
     simt::launch(grid, block, shmem, [=] { std::apply(kernel, params); });
+    if (dump_id >= 0) simt::dump_post(dump_id);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- device side

@@ -9,6 +9,8 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <map>
+#include <string>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -386,7 +388,83 @@ size_t total_mem() {
 }
 struct Hdr { size_t n; size_t magic; };
 constexpr size_t HDR = 256, MAGIC = 0x53494D54414C4C4Full;
+// every live allocation a kernel may touch (device and pinned host memory): what SIMT_DUMP_DIR snapshots
+std::mutex g_reg_mu;
+std::map<uintptr_t, size_t> g_reg;
+void reg_add(void *p, size_t n) { std::lock_guard<std::mutex> l(g_reg_mu); g_reg[(uintptr_t)p] = n; }
+void reg_del(void *p) { std::lock_guard<std::mutex> l(g_reg_mu); g_reg.erase((uintptr_t)p); }
 }  // namespace
+
+namespace simt {
+bool dump_wanted() {
+    static const bool on = getenv("SIMT_DUMP_DIR") != nullptr;
+    return on;
+}
+namespace {
+std::atomic<int> g_dump_seq{0};
+std::vector<std::pair<uintptr_t, size_t>> dump_allocs() {
+    const size_t cap = getenv("SIMT_DUMP_MAX_ALLOC") ? (size_t)atol(getenv("SIMT_DUMP_MAX_ALLOC")) : ((size_t)256 << 20);
+    std::lock_guard<std::mutex> l(g_reg_mu);
+    std::vector<std::pair<uintptr_t, size_t>> v;
+    for (auto &kv : g_reg) if (kv.second && kv.second <= cap) v.push_back(kv);
+    return v;
+}
+void dump_mem(const std::string &path, const std::vector<std::pair<uintptr_t, size_t>> &al) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { perror(path.c_str()); abort(); }
+    for (auto &a : al) fwrite((const void *)a.first, 1, a.second, f);
+    fclose(f);
+}
+std::mutex g_dump_mu;
+std::map<int, std::vector<std::pair<uintptr_t, size_t>>> g_dump_al;
+}  // namespace
+int dump_pre(const void *kernel, dim3 grid, dim3 block, size_t shmem, const void *kernarg, size_t kernarg_bytes) {
+    Dl_info di;
+    if (!dladdr(kernel, &di) || !di.dli_fbase) return -1;
+    const uintptr_t off = (uintptr_t)kernel - (uintptr_t)di.dli_fbase;
+    if (const char *e = getenv("SIMT_DUMP_OFFSETS")) {          // only these kernels (offsets into the library, hex, comma-separated)
+        bool hit = false;
+        for (const char *q = e; *q;) {
+            char *end = nullptr;
+            const uintptr_t v = (uintptr_t)strtoull(q, &end, 16);
+            if (end == q) break;
+            hit |= v == off;
+            q = *end ? end + 1 : end;
+        }
+        if (!hit) return -1;
+    }
+    const int id = g_dump_seq.fetch_add(1);
+    const std::string base = std::string(getenv("SIMT_DUMP_DIR")) + "/L" + std::to_string(id);
+    auto al = dump_allocs();
+    dump_mem(base + ".pre", al);
+    FILE *f = fopen((base + ".json").c_str(), "w");
+    if (!f) { perror(base.c_str()); abort(); }
+    fprintf(f, "{\"lib\": \"%s\", \"offset\": %llu, \"grid\": [%u, %u, %u], \"block\": [%u, %u, %u], \"shmem\": %zu, \"kernarg\": \"",
+            di.dli_fname ? di.dli_fname : "", (unsigned long long)off, grid.x, grid.y, grid.z, block.x, block.y, block.z, shmem);
+    for (size_t i = 0; i < kernarg_bytes; ++i) fprintf(f, "%02x", ((const unsigned char *)kernarg)[i]);
+    fprintf(f, "\", \"allocs\": [");
+    for (size_t i = 0; i < al.size(); ++i) fprintf(f, "%s[%llu, %zu]", i ? ", " : "", (unsigned long long)al[i].first, al[i].second);
+    fprintf(f, "]}\n");
+    fclose(f);
+    std::lock_guard<std::mutex> l(g_dump_mu);
+    g_dump_al[id] = std::move(al);
+    return id;
+}
+}  // namespace simt
+// memory the caller owns (numpy arrays handed in as "device" pointers) joins / leaves the snapshots
+extern "C" void simt_dump_register(void *p, size_t n) { if (simt::dump_wanted()) reg_add(p, n); }
+extern "C" void simt_dump_unregister(void *p) { if (simt::dump_wanted()) reg_del(p); }
+namespace simt {
+void dump_post(int id) {
+    std::vector<std::pair<uintptr_t, size_t>> al;
+    {
+        std::lock_guard<std::mutex> l(g_dump_mu);
+        al = std::move(g_dump_al[id]);
+        g_dump_al.erase(id);
+    }
+    dump_mem(std::string(getenv("SIMT_DUMP_DIR")) + "/L" + std::to_string(id) + ".post", al);
+}
+}  // namespace simt
 
 struct simt_stream { int id; };
 struct simt_event { std::chrono::steady_clock::time_point t; bool recorded = false; };
@@ -401,6 +479,7 @@ hipError_t hipMalloc(void **p, size_t n) {
     memset(raw + HDR, 0xEE, n + 64);
     g_allocated.fetch_add(n);
     *p = raw + HDR;
+    if (simt::dump_wanted()) reg_add(*p, n + 64);
     return hipSuccess;
 }
 hipError_t hipFree(void *p) {
@@ -408,6 +487,7 @@ hipError_t hipFree(void *p) {
     char *raw = (char *)p - HDR;
     if (((Hdr *)raw)->magic != MAGIC) { fprintf(stderr, "simt: hipFree of a pointer hipMalloc did not return\n"); abort(); }
     ((Hdr *)raw)->magic = 0;
+    if (simt::dump_wanted()) reg_del(p);
     g_allocated.fetch_sub(((Hdr *)raw)->n);
     free(raw);
     return hipSuccess;
@@ -418,9 +498,10 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
     void *q = nullptr;
     if (posix_memalign(&q, 256, n ? n : 1) != 0) { *p = nullptr; return hipErrorOutOfMemory; }
     *p = q;
+    if (simt::dump_wanted()) reg_add(q, n);
     return hipSuccess;
 }
-hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipHostFree(void *p) { if (simt::dump_wanted()) reg_del(p); free(p); return hipSuccess; }
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
 hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
