@@ -293,7 +293,7 @@ __device__ __forceinline__ void screen_planes(const AD &A, const u32 (&NX)[4][NW
 // either fits the 64 match bits (adapters up to 64 characters: 255 + 63 < the planes' 320 positions) or walks the row.
 // *hit_c: the position returned is a phase C one (a later block's phase C hit takes precedence: descending offsets, :765-788).
 template <int NW, bool FULL, class AD>
-__device__ int adapter_tile(const AD &A, const DevAdapter &AG, const u32 (&X)[4][NW], const u32 (&XN)[NW],
+__device__ __forceinline__ int adapter_tile(const AD &A, const DevAdapter &AG, const u32 (&X)[4][NW], const u32 (&XN)[NW],
                             int len, bool todo, const uint8_t *sptr, bool doA = true, bool doC = true, bool seq_lane = false,
                             int nofs = 32 * NW, bool *hit_c = nullptr) {
     const int al = A.len, S = max(A.S, 1), edge = A.edge, mis = A.mis;

@@ -1,7 +1,10 @@
-"""Child process of tests/test_isa_interp.py: one batch through the tiled kernel of the EMULATED library with SIMT_DUMP_DIR set
-(tests/simt/simt_runtime.cpp: kernarg segment and all device memory before and after every launch of the kernels whose library
-offsets SIMT_DUMP_OFFSETS names).  argv: case, pairs, read length, variable lengths (0 / 1), paired (0 / 1) [, seed]."""
+"""Child process of tests/test_simt_isa_interp.py: one batch through the tiled kernel of the EMULATED library with SIMT_DUMP_DIR
+set (tests/simt/simt_runtime.cpp: kernarg segment and all device memory before and after every launch of the kernels whose
+library offsets SIMT_DUMP_OFFSETS names).  argv[1]: a JSON object -- case (tests/cases.py), n, L, var_len, paired, pitch, seed,
+lower (fraction of the reads that get lower-case letters or many N: the sequential fall-back inside the kernel),
+first (the batch starts at this row: planes that are not 16-byte aligned)."""
 import ctypes as C
+import json
 import sys
 
 import numpy as np
@@ -13,17 +16,39 @@ from soapnuke_amd import abi, synth
 
 
 def main():
-    case, n, L, var_len, paired = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == "1", sys.argv[5] == "1"
-    seed = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+    spec = json.loads(sys.argv[1])
+    n, L, paired = int(spec["n"]), int(spec.get("L", 150)), bool(spec.get("paired", True))
     lib = S.lib()
     lib.simt_dump_register.argtypes = [C.c_void_p, C.c_size_t]
-    d = synth.make_batch(n, L, paired=paired, seed=seed, var_len=var_len)
-    p = abi.default_params(paired=paired, max_read_len=L, **PE_CASES[case])
+    d = synth.make_batch(n, L, paired=paired, seed=int(spec.get("seed", 5)), var_len=bool(spec.get("var_len", False)), pitch=spec.get("pitch"),
+                         dimer_frac=float(spec.get("dimer_frac", 0.0)))
+    if spec.get("lower"):
+        rng = np.random.default_rng(99)
+        for m in range(len(d["seq"])):
+            rows = rng.choice(n, max(1, int(n * float(spec["lower"]))), replace=False)
+            for r in rows:
+                ln = int(d["len"][m][r]) if d["len"][m] is not None else L
+                k = int(rng.integers(0, 3))
+                if k == 0:
+                    d["seq"][m][r, :ln] |= 0x20                                  # all lower case
+                elif k == 1:
+                    d["seq"][m][r, int(rng.integers(0, ln)):] |= 0x20            # lower case from somewhere on
+                else:
+                    d["seq"][m][r, :ln][rng.random(ln) < 0.3] = ord("N")
+    first = int(spec.get("first", 0))
+    if first:
+        d = {"n": n - first, "L": d["L"], "pitch": d["pitch"], "seq": [x[first:] for x in d["seq"]], "qual": [x[first:] for x in d["qual"]],
+             "len": [None if x is None else x[first:] for x in d["len"]]}
+    kw = dict(PE_CASES[spec["case"]])
+    if not paired:
+        kw = {k: v for k, v in kw.items() if not k.endswith("2")}
+    p = abi.default_params(paired=paired, max_read_len=L, **kw)
     keep = []
     for key in ("seq", "qual", "len"):
         for a in d[key]:
             if a is not None:
-                lib.simt_dump_register(a.ctypes.data, a.nbytes)
+                base = a.base if a.base is not None else a
+                lib.simt_dump_register(base.ctypes.data, base.nbytes)
                 keep.append(a)
     real_zeros = np.zeros
 

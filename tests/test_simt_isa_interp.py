@@ -1,0 +1,149 @@
+"""The gfx950 INSTRUCTIONS of the tiled kernel -- the assembly hipcc leaves next to the object the product ships
+(soapnuke_amd/csrc/build/*.s) -- run on the CPU by tools/gfx950_interp.py, on launches captured from the emulated library
+(tests/simt: SIMT_DUMP_DIR), and compared byte for byte with the device memory the emulated C++ twin left behind (which the capture
+has compared with the oracle).  No GPU.
+
+What this adds to tests/test_simt_kernels.py (HIP sources compiled for the host): the compiler's output and the hand-placed gfx950
+blocks themselves are executed -- ds_read / ds_add with immediate offsets behind counted s_waitcnt, the LDS DMA, DPP and permlane
+transposes, v_writelane / v_readlane spills, scratch spills, s_set_gpr_idx -- under an adversarial completion model: every
+asynchronous result stays poisoned until the s_waitcnt that covers it by the counters' rules (in-order vmcnt / LDS lgkmcnt, scalar
+loads out of order), reading it earlier is a failure.  The negative controls at the end show the checker has teeth.
+What it still is not: hardware.  Timing, cache behaviour and the ISA manual's own errata stay with the first run on an MI355X."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+import snk_testlib as T
+
+sys.path.insert(0, os.path.join(T.ROOT, "tools"))
+import gfx950_interp as G          # noqa: E402
+
+ASM = os.path.join(T.ROOT, "soapnuke_amd", "csrc", "build", "snk_tiled-hip-amdgcn-amd-amdhsa-gfx950.s")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# name -> (capture spec, environment of the capture, part of the kernel instance's mangled name that must have run)
+CASES = {
+    "pe150_c2_static": (dict(case="C2_adatrim_lowq", n=1100, L=150), {}, "ILi5ELb0ELb1ELi16ENS_9TileShapeILi160"),
+    "pe150_c3_full_ragged": (dict(case="C3_full", n=1100, L=150, var_len=True), {}, "ILi5ELb1ELb1ELi16ENS_9TileShapeILi160"),
+    "pe250_c3_full_ragged": (dict(case="C3_full", n=1100, L=250, var_len=True), {}, "ILi8ELb1ELb1ELi16ENS_9TileShapeILi256"),
+    "pe250_c2": (dict(case="C2_adatrim_lowq", n=700, L=250), {}, "ILi8ELb0ELb1ELi16ENS_9TileShapeILi256"),
+    "pe200_c3_runtime_shape": (dict(case="C3_full", n=700, L=200, var_len=True), {}, "ILi8ELb1ELb1ELi16ENS_9TileShapeILi0"),
+    "pe150_runtime_shape": (dict(case="C3_full", n=700, L=150, var_len=True), {"SNK_TILED_RUNTIME_SHAPE": "1"}, "ILi5ELb1ELb1ELi16ENS_9TileShapeILi0"),
+    "se100_c3": (dict(case="C3_full", n=1100, L=100, paired=False, var_len=True), {}, "ILi4ELb1ELb1"),
+    "pe50_c2": (dict(case="C2_adatrim_lowq", n=700, L=50), {}, "ILi2ELb0ELb1"),
+    "pe180_c3": (dict(case="C3_full", n=700, L=180, var_len=True), {}, "ILi6ELb1ELb1"),
+    "pitch152_register_path": (dict(case="C3_full", n=701, L=150, pitch=152, var_len=True, first=1), {}, "ILi5ELb1ELb0"),
+    "pitch152_c2_register_path": (dict(case="C2_adatrim_lowq", n=700, L=150, pitch=152), {}, "ILi5ELb0ELb0"),
+    "lower_case_and_many_n": (dict(case="C3_full", n=700, L=150, var_len=True, lower=0.06), {}, "ILi5ELb1ELb1"),
+    "meanq_polyx": (dict(case="meanq_polyx", n=700, L=150), {}, "ILi5ELb1ELb1"),
+    "hard_lq_trim": (dict(case="hard_lq_trim", n=700, L=150, var_len=True), {}, "ILi5E"),
+    "adapter_lists": (dict(case="multi_adapter_params2", n=700, L=150, dimer_frac=0.3), {}, "ILi5E"),
+    "short_adapter_edge": (dict(case="short_adapter_edge", n=700, L=150, dimer_frac=0.3), {}, "ILi5E"),
+    "many_flushes_one_workgroup": (dict(case="C3_full", n=3000, L=150, var_len=True), {"SNK_TEST_MAX_WGS": "1", "SNK_TEST_FLUSH_EVERY": "1"}, "ILi5ELb1ELb1"),
+}
+# an ordinary run (see tests/conftest.py: SNK_SIMT_FULL=1 takes everything)
+CORE = ["test_assembly_matches_the_emulated_twin[pe150_c2_static]", "test_assembly_matches_the_emulated_twin[pe150_c3_full_ragged]",
+        "test_a_weakened_wait_is_caught", "test_a_changed_instruction_is_caught"]
+
+
+def simt_lib_path():
+    import simt_lib as S
+    return S.build_module().build()
+
+
+def capture(tmp, spec, env=None, cus=2):
+    lib = simt_lib_path()
+    offs = ",".join("%x" % o for o in G.kernel_offsets(lib, "snk_tiled"))
+    e = dict(os.environ, SIMT_DUMP_DIR=str(tmp), SIMT_DUMP_OFFSETS=offs, SIMT_CUS=str(cus),
+             PYTHONPATH=os.pathsep.join([HERE, T.ROOT, os.environ.get("PYTHONPATH", "")]))
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(HERE, "isa_interp_capture.py"), json.dumps(spec)], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "captured" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    return sorted(int(f[1:-5]) for f in os.listdir(tmp) if f.endswith(".json"))
+
+
+needs_asm = pytest.mark.skipif(not os.path.exists(ASM), reason="the build's kept assembly is not there (python __graft_entry__.py)")
+
+
+@needs_asm
+@pytest.mark.parametrize("name", list(CASES))
+def test_assembly_matches_the_emulated_twin(name, tmp_path):
+    spec, env, instance = CASES[name]
+    launches = capture(tmp_path, spec, env)
+    assert len(launches) >= 2                     # the tiled kernel and the reduce kernel behind it
+    seen = []
+    for k in launches:
+        info, diffs = G.replay(str(tmp_path), k, ASM, verbose=False)
+        seen.append(info["symbol"])
+        assert info["instructions"] > 0
+        assert not diffs, (info, diffs)
+    assert any(instance in s for s in seen), seen
+    assert any("snk_tiled_reduce_kernel" in s for s in seen), seen
+
+
+def mutated(tmp_path, symbol, edit):
+    """a copy of the assembly with `edit` applied to the text of one function"""
+    text = open(ASM).read()
+    a = text.find("\n" + symbol + ":")
+    b = text.find("s_endpgm", a)
+    body = edit(text[a:b])
+    out = os.path.join(str(tmp_path), "mutated.s")
+    open(out, "w").write(text[:a] + body + text[b:])
+    return out
+
+
+@pytest.fixture
+def c2_capture(tmp_path):
+    capture(tmp_path, CASES["pe150_c2_static"][0])
+    meta = json.load(open(os.path.join(str(tmp_path), "L0.json")))
+    return str(tmp_path), G.symbol_at(meta["lib"], meta["offset"])
+
+
+@needs_asm
+def test_a_weakened_wait_is_caught(tmp_path, c2_capture):
+    """the counted waits of phase 1's loop, each one entry too generous: a read's result is used before the wait that covers it"""
+    d, sym = c2_capture
+
+    def edit(body):
+        body, n = re.subn(r"s_waitcnt lgkmcnt\(([1-9]\d*)\)", lambda m: "s_waitcnt lgkmcnt(%d)" % (int(m.group(1)) + 1), body)
+        assert n >= 8
+        return body
+
+    with pytest.raises(G.Hazard, match="before the wait"):
+        G.replay(d, 0, mutated(tmp_path, sym, edit), verbose=False)
+
+
+@needs_asm
+def test_a_missing_dma_wait_is_caught(tmp_path, c2_capture):
+    """no vmcnt wait between the LDS DMA of a chunk and the LDS reads of its rows"""
+    d, sym = c2_capture
+
+    def edit(body):
+        body, n = re.subn(r"s_waitcnt vmcnt\(\d+\)\n", "s_nop 0\n", body)
+        assert n >= 8
+        return body
+
+    # (a vector load's register used early is a hazard; rows read from LDS under their DMA come back as garbage: a different image)
+    try:
+        info, diffs = G.replay(d, 0, mutated(tmp_path, sym, edit), verbose=False)
+    except G.Hazard:
+        return
+    assert diffs and info["lds_bytes_read_under_a_dma"] > 0
+
+
+@needs_asm
+def test_a_changed_instruction_is_caught(tmp_path, c2_capture):
+    """the two data operands of the v_bfi_b32 of the bit transposes exchanged: the memory image differs from the emulated twin's"""
+    d, sym = c2_capture
+
+    def edit(body):
+        body, n = re.subn(r"v_bfi_b32 (v\d+), (v\d+), (v\d+), (v\d+)", r"v_bfi_b32 \1, \2, \4, \3", body)
+        assert n >= 8
+        return body
+
+    info, diffs = G.replay(d, 0, mutated(tmp_path, sym, edit), verbose=False)
+    assert diffs

@@ -279,6 +279,7 @@ class Wave:
         self.count = {}
         self._exec_cache = (None, None)
         self.cur = None
+        self.scratch = np.full((64, kd.get("private_segment_fixed_size", 0) + 16), 0xEE, dtype=np.uint8)
 
     # ---- registers
     def sget(self, n):
@@ -342,7 +343,7 @@ class Wave:
         """vector source as uint32[64]"""
         if op.kind == "v":
             self.chk_v(op.n)
-            return self.v[op.n]
+            return self.v[op.n].copy()          # (a copy: the destination may be the same register)
         return np.full(64, self.rd_s(op), dtype=U32)
 
     def rd64(self, op):
@@ -627,6 +628,7 @@ VOP = {
     "v_xad_u32": lambda a, b, c: (a ^ b) + c,
     "v_mad_u32_u24": lambda a, b, c: (a & U32(0xFFFFFF)) * (b & U32(0xFFFFFF)) + c,
     "v_sad_u8": sad_u8,
+    "v_sad_hi_u8": lambda a, b, c: (sad_u8(a, b, np.zeros(64, dtype=U32)) << U32(16)) + c,
     # 16-bit operations: the low halves, the high half of the destination cleared (gfx9)
     "v_add_u16": lambda a, b: (a + b) & U32(0xFFFF),
     "v_lshlrev_b16": lambda a, b: (b << (a & U32(15))) & U32(0xFFFF),
@@ -1056,6 +1058,44 @@ def ex_gstore(w, ins):
     w.vm.append(("store", []))
 
 
+def scratch_addr(w, ins, vaddr, saddr):
+    a = np.zeros(64, dtype=np.int64)
+    if vaddr.kind == "v":
+        a = a + w.rd32(vaddr).astype(np.int64)
+    if saddr.kind == "s":
+        a = a + w.rd_s(saddr)
+    return a + int(ins.mods.get("offset", "0"), 0)
+
+
+def ex_scratch(w, ins):
+    """the wave's private segment (architected flat scratch): lane l's bytes at scratch[l, address]"""
+    load = ins.base.startswith("scratch_load_")
+    nb = GL_BYTES[ins.base[len("scratch_load_" if load else "scratch_store_"):]]
+    m = w.execm()
+    if load:
+        a = scratch_addr(w, ins, ins.ops[1], ins.ops[2])
+    else:
+        a = scratch_addr(w, ins, ins.ops[0], ins.ops[2])
+    if m.any() and (int(a[m].min()) < 0 or int(a[m].max()) + nb > w.scratch.shape[1]):
+        raise Hazard("scratch access outside the private segment at line %d (%s)" % (ins.line, ins.text))
+    idx = a[:, None] + np.arange(nb)[None, :]
+    if load:
+        raw = np.zeros((64, nb), dtype=np.uint8)
+        raw[m] = w.scratch[LANES[m][:, None], idx[m]]
+        d = ins.ops[0].n
+        regs = []
+        for k in range(max(1, nb // 4)):
+            if d + k in w.pv:
+                raise Hazard("v%d reloaded while outstanding (line %d)" % (d + k, ins.line))
+            w.v[d + k] = np.where(m, words(raw, k), w.v[d + k])
+            regs.append(("v", d + k))
+        w.poison(w.vm, "load", regs)
+    else:
+        data = vbytes(w, ins.ops[1], nb)
+        w.scratch[LANES[m][:, None], idx[m]] = data[m]
+        w.vm.append(("store", []))
+
+
 def ex_gatomic(w, ins):
     b = ins.base[len("global_atomic_"):]
     wide = b.endswith("_x2")
@@ -1115,9 +1155,16 @@ def lds_rd(w, addrs, nb, m, ins):
         if int(a[m].max()) + nb > lds.size:
             raise Hazard("LDS read past the allocation at line %d (%s)" % (ins.line, ins.text))
         idx = a[m][:, None] + np.arange(nb)[None, :]
-        if w.wg.lds_poison[idx].any():
-            raise Hazard("LDS bytes of an outstanding DMA are read at line %d (%s)" % (ins.line, ins.text))
-        out[m] = lds[idx]
+        got = lds[idx]
+        racy = w.wg.lds_poison[idx] != 0
+        if racy.any():
+            # bytes of a DMA that is still in flight: the hardware returns old or new bytes.  Not an error by itself (lanes past a
+            # row's pitch over-read into the next buffer and never use what they get) -- the read returns GARBAGE here, so a result
+            # that depends on it no longer matches the emulated twin's
+            got = np.where(racy, np.uint8(0xD7), got)
+            w.wg.racy_reads += int(racy.sum())
+            w.wg.racy_lines.add(ins.line)
+        out[m] = got
     return out
 
 
@@ -1247,6 +1294,8 @@ def handler(ins):
         return ex_sload
     if b == "global_load_lds_dwordx4":
         return ex_dma
+    if b.startswith("scratch_load_") or b.startswith("scratch_store_"):
+        return ex_scratch
     if b.startswith("global_load_"):
         return ex_gload
     if b.startswith("global_store_"):
@@ -1277,6 +1326,8 @@ class Workgroup:
         self.lds = np.zeros(lds_bytes + 4096, dtype=np.uint8)          # (+ slack: the kernel's own over-read margin is inside its allocation)
         self.lds[:] = 0xEE
         self.lds_poison = np.zeros(lds_bytes + 4096, dtype=np.uint8)
+        self.racy_reads = 0
+        self.racy_lines = set()
 
 
 KERNARG_BASE = 0x7E0000000000
@@ -1287,12 +1338,13 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
     prog, labels, kd = parse_function(asm_path, symbol)
     bind(prog)
     kernarg = kernarg_segment(asm_path, symbol, kernarg, grid, block, shmem)
-    if kd.get("user_sgpr_count", 2) != 2 or not kd.get("user_sgpr_kernarg_segment_ptr", 1) or kd.get("enable_private_segment", 0):
+    if kd.get("user_sgpr_count", 2) != 2 or not kd.get("user_sgpr_kernarg_segment_ptr", 1):
         raise Unknown("kernel ABI other than {kernarg pointer, workgroup id x}")
-    mem.add(KERNARG_BASE, bytes(kernarg) + bytes(256))
+    if KERNARG_BASE not in mem.bases:
+        mem.add(KERNARG_BASE, bytes(kernarg) + bytes(256))
     static_lds = kd.get("group_segment_fixed_size", 0)
     nthreads = block[0] * block[1] * block[2]
-    total = 0
+    total, racy, racy_lines = 0, 0, set()
     for wgx in (range(grid[0]) if workgroups is None else workgroups):
         wg = Workgroup(static_lds + shmem)
         waves = []
@@ -1320,11 +1372,11 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
             live = at_barrier
         for w in waves:
             total += w.nexec
-            if w.lgkm and any(e[0] == "dma" for e in w.vm):
-                pass
+        racy += wg.racy_reads
+        racy_lines |= wg.racy_lines
         if progress:
             progress(wgx, total)
-    return {"instructions": total}
+    return {"instructions": total, "lds_bytes_read_under_a_dma": racy, "at_lines": sorted(racy_lines)}
 
 
 # ------------------------------------------------------------------------------------------------------------ captured launches
