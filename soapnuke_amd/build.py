@@ -25,13 +25,14 @@ def needs_build():
     return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, f) for f in SOURCES] + _headers())
 
 
-OBJ = os.path.join(CSRC, "build")            # objects + the tiled kernel's gfx950 assembly (git-ignored, not shipped to the GPU box)
+OBJ = os.path.join(CSRC, "build")            # objects + every source's gfx950 assembly (git-ignored, not shipped to the GPU box)
 TILED_ASM = os.path.join(OBJ, "snk_tiled-hip-amdgcn-amd-amdhsa-gfx950.s")
 
 
 def build(force=False, verbose=False, lint=True):
-    """every source to its own object (in parallel), one link; the tiled kernel's device assembly is kept (-save-temps) and
-    checked by tools/isa_lint.py: no use of an LDS row register ahead of the s_waitcnt that covers it"""
+    """every source to its own object (in parallel), one link; the device assembly is kept (-save-temps: tools/isa_*.py read it,
+    tools/gfx950_interp.py runs it); the tiled kernel's is checked by tools/isa_lint.py: no use of an LDS row register ahead of
+    the s_waitcnt that covers it"""
     if not force and not needs_build():
         return LIB
     import concurrent.futures as cf
@@ -40,7 +41,7 @@ def build(force=False, verbose=False, lint=True):
 
     def compile_one(src):
         obj = os.path.join(OBJ, src.replace(".", "_") + ".o")
-        cmd = [HIPCC] + flags + ["-c", os.path.join("..", src), "-o", obj] + (["-save-temps=obj"] if src == "snk_tiled.hip" else [])
+        cmd = [HIPCC] + flags + ["-c", os.path.join("..", src), "-o", obj] + ["-save-temps=obj"]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, cwd=OBJ, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

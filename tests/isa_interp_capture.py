@@ -2,7 +2,8 @@
 set (tests/simt/simt_runtime.cpp: kernarg segment and all device memory before and after every launch of the kernels whose
 library offsets SIMT_DUMP_OFFSETS names).  argv[1]: a JSON object -- case (tests/cases.py), n, L, var_len, paired, pitch, seed,
 lower (fraction of the reads that get lower-case letters or many N: the sequential fall-back inside the kernel),
-first (the batch starts at this row: planes that are not 16-byte aligned)."""
+first (the batch starts at this row: planes that are not 16-byte aligned), contam (a CONTAM_CASES name), kernel (the C ABI's
+kernel selector: 2 tiled, 0 auto -- long reads take the long path)."""
 import ctypes as C
 import json
 import sys
@@ -11,7 +12,7 @@ import numpy as np
 
 import simt_lib as S
 import snk_testlib as T
-from cases import PE_CASES
+from cases import CONTAM_CASES, PE_CASES, contam_kwargs, plant_contams
 from soapnuke_amd import abi, synth
 
 
@@ -42,6 +43,10 @@ def main():
     kw = dict(PE_CASES[spec["case"]])
     if not paired:
         kw = {k: v for k, v in kw.items() if not k.endswith("2")}
+    if spec.get("contam"):                               # contaminant lists on top (tests/cases.py CONTAM_CASES), copies planted in the reads
+        ck = CONTAM_CASES[spec["contam"]]
+        plant_contams(d, ck)
+        kw.update(contam_kwargs(ck, paired))
     p = abi.default_params(paired=paired, max_read_len=L, **kw)
     keep = []
     for key in ("seq", "qual", "len"):
@@ -61,7 +66,7 @@ def main():
 
     np.zeros = zeros
     try:
-        got = S.run_device(p, d, kernel=2)
+        got = S.run_device(p, d, kernel=int(spec.get("kernel", 2)))
     finally:
         np.zeros = real_zeros
     want = T.run_oracle(p, d)

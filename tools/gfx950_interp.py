@@ -86,6 +86,12 @@ def parse_operand(t):
         return Op("c", val=int(t, 0) & 0xFFFFFFFFFFFFFFFF, text=t)
     except ValueError:
         pass
+    m = re.match(r"^\((\S+)-(\S+)\)(&4294967295|>>32)$", t)
+    if m:                                   # a long branch: the halves of the distance between two labels
+        return Op("diff", n=1 if m.group(3) == ">>32" else 0, val=m.group(2), text=m.group(1))
+    m = re.match(r"^(\S+)@rel32@(lo|hi)\+\d+$", t)
+    if m:                                   # the two halves of `symbol - (the pc s_getpc_b64 returned)`, see ex_call
+        return Op("rel", n=1 if m.group(2) == "hi" else 0, text=m.group(1))
     return Op("label", text=t)
 
 
@@ -113,31 +119,32 @@ def split_commas(s):
     return out
 
 
-def parse_function(asm_path, symbol):
-    """-> (list of Ins, labels {name: index}, kernel descriptor {key: int})"""
+_FILES = {}
+CODE_BASE = 0x7D0000000000          # instruction k of a file "sits" at CODE_BASE + 4 k (s_getpc_b64 / s_swappc_b64 / s_setpc_b64)
+
+
+def parse_file(asm_path):
+    """-> (list of Ins of the whole file, labels {name: index} -- function symbols included --, text); cached"""
+    key = (asm_path, os.path.getmtime(asm_path))
+    if key in _FILES:
+        return _FILES[key]
     text = open(asm_path).read()
-    start = text.find("\n" + symbol + ":")
-    if start < 0:
-        raise KeyError("no function %s in %s" % (symbol, asm_path))
-    line0 = text.count("\n", 0, start) + 2
-    body = text[start + 1:]
-    end = body.find("s_endpgm")
-    body = body[:body.find("\n", end)]
+    code = text[:text.find(".amdgpu_metadata")] if ".amdgpu_metadata" in text else text
     prog, labels = [], {}
-    for k, raw in enumerate(body.split("\n")[1:]):
+    for k, raw in enumerate(code.split("\n")):
         line = raw.split(";")[0].strip()
-        if not line:
+        if not line or line.startswith("."):
+            if line.endswith(":"):
+                labels[line[:-1]] = len(prog)
             continue
         if line.endswith(":"):
             labels[line[:-1]] = len(prog)
-            continue
-        if line.startswith("."):
             continue
         parts = line.split(None, 1)
         ins = Ins()
         ins.mn = parts[0]
         ins.base = SUFFIX.sub("", ins.mn)
-        ins.line = line0 + k
+        ins.line = k + 1
         ins.text = line
         rest = parts[1] if len(parts) > 1 else ""
         ins.mods = {}
@@ -158,7 +165,20 @@ def parse_function(asm_path, symbol):
                 ins.flags.add(m.group(1))
             rest = MOD_FLAG.sub("", rest)
             ins.ops = [parse_operand(t) for t in split_commas(rest) if t.strip()]
+        try:
+            ins.fn = handler(ins)
+        except Unknown:
+            ins.fn = ex_unknown
         prog.append(ins)
+    _FILES[key] = (prog, labels, text)
+    return _FILES[key]
+
+
+def parse_function(asm_path, symbol):
+    """-> (the file's program, labels, the kernel descriptor of `symbol` {key: int})"""
+    prog, labels, text = parse_file(asm_path)
+    if symbol not in labels:
+        raise KeyError("no function %s in %s" % (symbol, asm_path))
     kd = {}
     m = re.search(r"\.amdhsa_kernel " + re.escape(symbol) + r"\n(.*?)\.end_amdhsa_kernel", text, re.S)
     if m:
@@ -170,6 +190,15 @@ def parse_function(asm_path, symbol):
                 except ValueError:
                     pass
     return prog, labels, kd
+
+
+def find_asm(build_dir, symbol):
+    """the device assembly file (of the build's kept temporaries) that defines `symbol`"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(build_dir, "*-hip-amdgcn-amd-amdhsa-gfx950.s"))):
+        if ("\n" + symbol + ":") in open(f).read():
+            return f
+    raise KeyError("no assembly for " + symbol)
 
 
 def kernarg_segment(asm_path, symbol, explicit, grid, block, shmem):
@@ -269,8 +298,10 @@ class Wave:
         self.v = np.zeros((512, 64), dtype=U32)
         self.scc = 0
         self.pc = 0
+        self.getpc = 0
         self.done = False
         self.idx_dst = None                              # s_set_gpr_idx_on ... gpr_idx(DST): offset added to a VALU destination
+        self.idx_src0 = None                             # ... gpr_idx(SRC0): to a VALU instruction's first source
         self.lgkm = []                                   # outstanding: ("lds" | "smem", [poisoned registers])
         self.vm = []                                     # outstanding: ("load" | "store" | "dma", registers / LDS range)
         self.pv = {}                                     # poisoned VGPR -> line of the load
@@ -326,6 +357,12 @@ class Wave:
             return op.val & M32
         if op.kind == "scc":
             return self.scc
+        if op.kind == "diff":
+            d = (4 * (self.labels[op.text] - self.labels[op.val])) & 0xFFFFFFFFFFFFFFFF
+            return (d >> 32) & M32 if op.n else d & M32
+        if op.kind == "rel":
+            d = (CODE_BASE + 4 * self.labels[op.text] - self.getpc) & 0xFFFFFFFFFFFFFFFF
+            return (d >> 32) & M32 if op.n else d & M32
         raise Unknown("scalar operand %r in %s" % (op, self.cur.text))
 
     def rd_s64(self, op):
@@ -594,6 +631,9 @@ VOP = {
     "v_cvt_u32_f32": cvt_u32_f32,
     "v_rcp_iflag_f32": lambda a: (np.float32(1.0) / f32(a)).astype(np.float32).view(U32),
     "v_mul_f32": lambda a, b: (f32(a) * f32(b)).astype(np.float32).view(U32),
+    "v_rcp_f32": lambda a: (np.float32(1.0) / f32(a)).astype(np.float32).view(U32),
+    "v_trunc_f32": lambda a: np.trunc(f32(a)).astype(np.float32).view(U32),
+    "v_fmamk_f32": lambda a, k, c: (f32(a).astype(np.float64) * f32(k).astype(np.float64) + f32(c).astype(np.float64)).astype(np.float32).view(U32),
     "v_add_u32": lambda a, b: a + b,
     "v_sub_u32": lambda a, b: a - b,
     "v_subrev_u32": lambda a, b: b - a,
@@ -640,6 +680,9 @@ def ex_valu(w, ins):
     fn = VOP[ins.base]
     ops = ins.ops
     srcs = [w.rd32(o) for o in ops[1:]]
+    if w.idx_src0 is not None and ops[1].kind == "v":
+        w.chk_v(ops[1].n + w.idx_src0)
+        srcs[0] = w.v[ops[1].n + w.idx_src0].copy()
     mask = None
     if ins.mn.endswith("_dpp"):
         srcs[0], mask = dpp_source(w, ins, srcs[0])
@@ -649,6 +692,11 @@ def ex_valu(w, ins):
     if ins.mn.endswith("_sdwa"):
         r = sdwa_dst(ins, u32(r))
     w.wr32(ops[0], r, mask)
+
+
+def ex_fmac(w, ins):
+    a, b, c = w.rd32(ins.ops[1]), w.rd32(ins.ops[2]), w.rd32(ins.ops[0])
+    w.wr32(ins.ops[0], (f32(a).astype(np.float64) * f32(b).astype(np.float64) + f32(c).astype(np.float64)).astype(np.float32).view(U32))
 
 
 def ex_bitop3(w, ins):
@@ -686,6 +734,12 @@ def ex_vcmp(w, ins):
 def ex_cndmask(w, ins):
     a, b = w.rd32(ins.ops[1]), w.rd32(ins.ops[2])
     m = w.rd_mask(ins.ops[3])
+    if ins.mn.endswith("_sdwa"):
+        a, b = sdwa_src(ins, 0, a), sdwa_src(ins, 1, b)
+        w.wr32(ins.ops[0], sdwa_dst(ins, np.where(m, b, a)))
+        return
+    if ins.mn.endswith("_dpp"):
+        raise Unknown(ins.text)
     w.wr32(ins.ops[0], np.where(m, b, a))
 
 
@@ -927,6 +981,40 @@ def ex_salu(w, ins):
         r = (x >> off) & ((1 << wd) - 1) if wd else 0
         w.sset(o[0].n, r)
         w.scc = int(r != 0)
+    elif b == "s_ashr_i64":
+        r = (sx64(g64(o[1])) >> (g(o[2]) & 63)) & 0xFFFFFFFFFFFFFFFF
+        w.sset64(o[0].n, r)
+        w.scc = int(r != 0)
+    elif b == "s_bfe_i32":
+        x, c = g(o[1]), g(o[2])
+        off, wd = c & 31, (c >> 16) & 0x7F
+        r = (x >> off) & ((1 << wd) - 1) if wd else 0
+        if wd and wd < 32 and r & (1 << (wd - 1)):
+            r |= M32 & ~((1 << wd) - 1)
+        w.sset(o[0].n, r)
+        w.scc = int(r != 0)
+    elif b == "s_bfe_i64":
+        x, c = g64(o[1]), g(o[2])
+        off, wd = c & 63, (c >> 16) & 0x7F
+        r = (x >> off) & ((1 << wd) - 1) if wd else 0
+        if wd and wd < 64 and r & (1 << (wd - 1)):
+            r |= 0xFFFFFFFFFFFFFFFF & ~((1 << wd) - 1)
+        w.sset64(o[0].n, r)
+        w.scc = int(r != 0)
+    elif b in ("s_bitset0_b32", "s_bitset1_b32"):
+        bit = 1 << (g(o[1]) & 31)
+        w.sset(o[0].n, (g(o[0]) | bit) if b == "s_bitset1_b32" else (g(o[0]) & ~bit))
+    elif b == "s_brev_b32":
+        w.sset(o[0].n, int("{:032b}".format(g(o[1]))[::-1], 2))
+    elif b in ("s_min_u32", "s_max_u32"):
+        x, y = g(o[1]), g(o[2])
+        first = x <= y if b == "s_min_u32" else x >= y
+        w.sset(o[0].n, x if first else y)
+        w.scc = int(first)
+    elif b == "s_nor_b64":
+        r = ~(g64(o[1]) | g64(o[2])) & 0xFFFFFFFFFFFFFFFF
+        w.sset64(o[0].n, r)
+        w.scc = int(r != 0)
     elif b == "s_pack_ll_b32_b16":
         w.sset(o[0].n, (g(o[1]) & 0xFFFF) | ((g(o[2]) & 0xFFFF) << 16))
     elif b in ("s_and_saveexec_b64", "s_or_saveexec_b64", "s_andn2_saveexec_b64"):
@@ -955,6 +1043,26 @@ def ex_nop(w, ins):
     return None
 
 
+def ex_unknown(w, ins):
+    raise Unknown("no semantics for: %s (line %d)" % (ins.text, ins.line))
+
+
+def ex_call(w, ins):
+    b = ins.base
+    nxt = CODE_BASE + 4 * w.pc                       # (pc already points behind this instruction)
+    if b == "s_getpc_b64":
+        w.sset64(ins.ops[0].n, nxt)
+        w.getpc = nxt
+        return
+    tgt = w.rd_s64(ins.ops[1] if b == "s_swappc_b64" else ins.ops[0])
+    k = tgt - CODE_BASE
+    if k < 0 or k & 3 or (k >> 2) >= len(w.prog):
+        raise Hazard("jump to %#x at line %d (%s)" % (tgt, ins.line, ins.text))
+    if b == "s_swappc_b64":
+        w.sset64(ins.ops[0].n, nxt)
+    w.pc = k >> 2
+
+
 def ex_waitcnt(w, ins):
     w.waitcnt(ins)
 
@@ -969,15 +1077,18 @@ def ex_endpgm(w, ins):
 
 
 def ex_gpr_idx_on(w, ins):
-    if ins.mods.get("gpr_idx") != "DST":
+    mode = ins.mods.get("gpr_idx")
+    if mode not in ("DST", "SRC0"):
         raise Unknown(ins.text)
     idx = w.rd_s(ins.ops[0]) & 0xFF
-    w.sset(M0, (w.sget(M0) & ~0xF0FF) | idx | (8 << 12))
-    w.idx_dst = idx
+    w.sset(M0, (w.sget(M0) & ~0xF0FF) | idx | ((8 if mode == "DST" else 1) << 12))
+    w.idx_dst = idx if mode == "DST" else None
+    w.idx_src0 = idx if mode == "SRC0" else None
 
 
 def ex_gpr_idx_off(w, ins):
     w.idx_dst = None
+    w.idx_src0 = None
 
 
 # ------------------------------------------------------------------------------------------------------------ memory instructions
@@ -1016,9 +1127,12 @@ def gaddr(w, ins, vaddr, saddr):
 
 
 def ex_gload(w, ins):
-    ty = ins.base[len("global_load_"):]
+    ty = ins.base[ins.base.index("_load_") + 6:]
     nb = GL_BYTES[ty]
-    addr = gaddr(w, ins, ins.ops[1], ins.ops[2])
+    if ins.base.startswith("flat_"):                    # (a flat address of these kernels is a global one: no LDS / scratch apertures in use)
+        addr = (w.rd64(ins.ops[1]).view(I64) + I64(int(ins.mods.get("offset", "0"), 0))).view(U64)
+    else:
+        addr = gaddr(w, ins, ins.ops[1], ins.ops[2])
     m = w.execm()
     raw = w.mem.read(addr, nb, m, ins.text)
     d = ins.ops[0].n
@@ -1038,6 +1152,8 @@ def ex_gload(w, ins):
         w.v[d + k] = np.where(m, val, w.v[d + k])
         regs.append(("v", d + k))
     w.poison(w.vm, "load", regs)
+    if ins.base.startswith("flat_"):
+        w.lgkm.append(("lds", []))                   # (a flat access counts on both counters)
 
 
 def vbytes(w, op, nb):
@@ -1214,6 +1330,19 @@ def ex_ds(w, ins):
                 raise Hazard("LDS bytes of an outstanding DMA are written at line %d" % ins.line)
             lds[a:a + nb] = data[l]
         w.lgkm.append(("lds", []))
+    elif b in ("ds_write2_b32", "ds_write2st64_b32", "ds_write2_b64", "ds_write2st64_b64"):
+        el = 8 if b.endswith("b64") else 4
+        stride = el * (64 if "st64" in b else 1)
+        base = w.rd32(o[0]).astype(np.int64)
+        for h, key in enumerate(("offset0", "offset1")):
+            addr = base + off_of(ins, key) * stride
+            data = vbytes(w, o[1 + h], el)
+            for l in np.nonzero(m)[0]:
+                a = int(addr[l])
+                if w.wg.lds_poison[a:a + el].any():
+                    raise Hazard("LDS bytes of an outstanding DMA are written at line %d" % ins.line)
+                lds[a:a + el] = data[l]
+        w.lgkm.append(("lds", []))
     elif b in ("ds_add_u32", "ds_or_b32", "ds_max_u32", "ds_min_u32"):
         addr = (w.rd32(o[0]) + U32(off_of(ins))).astype(np.int64)
         data = w.rd32(o[1])
@@ -1256,6 +1385,8 @@ def handler(ins):
         return ex_valu
     if b in ("v_bitop3_b32", "v_bitop3_b16"):
         return ex_bitop3
+    if b == "v_fmac_f32":
+        return ex_fmac
     if b.startswith("v_cmp_"):
         return ex_vcmp
     if b == "v_cndmask_b32":
@@ -1276,6 +1407,8 @@ def handler(ins):
         return ex_writelane
     if b in ("v_permlane16_swap_b32", "v_permlane32_swap_b32"):
         return ex_permlane_swap
+    if b in ("s_getpc_b64", "s_swappc_b64", "s_setpc_b64"):
+        return ex_call
     if b in ("s_branch",) or b.startswith("s_cbranch_"):
         return ex_branch
     if b in ("s_nop", "s_setprio", "buffer_wbl2", "buffer_inv", "s_sleep", "s_sethalt"):
@@ -1296,7 +1429,7 @@ def handler(ins):
         return ex_dma
     if b.startswith("scratch_load_") or b.startswith("scratch_store_"):
         return ex_scratch
-    if b.startswith("global_load_"):
+    if b.startswith("global_load_") or b.startswith("flat_load_"):
         return ex_gload
     if b.startswith("global_store_"):
         return ex_gstore
@@ -1336,7 +1469,6 @@ KERNARG_BASE = 0x7E0000000000
 def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=None, trace=None, progress=None):
     """runs the workgroups (all of them by default) one after the other; -> {instructions, hazards: [...]}"""
     prog, labels, kd = parse_function(asm_path, symbol)
-    bind(prog)
     kernarg = kernarg_segment(asm_path, symbol, kernarg, grid, block, shmem)
     if kd.get("user_sgpr_count", 2) != 2 or not kd.get("user_sgpr_kernarg_segment_ptr", 1):
         raise Unknown("kernel ABI other than {kernarg pointer, workgroup id x}")
@@ -1350,6 +1482,7 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
         waves = []
         for wi in range((nthreads + 63) // 64):
             w = Wave(wg, wi, prog, labels, mem, kd)
+            w.pc = labels[symbol]
             w.sset64(0, KERNARG_BASE)
             w.sset(2, wgx)
             tid = wi * 64 + LANES
@@ -1403,9 +1536,12 @@ def kernel_offsets(lib, pattern):
 
 
 def replay(dump_dir, k, asm_path, workgroups=None, verbose=True):
-    """runs launch k of a dump through the assembly; -> (summary, list of differing (allocation, first offset, count))"""
+    """runs launch k of a dump through the assembly (a file, or the build directory whose kept files are searched for the kernel);
+    -> (summary, list of differing (allocation, first offset, count))"""
     meta, pre, post = load_dump(dump_dir, k)
     sym = symbol_at(meta["lib"], meta["offset"])
+    if os.path.isdir(asm_path):
+        asm_path = find_asm(asm_path, sym)
     mem = Memory()
     o = 0
     spans = []
