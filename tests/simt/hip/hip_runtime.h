@@ -26,6 +26,7 @@
 #include <math.h>
 #include <algorithm>
 #include <functional>
+#include <mutex>
 #include <tuple>
 #include <vector>
 #include <type_traits>
@@ -127,8 +128,10 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b);
 template <class F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 template <class T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipHostMalloc((void **)p, n, f); }
+extern "C" void simt_dump_register(void *p, size_t n);
 template <class T> static inline hipError_t hipMemcpyToSymbol(T &sym, const void *src, size_t n, size_t off = 0, hipMemcpyKind = hipMemcpyHostToDevice) {
     memcpy((char *)&sym + off, src, n);
+    simt_dump_register((void *)&sym, sizeof(T));          // (a device variable the host fills: part of SIMT_DUMP_DIR's snapshots from here on)
     return hipSuccess;
 }
 
@@ -222,13 +225,16 @@ namespace simt {
 bool dump_wanted();
 int dump_pre(const void *kernel, dim3 grid, dim3 block, size_t shmem, const void *kernarg, size_t kernarg_bytes);
 void dump_post(int id);
+std::mutex &dump_serial();          // while snapshots are taken, launches and copies of all host threads take turns (a snapshot pair must show one kernel's work only)
 }  // namespace simt
 
 template <class... P, class... A>
 static inline void hipLaunchKernelGGL(void (*kernel)(P...), dim3 grid, dim3 block, size_t shmem, hipStream_t, A... args) {
     std::tuple<typename std::decay<P>::type...> params(static_cast<typename std::decay<P>::type>(args)...);
     int dump_id = -1;
+    std::unique_lock<std::mutex> serial;
     if (simt::dump_wanted()) {
+        serial = std::unique_lock<std::mutex>(simt::dump_serial());
         std::vector<char> ka;
         size_t off = 0;
         auto pack = [&](const auto &p) {

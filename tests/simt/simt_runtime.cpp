@@ -400,6 +400,7 @@ bool dump_wanted() {
     static const bool on = getenv("SIMT_DUMP_DIR") != nullptr;
     return on;
 }
+std::mutex &dump_serial() { static std::mutex m; return m; }
 namespace {
 std::atomic<int> g_dump_seq{0};
 std::vector<std::pair<uintptr_t, size_t>> dump_allocs() {
@@ -409,10 +410,41 @@ std::vector<std::pair<uintptr_t, size_t>> dump_allocs() {
     for (auto &kv : g_reg) if (kv.second && kv.second <= cap) v.push_back(kv);
     return v;
 }
-void dump_mem(const std::string &path, const std::vector<std::pair<uintptr_t, size_t>> &al) {
+// (under g_reg_mu: another host thread cannot free an allocation while it is being written; one that went away between the two
+// snapshots of a launch -- or came back with another size -- is written as zeros and named in L<k>.gone: the replay skips it)
+void dump_mem(const std::string &path, const std::vector<std::pair<uintptr_t, size_t>> &al, std::vector<size_t> *gone = nullptr) {
+    // the file: "SNKDUMP1", u64 total bytes, then {u64 offset into the concatenated allocations, u64 n, n bytes} for every 4 KiB piece
+    // that is not all 0xEE (what hipMalloc leaves behind: most of a run's buffers most of the time; n with bit 63 set: one byte
+    // follows, the piece holds it n times); the reader starts from 0xEE
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) { perror(path.c_str()); abort(); }
-    for (auto &a : al) fwrite((const void *)a.first, 1, a.second, f);
+    std::lock_guard<std::mutex> l(g_reg_mu);
+    static const std::vector<unsigned char> fill(4096, 0xEE);
+    uint64_t total = 0, off = 0;
+    for (auto &a : al) total += a.second;
+    fwrite("SNKDUMP1", 1, 8, f);
+    fwrite(&total, 8, 1, f);
+    for (size_t i = 0; i < al.size(); off += al[i].second, ++i) {
+        auto it = g_reg.find(al[i].first);
+        if (it == g_reg.end() || it->second != al[i].second) {
+            if (gone) gone->push_back(i);
+            continue;
+        }
+        const unsigned char *p = (const unsigned char *)al[i].first;
+        for (size_t o = 0; o < al[i].second; o += 4096) {
+            const uint64_t n = std::min<size_t>(4096, al[i].second - o), at = off + o;
+            if (memcmp(p + o, fill.data(), n) == 0) continue;
+            fwrite(&at, 8, 1, f);
+            if (n > 1 && memcmp(p + o, p + o + 1, n - 1) == 0) {          // one byte value all over (cleared tables): {offset, n | 1 << 63, the byte}
+                const uint64_t tagged = n | (1ull << 63);
+                fwrite(&tagged, 8, 1, f);
+                fwrite(p + o, 1, 1, f);
+                continue;
+            }
+            fwrite(&n, 8, 1, f);
+            fwrite(p + o, 1, n, f);
+        }
+    }
     fclose(f);
 }
 std::mutex g_dump_mu;
@@ -433,14 +465,20 @@ int dump_pre(const void *kernel, dim3 grid, dim3 block, size_t shmem, const void
         }
         if (!hit) return -1;
     }
+    if (const char *e = getenv("SIMT_DUMP_PER_KERNEL")) {      // at most this many launches of one kernel (a whole CLI run launches hundreds)
+        static std::mutex mu;
+        static std::map<uintptr_t, int> seen;
+        std::lock_guard<std::mutex> l(mu);
+        if (seen[off]++ >= atoi(e)) return -1;
+    }
     const int id = g_dump_seq.fetch_add(1);
     const std::string base = std::string(getenv("SIMT_DUMP_DIR")) + "/L" + std::to_string(id);
     auto al = dump_allocs();
     dump_mem(base + ".pre", al);
     FILE *f = fopen((base + ".json").c_str(), "w");
     if (!f) { perror(base.c_str()); abort(); }
-    fprintf(f, "{\"lib\": \"%s\", \"offset\": %llu, \"grid\": [%u, %u, %u], \"block\": [%u, %u, %u], \"shmem\": %zu, \"kernarg\": \"",
-            di.dli_fname ? di.dli_fname : "", (unsigned long long)off, grid.x, grid.y, grid.z, block.x, block.y, block.z, shmem);
+    fprintf(f, "{\"lib\": \"%s\", \"base\": %llu, \"offset\": %llu, \"grid\": [%u, %u, %u], \"block\": [%u, %u, %u], \"shmem\": %zu, \"kernarg\": \"",
+            di.dli_fname ? di.dli_fname : "", (unsigned long long)(uintptr_t)di.dli_fbase, (unsigned long long)off, grid.x, grid.y, grid.z, block.x, block.y, block.z, shmem);
     for (size_t i = 0; i < kernarg_bytes; ++i) fprintf(f, "%02x", ((const unsigned char *)kernarg)[i]);
     fprintf(f, "\", \"allocs\": [");
     for (size_t i = 0; i < al.size(); ++i) fprintf(f, "%s[%llu, %zu]", i ? ", " : "", (unsigned long long)al[i].first, al[i].second);
@@ -462,7 +500,13 @@ void dump_post(int id) {
         al = std::move(g_dump_al[id]);
         g_dump_al.erase(id);
     }
-    dump_mem(std::string(getenv("SIMT_DUMP_DIR")) + "/L" + std::to_string(id) + ".post", al);
+    std::vector<size_t> gone;
+    const std::string base = std::string(getenv("SIMT_DUMP_DIR")) + "/L" + std::to_string(id);
+    dump_mem(base + ".post", al, &gone);
+    if (!gone.empty()) {
+        FILE *f = fopen((base + ".gone").c_str(), "w");
+        if (f) { for (size_t i : gone) fprintf(f, "%zu\n", i); fclose(f); }
+    }
 }
 }  // namespace simt
 
@@ -502,10 +546,20 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
     return hipSuccess;
 }
 hipError_t hipHostFree(void *p) { if (simt::dump_wanted()) reg_del(p); free(p); return hipSuccess; }
-hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
+    std::unique_lock<std::mutex> serial;
+    if (simt::dump_wanted()) serial = std::unique_lock<std::mutex>(simt::dump_serial());
+    if (n) memmove(d, s, n);
+    return hipSuccess;
+}
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
-hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { return hipMemcpy(d, s, n, hipMemcpyDeviceToDevice); }
+hipError_t hipMemset(void *d, int v, size_t n) {
+    std::unique_lock<std::mutex> serial;
+    if (simt::dump_wanted()) serial = std::unique_lock<std::mutex>(simt::dump_serial());
+    if (n) memset(d, v, n);
+    return hipSuccess;
+}
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { return hipMemset(d, v, n); }
 hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
     const size_t t = total_mem(), a = g_allocated.load();

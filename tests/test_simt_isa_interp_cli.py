@@ -1,0 +1,138 @@
+"""Every kernel a run of the CLI launches, replayed from the gfx950 assembly the build keeps (tools/gfx950_interp.py).
+
+tests/test_simt_isa_interp.py does this for the tiled kernel's instances on launches of the C ABI.  Here the EMULATED CLI
+(tests/simt: soapnuke_amd/host against the emulated library) runs whole scenarios with SIMT_DUMP_DIR set -- FASTQ ingest, inflate,
+the filter kernels, duplicate marking, formatting, gzip --, the first launch(es) of every kernel are captured (kernarg segment and
+all device memory before / after; while snapshots are taken the launches and copies of all host threads take turns), and each one
+is run again from the kernel's gfx950 instructions on the captured state: the memory it leaves must be the emulated twin's, byte for
+byte, and no result may be used before the s_waitcnt that covers it.  What the emulated CLI writes is compared with the reference
+binary by tests/test_simt_cli.py; this file compares the instructions with the emulated twins.
+
+First run of this file (round 5): 42 kernels, all identical -- the device inflate (search / lane-0 decode / cooperative decode /
+chain / resolve), the FASTQ index / scatter / format kernels and their scans, the deflate kernels with their run-time constant
+tables (hipMemcpyToSymbol'd device variables reached through the global offset table), hash / insert / look-up of one- and
+two-pass duplicate marking, the contaminant and long-read kernels, the generic kernel.  No GPU."""
+import concurrent.futures
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import simt_lib as S
+import snk_testlib as T
+from soapnuke_amd import synth
+
+sys.path.insert(0, os.path.join(T.ROOT, "tools"))
+import gfx950_interp as G          # noqa: E402
+
+BUILD = os.path.join(T.ROOT, "soapnuke_amd", "csrc", "build")
+ADAPTERS = ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2]
+from cases import CT1, CT2, GC1, plant_contams          # noqa: E402
+
+CONTAM_KW = dict(contam1=CT1 + ",GGGGGGGGGGGGGGGGGGGGGGGG", contam2=CT2, global_contams=GC1)
+CONTAM_CFG = ["contam1=" + CONTAM_KW["contam1"], "ctMatchR=0.6,0.7", "global_contams=" + GC1, "glob_cotm_mR=0.4", "glob_cotm_mM=1"]
+
+# name -> dict(n, L, paired, gz_in, gz_out, cfg lines, extra command line, environment, kernels that must have been replayed)
+SCENARIOS = {
+    # the README shape: .gz in, .gz out, duplicates marked in one pass, the device decodes the input (cooperative decode)
+    "pe150_gz_rmdup_device_inflate": dict(
+        n=240, L=150, paired=True, gz_in=True, gz_out=True, cfg=["rmdup"], cli=ADAPTERS + ["-J", "-l", "10", "-q", "0.1"],
+        env={"SNK_DEVICE_INFLATE": "1", "SNK_DGZ_WINDOW_MB": "1", "SNK_DGZ_CHUNK_KB": "8", "SNK_BATCH_PAIRS": "128"},
+        expect=["inf_search_kernel", "inf_decode_coop_kernel", "inf_chain_kernel", "inf_resolve_kernel", "fq_count_kernel", "fq_index_kernel",
+                "scan_sums_kernel", "scan_top_kernel", "scan_apply_kernel", "fq_scatter_kernel", "snk_hash_lds_kernel", "snk_stream_insert_kernel",
+                "snk_stream_lookup_kernel", "snk_tiled_kernel", "snk_tiled_reduce_kernel", "fq_outlen_kernel", "fq_format_kernel", "dfl_hist_kernel",
+                "dfl_build_kernel", "dfl_bits_kernel", "dfl_member_kernel", "dfl_emit_kernel", "snk_finalize_kernel"]),
+    # single end, the lane-0 decoder, two passes of duplicate marking, a contaminant list on 150-position reads
+    "se150_gz_two_pass_rmdup_contam": dict(
+        n=300, L=150, paired=False, gz_in=True, gz_out=False, cfg=["rmdup"] + CONTAM_CFG, cli=["-f", synth.ADAPTER1, "-l", "10", "-q", "0.2"],
+        env={"SNK_DEVICE_INFLATE": "1", "SNK_DGZ_COOP": "0", "SNK_DGZ_WINDOW_MB": "1", "SNK_DGZ_CHUNK_KB": "8", "SNK_BATCH_PAIRS": "128", "SNK_RMDUP_TWO_PASS": "1"},
+        expect=["inf_decode_kernel", "snk_mark_insert_kernel", "snk_mark_lookup_kernel", "snk_contam_kernel", "snk_tiled_kernel"]),
+    # reads of 400 positions: the long-read path (prep / decide / histograms) and its contaminant kernel
+    "pe400_long_reads_contam": dict(
+        n=120, L=400, paired=True, gz_in=False, gz_out=False, cfg=CONTAM_CFG + ["contam2=" + CT2], cli=ADAPTERS + ["-J", "-l", "10", "-q", "0.2"],
+        env={"SNK_BATCH_PAIRS": "64"},
+        expect=["snk_long_prep_kernel", "snk_long_decide_kernel", "snk_long_hist_kernel", "snk_long_contam_kernel"]),
+    # outside the envelope SNK_PROVEN_ONLY=1 keeps for the tiled kernel (a five-character adapter): the generic kernel decides
+    "pe150_generic_kernel": dict(
+        n=200, L=150, paired=True, gz_in=False, gz_out=False, cfg=[], cli=["-f", "AAGTC", "-r", "AAGTC", "-l", "10", "-q", "0.2"],
+        env={"SNK_PROVEN_ONLY": "1", "SNK_BATCH_PAIRS": "128"},
+        expect=["snk_generic_kernel"]),
+    # 250 positions: the eight-plane-word instances of the tiled and the contaminant kernel (BASELINE configs[4]'s shape)
+    "pe250_contam_rmdup": dict(
+        n=160, L=250, paired=True, gz_in=False, gz_out=True, cfg=["rmdup"] + CONTAM_CFG + ["contam2=" + CT2],
+        cli=ADAPTERS + ["-J", "-l", "10", "-q", "0.2", "-n", "0.01", "-m", "20", "-g", "10", "-X", "50", "-p", "0.8"],
+        env={"SNK_BATCH_PAIRS": "96"},
+        expect=["snk_tiled_kernel", "snk_contam_kernel", "snk_hash_lds_kernel"]),
+}
+# an ordinary run (tests/conftest.py: SNK_SIMT_FULL=1 takes everything)
+CORE = ["test_every_kernel_of_a_run_matches_its_emulated_twin[pe150_gz_rmdup_device_inflate]"]
+pytestmark = pytest.mark.skipif(not os.path.isdir(BUILD), reason="the build's kept assembly is not there (python __graft_entry__.py)")
+
+
+def write_inputs(work, sc):
+    n, L, paired = sc["n"], sc["L"], sc["paired"]
+    d = synth.make_batch(n, L, paired=paired, seed=17, var_len=True, dimer_frac=0.1)
+    rows = max(8, n // 10)
+    if any(c.startswith("contam1=") for c in sc["cfg"]):       # whole / truncated copies of the contaminants in some reads
+        plant_contams(d, {k: v for k, v in CONTAM_KW.items() if paired or k != "contam2"})
+    for m in range(2 if paired else 1):                       # duplicates
+        for key in ("seq", "qual"):
+            d[key][m][n // 2:n // 2 + rows] = d[key][m][0:rows]
+        if d["len"][m] is not None:
+            d["len"][m][n // 2:n // 2 + rows] = d["len"][m][0:rows]
+    files = []
+    for m in range(2 if paired else 1):
+        f = os.path.join(work, "r%d.fq" % (m + 1))
+        synth.write_fastq(f, d["seq"][m], d["qual"][m], L, m + 1, lens=d["len"][m])
+        if sc["gz_in"]:
+            with open(f, "rb") as src, gzip.open(f + ".gz", "wb", compresslevel=6) as dst:
+                dst.write(src.read())
+            f += ".gz"
+        files.append(f)
+    return files
+
+
+def capture_run(work, sc, per_kernel=1):
+    cli = S.build_module().build_cli()
+    files = write_inputs(work, sc)
+    dump = os.path.join(work, "dump")
+    os.makedirs(dump)
+    ext = ".fq.gz" if sc["gz_out"] else ".fq"
+    cmd = [cli, "filter", "-1", files[0], "-C", "c1" + ext, "-o", os.path.join(work, "out"), "-T", "1"]
+    if sc["paired"]:
+        cmd += ["-2", files[1], "-D", "c2" + ext]
+    if sc["cfg"]:
+        with open(os.path.join(work, "cfg"), "w") as f:
+            f.write("\n".join(sc["cfg"]) + "\n")
+        cmd += ["-c", os.path.join(work, "cfg")]
+    env = dict(os.environ, SIMT_DUMP_DIR=dump, SIMT_DUMP_PER_KERNEL=str(per_kernel), SIMT_CUS="2", **sc["env"])
+    r = subprocess.run(cmd + sc["cli"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    return dump, sorted(int(f[1:-5]) for f in os.listdir(dump) if f.endswith(".json"))
+
+
+def replay_one(args):
+    dump, k = args
+    try:
+        info, diffs = G.replay(dump, k, BUILD, verbose=False)
+        return k, info["symbol"], info["instructions"], diffs, None
+    except Exception as e:                                    # (a hazard, an unknown instruction: the test names the kernel)
+        meta = json.load(open(os.path.join(dump, "L%d.json" % k)))
+        return k, G.symbol_at(meta["lib"], meta["offset"]), 0, [], "%s: %s" % (type(e).__name__, e)
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_every_kernel_of_a_run_matches_its_emulated_twin(name, tmp_path):
+    sc = SCENARIOS[name]
+    dump, launches = capture_run(str(tmp_path), sc)
+    assert launches
+    with concurrent.futures.ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        results = list(pool.map(replay_one, [(dump, k) for k in launches]))
+    bad = [(k, sym, err or diffs) for k, sym, n, diffs, err in results if err or diffs]
+    assert not bad, bad
+    seen = [sym for _, sym, n, _, _ in results if n > 0]
+    for want in sc["expect"]:
+        assert any(want in s for s in seen), (want, seen)

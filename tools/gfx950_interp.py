@@ -92,6 +92,9 @@ def parse_operand(t):
     m = re.match(r"^(\S+)@rel32@(lo|hi)\+\d+$", t)
     if m:                                   # the two halves of `symbol - (the pc s_getpc_b64 returned)`, see ex_call
         return Op("rel", n=1 if m.group(2) == "hi" else 0, text=m.group(1))
+    m = re.match(r"^(\S+)@gotpcrel32@(lo|hi)\+\d+$", t)
+    if m:                                   # the same for the symbol's entry in the global offset table (an s_load_dwordx2 fetches the address)
+        return Op("got", n=1 if m.group(2) == "hi" else 0, text=m.group(1))
     return Op("label", text=t)
 
 
@@ -174,6 +177,98 @@ def parse_file(asm_path):
     return _FILES[key]
 
 
+DATA_BASE = 0x7C0000000000          # the file's data sections (constant tables the compiler emits, device variables with initialisers)
+GOT_BASE = 0x7B0000000000           # one 8-byte entry per symbol taken through @gotpcrel32
+_DATA = {}
+_INT_DIRECTIVES = {".byte": 1, ".short": 2, ".2byte": 2, ".hword": 2, ".long": 4, ".4byte": 4, ".int": 4, ".quad": 8, ".8byte": 8}
+
+
+def _c_string(lit):
+    out, i = bytearray(), 0
+    esc = {"n": 10, "t": 9, "r": 13, "b": 8, "f": 12, "\\": 92, '"': 34, "v": 11, "a": 7}
+    while i < len(lit):
+        ch = lit[i]
+        if ch != "\\":
+            out.append(ord(ch))
+            i += 1
+            continue
+        i += 1
+        m = re.match(r"[0-7]{1,3}", lit[i:])
+        if m:
+            out.append(int(m.group(0), 8) & 0xFF)
+            i += len(m.group(0))
+        elif lit[i] == "x":
+            m = re.match(r"[0-9a-fA-F]+", lit[i + 1:])
+            out.append(int(m.group(0), 16) & 0xFF)
+            i += 1 + len(m.group(0))
+        else:
+            out.append(esc.get(lit[i], ord(lit[i])))
+            i += 1
+    return bytes(out)
+
+
+def parse_data(asm_path):
+    """the data sections of the file: -> ({symbol: offset into the image}, image bytes).  Code sections are skipped; a value that is
+    not a number (a relocation against another symbol) is stored as zero."""
+    key = (asm_path, os.path.getmtime(asm_path))
+    if key in _DATA:
+        return _DATA[key]
+    text = open(asm_path).read()
+    code = text[:text.find(".amdgpu_metadata")] if ".amdgpu_metadata" in text else text
+    syms, img, in_data = {}, bytearray(), False
+    for raw in code.split("\n"):
+        line = raw.strip()
+        if not line:
+            continue
+        if line.startswith(".text"):
+            in_data = False
+            continue
+        if line.startswith((".data", ".bss", ".rodata")):
+            in_data = True
+            continue
+        if line.startswith(".section"):
+            name = line.split()[1].split(",")[0].strip('"')
+            in_data = name.startswith((".rodata", ".data", ".bss")) and '"ax"' not in line and "amdhsa" not in name
+            continue
+        if not in_data:
+            continue
+        if line.startswith('.ascii') or line.startswith('.asciz') or line.startswith('.string'):
+            d, rest = line.split(None, 1)
+            for m in re.finditer(r'"((?:[^"\\]|\\.)*)"', rest):
+                img += _c_string(m.group(1)) + (b"\0" if d != ".ascii" else b"")
+            continue
+        line = line.split(";")[0].strip()
+        if not line:
+            continue
+        if line.endswith(":") and not line.startswith("."):
+            syms[line[:-1]] = len(img)
+            continue
+        if line.endswith(":"):
+            syms[line[:-1]] = len(img)
+            continue
+        p = line.split(None, 1)
+        d, rest = p[0], (p[1] if len(p) > 1 else "")
+        if d in _INT_DIRECTIVES:
+            for t in rest.split(","):
+                try:
+                    v = int(t.strip(), 0)
+                except ValueError:
+                    v = 0
+                img += (v & ((1 << (8 * _INT_DIRECTIVES[d])) - 1)).to_bytes(_INT_DIRECTIVES[d], "little")
+        elif d in (".zero", ".space", ".skip"):
+            a = [int(t.strip(), 0) for t in rest.split(",")]
+            img += bytes([a[1] & 0xFF if len(a) > 1 else 0]) * a[0]
+        elif d == ".fill":
+            a = [int(t.strip(), 0) for t in rest.split(",")] + [1, 0]
+            img += (a[2] & ((1 << (8 * a[1])) - 1)).to_bytes(a[1], "little") * a[0]
+        elif d in (".p2align", ".align", ".balign"):
+            a = int(rest.split(",")[0].strip(), 0)
+            a = 1 << a if d == ".p2align" else max(a, 1)
+            img += bytes(-len(img) % a)
+    _DATA[key] = (syms, bytes(img))
+    return _DATA[key]
+
+
 def parse_function(asm_path, symbol):
     """-> (the file's program, labels, the kernel descriptor of `symbol` {key: int})"""
     prog, labels, text = parse_file(asm_path)
@@ -239,6 +334,21 @@ class Memory:
 
     def __init__(self):
         self.bases, self.sizes, self.bufs = [], [], []
+        self.got = {}                       # symbol -> its entry's address in the table at GOT_BASE
+        self.symbol_address = None          # name -> address of a device variable (set by the caller; replay(): the emulated library's own copy)
+
+    def got_entry(self, name):
+        if name not in self.got:
+            if GOT_BASE not in self.bases:
+                self.add(GOT_BASE, bytes(8 * 512))
+            addr = self.symbol_address(name) if self.symbol_address else None
+            if addr is None:
+                raise Unknown("no address for the device variable " + name)
+            at = GOT_BASE + 8 * len(self.got)
+            j = self.bases.index(GOT_BASE)
+            self.bufs[j][at - GOT_BASE:at - GOT_BASE + 8] = np.frombuffer(int(addr).to_bytes(8, "little"), dtype=np.uint8)
+            self.got[name] = at
+        return self.got[name]
 
     def add(self, base, data):
         i = bisect.bisect_left(self.bases, base)
@@ -311,6 +421,7 @@ class Wave:
         self._exec_cache = (None, None)
         self.cur = None
         self.scratch = np.full((64, kd.get("private_segment_fixed_size", 0) + 16), 0xEE, dtype=np.uint8)
+        self.data_syms = {}                              # data symbols of the file (parse_data): offsets behind DATA_BASE
 
     # ---- registers
     def sget(self, n):
@@ -361,7 +472,11 @@ class Wave:
             d = (4 * (self.labels[op.text] - self.labels[op.val])) & 0xFFFFFFFFFFFFFFFF
             return (d >> 32) & M32 if op.n else d & M32
         if op.kind == "rel":
-            d = (CODE_BASE + 4 * self.labels[op.text] - self.getpc) & 0xFFFFFFFFFFFFFFFF
+            at = DATA_BASE + self.data_syms[op.text] if op.text in self.data_syms else CODE_BASE + 4 * self.labels[op.text]
+            d = (at - self.getpc) & 0xFFFFFFFFFFFFFFFF
+            return (d >> 32) & M32 if op.n else d & M32
+        if op.kind == "got":
+            d = (self.mem.got_entry(op.text) - self.getpc) & 0xFFFFFFFFFFFFFFFF
             return (d >> 32) & M32 if op.n else d & M32
         raise Unknown("scalar operand %r in %s" % (op, self.cur.text))
 
@@ -1128,6 +1243,10 @@ def gaddr(w, ins, vaddr, saddr):
 
 def ex_gload(w, ins):
     ty = ins.base[ins.base.index("_load_") + 6:]
+    d16 = None
+    if "_d16" in ty:                                     # 16 bits of the destination are written, the other half is kept
+        d16 = "hi" if ty.endswith("_d16_hi") else "lo"
+        ty = ty[:ty.index("_d16")]
     nb = GL_BYTES[ty]
     if ins.base.startswith("flat_"):                    # (a flat address of these kernels is a global one: no LDS / scratch apertures in use)
         addr = (w.rd64(ins.ops[1]).view(I64) + I64(int(ins.mods.get("offset", "0"), 0))).view(U64)
@@ -1149,6 +1268,10 @@ def ex_gload(w, ins):
             val = (val.astype(np.uint8).view(np.int8).astype(I32)).view(U32)
         if ty == "sshort":
             val = (val.astype(np.uint16).view(np.int16).astype(I32)).view(U32)
+        if d16 == "hi":
+            val = (w.v[d + k] & U32(0xFFFF)) | ((val & U32(0xFFFF)) << U32(16))
+        elif d16 == "lo":
+            val = (w.v[d + k] & U32(0xFFFF0000)) | (val & U32(0xFFFF))
         w.v[d + k] = np.where(m, val, w.v[d + k])
         regs.append(("v", d + k))
     w.poison(w.vm, "load", regs)
@@ -1168,9 +1291,13 @@ def vbytes(w, op, nb):
 
 def ex_gstore(w, ins):
     ty = ins.base[len("global_store_"):]
+    hi = ty.endswith("_d16_hi")                          # the upper 16 bits of the register are what is stored
+    if hi:
+        ty = ty[:-7]
     nb = GL_BYTES[ty]
     addr = gaddr(w, ins, ins.ops[0], ins.ops[2])
-    w.mem.write(addr, vbytes(w, ins.ops[1], nb), w.execm(), ins.text)
+    data = vbytes(w, ins.ops[1], 4)[:, 2:2 + nb] if hi else vbytes(w, ins.ops[1], nb)
+    w.mem.write(addr, data, w.execm(), ins.text)
     w.vm.append(("store", []))
 
 
@@ -1225,7 +1352,14 @@ def ex_gatomic(w, ins):
         vaddr, vdata, saddr = ops
     nb = 8 if wide else 4
     addr = gaddr(w, ins, vaddr, saddr)
-    data = w.rd64(vdata) if wide else w.rd32(vdata).astype(U64)
+    cmp = None
+    if op == "cmpswap":                     # DATA[0] = the value to store, DATA[1] = the value to compare with (two / four registers)
+        half = Op("v", vdata.n, vdata.cnt // 2, text="v%d" % vdata.n)
+        other = Op("v", vdata.n + vdata.cnt // 2, vdata.cnt // 2, text="v%d" % (vdata.n + vdata.cnt // 2))
+        data = w.rd64(half) if wide else w.rd32(half).astype(U64)
+        cmp = w.rd64(other) if wide else w.rd32(other).astype(U64)
+    else:
+        data = w.rd64(vdata) if wide else w.rd32(vdata).astype(U64)
     m = w.execm()
     old_out = np.zeros(64, dtype=U64)
     fmt = "<Q" if wide else "<I"
@@ -1237,7 +1371,10 @@ def ex_gatomic(w, ins):
         o = x - w.mem.bases[j]
         old = struct.unpack_from(fmt, buf, o)[0]
         d = int(data[l])
-        new = {"add": (old + d) & mask, "umin": min(old, d), "umax": max(old, d), "swap": d, "or": old | d, "and": old & d}[op]
+        if cmp is not None:
+            new = d if old == int(cmp[l]) else old
+        else:
+            new = {"add": (old + d) & mask, "umin": min(old, d), "umax": max(old, d), "swap": d, "or": old | d, "and": old & d}[op]
         struct.pack_into(fmt, buf, o, new)
         old_out[l] = old
     if ret:
@@ -1466,22 +1603,48 @@ class Workgroup:
 KERNARG_BASE = 0x7E0000000000
 
 
-def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=None, trace=None, progress=None):
-    """runs the workgroups (all of them by default) one after the other; -> {instructions, hazards: [...]}"""
+def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=None, trace=None, progress=None, schedule=None):
+    """runs the workgroups (all of them by default) one after the other; -> {instructions, hazards: [...]}
+
+    schedule: how the wavefronts of a workgroup take turns between two barriers (the hardware promises no order at all):
+      None / "forward"   wave 0 up to its barrier (or its end), then wave 1, ...               (the emulated twin's order)
+      "reverse"          the last wave first, the workgroups from the last one down
+      "random:SEED[:Q]"  pre-emptive: a random runnable wave runs 1..Q (default 40) instructions, then the next draw; the
+                         workgroups in a shuffled order.  A kernel whose waves hand data to each other through LDS or memory
+                         without a barrier in between leaves different memory under one of these orders -- unless it means to
+                         (a slot counter, first-come-first-kept tables): those kernels are named by their tests."""
     prog, labels, kd = parse_function(asm_path, symbol)
     kernarg = kernarg_segment(asm_path, symbol, kernarg, grid, block, shmem)
     if kd.get("user_sgpr_count", 2) != 2 or not kd.get("user_sgpr_kernarg_segment_ptr", 1):
         raise Unknown("kernel ABI other than {kernarg pointer, workgroup id x}")
     if KERNARG_BASE not in mem.bases:
         mem.add(KERNARG_BASE, bytes(kernarg) + bytes(256))
+    data_syms, image = parse_data(asm_path)
+    if image and DATA_BASE not in mem.bases:
+        mem.add(DATA_BASE, image + bytes(64))
+    if mem.symbol_address is None:
+        mem.symbol_address = lambda name: DATA_BASE + data_syms[name] if name in data_syms else None
     static_lds = kd.get("group_segment_fixed_size", 0)
     nthreads = block[0] * block[1] * block[2]
     total, racy, racy_lines = 0, 0, set()
-    for wgx in (range(grid[0]) if workgroups is None else workgroups):
+    wg_order = list(range(grid[0]) if workgroups is None else workgroups)
+    rng, quantum = None, 40
+    if schedule == "reverse":
+        wg_order.reverse()
+    elif schedule and schedule.startswith("random"):
+        import random
+        parts = schedule.split(":")
+        rng = random.Random(int(parts[1]) if len(parts) > 1 else 1)
+        quantum = int(parts[2]) if len(parts) > 2 else 40
+        rng.shuffle(wg_order)
+    elif schedule not in (None, "forward"):
+        raise ValueError("schedule: " + schedule)
+    for wgx in wg_order:
         wg = Workgroup(static_lds + shmem)
         waves = []
         for wi in range((nthreads + 63) // 64):
             w = Wave(wg, wi, prog, labels, mem, kd)
+            w.data_syms = data_syms
             w.pc = labels[symbol]
             w.sset64(0, KERNARG_BASE)
             w.sset(2, wgx)
@@ -1496,13 +1659,26 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
             w.trace = trace
             waves.append(w)
         live = list(waves)
+        if rng is not None:
+            waiting = []
+            while live or waiting:
+                if not live:                       # every wave that has not ended stands at the barrier
+                    live, waiting = waiting, []
+                    continue
+                w = live[rng.randrange(len(live))]
+                r = w.run(limit=w.nexec + rng.randint(1, quantum))
+                if r == "barrier":
+                    live.remove(w)
+                    waiting.append(w)
+                elif r == "end":
+                    live.remove(w)
         while live:
             at_barrier = []
-            for w in live:
+            for w in (reversed(live) if schedule == "reverse" else live):
                 r = w.run()
                 if r == "barrier":
                     at_barrier.append(w)
-            live = at_barrier
+            live = at_barrier[::-1] if schedule == "reverse" else at_barrier
         for w in waves:
             total += w.nexec
         racy += wg.racy_reads
@@ -1515,9 +1691,27 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
 # ------------------------------------------------------------------------------------------------------------ captured launches
 def load_dump(dump_dir, k):
     meta = json.load(open(os.path.join(dump_dir, "L%d.json" % k)))
-    pre = open(os.path.join(dump_dir, "L%d.pre" % k), "rb").read()
-    post = open(os.path.join(dump_dir, "L%d.post" % k), "rb").read()
-    return meta, pre, post
+    return meta, read_image(os.path.join(dump_dir, "L%d.pre" % k)), read_image(os.path.join(dump_dir, "L%d.post" % k))
+
+
+def read_image(path):
+    """a snapshot of tests/simt/simt_runtime.cpp's dump_mem: the pieces that are not all 0xEE, at their offsets"""
+    raw = open(path, "rb").read()
+    if raw[:8] != b"SNKDUMP1":
+        return raw
+    total = struct.unpack_from("<Q", raw, 8)[0]
+    img = bytearray(b"\xee") * total
+    o = 16
+    while o < len(raw):
+        at, n = struct.unpack_from("<QQ", raw, o)
+        if n >> 63:                         # one byte value all over the piece
+            n &= (1 << 63) - 1
+            img[at:at + n] = raw[o + 16:o + 17] * n
+            o += 17
+        else:
+            img[at:at + n] = raw[o + 16:o + 16 + n]
+            o += 16 + n
+    return bytes(img)
 
 
 def symbol_at(lib, offset):
@@ -1535,7 +1729,7 @@ def kernel_offsets(lib, pattern):
     return {int(p[0], 16): p[2] for p in (l.split() for l in out.split("\n")) if len(p) == 3 and pattern in p[2]}
 
 
-def replay(dump_dir, k, asm_path, workgroups=None, verbose=True):
+def replay(dump_dir, k, asm_path, workgroups=None, verbose=True, schedule=None):
     """runs launch k of a dump through the assembly (a file, or the build directory whose kept files are searched for the kernel);
     -> (summary, list of differing (allocation, first offset, count))"""
     meta, pre, post = load_dump(dump_dir, k)
@@ -1549,10 +1743,27 @@ def replay(dump_dir, k, asm_path, workgroups=None, verbose=True):
         mem.add(base, pre[o:o + size])
         spans.append((base, size, o))
         o += size
-    info = run_launch(asm_path, sym, bytes.fromhex(meta["kernarg"]), meta["grid"], meta["block"], meta["shmem"], mem, workgroups,
+    if "base" in meta:                     # a device variable the host fills (hipMemcpyToSymbol): the emulated library's own copy, if it was captured
+        data_syms, _ = parse_data(asm_path)
+        lib_syms = {v: k for k, v in kernel_offsets(meta["lib"], "").items()}
+
+        def symbol_address(name):
+            if name in lib_syms:
+                a = meta["base"] + lib_syms[name]
+                i = bisect.bisect_right(mem.bases, a) - 1
+                if i >= 0 and a < mem.bases[i] + mem.sizes[i]:
+                    return a
+            return DATA_BASE + data_syms[name] if name in data_syms else None
+        mem.symbol_address = symbol_address
+    gone = set()
+    if os.path.exists(os.path.join(dump_dir, "L%d.gone" % k)):          # freed while the kernel's snapshots were taken (another host thread)
+        gone = {int(x) for x in open(os.path.join(dump_dir, "L%d.gone" % k)).read().split()}
+    info = run_launch(asm_path, sym, bytes.fromhex(meta["kernarg"]), meta["grid"], meta["block"], meta["shmem"], mem, workgroups, schedule=schedule,
                       progress=(lambda g, n: print("  workgroup %d done, %d wave instructions so far" % (g, n), flush=True)) if verbose else None)
     diffs = []
-    for base, size, o in spans:
+    for n, (base, size, o) in enumerate(spans):
+        if n in gone:
+            continue
         i = mem.bases.index(base)
         want = np.frombuffer(post[o:o + size], dtype=np.uint8)
         ne = np.nonzero(mem.bufs[i] != want)[0]
@@ -1569,9 +1780,10 @@ def main():
     ap.add_argument("launch", type=int)
     ap.add_argument("asm")
     ap.add_argument("--workgroups", type=str, default=None)
+    ap.add_argument("--schedule", type=str, default=None, help="forward (default) | reverse | random:SEED[:QUANTUM]")
     a = ap.parse_args()
     wgs = [int(x) for x in a.workgroups.split(",")] if a.workgroups else None
-    info, diffs = replay(a.dump_dir, a.launch, a.asm, wgs)
+    info, diffs = replay(a.dump_dir, a.launch, a.asm, wgs, schedule=a.schedule)
     print(json.dumps(info))
     for d in diffs:
         print("DIFFERS: allocation %#x (%d bytes): %d bytes differ, the first at offset %d" % (d[0], d[3], d[2], d[1]))
