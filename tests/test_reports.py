@@ -40,6 +40,10 @@ def test_reports_match_golden(case, tmp_path):
 @pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")
 @pytest.mark.parametrize("case", R.REPORT_CASES[:2], ids=IDS[:2])
 def test_reports_match_live_reference(case, tmp_path):
+    if case[0] == "pe_adatrim_T4" and os.environ.get("SNK_SIMT_FULL") != "1":
+        # (70 s, sixty of them the reference's own wait in remove_tmpDir after a run with several threads; its reports are the
+        #  golden files test_reports_match_golden compares with on every run)
+        pytest.skip("the reference's -T 4 run takes 70 s: SNK_SIMT_FULL=1 runs it")
     d, p = R.case_inputs(case)
     ref = R.run_reference_cli(case, d, str(tmp_path / "work"))
     R.write_reports(p, R.vthread_stats(case, d, p, _oracle_run), str(tmp_path / "ours"))

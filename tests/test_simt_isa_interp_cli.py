@@ -39,8 +39,8 @@ CONTAM_CFG = ["contam1=" + CONTAM_KW["contam1"], "ctMatchR=0.6,0.7", "global_con
 SCENARIOS = {
     # the README shape: .gz in, .gz out, duplicates marked in one pass, the device decodes the input (cooperative decode)
     "pe150_gz_rmdup_device_inflate": dict(
-        n=240, L=150, paired=True, gz_in=True, gz_out=True, cfg=["rmdup"], cli=ADAPTERS + ["-J", "-l", "10", "-q", "0.1"],
-        env={"SNK_DEVICE_INFLATE": "1", "SNK_DGZ_WINDOW_MB": "1", "SNK_DGZ_CHUNK_KB": "8", "SNK_BATCH_PAIRS": "128"},
+        n=128, L=150, paired=True, gz_in=True, gz_out=True, cfg=["rmdup"], cli=ADAPTERS + ["-J", "-l", "10", "-q", "0.1"],
+        env={"SNK_DEVICE_INFLATE": "1", "SNK_DGZ_WINDOW_MB": "1", "SNK_DGZ_CHUNK_KB": "8", "SNK_BATCH_PAIRS": "64"},
         expect=["inf_search_kernel", "inf_decode_coop_kernel", "inf_chain_kernel", "inf_resolve_kernel", "fq_count_kernel", "fq_index_kernel",
                 "scan_sums_kernel", "scan_top_kernel", "scan_apply_kernel", "fq_scatter_kernel", "snk_hash_lds_kernel", "snk_stream_insert_kernel",
                 "snk_stream_lookup_kernel", "snk_tiled_kernel", "snk_tiled_reduce_kernel", "fq_outlen_kernel", "fq_format_kernel", "dfl_hist_kernel",
@@ -114,10 +114,14 @@ def capture_run(work, sc, per_kernel=1):
     return dump, sorted(int(f[1:-5]) for f in os.listdir(dump) if f.endswith(".json"))
 
 
+# the twin's own order of the waves, and -- in a full run -- a pre-emptive scheduler with a pace per wave (tests/test_simt_isa_schedules.py)
+SCHEDULES = [None, "skew:1"] if os.environ.get("SNK_SIMT_FULL") == "1" else [None]
+
+
 def replay_one(args):
-    dump, k = args
+    dump, k, schedule = args
     try:
-        info, diffs = G.replay(dump, k, BUILD, verbose=False)
+        info, diffs = G.replay(dump, k, BUILD, verbose=False, schedule=schedule)
         return k, info["symbol"], info["instructions"], diffs, None
     except Exception as e:                                    # (a hazard, an unknown instruction: the test names the kernel)
         meta = json.load(open(os.path.join(dump, "L%d.json" % k)))
@@ -130,7 +134,7 @@ def test_every_kernel_of_a_run_matches_its_emulated_twin(name, tmp_path):
     dump, launches = capture_run(str(tmp_path), sc)
     assert launches
     with concurrent.futures.ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-        results = list(pool.map(replay_one, [(dump, k) for k in launches]))
+        results = list(pool.map(replay_one, [(dump, k, s) for k in launches for s in SCHEDULES]))
     bad = [(k, sym, err or diffs) for k, sym, n, diffs, err in results if err or diffs]
     assert not bad, bad
     seen = [sym for _, sym, n, _, _ in results if n > 0]

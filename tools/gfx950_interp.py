@@ -1610,7 +1610,9 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
       None / "forward"   wave 0 up to its barrier (or its end), then wave 1, ...               (the emulated twin's order)
       "reverse"          the last wave first, the workgroups from the last one down
       "random:SEED[:Q]"  pre-emptive: a random runnable wave runs 1..Q (default 40) instructions, then the next draw; the
-                         workgroups in a shuffled order.  A kernel whose waves hand data to each other through LDS or memory
+                         workgroups in a shuffled order.
+      "skew:SEED[:Q]"    the same with a pace per wave and barrier interval (turns of at most 2, Q or 10 Q instructions): one wave
+                         can still be inside a loop the others left long ago.  A kernel whose waves hand data to each other through LDS or memory
                          without a barrier in between leaves different memory under one of these orders -- unless it means to
                          (a slot counter, first-come-first-kept tables): those kernels are named by their tests."""
     prog, labels, kd = parse_function(asm_path, symbol)
@@ -1631,11 +1633,12 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
     rng, quantum = None, 40
     if schedule == "reverse":
         wg_order.reverse()
-    elif schedule and schedule.startswith("random"):
+    elif schedule and schedule.split(":")[0] in ("random", "skew"):
         import random
         parts = schedule.split(":")
         rng = random.Random(int(parts[1]) if len(parts) > 1 else 1)
         quantum = int(parts[2]) if len(parts) > 2 else 40
+        skew = parts[0] == "skew"
         rng.shuffle(wg_order)
     elif schedule not in (None, "forward"):
         raise ValueError("schedule: " + schedule)
@@ -1661,12 +1664,18 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
         live = list(waves)
         if rng is not None:
             waiting = []
+            fresh = True
             while live or waiting:
                 if not live:                       # every wave that has not ended stands at the barrier
                     live, waiting = waiting, []
+                    fresh = True
                     continue
+                if fresh:                          # "skew": between two barriers every wave has a pace of its own
+                    for w in live:
+                        w.qcap = rng.choice((2, quantum, 10 * quantum)) if skew else quantum
+                    fresh = False
                 w = live[rng.randrange(len(live))]
-                r = w.run(limit=w.nexec + rng.randint(1, quantum))
+                r = w.run(limit=w.nexec + rng.randint(1, w.qcap))
                 if r == "barrier":
                     live.remove(w)
                     waiting.append(w)

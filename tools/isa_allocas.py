@@ -22,7 +22,14 @@ def one(src, tmp):
     name = os.path.splitext(os.path.basename(src))[0]
     d = os.path.join(tmp, name)
     os.makedirs(d)
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "x.o", "-save-temps=obj"],
+    kept = os.path.join(CSRC, "build")           # soapnuke_amd/build.py keeps bitcode and assembly of the shipped objects (same flags)
+    kbc = os.path.join(kept, name + "-hip-amdgcn-amd-amdhsa-gfx950.bc")
+    if os.path.dirname(os.path.abspath(src)) == CSRC and os.path.exists(kbc) and os.path.exists(kbc[:-3] + ".s") and not os.environ.get("ISA_ALLOCAS_RECOMPILE"):
+        import glob
+        deps = [src] + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+        if all(os.path.getmtime(f) <= os.path.getmtime(kbc) for f in deps):
+            d = kept
+    r = subprocess.CompletedProcess([], 0) if d == kept else subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "x.o", "-save-temps=obj"],
                        cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode:
         return name, "compile failed:\n" + r.stdout[-2000:]
