@@ -163,7 +163,7 @@ def measured_traffic(workload, timeout_s=240):
         subprocess.call(["rm", "-rf", tmp])
 
 
-def end_to_end(n_pairs, threads=16, rmdup_pairs=4_000_000):
+def end_to_end(n_pairs, threads=16, rmdup_pairs=4_000_000, deadline=None):
     """This repo's CLI and the reference binary on the same /dev/shm FASTQ, whole-process wall clock (tools/bench_e2e.py):
     configs[1] parameters .gz -> .gz and .gz -> plain, plain -> plain for this CLI only (the reference's plain-INPUT run is
     its 60-s remove_tmpDir stall, SURVEY Q10: the plain speed-up is quoted against its .gz -> plain time), BASELINE configs[2]'s
@@ -174,13 +174,15 @@ def end_to_end(n_pairs, threads=16, rmdup_pairs=4_000_000):
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
     tmp = tempfile.mkdtemp(prefix="snkbench_", dir=shm)
     try:
-        res = bench_e2e.measure(tmp, n_pairs, threads, ["plain_ours", "gz", "gz2plain", "gz_c3"])
+        res = bench_e2e.measure(tmp, n_pairs, threads, ["gz", "gz2plain", "plain_ours", "gz_c3"], deadline=deadline)
     finally:
         subprocess.call(["rm", "-rf", tmp])
     # (plain_ours stays an absolute number: the reference's plain-INPUT run is its 60-s remove_tmpDir stall, SURVEY Q10, and a ratio
     # against its .gz-input time would compare two different workloads -- ADVICE r4)
     rmdup_pairs //= TEST_DIVISOR
-    if rmdup_pairs > 0:
+    if deadline is not None and time.time() > deadline:
+        res["pe250_rmdup"] = {"skipped": "bench.py's time budget (--budget-s) was spent before this leg"}
+    elif rmdup_pairs > 0:
         tmp = tempfile.mkdtemp(prefix="snkbench_", dir=shm)
         try:
             res["pe250_rmdup"] = bench_e2e.measure(tmp, rmdup_pairs, threads, ["gz"], c3=False, extra_cfg=["rmdup"], L=250, dup_frac=0.05)
@@ -236,6 +238,20 @@ def rmdup_kernels(n=10_000_000, L=250):
              "Mreads_per_s": round(2 * nn / ms_m / 1e3, 1), "algorithmic_GBps": round(9 * nn / ms_m / 1e6, 1),
              "frac_of_hbm_peak": round(9 * nn / ms_m / 1e6 / HBM_PEAK_GBS, 4), "error": 0,
              "note": "random access: 8 B hash in + 1 B flag out per pair are the algorithmic bytes, the table traffic is not counted"}]
+
+
+def other_workloads_child(timeout_s):
+    """other_workloads() in a process of its own: these rows launch every kernel family of the library, and a fault or a hang in one
+    of them (the process dies with the HIP runtime's abort) must not take the headline line down"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--child-other-workloads", "--no-cpu-baseline", "--no-traffic"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"the other_workloads child did not finish within {timeout_s:.0f} s (killed)"}
+    lines = [x for x in r.stdout.decode(errors="replace").split("\n") if x.startswith("[") or x.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"the other_workloads child ended with rc {r.returncode}", "stderr_tail": r.stderr[-300:].decode(errors="replace")}
+    return json.loads(lines[-1])
 
 
 def other_workloads():
@@ -323,9 +339,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-side legs (cpu_baseline, end_to_end)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS), help="c2 = the headline (BASELINE configs[1]); the others are profiling workloads")
+    ap.add_argument("--budget-s", type=float, default=600.0, help="wall-clock budget of the whole run: the optional legs behind the timed region "
+                    "(end_to_end legs, other_workloads) that would start after it are recorded as skipped -- the headline line always comes out")
+    ap.add_argument("--child-other-workloads", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--e2e-pairs", type=int, default=16_000_000, help="pairs of the end_to_end legs (0: only the cpu_baseline sample); 16 M: the reference needs "
                     "~50 s per .gz leg (three of them), ~40 s for the 4 M-pair PE250 + rmdup leg")
     args = ap.parse_args()
+    t_start = time.time()
+    if args.child_other_workloads:
+        print(json.dumps(other_workloads()), flush=True)
+        return
 
     # SNK_BENCH_FORCE_LAUNCHER=1: take the launcher branch, the nccl process group and the collective at world size 1 too
     # (tests/test_multirank_gpu.py drives the N > 1 code path on a one-GPU box this way)
@@ -470,7 +493,7 @@ def main():
             e2e = None
             if args.e2e_pairs > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "SOAPnuke")):
                 try:
-                    e2e = end_to_end(args.e2e_pairs)
+                    e2e = end_to_end(args.e2e_pairs, deadline=t_start + args.budget_s)
                 except Exception as ex:          # the host legs must never take the kernel line down
                     e2e = {"error": repr(ex)[:200]}
             # the reference's best leg of the three (plain -> plain carries its 60-s remove_tmpDir stall past one merge cycle,
@@ -487,10 +510,20 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(data, min(n_unique, 1_000_000))
             if e2e is not None:
                 out["end_to_end"] = e2e
-            try:
-                out["other_workloads"] = other_workloads()
-            except Exception as ex:
-                out["other_workloads"] = {"error": repr(ex)[:200]}
+            if time.time() > t_start + args.budget_s:
+                out["other_workloads"] = {"skipped": "bench.py's time budget (--budget-s) was spent before this leg"}
+            else:
+                # (our own device memory goes back first: the child brings its own batches)
+                del batch, rec, dev
+                ctx.close()
+                torch.cuda.empty_cache()
+                if os.environ.get("SNK_BENCH_INPROCESS") == "1":       # (tests/test_simt_bench.py: the emulated device lives in this process)
+                    try:
+                        out["other_workloads"] = other_workloads()
+                    except Exception as ex:
+                        out["other_workloads"] = {"error": repr(ex)[:200]}
+                else:
+                    out["other_workloads"] = other_workloads_child(max(120.0, t_start + args.budget_s + 240.0 - time.time()))
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -118,10 +118,37 @@ def capture_run(work, sc, per_kernel=1):
 SCHEDULES = [None, "skew:1"] if os.environ.get("SNK_SIMT_FULL") == "1" else [None]
 
 
+# Open-addressing tables are filled first come, first placed: under another schedule of the waves the same keys sit in other slots.
+# For these kernels the comparison is the table's CONTENT -- the set of (key, smallest index) pairs -- not its layout; what is read
+# from the table (the look-up kernels' flags) is compared byte for byte on those kernels' own launches.
+TABLE_FILLERS = ("snk_mark_insert_kernel", "snk_stream_insert_kernel")
+
+
+def same_table_content(differing):
+    """differing: [(base, got, want)] of the two allocations of a table (u64 keys, u32 smallest indices; 2^k slots each)"""
+    if len(differing) != 2:
+        return False
+    (_, ka, kb), (_, ia, ib) = sorted(differing, key=lambda d: -d[1].size)
+    cap = 1 << ((ka.size // 8).bit_length() - 1)
+    if (ia.size // 4) < cap:
+        return False
+    import numpy as np
+    pairs = []
+    for keys, idx in ((ka, ia), (kb, ib)):
+        k64 = keys[:cap * 8].view(np.uint64)
+        i32 = idx[:cap * 4].view(np.uint32)
+        used = k64 != np.uint64(0xFFFFFFFFFFFFFFFF)
+        pairs.append(sorted(zip(k64[used].tolist(), i32[used].tolist())))
+    return pairs[0] == pairs[1] and len(pairs[0]) > 0 and bytes(ka[cap * 8:]) == bytes(kb[cap * 8:]) and bytes(ia[cap * 4:]) == bytes(ib[cap * 4:])
+
+
 def replay_one(args):
     dump, k, schedule = args
     try:
-        info, diffs = G.replay(dump, k, BUILD, verbose=False, schedule=schedule)
+        info, diffs = G.replay(dump, k, BUILD, verbose=False, schedule=schedule, keep_memory=schedule is not None)
+        if diffs and schedule is not None and any(t in info["symbol"] for t in TABLE_FILLERS) and same_table_content(info.get("differing", [])):
+            diffs = []
+        info.pop("differing", None)
         return k, info["symbol"], info["instructions"], diffs, None
     except Exception as e:                                    # (a hazard, an unknown instruction: the test names the kernel)
         meta = json.load(open(os.path.join(dump, "L%d.json" % k)))

@@ -103,7 +103,10 @@ def command(exe, inputs, out_dir, ext, threads, c3=None, extra_cfg=None):
 def run(exe, inputs, out_dir, ext, threads, env=None, c3=None, extra_cfg=None):
     cmd, _ = command(exe, inputs, out_dir, ext, threads, c3, extra_cfg)
     t0 = time.time()
-    r = subprocess.run(cmd, capture_output=True, env=env)
+    try:      # (a run that hangs -- a first contact of new device code with the hardware -- must not take the caller's bench line with it)
+        r = subprocess.run(cmd, capture_output=True, env=env, timeout=float(os.environ.get("SNK_E2E_TIMEOUT", "900")))
+    except subprocess.TimeoutExpired as ex:
+        r = subprocess.CompletedProcess(cmd, -9, ex.stdout or b"", (ex.stderr or b"") + b"\n[bench_e2e: timed out, killed]")
     return time.time() - t0, r
 
 
@@ -127,7 +130,8 @@ def compare(tmp, mode, ext, entry, side_prefix=None):
         entry["side_files_identical"] = all(os.path.exists(os.path.join(a, x)) and md5_of(os.path.join(a, x)) == md5_of(os.path.join(b, x)) for x in names)
 
 
-def measure(tmp, n, T, modes, c3=None, extra_cfg=None, L=150, dup_frac=0.0):
+def measure(tmp, n, T, modes, c3=None, extra_cfg=None, L=150, dup_frac=0.0, deadline=None):
+    """deadline (time.time() value): legs that would start after it are recorded as skipped"""
     c3 = C3 if c3 is None else c3
     extra_cfg = EXTRA_CFG if extra_cfg is None else extra_cfg
     res = {"pairs": n, "read_len": L, "threads_T": T, "host_cores": os.cpu_count(), "params": params_text(c3, extra_cfg),
@@ -139,6 +143,9 @@ def measure(tmp, n, T, modes, c3=None, extra_cfg=None, L=150, dup_frac=0.0):
         res["generate_s"] = round(t_gen, 1)
         res["gzip_inputs_s"] = round(t_gz, 1)
         for mode in modes:
+            if deadline is not None and time.time() > deadline:
+                res["modes"][mode] = {"skipped": "the caller's time budget was spent before this leg"}
+                continue
             # plain: plain -> plain; gz: .gz -> .gz; gz2plain: .gz -> plain (the reference's plain-INPUT path stalls 60 s in
             # remove_tmpDir past one merge cycle and loses a patch, SURVEY Q10: this leg is its plain-output time without that);
             # gz_c3: .gz -> .gz with BASELINE configs[2]'s parameters on the same files; plain_ours: plain -> plain, this CLI only

@@ -1738,7 +1738,7 @@ def kernel_offsets(lib, pattern):
     return {int(p[0], 16): p[2] for p in (l.split() for l in out.split("\n")) if len(p) == 3 and pattern in p[2]}
 
 
-def replay(dump_dir, k, asm_path, workgroups=None, verbose=True, schedule=None):
+def replay(dump_dir, k, asm_path, workgroups=None, verbose=True, schedule=None, keep_memory=False):
     """runs launch k of a dump through the assembly (a file, or the build directory whose kept files are searched for the kernel);
     -> (summary, list of differing (allocation, first offset, count))"""
     meta, pre, post = load_dump(dump_dir, k)
@@ -1778,6 +1778,8 @@ def replay(dump_dir, k, asm_path, workgroups=None, verbose=True, schedule=None):
         ne = np.nonzero(mem.bufs[i] != want)[0]
         if ne.size:
             diffs.append((base, int(ne[0]), int(ne.size), size))
+            if keep_memory:                  # (for kernels whose memory is order-dependent by design: the caller compares what matters)
+                info.setdefault("differing", []).append((base, mem.bufs[i].copy(), want.copy()))
     info.update(symbol=sym, grid=meta["grid"], block=meta["block"], shmem=meta["shmem"])
     return info, diffs
 
