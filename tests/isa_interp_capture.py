@@ -21,6 +21,15 @@ def main():
     n, L, paired = int(spec["n"]), int(spec.get("L", 150)), bool(spec.get("paired", True))
     lib = S.lib()
     lib.simt_dump_register.argtypes = [C.c_void_p, C.c_size_t]
+    if "any_length" in spec or "long_any_length" in spec:
+        # the contexts of the GPU tier's first-contact tests (adapters of 1..255 characters, adaEdge beyond the adapter), smaller
+        if "any_length" in spec:
+            from test_adapter_fuzz_gpu import any_length_context
+            p, d = any_length_context(int(spec["any_length"]), n)
+        else:
+            from test_long_reads_gpu import long_any_length_context
+            p, d = long_any_length_context(*spec["long_any_length"], n=n)
+        return run_and_check(lib, spec, p, d, True)
     d = synth.make_batch(n, L, paired=paired, seed=int(spec.get("seed", 5)), var_len=bool(spec.get("var_len", False)), pitch=spec.get("pitch"),
                          dimer_frac=float(spec.get("dimer_frac", 0.0)))
     if spec.get("lower"):
@@ -48,6 +57,10 @@ def main():
         plant_contams(d, ck)
         kw.update(contam_kwargs(ck, paired))
     p = abi.default_params(paired=paired, max_read_len=L, **kw)
+    return run_and_check(lib, spec, p, d, paired)
+
+
+def run_and_check(lib, spec, p, d, paired):
     keep = []
     for key in ("seq", "qual", "len"):
         for a in d[key]:

@@ -166,14 +166,9 @@ def test_long_adapter_lists_and_lower_case_on_the_fast_paths(i):
     assert_same(p, run_hip_device(p, d, 1), want, paired)
 
 
-# ---- round 4: adapters of any length on the tiled kernel (65..200 characters, shorter than 6, adaEdge beyond the adapter)
-@T.first_contact
-@pytest.mark.parametrize("i", range(12))
-def test_adapters_of_any_length_on_the_tiled_kernel(i):
-    """VERDICT r3 #7: the reference takes adapters of any length (src/read_filter.cpp:707-790); the bit paths took 6..64
-    characters and everything else fell back to the generic kernel (40 x slower).  Now kernel = 2 accepts 1..255 characters:
-    the screen looks at an adapter's first 64 characters, survivors of longer adapters are decided character by character, reads
-    shorter than the adapter take the sequential matcher in their lane, adaEdge may exceed the adapter (no phase C)."""
+def any_length_context(i, n_pairs):
+    """parameters and batch of context i of test_adapters_of_any_length_on_the_tiled_kernel (tests/isa_interp_capture.py replays
+    some of them from the gfx950 assembly at a smaller size)"""
     rng = np.random.default_rng(8100 + i)
     L = 150 if i % 3 else 250
     if i % 4 == 0:
@@ -188,11 +183,23 @@ def test_adapters_of_any_length_on_the_tiled_kernel(i):
     edge = (int(rng.integers(1, 9)), int(rng.integers(1, 9)))
     if i % 4 == 3:
         edge = (len(ada[0][0]) + int(rng.integers(0, 4)), len(ada[1][0]) + 1)
-    d = synth.make_batch(READS // 2, L, paired=True, var_len=bool(i % 2), seed=9500 + i, adapters=(ada[0][0], ada[1][0]))
+    d = synth.make_batch(n_pairs, L, paired=True, var_len=bool(i % 2), seed=9500 + i, adapters=(ada[0][0], ada[1][0]))
     for m in range(2):
         plant(rng, d["seq"][m], d["len"][m], L, ada[m], 0.3)
     p = abi.default_params(paired=True, max_read_len=L, adapters1=ada[0], adapters2=ada[1], ada_trim=int(rng.integers(0, 2)),
                            ada_mis=(int(rng.integers(0, 4)), int(rng.integers(0, 4))), ada_mr=(float(rng.choice([0.3, 0.5, 0.7])), 0.5),
                            ada_edge=edge, low_qual=10, low_qual_ratio=0.3, min_read_length=30)
+    return p, d
+
+
+# ---- round 4: adapters of any length on the tiled kernel (65..200 characters, shorter than 6, adaEdge beyond the adapter)
+@T.first_contact
+@pytest.mark.parametrize("i", range(12))
+def test_adapters_of_any_length_on_the_tiled_kernel(i):
+    """VERDICT r3 #7: the reference takes adapters of any length (src/read_filter.cpp:707-790); the bit paths took 6..64
+    characters and everything else fell back to the generic kernel (40 x slower).  Now kernel = 2 accepts 1..255 characters:
+    the screen looks at an adapter's first 64 characters, survivors of longer adapters are decided character by character, reads
+    shorter than the adapter take the sequential matcher in their lane, adaEdge may exceed the adapter (no phase C)."""
+    p, d = any_length_context(i, READS // 2)
     want = T.run_oracle(p, d)
     assert_same(p, run_hip_device(p, d, 2, chunks=2), want, True)          # kernel = 2: the fast path must take it

@@ -148,16 +148,8 @@ def test_long_reads_plane_store_group_edges_and_regrowth():
         ctx.close()
 
 
-@T.first_contact
-@pytest.mark.parametrize("L,alen,edge,mr", [(600, 100, 6, 0.5), (600, 3, 2, 0.7), (600, 200, 6, 0.5), (1000, 255, 10, 0.3), (600, 40, 60, 0.5), (640, 5, 6, 1.0),
-                                            (1000, 130, 3, 0.5)])
-def test_long_reads_adapters_of_any_length(L, alen, edge, mr):
-    """VERDICT r4 #8: the long-read path takes the adapters the tiled kernel takes -- 1..255 characters, adaEdge beyond the adapter --
-    instead of falling back to the generic kernel (`kernel=2`: fast path required).  A block of the read is told how much of the
-    read is left and which offsets are its own (csrc/snk_adapter_bits.hip.h): the phase C offsets of an adapter of more than 64
-    characters can lie in the read's last TWO blocks, where the later block's hit comes first (descending offsets,
-    src/read_filter.cpp:765-788)."""
-    n = 1500
+def long_any_length_context(L, alen, edge, mr, n=1500):
+    """parameters and batch of test_long_reads_adapters_of_any_length (tests/isa_interp_capture.py replays some from the gfx950 assembly)"""
     rng = np.random.default_rng(1000 + alen)
     ada = ["".join("ACGT"[int(x)] for x in rng.integers(0, 4, alen)) for _ in range(2)]
     d = synth.make_batch(n, L, paired=True, var_len=True, seed=900 + alen)
@@ -172,6 +164,20 @@ def test_long_reads_adapters_of_any_length(L, alen, edge, mr):
                 d["seq"][m][r, rl - k:rl] = a0[:k]
     p = abi.default_params(paired=True, max_read_len=L, adapters1=[ada[0]], adapters2=[ada[1]], ada_trim=1, ada_mis=(2, 1), ada_mr=(mr, mr),
                            ada_edge=(edge, edge), low_qual=10, low_qual_ratio=0.5)
+    return p, d
+
+
+@T.first_contact
+@pytest.mark.parametrize("L,alen,edge,mr", [(600, 100, 6, 0.5), (600, 3, 2, 0.7), (600, 200, 6, 0.5), (1000, 255, 10, 0.3), (600, 40, 60, 0.5), (640, 5, 6, 1.0),
+                                            (1000, 130, 3, 0.5)])
+def test_long_reads_adapters_of_any_length(L, alen, edge, mr):
+    """VERDICT r4 #8: the long-read path takes the adapters the tiled kernel takes -- 1..255 characters, adaEdge beyond the adapter --
+    instead of falling back to the generic kernel (`kernel=2`: fast path required).  A block of the read is told how much of the
+    read is left and which offsets are its own (csrc/snk_adapter_bits.hip.h): the phase C offsets of an adapter of more than 64
+    characters can lie in the read's last TWO blocks, where the later block's hit comes first (descending offsets,
+    src/read_filter.cpp:765-788)."""
+    n = 1500
+    p, d = long_any_length_context(L, alen, edge, mr, n)
     want = T.run_oracle(p, d)
     if alen >= 5:
         assert int((want["rec"][0]["adacut_pos"] >= 0).sum()) > n // 10

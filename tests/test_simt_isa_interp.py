@@ -54,9 +54,9 @@ def simt_lib_path():
     return S.build_module().build()
 
 
-def capture(tmp, spec, env=None, cus=2):
+def capture(tmp, spec, env=None, cus=2, kernels=("snk_tiled",)):
     lib = simt_lib_path()
-    offs = ",".join("%x" % o for o in G.kernel_offsets(lib, "snk_tiled"))
+    offs = ",".join("%x" % o for k in kernels for o in G.kernel_offsets(lib, k))
     e = dict(os.environ, SIMT_DUMP_DIR=str(tmp), SIMT_DUMP_OFFSETS=offs, SIMT_CUS=str(cus),
              PYTHONPATH=os.pathsep.join([HERE, T.ROOT, os.environ.get("PYTHONPATH", "")]))
     e.update(env or {})
@@ -82,6 +82,43 @@ def test_assembly_matches_the_emulated_twin(name, tmp_path):
         assert not diffs, (info, diffs)
     assert any(instance in s for s in seen), seen
     assert any("snk_tiled_reduce_kernel" in s for s in seen), seen
+
+
+# Round 5's envelopes that have met neither the hardware nor (until this test) their own instructions: the contexts of the GPU
+# tier's first-contact tests, smaller.  name -> (capture spec, kernels captured, kernel names that must have been replayed)
+BUILD = os.path.dirname(ASM)
+ENVELOPES = {
+    "adapters_shorter_than_6_pe250": (dict(any_length=0, n=500), ("snk_tiled",), ["snk_tiled_kernelILi8"]),
+    "adapters_of_65_to_120": (dict(any_length=1, n=500), ("snk_tiled",), ["snk_tiled_kernelILi5"]),
+    "adapter_of_130_to_200_and_a_short_one": (dict(any_length=2, n=500), ("snk_tiled",), ["snk_tiled_kernelILi5"]),
+    "ada_edge_beyond_the_adapter_pe250": (dict(any_length=3, n=500), ("snk_tiled",), ["snk_tiled_kernelILi8"]),
+    "long_reads_600_adapter_100": (dict(long_any_length=[600, 100, 6, 0.5], n=192, kernel=2), ("snk_long",),
+                                   ["snk_long_prep_kernel", "snk_long_decide_kernel", "snk_long_hist_kernel"]),
+    "long_reads_600_adapter_3": (dict(long_any_length=[600, 3, 2, 0.7], n=192, kernel=2), ("snk_long",), ["snk_long_decide_kernel"]),
+    "long_reads_1000_adapter_255": (dict(long_any_length=[1000, 255, 10, 0.3], n=128, kernel=2), ("snk_long",), ["snk_long_decide_kernel"]),
+    "long_reads_600_ada_edge_60_of_40": (dict(long_any_length=[600, 40, 60, 0.5], n=192, kernel=2), ("snk_long",), ["snk_long_decide_kernel"]),
+}
+
+
+def _replay(args):
+    d, k = args
+    info, diffs = G.replay(d, k, BUILD, verbose=False)
+    return k, info["symbol"], info["instructions"], diffs
+
+
+@needs_asm
+@pytest.mark.parametrize("name", list(ENVELOPES))
+def test_first_contact_envelopes_from_the_assembly(name, tmp_path):
+    import concurrent.futures
+    spec, kernels, expect = ENVELOPES[name]
+    launches = capture(tmp_path, spec, kernels=kernels)
+    assert launches
+    with concurrent.futures.ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        results = list(pool.map(_replay, [(str(tmp_path), k) for k in launches]))
+    bad = [(k, sym, diffs) for k, sym, n, diffs in results if diffs or n == 0]
+    assert not bad, bad
+    for want in expect:
+        assert any(want in sym for _, sym, _, _ in results), (want, [r[1] for r in results])
 
 
 def mutated(tmp_path, symbol, edit):
