@@ -25,6 +25,11 @@ def pytest_collection_modifyitems(config, items):
     """The emulated tier (tests/test_simt_*.py) re-runs the GPU tier's test functions on the CPU; all of it takes about twelve minutes,
     so an ordinary run takes each module's CORE selection (a few minutes) and SNK_SIMT_FULL=1 the rest as well
     (profiles/r04_simt_full.txt holds such a run)."""
+    # the emulated / instruction tiers re-use the GPU tier's test functions (star imports): none of them may carry the GPU tier's marker
+    # along (a module-level `pytestmark` travels with `import *` -- it took tests/test_simt_cli.py out of the CPU suite once)
+    stray = [it.nodeid for it in items if os.path.basename(str(it.fspath)).startswith("test_simt_") and it.get_closest_marker("gpu")]
+    if stray:
+        raise pytest.UsageError("CPU-tier tests carry the gpu marker: %s ..." % stray[:3])
     # first-contact tests go behind everything else (stable order otherwise): the driver runs `pytest -m gpu -x`
     items.sort(key=lambda it: it.get_closest_marker("first_contact") is not None)
     if os.environ.get("SNK_SIMT_FULL") == "1":

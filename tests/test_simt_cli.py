@@ -15,7 +15,6 @@ import test_gunzip_gpu as GZ
 CORE = ["test_cli_matches_reference_binary[pe_full_T3]", "test_cli_gz_in_gz_out", "test_cli_rmdup_one_pass_variants[small_batches]",
         "test_cli_sharded_ingest_emulated[True-True-True]", "test_cli_sharded_rmdup_and_wire_emulated[True-40000-True]", "test_cli_sharded_rmdup_and_wire_emulated[False-40100-False]", "test_cli_variants_as_sharded_runs[trim_pe]", "test_cli_variants_as_sharded_runs[tile]", "test_cli_variants_as_sharded_runs[gz_gz]", "test_cli_rmdup_single_end_one_pass_emulated[20100-700-one]",
         "test_cli_rmdup_one_pass_across_two_devices_emulated[False", "test_cli_streaming[True-2-50"]
-pytestmark = pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")
 
 
 @pytest.fixture(autouse=True)
@@ -27,6 +26,10 @@ def _emulated_cli(monkeypatch):
 
 from test_cli_gpu import *      # noqa: E402,F401,F403  (every test function of the GPU tier's module)
 from test_gunzip_gpu import test_cli_with_device_inflate_matches_the_reference_binary      # noqa: E402,F401
+
+# BEHIND the star import: it brings test_cli_gpu's own `pytestmark` (gpu) along, which would take this whole module out of the CPU
+# suite and into `pytest -m gpu` on the GPU box (it did, for part of round 5)
+pytestmark = pytest.mark.skipif(not os.path.exists(T.REF_BIN), reason="oracle/_ref/SOAPnuke not built")
 
 
 # ---- written while the GPU was closed (guarded in the GPU tier until they have run on hardware): this tier is where they run first
