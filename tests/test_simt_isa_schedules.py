@@ -44,7 +44,7 @@ CORE = ["test_a_missing_barrier_behind_the_flush"]
 def replay_one(args):
     d, k, asm, schedule = args
     try:
-        info, diffs = G.replay(d, k, asm, verbose=False, schedule=schedule)
+        info, diffs = G.replay(d, k, asm, verbose=False, schedule=schedule, garbage=3)      # (and the registers start as noise)
         return k, schedule, info["symbol"], info["instructions"], diffs, None
     except G.Hazard as e:
         return k, schedule, "", 0, [], "Hazard: %s" % e

@@ -1603,7 +1603,7 @@ class Workgroup:
 KERNARG_BASE = 0x7E0000000000
 
 
-def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=None, trace=None, progress=None, schedule=None):
+def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=None, trace=None, progress=None, schedule=None, garbage=None):
     """runs the workgroups (all of them by default) one after the other; -> {instructions, hazards: [...]}
 
     schedule: how the wavefronts of a workgroup take turns between two barriers (the hardware promises no order at all):
@@ -1649,6 +1649,16 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
             w = Wave(wg, wi, prog, labels, mem, kd)
             w.data_syms = data_syms
             w.pc = labels[symbol]
+            if garbage is not None:
+                # what a wave finds in its registers is what the wave before it left there: every VGPR, every SGPR but the ones the
+                # kernel descriptor asks for, VCC, M0 and SCC start as noise (seeded) -- code that counts on a zero it never wrote
+                # (a lane an EXEC-masked write skipped, a v_writelane into a register nobody initialised) leaves other memory
+                g = np.random.default_rng([int(garbage), wgx, wi])
+                w.v[:] = g.integers(0, 1 << 32, size=w.v.shape, dtype=np.uint64).astype(U32)
+                w.s[:106] = g.integers(0, 1 << 32, size=106, dtype=np.uint64)
+                w.s[VCC:VCC + 2] = g.integers(0, 1 << 32, size=2, dtype=np.uint64)
+                w.s[M0] = int(g.integers(0, 1 << 32))
+                w.scc = int(g.integers(0, 2))
             w.sset64(0, KERNARG_BASE)
             w.sset(2, wgx)
             tid = wi * 64 + LANES
@@ -1738,7 +1748,7 @@ def kernel_offsets(lib, pattern):
     return {int(p[0], 16): p[2] for p in (l.split() for l in out.split("\n")) if len(p) == 3 and pattern in p[2]}
 
 
-def replay(dump_dir, k, asm_path, workgroups=None, verbose=True, schedule=None, keep_memory=False):
+def replay(dump_dir, k, asm_path, workgroups=None, verbose=True, schedule=None, keep_memory=False, garbage=None):
     """runs launch k of a dump through the assembly (a file, or the build directory whose kept files are searched for the kernel);
     -> (summary, list of differing (allocation, first offset, count))"""
     meta, pre, post = load_dump(dump_dir, k)
@@ -1767,7 +1777,7 @@ def replay(dump_dir, k, asm_path, workgroups=None, verbose=True, schedule=None, 
     gone = set()
     if os.path.exists(os.path.join(dump_dir, "L%d.gone" % k)):          # freed while the kernel's snapshots were taken (another host thread)
         gone = {int(x) for x in open(os.path.join(dump_dir, "L%d.gone" % k)).read().split()}
-    info = run_launch(asm_path, sym, bytes.fromhex(meta["kernarg"]), meta["grid"], meta["block"], meta["shmem"], mem, workgroups, schedule=schedule,
+    info = run_launch(asm_path, sym, bytes.fromhex(meta["kernarg"]), meta["grid"], meta["block"], meta["shmem"], mem, workgroups, schedule=schedule, garbage=garbage,
                       progress=(lambda g, n: print("  workgroup %d done, %d wave instructions so far" % (g, n), flush=True)) if verbose else None)
     diffs = []
     for n, (base, size, o) in enumerate(spans):
@@ -1791,10 +1801,11 @@ def main():
     ap.add_argument("launch", type=int)
     ap.add_argument("asm")
     ap.add_argument("--workgroups", type=str, default=None)
-    ap.add_argument("--schedule", type=str, default=None, help="forward (default) | reverse | random:SEED[:QUANTUM]")
+    ap.add_argument("--schedule", type=str, default=None, help="forward (default) | reverse | random:SEED[:QUANTUM] | skew:SEED[:QUANTUM]")
+    ap.add_argument("--garbage", type=int, default=None, help="seed: registers start as noise instead of zeros (all but the ABI's)")
     a = ap.parse_args()
     wgs = [int(x) for x in a.workgroups.split(",")] if a.workgroups else None
-    info, diffs = replay(a.dump_dir, a.launch, a.asm, wgs, schedule=a.schedule)
+    info, diffs = replay(a.dump_dir, a.launch, a.asm, wgs, schedule=a.schedule, garbage=a.garbage)
     print(json.dumps(info))
     for d in diffs:
         print("DIFFERS: allocation %#x (%d bytes): %d bytes differ, the first at offset %d" % (d[0], d[3], d[2], d[1]))
