@@ -336,6 +336,11 @@ class Memory:
         self.bases, self.sizes, self.bufs = [], [], []
         self.got = {}                       # symbol -> its entry's address in the table at GOT_BASE
         self.symbol_address = None          # name -> address of a device variable (set by the caller; replay(): the emulated library's own copy)
+        # the scalar cache is not coherent with the vector path inside a launch: 64-byte lines a scalar load read, lines a vector
+        # store / atomic wrote.  A line in both sets is memory the kernel reads as constant and also changes (run_launch reports them)
+        self.scalar_lines, self.written_lines = set(), set()
+        self.written_words = set()          # dwords a vector store / atomic of this launch wrote
+        self.stale_scalar_reads = []        # (address, bytes) of scalar loads that read such a dword: the scalar cache may hold the old line
 
     def got_entry(self, name):
         if name not in self.got:
@@ -386,9 +391,14 @@ class Memory:
             x = int(addrs[l])
             j = self.find(x, x + nbytes, what)
             self.bufs[j][x - self.bases[j]:x - self.bases[j] + nbytes] = data[l]
+            self.written_lines.update(range(x >> 6, ((x + nbytes - 1) >> 6) + 1))
+            self.written_words.update(range(x >> 2, ((x + nbytes - 1) >> 2) + 1))
 
     def read_scalar(self, addr, nbytes):
         j = self.find(addr, addr + nbytes, "scalar load")
+        self.scalar_lines.update(range(addr >> 6, ((addr + nbytes - 1) >> 6) + 1))
+        if self.written_words and not self.written_words.isdisjoint(range(addr >> 2, ((addr + nbytes - 1) >> 2) + 1)):
+            self.stale_scalar_reads.append((addr, nbytes))
         return bytes(self.bufs[j][addr - self.bases[j]:addr - self.bases[j] + nbytes])
 
 
@@ -1704,7 +1714,10 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
         racy_lines |= wg.racy_lines
         if progress:
             progress(wgx, total)
-    return {"instructions": total, "lds_bytes_read_under_a_dma": racy, "at_lines": sorted(racy_lines)}
+    both = sorted(mem.scalar_lines & mem.written_lines)
+    return {"instructions": total, "lds_bytes_read_under_a_dma": racy, "at_lines": sorted(racy_lines),
+            "scalar_lines_also_written": len(both), "first_such_line": ("%#x" % (both[0] << 6)) if both else None,
+            "scalar_loads_of_words_written_in_this_launch": len(mem.stale_scalar_reads)}
 
 
 # ------------------------------------------------------------------------------------------------------------ captured launches
