@@ -11,7 +11,7 @@ for stage in "$@"; do
     stress)
       timeout 300 python tools/stress_parity.py 30 2>&1 | tail -12 | cut -c1-400 | tee gpurun_out/catchup_stress.txt ;;
     bench)
-      timeout 900 python bench.py > gpurun_out/catchup_bench.json 2> gpurun_out/catchup_bench.err; tail -c 6000 gpurun_out/catchup_bench.json ;;
+      timeout 1200 python bench.py > gpurun_out/catchup_bench.json 2> gpurun_out/catchup_bench.err; tail -c 6000 gpurun_out/catchup_bench.json ;;
     quick)   # the kernel numbers only
       for wl in c2 c3; do timeout 200 python bench.py --no-cpu-baseline --workload $wl | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$wl', d['roofline']['kernel_ms'], d['roofline']['frac'])"; done ;;
     prof)
