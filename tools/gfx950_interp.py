@@ -1637,6 +1637,8 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
     if mem.symbol_address is None:
         mem.symbol_address = lambda name: DATA_BASE + data_syms[name] if name in data_syms else None
     static_lds = kd.get("group_segment_fixed_size", 0)
+    if static_lds + shmem > 160 * 1024:
+        raise Hazard("%d + %d bytes of LDS (static + dynamic): more than a CU has" % (static_lds, shmem))
     nthreads = block[0] * block[1] * block[2]
     total, racy, racy_lines = 0, 0, set()
     wg_order = list(range(grid[0]) if workgroups is None else workgroups)
