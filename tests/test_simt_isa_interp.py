@@ -186,3 +186,21 @@ def test_a_changed_instruction_is_caught(tmp_path, c2_capture):
 
     info, diffs = G.replay(d, 0, mutated(tmp_path, sym, edit), verbose=False)
     assert diffs
+
+
+@needs_asm
+def test_a_missing_initialisation_is_caught_only_with_noise_in_the_registers(tmp_path, c2_capture):
+    """the kernel's first `v_mov_b32 v, 0` (the value its LDS words are cleared with) taken out: with registers that start as zeros
+    the replay still leaves the right memory -- which is why the replays start them as noise (--garbage)"""
+    d, sym = c2_capture
+
+    def edit(body):
+        body, n = re.subn(r"\tv_mov_b32_e32 (v\d+), 0\n", "\ts_nop 0\n", body, count=1)
+        assert n == 1
+        return body
+
+    asm = mutated(tmp_path, sym, edit)
+    info, diffs = G.replay(d, 0, asm, verbose=False)
+    assert not diffs                                  # (zeros happen to be what the code wanted)
+    info, diffs = G.replay(d, 0, asm, verbose=False, garbage=1)
+    assert diffs
