@@ -66,6 +66,30 @@ SCENARIOS = {
         cli=ADAPTERS + ["-J", "-l", "10", "-q", "0.2", "-n", "0.01", "-m", "20", "-g", "10", "-X", "50", "-p", "0.8"],
         env={"SNK_BATCH_PAIRS": "96"},
         expect=["snk_tiled_kernel", "snk_contam_kernel", "snk_hash_lds_kernel"]),
+    # single end, duplicates marked in one pass: the shift kernel that moves a batch's flags by one read, the single-end hash kernel
+    "se150_one_pass_rmdup": dict(
+        n=300, L=150, paired=False, gz_in=False, gz_out=False, cfg=["rmdup"], cli=["-f", synth.ADAPTER1, "-l", "10", "-q", "0.2"],
+        env={"SNK_BATCH_PAIRS": "128"},
+        expect=["snk_se_shift_kernel", "snk_hash_lds_kernelILb0E", "snk_stream_insert_kernel", "snk_stream_lookup_kernel"]),
+    # two shards on two (emulated) devices, the duplicate table sharded by hash % 2: owner count / scatter, the flags' way home
+    "pe150_sharded_rmdup_two_shards": dict(
+        n=400, L=150, paired=True, gz_in=False, gz_out=False, cfg=["rmdup"], cli=ADAPTERS + ["-J", "-l", "10", "-q", "0.2", "--devices", "0,1"],
+        env={"SNK_SHARDED": "1", "SNK_SHARD_WIRE": "host", "SNK_SHARD_MIN_RECORDS": "10", "SIMT_DEVICES": "2", "SIMT_DUMP_BY_PID": "1", "SNK_BATCH_PAIRS": "128"},
+        expect=["snk_owner_count_kernel", "snk_owner_scatter_kernel", "snk_flags_home_kernel", "snk_tiled_kernel"]),
+    # reads of 1000 positions with duplicate marking: the 64-lane prep instance, rows too long for the LDS-staged hash kernel
+    "pe1000_rmdup": dict(
+        n=96, L=1000, paired=True, gz_in=False, gz_out=False, cfg=["rmdup"], cli=ADAPTERS + ["-J", "-l", "10", "-q", "0.3"],
+        env={"SNK_BATCH_PAIRS": "64"},
+        expect=["snk_long_prep_kernelILi64E", "snk_hash_direct_kernelILb1E", "snk_long_decide_kernel", "snk_long_hist_kernel"]),
+    "se1000_rmdup": dict(
+        n=96, L=1000, paired=False, gz_in=False, gz_out=False, cfg=["rmdup"], cli=["-f", synth.ADAPTER1, "-l", "10", "-q", "0.3"],
+        env={"SNK_BATCH_PAIRS": "64"},
+        expect=["snk_hash_direct_kernelILb0E"]),
+    # 100 positions with contaminants: the contaminant kernel's run-time-shape instance (neither 5 nor 8 plane words)
+    "se100_contam": dict(
+        n=200, L=100, paired=False, gz_in=False, gz_out=False, cfg=CONTAM_CFG, cli=["-f", synth.ADAPTER1, "-l", "10", "-q", "0.2"],
+        env={"SNK_BATCH_PAIRS": "128"},
+        expect=["snk_contam_kernelILi0E"]),
 }
 # an ordinary run (tests/conftest.py: SNK_SIMT_FULL=1 takes everything)
 CORE = ["test_every_kernel_of_a_run_matches_its_emulated_twin[pe150_gz_rmdup_device_inflate]"]
@@ -118,7 +142,7 @@ def capture_run(work, sc, per_kernel=1):
 SCHEDULES = [None, "skew:1"] if os.environ.get("SNK_SIMT_FULL") == "1" else [None]
 
 
-# Open-addressing tables are filled first come, first placed: under another schedule of the waves the same keys sit in other slots.
+# Open-addressing tables are filled first come, first placed: under another order of waves or workgroups the same keys sit in other slots.
 # For these kernels the comparison is the table's CONTENT -- the set of (key, smallest index) pairs -- not its layout; what is read
 # from the table (the look-up kernels' flags) is compared byte for byte on those kernels' own launches.
 TABLE_FILLERS = ("snk_mark_insert_kernel", "snk_stream_insert_kernel")
@@ -145,9 +169,11 @@ def same_table_content(differing):
 def replay_one(args):
     dump, k, schedule = args
     try:
-        info, diffs = G.replay(dump, k, BUILD, verbose=False, schedule=schedule, keep_memory=schedule is not None,
+        info, diffs = G.replay(dump, k, BUILD, verbose=False, schedule=schedule, keep_memory=True,
                                garbage=None if schedule is None else 5)      # (the second pass: other wave order, registers start as noise)
-        if diffs and schedule is not None and any(t in info["symbol"] for t in TABLE_FILLERS) and same_table_content(info.get("differing", [])):
+        # (the first pass as well: the emulated twin runs the workgroups of a launch on two OS threads, so the layout IT left is one of
+        #  several -- seen once in a full run, with two workgroups' keys meeting in one slot)
+        if diffs and any(t in info["symbol"] for t in TABLE_FILLERS) and same_table_content(info.get("differing", [])):
             diffs = []
         info.pop("differing", None)
         if info["scalar_loads_of_words_written_in_this_launch"]:      # the scalar cache is not coherent with vector stores inside a launch
