@@ -1,5 +1,6 @@
 // SIMT emulator runtime (see hip/hip_runtime.h): fibers, the workgroup scheduler, the worker pool and the host API stand-ins.
 // Test infrastructure only.
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -471,7 +472,9 @@ int dump_pre(const void *kernel, dim3 grid, dim3 block, size_t shmem, const void
         std::lock_guard<std::mutex> l(mu);
         if (seen[off]++ >= atoi(e)) return -1;
     }
-    const int id = g_dump_seq.fetch_add(1);
+    // SIMT_DUMP_BY_PID=1: a run that spawns processes (the shards of a sharded run) numbers each process's launches in a range of its own
+    static const long pid_base = getenv("SIMT_DUMP_BY_PID") ? (long)(getpid() % 20000) * 10000 : 0;
+    const int id = (int)(pid_base + g_dump_seq.fetch_add(1));
     const std::string base = std::string(getenv("SIMT_DUMP_DIR")) + "/L" + std::to_string(id);
     auto al = dump_allocs();
     dump_mem(base + ".pre", al);
