@@ -97,6 +97,10 @@ ENVELOPES = {
                                    ["snk_long_prep_kernel", "snk_long_decide_kernel", "snk_long_hist_kernel"]),
     "long_reads_600_adapter_3": (dict(long_any_length=[600, 3, 2, 0.7], n=192, kernel=2), ("snk_long",), ["snk_long_decide_kernel"]),
     "long_reads_1000_adapter_255": (dict(long_any_length=[1000, 255, 10, 0.3], n=128, kernel=2), ("snk_long",), ["snk_long_decide_kernel"]),
+    # the generic kernel alone (kernel = 1) on reads of 300 positions with contaminant lists: the sequential matchers in its lanes
+    # (snk_contam_kernel<0>, the contaminant pass's sequential-only instance, is not reachable any more: the pass runs for <= 256 positions only)
+    "contaminants_300_positions_generic_kernel": (dict(case="C2_adatrim_lowq", n=200, L=300, contam="single", kernel=1, var_len=True), ("snk_contam", "snk_generic"),
+                                                  ["snk_generic_kernel"]),
     "long_reads_600_ada_edge_60_of_40": (dict(long_any_length=[600, 40, 60, 0.5], n=192, kernel=2), ("snk_long",), ["snk_long_decide_kernel"]),
 }
 
@@ -204,3 +208,34 @@ def test_a_missing_initialisation_is_caught_only_with_noise_in_the_registers(tmp
     assert not diffs                                  # (zeros happen to be what the code wanted)
     info, diffs = G.replay(d, 0, asm, verbose=False, garbage=1)
     assert diffs
+
+
+@needs_asm
+def test_the_bit_transposes_from_the_assembly(tmp_path):
+    """bittr_selftest_kernel (64 x 64 bit transposes: DPP row shifts, v_permlane32_swap / v_permlane16_swap, v_bfi -- the hand-over of the
+    tiled kernel uses the same functions) on random matrices: the instructions leave the words the emulated twin left, which the
+    capture checks against a numpy transpose"""
+    lib = simt_lib_path()
+    code = """
+import ctypes as C, numpy as np, sys
+import simt_lib as S
+lib = S.lib()
+rng = np.random.default_rng(4)
+n = 6
+m = (rng.random((n, 64, 64)) < 0.5).astype(np.uint64)
+w = (np.uint64(1) << np.arange(32, dtype=np.uint64))
+words = np.ascontiguousarray(np.stack([(m[..., :32] * w).sum(-1), (m[..., 32:] * w).sum(-1)], axis=-1).astype(np.uint32))
+out = np.zeros_like(words); lo = np.zeros((n, 64), dtype=np.uint32)
+rc = lib.snk_selftest_bit_transpose(0, words.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p), lo.ctypes.data_as(C.c_void_p))
+assert rc == 0
+got = ((out[..., None] >> np.arange(32, dtype=np.uint32)) & 1).astype(np.uint8).reshape(n, 64, 64)
+assert np.array_equal(got, m.transpose(0, 2, 1).astype(np.uint8))
+print("captured")
+"""
+    offs = ",".join("%x" % o for o in G.kernel_offsets(lib, "bittr_selftest"))
+    e = dict(os.environ, SIMT_DUMP_DIR=str(tmp_path), SIMT_DUMP_OFFSETS=offs, PYTHONPATH=os.pathsep.join([HERE, T.ROOT, os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "captured" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+    for sch in (None, "reverse"):
+        info, diffs = G.replay(str(tmp_path), 0, BUILD, verbose=False, garbage=4, schedule=sch)
+        assert "bittr_selftest_kernel" in info["symbol"] and info["instructions"] > 0 and not diffs, (info, diffs)
