@@ -46,7 +46,8 @@ CASES = {
     "many_flushes_one_workgroup": (dict(case="C3_full", n=3000, L=150, var_len=True), {"SNK_TEST_MAX_WGS": "1", "SNK_TEST_FLUSH_EVERY": "1"}, "ILi5ELb1ELb1"),
 }
 # an ordinary run (see tests/conftest.py: SNK_SIMT_FULL=1 takes everything)
-CORE = ["test_assembly_matches_the_emulated_twin[pe150_c3_full_ragged]", "test_a_weakened_wait_is_caught"]
+CORE = ["test_assembly_matches_the_emulated_twin[pe150_c3_full_ragged]", "test_a_weakened_wait_is_caught", "test_a_scalar_load_of_a_dword_written",
+        "test_the_bit_transposes_from_the_assembly"]
 
 
 def simt_lib_path():
@@ -239,3 +240,20 @@ print("captured")
     for sch in (None, "reverse"):
         info, diffs = G.replay(str(tmp_path), 0, BUILD, verbose=False, garbage=4, schedule=sch)
         assert "bittr_selftest_kernel" in info["symbol"] and info["instructions"] > 0 and not diffs, (info, diffs)
+
+
+def test_a_scalar_load_of_a_dword_written_in_the_launch_is_reported():
+    """the mechanism behind `scalar_loads_of_words_written_in_this_launch` (no kernel of the build does it, so no capture shows it):
+    a vector store, then scalar loads of the neighbouring dword (fine: same 64-byte line, other dword) and of the stored one (reported)"""
+    import numpy as np
+    mem = G.Memory()
+    mem.add(0x1000, bytes(256))
+    lanes = np.zeros(64, dtype=bool)
+    lanes[3] = True
+    addrs = np.zeros(64, dtype=np.uint64)
+    addrs[3] = 0x1000 + 40
+    mem.write(addrs, np.full((64, 4), 0xAB, dtype=np.uint8), lanes)
+    mem.read_scalar(0x1000 + 44, 4)
+    assert not mem.stale_scalar_reads and (0x1000 >> 6) in (mem.scalar_lines & mem.written_lines)
+    mem.read_scalar(0x1000 + 32, 16)
+    assert mem.stale_scalar_reads == [(0x1000 + 32, 16)]
