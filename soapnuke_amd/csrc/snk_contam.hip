@@ -671,13 +671,13 @@ void snk_launch_contam(const DevParams *dp, const DevBatch &b, unsigned char *cf
     const size_t shmem = (((size_t)256 * stride + 15) & ~(size_t)15) + (size_t)n_ct * sizeof(DevContam) + (size_t)n_gct * sizeof(DevGContam);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)snk_contam_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)snk_contam_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)snk_contam_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (lcap <= 160) hipLaunchKernelGGL(snk_contam_kernel<5>, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, dp, b, cf, stride);
-    else if (lcap <= 256) hipLaunchKernelGGL(snk_contam_kernel<8>, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, dp, b, cf, stride);
-    else hipLaunchKernelGGL(snk_contam_kernel<0>, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, dp, b, cf, stride);
+    else hipLaunchKernelGGL(snk_contam_kernel<8>, dim3((unsigned)blocks), dim3(256), shmem, (hipStream_t)stream, dp, b, cf, stride);
+    // (the caller runs this pass for lcap <= 256 only, snk_filter.cpp: longer reads take snk_launch_long_contam on the plane store;
+    //  the sequential-only instance <0> that used to stand here had been unreachable since round 3)
 }

@@ -99,7 +99,6 @@ ENVELOPES = {
     "long_reads_600_adapter_3": (dict(long_any_length=[600, 3, 2, 0.7], n=192, kernel=2), ("snk_long",), ["snk_long_decide_kernel"]),
     "long_reads_1000_adapter_255": (dict(long_any_length=[1000, 255, 10, 0.3], n=128, kernel=2), ("snk_long",), ["snk_long_decide_kernel"]),
     # the generic kernel alone (kernel = 1) on reads of 300 positions with contaminant lists: the sequential matchers in its lanes
-    # (snk_contam_kernel<0>, the contaminant pass's sequential-only instance, is not reachable any more: the pass runs for <= 256 positions only)
     "contaminants_300_positions_generic_kernel": (dict(case="C2_adatrim_lowq", n=200, L=300, contam="single", kernel=1, var_len=True), ("snk_contam", "snk_generic"),
                                                   ["snk_generic_kernel"]),
     "long_reads_600_ada_edge_60_of_40": (dict(long_any_length=[600, 40, 60, 0.5], n=192, kernel=2), ("snk_long",), ["snk_long_decide_kernel"]),
