@@ -329,6 +329,112 @@ def _workload_row(name, L, n, kern, kw, var_len):
         return res
 
 
+KERNEL_INSTANCE = {   # the tiled kernel's instance snk_filter.cpp picks for each bench workload (soapnuke_amd/csrc/snk_tiled.hip, PE150)
+    "c2": "snk_tiled_kernel<5,false,true,16,TileShape<160,768,4>>", "c3": "snk_tiled_kernel<5,true,true,16,TileShape<160,768,4>>",
+    "c2var": "snk_tiled_kernel<5,false,true,16,TileShape<0,0,0>>", "c3var": "snk_tiled_kernel<5,true,true,16,TileShape<0,0,0>>",
+}
+
+
+def headline_child(args):
+    """the timed region in a process of its own (`--child-headline`): its JSON line, or an error record that names the kernel"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--child-headline", "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--pairs", str(args.pairs), "--kernel", str(args.kernel), "--workload", args.workload, "--no-cpu-baseline", "--no-traffic"]
+    limit = float(os.environ.get("SNK_BENCH_HEADLINE_TIMEOUT_S", "420"))
+    err = None
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit)
+        lines = [x for x in r.stdout.decode(errors="replace").split("\n") if x.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        err = {"error": f"the headline child ended with rc {r.returncode}" + ("" if r.returncode >= 0 else f" (signal {-r.returncode})"),
+               "stderr_tail": r.stderr[-600:].decode(errors="replace")}
+    except subprocess.TimeoutExpired as ex:
+        err = {"error": f"the headline child did not finish within {limit:.0f} s (killed): a kernel hangs",
+               "stderr_tail": (ex.stderr or b"")[-600:].decode(errors="replace")}
+    return dict({"metric": "Mreads/s PE150 `filter` (adapter+qual), bit-exact vs ref", "value": None, "unit": "Mreads/s", "n_gpus": 1,
+                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                 "vs_baseline": None, "dtype": "u8", "data": "synthetic PE150",
+                 "config": {"workload": WORKLOADS[args.workload][0], "pairs_per_gpu_per_step": args.pairs, "read_len": L},
+                 "kernel_instance": KERNEL_INSTANCE.get(args.workload) if args.kernel in (0, 2) else f"kernel={args.kernel}",
+                 "roofline": None}, **err)
+
+
+def finish_single(args, out, data, t_start):
+    """N == 1, after the timed region: roofline.traffic (two rocprofv3 --pmc child runs), cpu_baseline, end_to_end, other_workloads --
+    every one of them in processes of their own -- then the ONE JSON line"""
+    n = out["config"]["pairs_per_gpu_per_step"]
+    if out.get("roofline") is not None:
+        # HBM bytes per launch: measured in this run by two rocprofv3 --pmc passes around a short child run of this command
+        # (measured_traffic), N == 1 only; failing that, the committed profile's figure -- but only while profiles/traffic.json
+        # was taken on the kernel sources of this tree (kernel_source_sha), never a stale constant
+        traffic, extra = None, {}
+        if not args.no_traffic and not args.no_cpu_baseline and TEST_DIVISOR == 1 and n == 10_000_000 and args.kernel in (0, 2):
+            mt = measured_traffic(args.workload)
+            if mt is not None:
+                traffic = mt["bytes"]
+                extra = {"traffic_measured_in_run": True, "traffic_how": "2 x FETCH_SIZE + WRITE_SIZE (KB), one rocprofv3 --pmc pass each, "
+                         "mean over the tiled kernel's launches of a 4-step child run", "fetch_kb_raw": round(mt["fetch_kb_raw"], 1),
+                         "write_kb_raw": round(mt["write_kb_raw"], 1), "traffic_over_algorithmic": round(mt["bytes"] / out["roofline"]["bytes_per_launch"], 3)}
+        if traffic is None and not args.no_traffic:
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+                    tj = json.load(fh)
+                if (n == 10_000_000 and args.kernel in (0, 2) and args.workload == "c2"
+                        and tj.get("kernel_source_sha") == kernel_source_sha()):
+                    traffic = int(tj["hbm_bytes_per_launch"])
+                    extra = {"traffic_measured_in_run": False, "traffic_source": tj["source"]}
+                else:
+                    extra = {"traffic_measured_in_run": False, "traffic_note": "no counter figure for this build: profiles/traffic.json "
+                             "was taken on other kernel sources and rocprofv3 did not produce one in this run"}
+            except (OSError, KeyError, ValueError):
+                pass
+
+        out["roofline"]["traffic"] = traffic
+        out["roofline"].update(extra)
+    if not args.no_cpu_baseline and args.workload == "c2":
+        e2e = None
+        if args.e2e_pairs > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "SOAPnuke")):
+            try:
+                e2e = end_to_end(args.e2e_pairs, deadline=t_start + args.budget_s)
+            except Exception as ex:          # the host legs must never take the kernel line down
+                e2e = {"error": repr(ex)[:200]}
+        # the reference's best leg of the three (plain -> plain carries its 60-s remove_tmpDir stall past one merge cycle,
+        # SURVEY Q10; .gz input does not): the most favourable number for the baseline
+        legs = [(m, v["reference"]) for m, v in (e2e or {}).get("modes", {}).items()
+                if isinstance(v, dict) and v.get("reference", {}).get("rc") == 0]
+        legs = [x for x in legs if x[0] in ("gz", "gz2plain")]       # configs[1] parameters only: the headline's workload
+        if legs:
+            m, best = max(legs, key=lambda x: x[1]["Mreads_per_s"])
+            out["cpu_baseline"] = {"value": best["Mreads_per_s"], "unit": "Mreads/s", "cores": 16, "kind": "reference",
+                                   "sample": f"{args.e2e_pairs} PE150 pairs in /dev/shm, `SOAPnuke filter -J -l 10 -q 0.1 -T 16`, leg `{m}` "
+                                             f"(the fastest of the reference's legs in end_to_end), whole-process wall {best['wall_s']}s"}
+        else:
+            if data is None:
+                from soapnuke_amd import synth
+                data = synth.make_batch(min(PAIRS_UNIQUE, args.pairs), L, paired=True, seed=synth.SEED)
+            out["cpu_baseline"] = cpu_baseline(data, min(data["n"], 1_000_000))
+        if e2e is not None:
+            out["end_to_end"] = e2e
+            # the PIPELINE's rate next to the resident-batch `value` (VERDICT r5 10): this CLI's whole-process wall clock, FASTQ files
+            # in /dev/shm -> clean FASTQ + the reports, per leg
+            ev = {m: v["ours"]["Mreads_per_s"] for m, v in e2e.get("modes", {}).items()
+                  if isinstance(v, dict) and isinstance(v.get("ours"), dict) and v["ours"].get("rc") == 0 and "Mreads_per_s" in v["ours"]}
+            if ev:
+                out["e2e_value"] = dict(ev, unit="Mreads/s", pairs=args.e2e_pairs,
+                                        what="`soapnuke_amd/SOAPnuke filter` end to end (FASTQ in /dev/shm -> clean FASTQ + reports), whole-process wall")
+        if time.time() > t_start + args.budget_s:
+            out["other_workloads"] = {"skipped": "bench.py's time budget (--budget-s) was spent before this leg"}
+        else:
+            if os.environ.get("SNK_BENCH_INPROCESS") == "1":       # (tests/test_simt_bench.py: the emulated device lives in this process)
+                try:
+                    out["other_workloads"] = other_workloads()
+                except Exception as ex:
+                    out["other_workloads"] = {"error": repr(ex)[:200]}
+            else:
+                out["other_workloads"] = other_workloads_child(max(120.0, t_start + args.budget_s + 240.0 - time.time()))
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,6 +448,7 @@ def main():
     ap.add_argument("--budget-s", type=float, default=600.0, help="wall-clock budget of the whole run: the optional legs behind the timed region "
                     "(end_to_end legs, other_workloads) that would start after it are recorded as skipped -- the headline line always comes out")
     ap.add_argument("--child-other-workloads", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--child-headline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--e2e-pairs", type=int, default=16_000_000, help="pairs of the end_to_end legs (0: only the cpu_baseline sample); 16 M: the reference needs "
                     "~50 s per .gz leg (three of them), ~40 s for the 4 M-pair PE250 + rmdup leg")
     args = ap.parse_args()
@@ -350,9 +457,18 @@ def main():
         print(json.dumps(other_workloads()), flush=True)
         return
 
+    forced = os.environ.get("SNK_BENCH_FORCE_LAUNCHER") == "1"
+    if (args.gpus == 1 and not forced and "WORLD_SIZE" not in os.environ and not args.child_headline
+            and os.environ.get("SNK_BENCH_INPROCESS") != "1"):
+        # N == 1: the timed region runs in a child.  A fault inside the kernel ends the process with the HIP runtime's
+        # abort and a hang ends at the child's time limit: either way this process still prints its ONE JSON line, with "error" and the
+        # kernel instance instead of a number, and the host-side legs (which run in processes of their own) are still measured.
+        out, data = headline_child(args), None
+        finish_single(args, out, data, t_start)
+        return
+
     # SNK_BENCH_FORCE_LAUNCHER=1: take the launcher branch, the nccl process group and the collective at world size 1 too
     # (tests/test_multirank_gpu.py drives the N > 1 code path on a one-GPU box this way)
-    forced = os.environ.get("SNK_BENCH_FORCE_LAUNCHER") == "1"
     if (args.gpus > 1 or forced) and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: become the launcher -- one rank per GPU under
         # torch.distributed.run (exactly the command line the driver uses), same arguments
@@ -449,30 +565,6 @@ def main():
         if var_len:      # SURVEY 8(d)'s per-read figure on the real lengths: 2 * len + 16
             bytes_launch = reps * int(sum(2 * int(x.astype(np.int64).sum()) + 16 * len(x) for x in data["len"]))
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        # HBM bytes per launch: measured in this run by two rocprofv3 --pmc passes around a short child run of this command
-        # (measured_traffic), N == 1 only; failing that, the committed profile's figure -- but only while profiles/traffic.json
-        # was taken on the kernel sources of this tree (kernel_source_sha), never a stale constant
-        traffic, extra = None, {}
-        if world == 1 and not args.no_traffic and not args.no_cpu_baseline and TEST_DIVISOR == 1 and n == 10_000_000 and args.kernel in (0, 2):
-            mt = measured_traffic(args.workload)
-            if mt is not None:
-                traffic = mt["bytes"]
-                extra = {"traffic_measured_in_run": True, "traffic_how": "2 x FETCH_SIZE + WRITE_SIZE (KB), one rocprofv3 --pmc pass each, "
-                         "mean over the tiled kernel's launches of a 4-step child run", "fetch_kb_raw": round(mt["fetch_kb_raw"], 1),
-                         "write_kb_raw": round(mt["write_kb_raw"], 1), "traffic_over_algorithmic": round(mt["bytes"] / bytes_launch, 3)}
-        if traffic is None and not args.no_traffic:
-            try:
-                with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-                    tj = json.load(fh)
-                if (n == 10_000_000 and args.kernel in (0, 2) and args.workload == "c2"
-                        and tj.get("kernel_source_sha") == kernel_source_sha()):
-                    traffic = int(tj["hbm_bytes_per_launch"])
-                    extra = {"traffic_measured_in_run": False, "traffic_source": tj["source"]}
-                else:
-                    extra = {"traffic_measured_in_run": False, "traffic_note": "no counter figure for this build: profiles/traffic.json "
-                             "was taken on other kernel sources and rocprofv3 did not produce one in this run"}
-            except (OSError, KeyError, ValueError):
-                pass
         out = {
             "metric": "Mreads/s PE150 `filter` (adapter+qual), bit-exact vs ref",
             "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world,
@@ -486,44 +578,20 @@ def main():
                        "parallelism": f"shard{world}" if world > 1 else "single",
                        "clean_pairs_per_step_per_gpu": kept // (args.steps * world)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel_ms": round(k_ms, 4), "bytes_per_launch": bytes_launch, **extra},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(k_ms, 4), "bytes_per_launch": bytes_launch},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
-            e2e = None
-            if args.e2e_pairs > 0 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "SOAPnuke")):
-                try:
-                    e2e = end_to_end(args.e2e_pairs, deadline=t_start + args.budget_s)
-                except Exception as ex:          # the host legs must never take the kernel line down
-                    e2e = {"error": repr(ex)[:200]}
-            # the reference's best leg of the three (plain -> plain carries its 60-s remove_tmpDir stall past one merge cycle,
-            # SURVEY Q10; .gz input does not): the most favourable number for the baseline
-            legs = [(m, v["reference"]) for m, v in (e2e or {}).get("modes", {}).items()
-                    if isinstance(v, dict) and v.get("reference", {}).get("rc") == 0]
-            legs = [x for x in legs if x[0] in ("gz", "gz2plain")]       # configs[1] parameters only: the headline's workload
-            if legs:
-                m, best = max(legs, key=lambda x: x[1]["Mreads_per_s"])
-                out["cpu_baseline"] = {"value": best["Mreads_per_s"], "unit": "Mreads/s", "cores": 16, "kind": "reference",
-                                       "sample": f"{args.e2e_pairs} PE150 pairs in /dev/shm, `SOAPnuke filter -J -l 10 -q 0.1 -T 16`, leg `{m}` "
-                                                 f"(the fastest of the reference's legs in end_to_end), whole-process wall {best['wall_s']}s"}
-            else:
-                out["cpu_baseline"] = cpu_baseline(data, min(n_unique, 1_000_000))
-            if e2e is not None:
-                out["end_to_end"] = e2e
-            if time.time() > t_start + args.budget_s:
-                out["other_workloads"] = {"skipped": "bench.py's time budget (--budget-s) was spent before this leg"}
-            else:
-                # (our own device memory goes back first: the child brings its own batches)
-                del batch, rec, dev
-                ctx.close()
-                torch.cuda.empty_cache()
-                if os.environ.get("SNK_BENCH_INPROCESS") == "1":       # (tests/test_simt_bench.py: the emulated device lives in this process)
-                    try:
-                        out["other_workloads"] = other_workloads()
-                    except Exception as ex:
-                        out["other_workloads"] = {"error": repr(ex)[:200]}
-                else:
-                    out["other_workloads"] = other_workloads_child(max(120.0, t_start + args.budget_s + 240.0 - time.time()))
+        if args.child_headline:
+            print(json.dumps(out), flush=True)
+            return
+        if world == 1:
+            del batch, rec, dev          # (our own device memory goes back first: the children bring their own batches)
+            ctx.close()
+            torch.cuda.empty_cache()
+            finish_single(args, out, data, t_start)
+            if use_dist:
+                dist.destroy_process_group()
+            return
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -44,6 +44,7 @@ def test_bench_line_has_every_leg(monkeypatch, capsys):
         leg = e2e["modes"][m]
         assert leg["ours"]["rc"] == 0 and leg["reference"]["rc"] == 0 and leg["report_identical"] is True, (m, leg)
     assert e2e["modes"]["plain_ours"]["ours"]["rc"] == 0 and "speedup_vs_reference_gz2plain" not in e2e["modes"]["plain_ours"]
+    assert set(out["e2e_value"]) >= {"gz", "gz2plain", "plain_ours", "gz_c3", "unit"} and out["e2e_value"]["gz"] == e2e["modes"]["gz"]["ours"]["Mreads_per_s"]
     rm = e2e["pe250_rmdup"]
     assert "error" not in rm and rm["modes"]["gz"]["report_identical"] is True, rm
     rows = out["other_workloads"]
