@@ -11,8 +11,10 @@
 
 namespace {
 
-// SNK_PROVEN_ONLY=1 in the environment: dispatch only to paths that have passed the GPU parity suite on hardware (the CLI reads the
-// same switch for single-end rmdup in one pass, host/snk_main.cpp)
+// SNK_PROVEN_ONLY=1 in the environment: dispatch only to paths that have passed the GPU parity suite on hardware -- the automatic
+// choice of snk_filter_batch_device() becomes kernel 1 (generic decisions + LDS histograms, csrc/snk_filter.cpp), the adapter
+// envelope of an explicitly requested tiled kernel is the hardware-green one (below), and the CLI reads the same switch for
+// single-end rmdup in one pass (host/snk_main.cpp)
 inline bool snk_proven_only() {
     static const bool v = [] { const char *e = getenv("SNK_PROVEN_ONLY"); return e && e[0] == '1' && !e[1]; }();
     return v;

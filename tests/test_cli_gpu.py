@@ -878,3 +878,19 @@ def test_cli_device_gzip_and_its_host_fallback(tmp_path):
             assert _cat(os.path.join(out, c + ".gz")) == _cat(os.path.join(ref, c)), (tag, c)
         sizes[tag] = os.path.getsize(os.path.join(out, "c1.fq.gz"))
     assert sizes["dev"] < 1.10 * sizes["host"], sizes
+
+
+@pytest.mark.first_contact
+@pytest.mark.parametrize("case", [R.REPORT_CASES[1], R.REPORT_CASES[4]], ids=lambda c: c[0])
+def test_cli_proven_only_switch(case, tmp_path):
+    """SNK_PROVEN_ONLY=1 (csrc/snk_tables.h, csrc/snk_filter.cpp): the run's automatic dispatch takes the generic kernel + the LDS
+    histogram kernel -- the device sources of the last hardware-green record -- instead of the tiled kernel; same bytes as the
+    reference binary either way.  With a red first contact of the rewritten kernels this is the A/B inside one library."""
+    d, p = R.case_inputs(case)
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ours = _run_ours(case, work, gz=False, env={"SNK_PROVEN_ONLY": "1"})
+    for f in (R.REPORT_FILES_PE if case[1] else R.REPORT_FILES_SE):
+        assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
+    for c in (["c1.fq", "c2.fq"] if case[1] else ["c1.fq"]):
+        assert _cat(os.path.join(ours, c)) == _cat(os.path.join(ref, c)), c

@@ -13,7 +13,8 @@ import test_gunzip_gpu as GZ
 
 # what an ordinary run takes (substrings of the test ids); SNK_SIMT_FULL=1: everything (tests/conftest.py)
 CORE = ["test_cli_matches_reference_binary[se_trim_T2]", "test_cli_gz_in_gz_out", "test_cli_rmdup_one_pass_variants[small_batches]",
-        "test_cli_sharded_ingest_emulated[True-True-True]", "test_cli_sharded_rmdup_and_wire_emulated[True-40000-True]"]
+        "test_cli_sharded_ingest_emulated[True-True-True]", "test_cli_sharded_rmdup_and_wire_emulated[True-40000-True]",
+        "test_cli_proven_only_launches_no_rewritten_kernel"]
 
 
 @pytest.fixture(autouse=True)
@@ -99,3 +100,34 @@ def test_cli_rmdup_one_pass_across_two_devices_emulated(paired, two_emulated_dev
         assert b"rmdup: one pass" in open(os.path.join(str(tmp_path), "ours", "log"), "rb").read()
     else:
         CG.test_cli_rmdup_single_end_one_pass(20100, "2048", "two_devices", tmp_path)
+
+
+def test_cli_proven_only_launches_no_rewritten_kernel(tmp_path):
+    """SNK_PROVEN_ONLY=1 on the emulated CLI with every launch recorded (SIMT_DUMP_DIR): the filter step is the generic kernel + the
+    LDS histogram kernel and nothing of the tiled / long-read / contaminant families; without the switch the tiled kernel runs"""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(T.ROOT, "tools"))
+    import gfx950_interp as G
+    n, L = 600, 150
+    d = CG.synth.make_batch(n, L, paired=True, seed=91)
+    for m in range(2):
+        CG.synth.write_fastq(os.path.join(str(tmp_path), "r%d.fq" % (m + 1)), d["seq"][m], d["qual"][m], L, m + 1)
+    seen = {}
+    for tag, env in (("proven", {"SNK_PROVEN_ONLY": "1"}), ("default", {})):
+        dump = os.path.join(str(tmp_path), "dump_" + tag)
+        os.makedirs(dump)
+        cmd = [CG.CLI, "filter", "-1", os.path.join(str(tmp_path), "r1.fq"), "-2", os.path.join(str(tmp_path), "r2.fq"), "-C", "c1.fq", "-D", "c2.fq",
+               "-o", os.path.join(str(tmp_path), tag), "-T", "1", "-f", CG.synth.ADAPTER1, "-r", CG.synth.ADAPTER2, "-J", "-l", "10", "-q", "0.1"]
+        r = subprocess.run(cmd, capture_output=True, timeout=600,
+                           env=dict(os.environ, SIMT_DUMP_DIR=dump, SIMT_DUMP_PER_KERNEL="1", SIMT_DUMP_MAX_ALLOC="1", SIMT_CUS="2", **env))
+        assert r.returncode == 0, r.stderr[-800:]
+        metas = [json.load(open(os.path.join(dump, f))) for f in os.listdir(dump) if f.endswith(".json")]
+        seen[tag] = {G.symbol_at(m["lib"], m["offset"]) for m in metas}
+    rewritten = ("snk_tiled_kernel", "snk_long_decide", "snk_long_prep", "snk_contam_kernel")
+    assert any("snk_generic_kernel" in k for k in seen["proven"]) and any("snk_long_hist_kernel" in k for k in seen["proven"]), seen["proven"]
+    assert not [k for k in seen["proven"] if any(x in k for x in rewritten)], seen["proven"]
+    assert any("snk_tiled_kernel" in k for k in seen["default"]) and not any("snk_generic_kernel" in k for k in seen["default"])
+    for f in ("c1.fq", "c2.fq", "Basic_Statistics_of_Sequencing_Quality.txt", "Statistics_of_Filtered_Reads.txt"):
+        assert open(os.path.join(str(tmp_path), "proven", f), "rb").read() == open(os.path.join(str(tmp_path), "default", f), "rb").read(), f
