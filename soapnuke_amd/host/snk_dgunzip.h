@@ -271,8 +271,10 @@ private:
         if (at_member_seam) {                  // (all of the member's text has been checked above: mlen_ is 0 here)
             const uint64_t p = pos_bit_ >> 3;
             uint64_t fb = 0;
-            if (n_ - p < 18) { pfail("truncated gzip member"); return false; }                  // as GzipInflate::member_header()
-            if (in_[p] != 0x1F || in_[p + 1] != 0x8B) stream_done_ = true;                      // trailing garbage: zlib's gzread stops quietly
+            // as GzipInflate::member_header(): the magic first -- whatever is not 1F 8B behind a member is trailing garbage (zlib's
+            // gzread stops quietly), a member that begins within the last 17 bytes is truncated
+            if (n_ - p < 2 || in_[p] != 0x1F || in_[p + 1] != 0x8B) stream_done_ = true;
+            else if (n_ - p < 18) { pfail("truncated gzip member"); return false; }
             else if (member_header_at(p, fb)) { pos_bit_ = fb; first_of_member_ = true; }
             else { pfail("invalid gzip data (member header)"); return false; }
         }

@@ -166,12 +166,14 @@ protected:
     bool member_header() {
         byte_align();
         if (in_ == in_end_) { state_ = DONE; return false; }
-        if (in_end_ - in_ < 18) { err_ = "truncated gzip member"; return false; }
-        if (in_[0] != 0x1f || in_[1] != 0x8b) {
-            // trailing garbage after a member: zlib's gzread stops quietly here
+        // the magic first (zlib's gz_look): behind a member anything that is not 1F 8B -- a single byte included -- is trailing
+        // garbage and gzread stops quietly, however few bytes there are; only a member that BEGINS and cannot be complete is truncated
+        // (the length test used to come first: fewer than 18 bytes of padding were an error, 18 or more were not -- ADVICE r5)
+        if (in_end_ - in_ < 2 || in_[0] != 0x1f || in_[1] != 0x8b) {
             if (members_) { state_ = DONE; return false; }
-            err_ = "not in gzip format"; return false;
+            err_ = in_end_ - in_ < 2 ? "truncated gzip member" : "not in gzip format"; return false;
         }
+        if (in_end_ - in_ < 18) { err_ = "truncated gzip member"; return false; }
         if (in_[2] != 8) { err_ = "unknown gzip compression method"; return false; }
         const int flg = in_[3];
         const uint8_t *p = in_ + 10;

@@ -1636,10 +1636,12 @@ int main(int argc, char **argv) {
                 ShardEnv::Gz z;
                 long long bit = -1;
                 unsigned long long sb = 0, sr = 0, nr = 0;
-                char wp[4096] = "";
-                if (sscanf(v, "%lld,%llu,%llu,%llu,%4095s", &bit, &sb, &sr, &nr, wp) < 4) die("bad SNK_SHARD environment");
+                // (the window file's path travels in a variable of its own: an output directory may hold blanks)
+                const char *wp = getenv(m ? "SNK_SHARD_GZWIN2" : "SNK_SHARD_GZWIN1");
+                if (sscanf(v, "%lld,%llu,%llu,%llu", &bit, &sb, &sr, &nr) != 4) die("bad SNK_SHARD environment");
                 z.skip_bytes = sb; z.skip_records = sr; z.nrec = nr;
                 if (bit >= 0) {
+                    if (!wp) die("bad SNK_SHARD environment");
                     z.bit = (uint64_t)bit;
                     z.win.resize(snk::GzipInflate::HIST);
                     FILE *f = fopen(wp, "rb");
@@ -1677,6 +1679,16 @@ int main(int argc, char **argv) {
             FILE *f = fopen(g_shard.stats_path.c_str(), "wb");
             if (!f || fwrite(&h, sizeof h, 1, f) != 1 || fwrite(z.data(), 8, z.size(), f) != z.size() || fclose(f) != 0) die("fake shard: stats");
             _exit(0);
+        }
+        // The wire comes up NOW, before a byte of input is read, and stays open: every shard has just been started by the
+        // same parent, so the 600 s of HostWire::connect -- the RCCL bootstrap goes through the same socket -- bound the start-up only.
+        // Made on first use (the rmdup exchange, or the all-reduce at the very end) the rendezvous was a race between shards that
+        // finish minutes apart -- .gz borders are cut by compressed bytes, a GPU may be shared or slow --: the early one gave up, the
+        // parent killed the rest, the finished work was lost.  Behind the rendezvous a shard waits for its peers as long as it takes
+        // (blocking reads; a peer that DIES closes its socket, and the parent ends the run).
+        if (g_shard.wire_kind == "rccl" || g_shard.wire_kind == "host") {
+            HIPCHK(hipSetDevice(o.devices[0]));
+            (void)shard_wire();
         }
     }
     // (opt-in until it has met the hardware: SNK_SHARDED=1; without it several devices are fed batch by batch from one reader)
@@ -1764,14 +1776,15 @@ int main(int argc, char **argv) {
                     for (int m = 0; m < mates; ++m) {
                         // shard g of file m: from the stream's header (g = 0) or from the scout's place for border g; the records between
                         // that place and the border record belong to the shard in front
-                        string v = "-1,0,0," + std::to_string(rec[(size_t)g + 1] - rec[(size_t)g]) + ",-";
+                        string v = "-1,0,0," + std::to_string(rec[(size_t)g + 1] - rec[(size_t)g]);
                         if (g > 0) {
                             const GzCut &c = sc[m].cuts[(size_t)g - 1];
                             const string wp = o.out_dir + "/shard." + std::to_string(g) + "." + std::to_string(m) + ".win";
                             FILE *f = fopen(wp.c_str(), "wb");
                             if (!f || fwrite(c.win.data(), 1, c.win.size(), f) != c.win.size() || fclose(f) != 0) die("cannot write to the file," + wp);
                             v = std::to_string(c.bit) + "," + std::to_string(c.skip_bytes) + "," + std::to_string(rec[(size_t)g] - c.rec) + "," +
-                                std::to_string(rec[(size_t)g + 1] - rec[(size_t)g]) + "," + wp;
+                                std::to_string(rec[(size_t)g + 1] - rec[(size_t)g]);
+                            env.push_back(string(m ? "SNK_SHARD_GZWIN2=" : "SNK_SHARD_GZWIN1=") + wp);
                         }
                         env.push_back(string(m ? "SNK_SHARD_GZ2=" : "SNK_SHARD_GZ1=") + v);
                     }

@@ -296,6 +296,9 @@ public:
                 std::vector<char> c;
                 if (!get_msg(fd_[(size_t)p], c) || c.size() != (size_t)world * 8 || !get_msg(fd_[(size_t)p], pay[(size_t)p])) { err = "host wire: a shard went away"; return false; }
                 memcpy(cnt[(size_t)p].data(), c.data(), c.size());
+                uint64_t tot = 0;                            // (a peer's payload must be what its counts say: the slices below trust them)
+                for (int q = 0; q < world; ++q) tot += cnt[(size_t)p][(size_t)q];
+                if (pay[(size_t)p].size() != (size_t)(tot * elem)) { err = "host wire: a shard's payload does not match its counts"; return false; }
             }
             for (int dst = 0; dst < world; ++dst) {
                 std::vector<char> msg;

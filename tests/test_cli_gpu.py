@@ -611,13 +611,13 @@ def test_cli_sharded_rmdup_and_wire(paired, n, gz_in, tmp_path):
     work = str(tmp_path)
     ref = R.run_reference_cli(case, d, work, gz_input=True)
     ext = ".fq.gz" if gz_in else ".fq"
-    cmd = [CLI, "filter", "-1", os.path.join(work, "r1" + ext), "-C", "c1.fq", "-o", os.path.join(work, "ours"), "-T", str(threads), "--devices", devs,
+    ours = os.path.join(work, "ours with blanks" if gz_in else "ours")      # (.gz: the shards' window files live there, their paths travel through the environment)
+    cmd = [CLI, "filter", "-1", os.path.join(work, "r1" + ext), "-C", "c1.fq", "-o", ours, "-T", str(threads), "--devices", devs,
            "-c", os.path.join(work, "cfg")]
     if paired:
         cmd += ["-2", os.path.join(work, "r2" + ext), "-D", "c2.fq"]
     r = subprocess.run(cmd + cli, capture_output=True, env=dict(os.environ, SNK_SHARDED="1", SNK_BATCH_PAIRS="4096", SNK_GZ_CHUNK="262144"))
     assert r.returncode == 0, (r.stdout[-300:], r.stderr[-800:])
-    ours = os.path.join(work, "ours")
     log = open(os.path.join(ours, "log"), "rb").read()
     assert b"sharded run: 2 shards" in log and b"statistics merged over" in log and b"Warning" not in r.stderr, (log[-600:], r.stderr[-400:])
     _compare_dirs(ours, ref, paired)

@@ -43,6 +43,10 @@ def test_identical_to_zlib(exe, tmp_path):
     files["random"] = gzip.compress(np.random.default_rng(1).integers(0, 256, 1_000_000, dtype=np.uint8).tobytes(), 6)
     co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, zlib.Z_FIXED)                  # fixed Huffman blocks
     files["fixed"] = co.compress(raw[:300000]) + co.flush()
+    # trailing garbage behind the last member, of any length (zlib's gzread looks at the magic first and stops quietly; ADVICE r5: fewer
+    # than 18 bytes used to be "truncated gzip member" here)
+    for k, pad in enumerate((b"\0", b"\0" * 7, b"\x1f", b"\x1f\x00pad", b"\0" * 64)):
+        files[f"garbage{k}"] = gzip.compress(raw[:40000], 6) + pad
     files["named_header"] = b"\x1f\x8b\x08\x08\x00\x00\x00\x00\x00\x03name.fq\x00" + gzip.compress(raw[:50000])[10:]
     for name, blob in files.items():
         p = str(tmp_path / (name + ".gz"))
