@@ -72,6 +72,7 @@ def build(force=False, verbose=False, lint=True):
 HOST = os.path.join(HERE, "host")
 CLI = os.path.join(HERE, "SOAPnuke")
 REPORT_LIB = os.path.join(HERE, "libsnk_report.so")
+WIRE_TEST = os.path.join(HERE, "snk_wire_selftest")
 
 
 def build_host(force=False, verbose=False):
@@ -91,6 +92,12 @@ def build_host(force=False, verbose=False):
         # (tools/micro/inflate_test.cpp, gzip -1 FASTQ, this container)
         cmd = [HIPCC, "-O2", "-march=x86-64-v3", "-std=c++17", "-o", CLI, "snk_main.cpp", "snk_report.cpp", "-L" + HERE, "-lsnk_filter", "-lz", "-pthread",
                "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=HOST)
+    if force or not os.path.exists(WIRE_TEST) or os.path.getmtime(WIRE_TEST) < newest:
+        # the wires of the sharded run at world size 1 (test infrastructure: tests/test_wire_gpu.py)
+        cmd = [HIPCC, "-O2", "-std=c++17", "-o", WIRE_TEST, "snk_wire_selftest.cpp", "-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=HOST)

@@ -84,6 +84,18 @@ def build_cli(force=False, extra=(), tag="", lib_tag=None):
     return cli
 
 
+def build_wire_selftest(force=False):
+    """soapnuke_amd/host/snk_wire_selftest.cpp against the emulated runtime: the host wire's checks run, the RCCL half says why it cannot"""
+    lib = build(force)
+    exe = os.path.join(OUT, "snk_wire_selftest_simt")
+    host = os.path.join(ROOT, "soapnuke_amd", "host")
+    srcs = [os.path.join(host, f) for f in ("snk_wire_selftest.cpp", "snk_wire.h")]
+    if not force and os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(f) for f in srcs + [lib]):
+        return exe
+    subprocess.check_call([CXX] + FLAGS + ["-x", "c++", srcs[0], "-x", "none", "-o", exe, "-L" + OUT, "-lsnk_filter_simt", "-ldl", "-Wl,-rpath," + OUT])
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force=True))
     print(build_cli(force=True))
