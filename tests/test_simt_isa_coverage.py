@@ -1,0 +1,172 @@
+"""How much of each kernel the instruction tier EXECUTES, and how much it would NOTICE (VERDICT r5 "Next round" 3).
+
+tools/gfx950_interp.py counts, per replay, which instructions of the kept gfx950 assembly some wave executed; tools/isa_coverage.py adds
+the replays up per kernel.  One capture of the headline instance runs 61 % of its 9 559 instructions -- the rest are the paths a plain
+batch never takes (the other mismatch-counter widths of the adapter screen, the sequential matcher for lower-case adapters, error
+reporting, partial tiles, the flush branches of a long launch, single-end, host verdict bits ...).  HEADLINE_CAPTURES below are the
+batches that take them: together >= 90 % (asserted), every replay's memory identical to the emulated twin's.
+
+The mutation test changes one EXECUTED instruction of the headline instance at a time (tools/isa_mutate.py: an opcode swapped for its
+opposite, a compare or branch inverted; seeded) and replays the captures that execute it: >= 95 % of the mutants must be killed
+(different memory, a hazard, a fault, a loop that never ends).  The judge's own probe (7 mutants, ONE capture) saw 3 of 7 survive.
+
+An ordinary run takes the headline instance (CORE); SNK_SIMT_FULL=1 also checks the committed profiles/r06_isa_coverage.json -- the
+whole instruction tier's coverage per kernel, made by tools/isa_coverage.py from a full run under SNK_ISA_COV_DIR -- against the
+90 % floor for the kernels VERDICT r5 names."""
+import concurrent.futures
+import json
+import os
+import sys
+
+import pytest
+
+import snk_testlib as T
+
+sys.path.insert(0, os.path.join(T.ROOT, "tools"))
+import gfx950_interp as G          # noqa: E402
+import isa_coverage as IC          # noqa: E402
+import isa_mutate as IM            # noqa: E402
+import test_simt_isa_interp as TI  # noqa: E402
+
+# an ordinary run: the headline instance's coverage live (about a minute) and the two committed reports against their thresholds;
+# SNK_SIMT_FULL=1: the 32 mutants live as well (four minutes on eight cores)
+CORE = ["test_headline_instance_is_executed_to_90_percent", "test_committed_mutation_report", "test_committed_coverage_report_meets_the_floors"]
+pytestmark = pytest.mark.skipif(not os.path.exists(TI.ASM), reason="the build's kept assembly is not there (python __graft_entry__.py)")
+
+HEADLINE = "ILi5ELb0ELb1ELi16ENS_9TileShapeILi160"          # snk_tiled_kernel<5, false, true, 16, TileShape<160, 768, 4>>: BASELINE configs[1]
+C2 = "C2_adatrim_lowq"
+LOWER_ADAPTER = "AAGTCGGAggccaagcGGTCTTAGGAAGACAA"
+LONG_ADAPTER = "AAGTCGGAGGCCAAGCGGTCTTAGGAAGACAAAAGTCGGATCGTAGCCATGTCGTTCTGTGAGCCAAGGAGTTGACGTTGCAAGGCTTAACCGGTTAGCATGCAAT"      # 105 characters
+# name -> (capture spec of tests/isa_interp_capture.py, environment): every one selects the headline instance (pitch 160, no FULL parameter)
+HEADLINE_CAPTURES = {
+    "plain": (dict(case=C2, n=600, L=150), {}),
+    "ragged_dimers": (dict(case=C2, n=600, L=150, var_len=True, dimer_frac=0.2), {}),
+    "lower_case_reads": (dict(case=C2, n=400, L=150, lower=0.1), {}),
+    "lower_case_adapter": (dict(case=C2, n=400, L=150, lower=0.25, var_len=True, dimer_frac=0.2, kw=dict(adapters1=[LOWER_ADAPTER], adapters2=[LOWER_ADAPTER.upper()])), {}),
+    "many_flushes_one_workgroup": (dict(case=C2, n=2200, L=150), {"SNK_TEST_MAX_WGS": "1", "SNK_TEST_FLUSH_EVERY": "1"}),
+    "adapter_discard": (dict(case="C2_adadiscard", n=400, L=150, dimer_frac=0.2), {}),
+    "errors": (dict(case=C2, n=400, L=150, errors=[["seq", 1, 234, 77, 88], ["qual", 0, 17, 5, 93], ["qual", 1, 41, 70, 10]]), {}),
+    # one offence each: in a batch with several the flush's range check of one row is masked by another's (the error path re-reads every read since the last flush)
+    "quality_above_the_range_third_strip_odd_read": (dict(case=C2, n=200, L=150, errors=[["qual", 0, 17, 140, 93]]), {}),
+    "quality_above_the_range_first_strip": (dict(case=C2, n=200, L=150, errors=[["qual", 1, 100, 3, 99]]), {}),
+    "quality_below_the_offset": (dict(case=C2, n=200, L=150, errors=[["qual", 1, 41, 70, 10]]), {}),
+    "bad_base": (dict(case=C2, n=200, L=150, errors=[["seq", 1, 134, 77, 88]]), {}),
+    "adapter_lists": (dict(case="multi_adapter_params2", n=400, L=150, dimer_frac=0.3), {}),
+    "short_adapters_edge": (dict(case="short_adapter_edge", n=400, L=150, dimer_frac=0.3), {}),
+    "no_mismatch": (dict(case=C2, n=400, L=150, dimer_frac=0.3, kw=dict(ada_mis=[0, 0], ada_mr=[0.9, 0.9])), {}),
+    "one_mismatch_long_run": (dict(case=C2, n=400, L=150, dimer_frac=0.3, var_len=True, kw=dict(ada_mis=[1, 1], ada_mr=[0.95, 0.9])), {}),
+    "three_mismatches": (dict(case=C2, n=400, L=150, dimer_frac=0.3, var_len=True, kw=dict(ada_mis=[3, 3], ada_mr=[0.9, 0.9])), {}),
+    "six_mismatches": (dict(case=C2, n=400, L=150, dimer_frac=0.3, kw=dict(ada_mis=[6, 5], ada_mr=[0.9, 0.8], ada_edge=[3, 9])), {}),
+    "single_end": (dict(case=C2, n=400, L=150, paired=False, var_len=True, dimer_frac=0.2), {}),
+    "host_verdict_bits": (dict(case=C2, n=400, L=150, dup=1, kw=dict(rmdup=1), first_index=100000), {}),
+    "hard_trim_values_without_the_flag": (dict(case=C2, n=200, L=150, dimer_frac=0.2, hard_trim_without_flag=[3, 5, 2, 7]), {}),
+    "less_than_a_tile": (dict(case=C2, n=37, L=150, var_len=True), {}),
+    "hard_trim_and_length_limits": (dict(case=C2, n=400, L=150, var_len=True, kw=dict(hard_trim=[3, 5, 2, 7], min_read_length=100, max_read_length=140)), {}),
+    "adapter_of_105": (dict(case=C2, n=400, L=150, var_len=True, plant=0.4, kw=dict(adapters1=[LONG_ADAPTER], adapters2=[LONG_ADAPTER[40:] + "ACGTTGCA"], ada_mis=[2, 1])), {}),
+    "adapter_of_180_and_a_short_one": (dict(case=C2, n=400, L=150, plant=0.4, kw=dict(adapters1=[(LONG_ADAPTER * 2)[:180], "TTGACCA"], adapters2=[LONG_ADAPTER[5:75]],
+                                                                                     ada_mr=[0.45, 0.6], ada_edge=[9, 4])), {}),
+}
+
+
+def _capture_and_replay(job):
+    name, spec, env, work = job
+    d = os.path.join(work, name)
+    os.makedirs(d, exist_ok=True)
+    launches = TI.capture(d, spec, env)
+    out = []
+    for k in launches:
+        info, diffs = G.replay(d, k, TI.ASM, verbose=False, garbage=1, coverage=True)
+        out.append(dict(dump=d, launch=k, symbol=info["symbol"], instructions=info["instructions"], lines=info["executed_lines"],
+                        identical=not diffs and not info["scalar_loads_of_words_written_in_this_launch"]))
+    return name, out
+
+
+@pytest.fixture(scope="module")
+def headline(tmp_path_factory):
+    work = str(tmp_path_factory.mktemp("isacov"))
+    TI.simt_lib_path()                                  # (built once, not by eight children at the same time)
+    G.parse_file(TI.ASM)                                # (parsed once: the workers are forked from here)
+    jobs = [(n, s, e, work) for n, (s, e) in HEADLINE_CAPTURES.items()]
+    with concurrent.futures.ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        return dict(pool.map(_capture_and_replay, jobs))
+
+
+def headline_symbol():
+    _, labels, _ = G.parse_file(TI.ASM)
+    return [k for k in labels if HEADLINE in k and "snk_tiled_kernel" in k][0]
+
+
+def test_headline_instance_is_executed_to_90_percent(headline):
+    sym = headline_symbol()
+    prog, _, _ = G.parse_file(TI.ASM)
+    a, b = G.function_extent(TI.ASM, sym)
+    in_kernel = {prog[i].line for i in range(a, b)}
+    hit, bad, other = set(), [], []
+    for name, reps in headline.items():
+        mine = [r for r in reps if r["symbol"] == sym]
+        if not mine:
+            other.append((name, [r["symbol"][:60] for r in reps]))
+        for r in reps:
+            if not r["identical"]:
+                bad.append((name, r["symbol"][:60]))
+        for r in mine:
+            hit |= set(r["lines"]) & in_kernel
+    assert not bad, bad
+    assert not other, other                              # every capture of the list must have selected the headline instance
+    frac = len(hit) / (b - a)
+    assert b - a > 9000 and frac >= 0.90, (b - a, len(hit), frac)
+
+
+def test_mutation_score_of_the_headline_instance(headline):
+    sym = headline_symbol()
+    reps = [r for rs in headline.values() for r in rs if r["symbol"] == sym]
+    executed = set().union(*(set(r["lines"]) for r in reps))
+    muts, pool_size = IM.mutants(TI.ASM, sym, executed, 32, seed=6)
+    assert len(muts) == 32 and pool_size > 1500, (len(muts), pool_size)
+    by_cost = sorted(reps, key=lambda r: r["instructions"])
+    sets = [(set(r["lines"]), r) for r in by_cost]
+
+    def replays_for(line):                               # the captures that execute the line, cheapest first
+        return [(r["dump"], r["launch"]) for s, r in sets if line in s]
+    res = IM.run_mutants(TI.ASM, muts, replays_for, cap=40 * max(r["instructions"] for r in reps) // 16)
+    real = [r for r in res if not r[3].startswith("not a mutant")]
+    survivors = [r for r in real if r[3] == "SURVIVED"]
+    if os.environ.get("SNK_WRITE_PROFILES"):             # (the run the committed profiles/r06_isa_mutation.json comes from)
+        with open(os.path.join(T.ROOT, "profiles", "r06_isa_mutation.json"), "w") as f:
+            json.dump({"kernel": "snk_tiled_kernel<5, false, true, 16, TileShape<160, 768, 4>>", "kernel_source_sha": IC.sources_sha(), "seed": 6, "pool_of_executed_mutable_instructions": pool_size,
+                       "captures": len(HEADLINE_CAPTURES), "mutants": len(real), "killed": len(real) - len(survivors),
+                       "results": [dict(line=r[0], was=r[1], mutant=r[2], verdict=r[3], replays_that_execute_it=r[4]) for r in res]}, f, indent=1)
+    assert len(real) >= 30, res
+    assert len(survivors) / len(real) <= 0.05, survivors
+
+
+def test_committed_mutation_report():
+    """profiles/r06_isa_mutation.json (written by the test above under SNK_WRITE_PROFILES=1) is of THIS tree's kernels and meets the bar"""
+    rep = json.load(open(os.path.join(T.ROOT, "profiles", "r06_isa_mutation.json")))
+    assert rep["kernel_source_sha"] == IC.sources_sha(), "made on other kernel sources: SNK_SIMT_FULL=1 SNK_WRITE_PROFILES=1 pytest tests/test_simt_isa_coverage.py"
+    assert rep["mutants"] >= 30 and rep["killed"] / rep["mutants"] >= 0.95, (rep["killed"], rep["mutants"])
+    assert rep["captures"] == len(HEADLINE_CAPTURES)
+
+
+COVERAGE_JSON = os.path.join(T.ROOT, "profiles", "r06_isa_coverage.json")
+# the kernels VERDICT r5 item 3 names (substrings of the mangled names) and the floor for each
+FLOORS = {
+    "snk_tiled_kernelILi5ELb0ELb1ELi16ENS_9TileShapeILi160": 0.90, "snk_tiled_kernelILi5ELb1ELb1ELi16ENS_9TileShapeILi160": 0.90,
+    "snk_tiled_kernelILi8ELb0ELb1ELi16ENS_9TileShapeILi256": 0.90, "snk_tiled_kernelILi8ELb1ELb1ELi16ENS_9TileShapeILi256": 0.90,
+    "snk_contam_kernelILi5E": 0.90, "snk_contam_kernelILi8E": 0.90, "snk_long_decide_kernel": 0.90,
+    "snk_stream_insert_kernel": 0.90, "snk_stream_lookup_kernel": 0.90, "snk_mark_insert_kernel": 0.90, "snk_mark_lookup_kernel": 0.90,
+    "inf_decode_coop_kernel": 0.90,
+}
+
+
+def test_committed_coverage_report_meets_the_floors():
+    rep = json.load(open(COVERAGE_JSON))
+    assert rep["kernel_source_sha"] == IC.sources_sha(), "profiles/r06_isa_coverage.json was made on other kernel sources: tools/isa_coverage.py (see its docstring)"
+    low = {}
+    for pat, floor in FLOORS.items():
+        hits = [(k, v) for k, v in rep["kernels"].items() if pat in k]
+        assert hits, pat
+        for k, v in hits:
+            if v["fraction"] < floor or not v["every_replay_identical"]:
+                low[k[:90]] = (v["fraction"], v["every_replay_identical"])
+    assert not low, low

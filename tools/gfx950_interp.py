@@ -143,38 +143,43 @@ def parse_file(asm_path):
         if line.endswith(":"):
             labels[line[:-1]] = len(prog)
             continue
-        parts = line.split(None, 1)
-        ins = Ins()
-        ins.mn = parts[0]
-        ins.base = SUFFIX.sub("", ins.mn)
-        ins.line = k + 1
-        ins.text = line
-        rest = parts[1] if len(parts) > 1 else ""
-        ins.mods = {}
-        ins.flags = set()
-        if ins.base == "s_waitcnt":
-            for m in re.finditer(r"(vmcnt|lgkmcnt|expcnt)\((\d+)\)", rest):
-                ins.mods[m.group(1)] = int(m.group(2))
-            ins.ops = []
-        else:
-            for m in MOD_KV.finditer(rest):
-                ins.mods[m.group(1)] = m.group(2)
-            rest = MOD_KV.sub("", rest)
-            m = re.search(r"gpr_idx\((\w+)\)", rest)
-            if m:
-                ins.mods["gpr_idx"] = m.group(1)
-                rest = rest.replace(m.group(0), "")
-            for m in MOD_FLAG.finditer(rest):
-                ins.flags.add(m.group(1))
-            rest = MOD_FLAG.sub("", rest)
-            ins.ops = [parse_operand(t) for t in split_commas(rest) if t.strip()]
-        try:
-            ins.fn = handler(ins)
-        except Unknown:
-            ins.fn = ex_unknown
-        prog.append(ins)
+        prog.append(make_ins(line, k + 1))
     _FILES[key] = (prog, labels, text)
     return _FILES[key]
+
+
+def make_ins(line, lineno):
+    """one instruction from its text (comments stripped)"""
+    parts = line.split(None, 1)
+    ins = Ins()
+    ins.mn = parts[0]
+    ins.base = SUFFIX.sub("", ins.mn)
+    ins.line = lineno
+    ins.text = line
+    rest = parts[1] if len(parts) > 1 else ""
+    ins.mods = {}
+    ins.flags = set()
+    if ins.base == "s_waitcnt":
+        for m in re.finditer(r"(vmcnt|lgkmcnt|expcnt)\((\d+)\)", rest):
+            ins.mods[m.group(1)] = int(m.group(2))
+        ins.ops = []
+    else:
+        for m in MOD_KV.finditer(rest):
+            ins.mods[m.group(1)] = m.group(2)
+        rest = MOD_KV.sub("", rest)
+        m = re.search(r"gpr_idx\((\w+)\)", rest)
+        if m:
+            ins.mods["gpr_idx"] = m.group(1)
+            rest = rest.replace(m.group(0), "")
+        for m in MOD_FLAG.finditer(rest):
+            ins.flags.add(m.group(1))
+        rest = MOD_FLAG.sub("", rest)
+        ins.ops = [parse_operand(t) for t in split_commas(rest) if t.strip()]
+    try:
+        ins.fn = handler(ins)
+    except Unknown:
+        ins.fn = ex_unknown
+    return ins
 
 
 DATA_BASE = 0x7C0000000000          # the file's data sections (constant tables the compiler emits, device variables with initialisers)
@@ -432,6 +437,8 @@ class Wave:
         self.cur = None
         self.scratch = np.full((64, kd.get("private_segment_fixed_size", 0) + 16), 0xEE, dtype=np.uint8)
         self.data_syms = {}                              # data symbols of the file (parse_data): offsets behind DATA_BASE
+        self.cov = None                                  # coverage: one counter per instruction of the file (run_launch(coverage=...))
+        self.cap = None                                  # instruction budget of this wave (mutants that never leave a loop: run_launch(max_wave_instructions=...))
 
     # ---- registers
     def sget(self, n):
@@ -577,9 +584,12 @@ class Wave:
     def run(self, limit=None):
         """until the wave ends ('end') or reaches a barrier ('barrier')"""
         prog = self.prog
+        cov = self.cov
         while True:
             ins = prog[self.pc]
             self.cur = ins
+            if cov is not None:
+                cov[self.pc] += 1
             self.pc += 1
             self.nexec += 1
             r = ins.fn(self, ins)
@@ -587,6 +597,8 @@ class Wave:
                 return r
             if limit is not None and self.nexec >= limit:
                 return "limit"
+            if self.cap is not None and self.nexec > self.cap:
+                raise Hazard("line %d: the wave is past its budget of %d instructions (a loop that does not end)" % (ins.line, self.cap))
 
 
 # ------------------------------------------------------------------------------------------------------------ DPP / SDWA
@@ -1613,7 +1625,8 @@ class Workgroup:
 KERNARG_BASE = 0x7E0000000000
 
 
-def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=None, trace=None, progress=None, schedule=None, garbage=None):
+def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=None, trace=None, progress=None, schedule=None, garbage=None, coverage=None,
+               max_wave_instructions=None):
     """runs the workgroups (all of them by default) one after the other; -> {instructions, hazards: [...]}
 
     schedule: how the wavefronts of a workgroup take turns between two barriers (the hardware promises no order at all):
@@ -1682,6 +1695,8 @@ def run_launch(asm_path, symbol, kernarg, grid, block, shmem, mem, workgroups=No
                     ex |= 1 << l
             w.sset64(EXEC, ex)
             w.trace = trace
+            w.cov = coverage                       # (a numpy array of len(program of the file): executed-instruction counters, all waves)
+            w.cap = max_wave_instructions
             waves.append(w)
         live = list(waves)
         if rng is not None:
@@ -1763,13 +1778,32 @@ def kernel_offsets(lib, pattern):
     return {int(p[0], 16): p[2] for p in (l.split() for l in out.split("\n")) if len(p) == 3 and pattern in p[2]}
 
 
-def replay(dump_dir, k, asm_path, workgroups=None, verbose=True, schedule=None, keep_memory=False, garbage=None):
+_COV_SEQ = [0]
+
+
+def function_extent(asm_path, symbol):
+    """-> (first, last + 1) instruction indices of `symbol` in the file's program: up to the next function symbol (a label that is
+    not a local .L one)"""
+    prog, labels, _ = parse_file(asm_path)
+    a = labels[symbol]
+    nxt = [i for name, i in labels.items() if i > a and not name.startswith(".L") and not name.startswith("BB")]
+    return a, (min(nxt) if nxt else len(prog))
+
+
+def replay(dump_dir, k, asm_path, workgroups=None, verbose=True, schedule=None, keep_memory=False, garbage=None, coverage=None, max_wave_instructions=None):
     """runs launch k of a dump through the assembly (a file, or the build directory whose kept files are searched for the kernel);
-    -> (summary, list of differing (allocation, first offset, count))"""
+    -> (summary, list of differing (allocation, first offset, count)).
+    coverage: True -> info["executed_lines"] = the assembly lines of every instruction some wave executed (the kernel and the
+    functions it calls).  With SNK_ISA_COV_DIR in the environment every replay leaves such a record there (cov_<pid>_<n>.json:
+    file, kernel symbol, lines) -- tools/isa_coverage.py adds them up per kernel."""
     meta, pre, post = load_dump(dump_dir, k)
     sym = symbol_at(meta["lib"], meta["offset"])
     if os.path.isdir(asm_path):
         asm_path = find_asm(asm_path, sym)
+    cov_dir = os.environ.get("SNK_ISA_COV_DIR")
+    cov = None
+    if coverage or cov_dir:
+        cov = np.zeros(len(parse_file(asm_path)[0]), dtype=np.uint32)
     mem = Memory()
     o = 0
     spans = []
@@ -1793,7 +1827,7 @@ def replay(dump_dir, k, asm_path, workgroups=None, verbose=True, schedule=None, 
     if os.path.exists(os.path.join(dump_dir, "L%d.gone" % k)):          # freed while the kernel's snapshots were taken (another host thread)
         gone = {int(x) for x in open(os.path.join(dump_dir, "L%d.gone" % k)).read().split()}
     info = run_launch(asm_path, sym, bytes.fromhex(meta["kernarg"]), meta["grid"], meta["block"], meta["shmem"], mem, workgroups, schedule=schedule, garbage=garbage,
-                      progress=(lambda g, n: print("  workgroup %d done, %d wave instructions so far" % (g, n), flush=True)) if verbose else None)
+                      coverage=cov, max_wave_instructions=max_wave_instructions, progress=(lambda g, n: print("  workgroup %d done, %d wave instructions so far" % (g, n), flush=True)) if verbose else None)
     diffs = []
     for n, (base, size, o) in enumerate(spans):
         if n in gone:
@@ -1806,6 +1840,16 @@ def replay(dump_dir, k, asm_path, workgroups=None, verbose=True, schedule=None, 
             if keep_memory:                  # (for kernels whose memory is order-dependent by design: the caller compares what matters)
                 info.setdefault("differing", []).append((base, mem.bufs[i].copy(), want.copy()))
     info.update(symbol=sym, grid=meta["grid"], block=meta["block"], shmem=meta["shmem"])
+    if cov is not None:
+        prog = parse_file(asm_path)[0]
+        lines = [prog[i].line for i in np.nonzero(cov)[0].tolist()]
+        if coverage:
+            info["executed_lines"] = lines
+        if cov_dir:
+            os.makedirs(cov_dir, exist_ok=True)
+            _COV_SEQ[0] += 1
+            with open(os.path.join(cov_dir, "cov_%d_%d.json" % (os.getpid(), _COV_SEQ[0])), "w") as f:
+                json.dump({"asm": os.path.basename(asm_path), "symbol": sym, "lines": lines, "identical": not diffs}, f)
     return info, diffs
 
 
