@@ -64,7 +64,8 @@ def plant_contams(d, kw, seed=4):
             b = np.frombuffer(s.encode(), dtype=np.uint8)
             for r in rng.choice(n, n // 20, replace=False):
                 L = int(d["len"][m][r]) if d["len"][m] is not None else d["L"]
-                k, mode = int(rng.integers(8, len(b) + 1)), int(rng.integers(0, 3))
+                k, mode = int(rng.integers(min(8, len(b)), len(b) + 1)), int(rng.integers(0, 3))
+                k = min(k, L)                                 # (a contaminant longer than the read: as much of it as fits)
                 if mode == 0 and L >= len(b):
                     p = int(rng.integers(0, L - len(b) + 1))
                     d["seq"][m][r, p:p + len(b)] = b

@@ -66,7 +66,7 @@ def main():
     if not paired:
         kw = {k: v for k, v in kw.items() if not k.endswith("2")}
     if spec.get("contam"):                               # contaminant lists on top (tests/cases.py CONTAM_CASES), copies planted in the reads
-        ck = CONTAM_CASES[spec["contam"]]
+        ck = CONTAM_CASES[spec["contam"]] if isinstance(spec["contam"], str) else {k: (tuple(v) if isinstance(v, list) else v) for k, v in spec["contam"].items()}
         plant_contams(d, ck)
         kw.update(contam_kwargs(ck, paired))
     kw.update(spec.get("kw", {}))                        # any parameter of abi.default_params on top of the case

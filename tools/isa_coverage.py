@@ -111,9 +111,11 @@ def report(cov_dir, loc_dir=None):
         if not os.path.exists(os.path.join(BUILD, r["asm"])):      # (a negative control's mutated copy of the assembly: not the shipped code)
             continue
         e = per.setdefault((r["asm"], r["symbol"]), {"lines": set(), "replays": 0, "all_identical": True})
+        e["all_identical"] &= bool(r.get("identical", True))
+        if not r.get("identical", True):                 # (a replay that left other memory than the twin is a finding, not coverage)
+            continue
         e["lines"].update(r["lines"])
         e["replays"] += 1
-        e["all_identical"] &= bool(r.get("identical", True))
     out = {}
     for (asm, sym), e in sorted(per.items()):
         path = os.path.join(BUILD, asm)

@@ -69,6 +69,7 @@ def mutants(asm_path, symbol, executed_lines, n, seed):
 
 def _one(job):
     asm_path, (idx, line, old, new), replays, cap = job
+    os.environ.pop("SNK_ISA_COV_DIR", None)             # (a mutant's replays are no evidence of what the shipped code executes)
     prog, _, _ = G.parse_file(asm_path)
     keep = prog[idx]
     verdict = None
