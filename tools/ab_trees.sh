@@ -34,7 +34,10 @@ case ${1:-build} in
         for wl in c2 c3; do
           timeout 300 python bench.py --no-cpu-baseline --workload $wl 2>/dev/null | tail -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); r = d.get('roofline') or {}
+t = sys.stdin.read().strip()
+if not t.startswith('{'):
+    print('$tag', '$wl', 'no bench line (the run died: an older bench.py has no child for its timed region)'); sys.exit(0)
+d = json.loads(t); r = d.get('roofline') or {}
 print('$tag', '$wl', 'kernel_ms', r.get('kernel_ms'), 'frac', r.get('frac'), 'ms_per_step', d.get('ms_per_step'), d.get('error', ''))"
         done ) > gpurun_out/ab/$tag.txt 2>&1
       echo "== $tag"; cat gpurun_out/ab/$tag.txt
