@@ -826,6 +826,19 @@ def ex_valu(w, ins):
     elif ins.mn.endswith("_sdwa"):
         srcs = [sdwa_src(ins, k, a) for k, a in enumerate(srcs)]
     r = fn(*srcs)
+    if "clamp" in ins.flags:
+        # the integer clamp of VOP3 / SDWA: the result saturates instead of wrapping (unsigned: 0 .. 2^32 - 1).  Found ignored in round 6
+        # by the widened captures: `v_sub_u32_e64 v4, v82, v5 clamp` is how the compiler spells trim_finish()'s "cuts longer than the
+        # read -> clean length 0", and no capture before had a read whose cuts exceeded it inside the tiled kernel.
+        a, b = (x.astype(np.int64) for x in srcs[:2])
+        if ins.base == "v_sub_u32":
+            r = np.maximum(a - b, 0).astype(U32)
+        elif ins.base == "v_subrev_u32":
+            r = np.maximum(b - a, 0).astype(U32)
+        elif ins.base == "v_add_u32":
+            r = np.minimum(a + b, M32).astype(U32)
+        else:
+            raise Unknown("clamp on %s" % ins.text)
     if ins.mn.endswith("_sdwa"):
         r = sdwa_dst(ins, u32(r))
     w.wr32(ops[0], r, mask)
