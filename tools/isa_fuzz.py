@@ -18,7 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path[:0] = [os.path.join(ROOT, "tests"), ROOT, HERE]
 
-SHAPES = [(150, None), (250, None), (100, None), (50, None), (180, None), (200, None), (140, None), (150, 152), (100, 104), (64, None), (33, None), (256, None)]
+SHAPES = [(150, None), (250, None), (100, None), (50, None), (180, None), (200, None), (140, None), (150, 152), (100, 104), (64, None), (33, None), (256, None),
+          (300, None), (600, None), (1000, None), (150, None), (250, None)]      # (beyond 256 positions: the long-read kernels)
 
 
 def context(seed):
@@ -44,6 +45,12 @@ def context(seed):
     if rng.random() < 0.2:
         spec["dup"] = 1
         spec["kw"]["rmdup"] = 1
+    if L > 256:
+        spec["kernel"], spec["n"] = 0, min(spec["n"], 96)
+    if rng.random() < 0.25:                              # contaminant lists on top (their kernels run in front of the tiled / long-read decide kernel)
+        from cases import CONTAM_CASES
+        spec["contam"] = str(rng.choice(sorted(CONTAM_CASES)))
+        spec["kernel"] = 0 if L > 256 else 2
     return spec
 
 
@@ -54,7 +61,7 @@ def one(seed):
     out = []
     try:
         with tempfile.TemporaryDirectory(prefix="isafuzz_") as tmp:
-            launches = TI.capture(tmp, spec)
+            launches = TI.capture(tmp, spec, kernels=("snk_tiled", "snk_long", "snk_contam"))
             for k in launches:
                 info, diffs = G.replay(tmp, k, TI.BUILD, verbose=False, garbage=seed)
                 bad = bool(diffs) or bool(info["scalar_loads_of_words_written_in_this_launch"])
