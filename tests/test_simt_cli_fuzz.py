@@ -109,6 +109,8 @@ def _context(i):
         env["SNK_SHARD_MIN_RECORDS"] = "700"                 # (the parent shards inputs of 4096 records per shard and more: these are smaller)
         env["SNK_GZ_CHUNK"] = "65536"
         env.setdefault("SNK_BATCH_PAIRS", "1536")
+    if rng.random() < 0.1:                                    # (drawn last: the contexts of earlier rounds stay what they were)
+        env["SNK_PROVEN_ONLY"] = "1"                          # round 6: every automatic dispatch takes the generic + LDS-histogram kernels
     return dict(paired=paired, L=L, n=n, d=d, cli=cli, cfg=cfg, threads=threads, patch=patch, rmdup=rmdup, env=env, ours_cli=ours_cli, gz_in=gz_in, gz_out=gz_out)
 
 
