@@ -396,12 +396,13 @@ def test_committed_mutation_report():
 
 COVERAGE_JSON = os.path.join(T.ROOT, "profiles", "r06_isa_coverage.json")
 # the kernels VERDICT r5 item 3 names (substrings of the mangled names) and the floor asserted for each: 0.90 where the capture lists
-# reach it, else what they reach today (contaminant kernels, long-read decide, cooperative inflate -- the report lists their unexecuted blocks)
+# reach it, else what they reach today (contaminant kernels and long-read decide: 0.82 with the 248 random contaminant contexts of
+# `SNK_ISA_FUZZ_CONTAM=1 tools/isa_fuzz.py` on top of the lists below; cooperative inflate -- the report lists their unexecuted blocks)
 FLOORS = {
     "snk_tiled_kernelILi5ELb0ELb1ELi16ENS_9TileShapeILi160": 0.90, "snk_tiled_kernelILi5ELb1ELb1ELi16ENS_9TileShapeILi160": 0.90,
     "snk_tiled_kernelILi8ELb0ELb1ELi16ENS_9TileShapeILi256": 0.90, "snk_tiled_kernelILi8ELb1ELb1ELi16ENS_9TileShapeILi256": 0.90,
     "snk_stream_insert_kernel": 0.90, "snk_stream_lookup_kernel": 0.90, "snk_mark_insert_kernel": 0.90, "snk_mark_lookup_kernel": 0.90,
-    "snk_contam_kernelILi5E": 0.66, "snk_contam_kernelILi8E": 0.75, "snk_long_decide_kernel": 0.78, "inf_decode_coop_kernel": 0.55,
+    "snk_contam_kernelILi5E": 0.80, "snk_contam_kernelILi8E": 0.80, "snk_long_decide_kernel": 0.80, "inf_decode_coop_kernel": 0.55,
 }
 
 

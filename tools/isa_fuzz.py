@@ -47,7 +47,31 @@ def context(seed):
         spec["kw"]["rmdup"] = 1
     if L > 256:
         spec["kernel"], spec["n"] = 0, min(spec["n"], 96)
-    if rng.random() < 0.25:                              # contaminant lists on top (their kernels run in front of the tiled / long-read decide kernel)
+    if os.environ.get("SNK_ISA_FUZZ_CONTAM") == "1":    # every context with RANDOM contaminant lists (lengths, ratios, budgets, global contaminants)
+        B = "ACGT"
+        word = lambda a, z: "".join(B[int(x)] for x in rng.integers(0, 4, int(rng.integers(a, z))))      # noqa: E731
+        hi = min(64, max(12, (L if not var_len else L // 2) - 4))
+        ck = {}
+        if rng.random() < 0.8:
+            k = int(rng.integers(1, 3))
+            ck["contam1"] = ",".join(word(8, hi) for _ in range(k))
+            if paired:
+                ck["contam2"] = ",".join(word(8, hi) for _ in range(k))
+            ck["ct_match_r"] = ",".join(str(rng.choice([0.2, 0.4, 0.5, 0.7, 0.9, 1.0])) for _ in range(k)) if k > 1 else str(rng.choice([0.2, 0.5, 0.8, 1.0]))
+        if rng.random() < 0.6 or not ck:
+            k = int(rng.integers(1, 3))
+            ck["global_contams"] = ",".join(word(12, hi) for _ in range(k))
+            ck["g_mrs"] = ",".join(str(rng.choice([0.3, 0.5, 0.7, 1.0])) for _ in range(k))
+            ck["g_mms"] = ",".join(str(int(rng.integers(0, 5))) for _ in range(k))
+        if rng.random() < 0.5:
+            ck["contam_trim"] = 1
+        ck["ada_mis"] = [int(rng.integers(0, 6)), int(rng.integers(0, 6))]
+        ck["ada_edge"] = [int(rng.integers(1, 8)), int(rng.integers(1, 8))]
+        for k in ("ada_mis", "ada_edge"):
+            spec["kw"].pop(k, None)
+        spec["contam"] = json.loads(json.dumps(ck))
+        spec["kernel"] = 0 if L > 256 else 2
+    elif rng.random() < 0.25:                            # contaminant lists on top (their kernels run in front of the tiled / long-read decide kernel)
         from cases import CONTAM_CASES
         spec["contam"] = str(rng.choice(sorted(CONTAM_CASES)))
         spec["kernel"] = 0 if L > 256 else 2
