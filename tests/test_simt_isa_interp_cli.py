@@ -107,8 +107,12 @@ def write_inputs(work, sc):
         f = os.path.join(work, "r%d.fq" % (m + 1))
         synth.write_fastq(f, d["seq"][m], d["qual"][m], L, m + 1, lens=d["len"][m])
         if sc["gz_in"]:
-            with open(f, "rb") as src, gzip.open(f + ".gz", "wb", compresslevel=6) as dst:
-                dst.write(src.read())
+            # (tools/isa_fuzz_cli.py: other compression levels, several members, a stored member in between)
+            raw, level, members = open(f, "rb").read(), int(sc.get("gz_level", 6)), int(sc.get("gz_members", 1))
+            cuts = [len(raw) * k // members for k in range(members + 1)]
+            with open(f + ".gz", "wb") as dst:
+                for k in range(members):
+                    dst.write(gzip.compress(raw[cuts[k]:cuts[k + 1]], compresslevel=0 if (sc.get("gz_stored") and k == 1) else level))
             f += ".gz"
         files.append(f)
     return files

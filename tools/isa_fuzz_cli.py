@@ -42,7 +42,8 @@ def scenario(seed):
             env["SNK_DGZ_COOP"] = "0"
     if rng.random() < 0.15:
         env["SNK_PROVEN_ONLY"] = "1"
-    return dict(n=int(rng.integers(100, 320)), L=L, paired=paired, gz_in=gz_in, gz_out=gz_out, cfg=cfg, cli=cli, env=env, expect=[])
+    return dict(n=int(rng.integers(100, 320)), L=L, paired=paired, gz_in=gz_in, gz_out=gz_out, cfg=cfg, cli=cli, env=env, expect=[],
+                gz_level=pick([1, 1, 4, 6, 9]), gz_members=pick([1, 1, 2, 3]), gz_stored=bool(rng.random() < 0.2))
 
 
 def main():
