@@ -402,7 +402,7 @@ FLOORS = {
     "snk_tiled_kernelILi5ELb0ELb1ELi16ENS_9TileShapeILi160": 0.90, "snk_tiled_kernelILi5ELb1ELb1ELi16ENS_9TileShapeILi160": 0.90,
     "snk_tiled_kernelILi8ELb0ELb1ELi16ENS_9TileShapeILi256": 0.90, "snk_tiled_kernelILi8ELb1ELb1ELi16ENS_9TileShapeILi256": 0.90,
     "snk_stream_insert_kernel": 0.90, "snk_stream_lookup_kernel": 0.90, "snk_mark_insert_kernel": 0.90, "snk_mark_lookup_kernel": 0.90,
-    "snk_contam_kernelILi5E": 0.80, "snk_contam_kernelILi8E": 0.80, "snk_long_decide_kernel": 0.80, "inf_decode_coop_kernel": 0.55,
+    "snk_contam_kernelILi5E": 0.80, "snk_contam_kernelILi8E": 0.80, "snk_long_decide_kernel": 0.80, "inf_decode_coop_kernel": 0.70,
 }
 
 
