@@ -1499,7 +1499,71 @@ struct RecordIndex {
 struct GzCut { uint64_t bit = 0, text_off = 0, rec = 0, skip_bytes = 0, nl_left = 0; bool have_win = false, resolved = false; std::vector<uint8_t> win; };
 struct GzScout { uint64_t n_records = 0; std::vector<GzCut> cuts; string why; };
 
-bool scout_gz(const string &path, int workers, int G, GzScout &out) {
+// The scout's result kept between runs: SNK_GZ_INDEX_DIR=<dir> -- one small file per input, shard count and chunk size,
+// named after the input's base name, size and modification time; a later run over the SAME file (size and mtime unchanged) with the same
+// shard count reads the borders from it instead of decoding the input once more in front of the run.  What the index does not repeat is
+// the scout's check of every member's CRC-32: the file was checked by the run that wrote the index (a shard that enters a member in its
+// middle cannot check it), which is why this is opt-in.
+struct GzIndexHeader { char magic[8]; uint64_t size, mtime_ns, n_records, chunk; uint32_t G, ncuts; };
+string gz_index_path(const string &path, int G, uint64_t chunk, uint64_t &size, uint64_t &mtime_ns) {
+    const char *dir = getenv("SNK_GZ_INDEX_DIR");
+    struct stat st;
+    if (!dir || !*dir || stat(path.c_str(), &st) != 0) return "";
+    size = (uint64_t)st.st_size;
+    mtime_ns = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
+    const size_t k = path.find_last_of('/');
+    return string(dir) + "/" + (k == string::npos ? path : path.substr(k + 1)) + "." + std::to_string(size) + "." + std::to_string(mtime_ns) + "." +
+           std::to_string(G) + "." + std::to_string(chunk) + ".snkidx";
+}
+bool gz_index_load(const string &ip, uint64_t size, uint64_t mtime_ns, int G, uint64_t chunk, GzScout &out) {
+    FILE *f = ip.empty() ? nullptr : fopen(ip.c_str(), "rb");
+    if (!f) return false;
+    GzIndexHeader h;
+    bool ok = fread(&h, sizeof h, 1, f) == 1 && !memcmp(h.magic, "SNKGZIX1", 8) && h.size == size && h.mtime_ns == mtime_ns && h.G == (uint32_t)G &&
+              h.chunk == chunk && h.ncuts == (uint32_t)(G - 1);
+    std::vector<GzCut> cuts;
+    for (uint32_t k = 0; ok && k < h.ncuts; ++k) {
+        GzCut c;
+        uint64_t v[4];
+        c.win.resize(snk::GzipInflate::HIST);
+        ok = fread(v, 8, 4, f) == 4 && fread(c.win.data(), 1, c.win.size(), f) == c.win.size();
+        c.bit = v[0]; c.text_off = v[1]; c.rec = v[2]; c.skip_bytes = v[3];
+        c.have_win = c.resolved = true;
+        ok = ok && c.rec < h.n_records && (c.bit >> 3) < size;
+        cuts.push_back(std::move(c));
+    }
+    fclose(f);
+    if (!ok) return false;                         // (a stale, foreign or cut-off index: the scout runs and writes a new one)
+    out.n_records = h.n_records;
+    out.cuts = std::move(cuts);
+    out.why.clear();
+    return true;
+}
+void gz_index_store(const string &ip, uint64_t size, uint64_t mtime_ns, int G, uint64_t chunk, const GzScout &sc) {
+    if (ip.empty()) return;
+    const string tmp = ip + ".tmp" + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;                                // (an index is a convenience: a directory that cannot be written costs nothing but the next scout)
+    GzIndexHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "SNKGZIX1", 8);
+    h.size = size; h.mtime_ns = mtime_ns; h.n_records = sc.n_records; h.chunk = chunk; h.G = (uint32_t)G; h.ncuts = (uint32_t)sc.cuts.size();
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+    for (const GzCut &c : sc.cuts) {
+        const uint64_t v[4] = {c.bit, c.text_off, c.rec, c.skip_bytes};
+        ok = ok && fwrite(v, 8, 4, f) == 4 && fwrite(c.win.data(), 1, c.win.size(), f) == c.win.size();
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), ip.c_str()) != 0) unlink(tmp.c_str());
+}
+
+bool scout_gz(const string &path, int workers, int G, GzScout &out, bool *from_index = nullptr) {
+    size_t pg_chunk_key = (size_t)2 << 20;
+    if (const char *e = getenv("SNK_GZ_CHUNK")) { const long v = atol(e); if (v >= 65536) pg_chunk_key = (size_t)v; }
+    uint64_t isize = 0, imtime = 0;
+    const string ipath = gz_index_path(path, G, pg_chunk_key, isize, imtime);
+    if (from_index) *from_index = false;
+    if (gz_index_load(ipath, isize, imtime, G, pg_chunk_key, out)) { if (from_index) *from_index = true; return true; }
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) die("cannot open file," + path);
     struct stat st;
@@ -1572,6 +1636,7 @@ bool scout_gz(const string &path, int workers, int G, GzScout &out) {
     close(fd);
     if (out.why.empty() && (int)out.cuts.size() != G - 1) out.why = "the stream offers too few places to start from (few deflate blocks, or a stream the parallel decoder walks sequentially)";
     for (const GzCut &c : out.cuts) if (out.why.empty() && (!c.resolved || c.rec >= out.n_records)) out.why = "a border fell behind the last record";
+    if (out.why.empty()) gz_index_store(ipath, isize, imtime, G, pg_chunk_key, out);
     return out.why.empty();
 }
 
@@ -1722,10 +1787,10 @@ int main(int argc, char **argv) {
         } else {
             // .gz: the scout pass over both files at once (scout_gz above); the border records are the later of the two files' places
             const long long t_sc = StageClock::now();
-            bool ok[2] = {true, true};
+            bool ok[2] = {true, true}, idx[2] = {false, false};
             {
                 std::vector<std::thread> th;
-                for (int m = 0; m < mates; ++m) th.emplace_back([&, m] { ok[m] = scout_gz(inputs[m], std::max(1, ht / mates), G, sc[m]); });
+                for (int m = 0; m < mates; ++m) th.emplace_back([&, m] { ok[m] = scout_gz(inputs[m], std::max(1, ht / mates), G, sc[m], &idx[m]); });
                 for (auto &t : th) t.join();
             }
             nrec[0] = sc[0].n_records; nrec[1] = sc[1].n_records;
@@ -1739,7 +1804,10 @@ int main(int argc, char **argv) {
                 }
                 for (int g = 0; g < G; ++g) if (rec[(size_t)g] >= rec[(size_t)g + 1]) plan = false;
             }
-            log << local_time() << "\tscout pass over the .gz input: " << nrec[0] << (mates == 2 ? " pairs, " : " reads, ") << (double)(StageClock::now() - t_sc) * 1e-9 << " s"
+            const bool all_idx = idx[0] && (mates == 1 || idx[1]);
+            log << local_time() << (all_idx ? "\tborders of the .gz input from the index in SNK_GZ_INDEX_DIR (no decode in front of the run): "
+                                            : "\tscout pass over the .gz input: ")
+                << nrec[0] << (mates == 2 ? " pairs, " : " reads, ") << (double)(StageClock::now() - t_sc) * 1e-9 << " s"
                 << (plan ? "" : "; not sharded (" + (!ok[0] ? sc[0].why : !ok[1] ? sc[1].why : string("the borders do not leave every shard a record")) + ")") << endl;
             for (int m = 0; m < mates; ++m) { off[m].assign((size_t)G + 1, 0); }
         }

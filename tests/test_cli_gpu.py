@@ -894,3 +894,47 @@ def test_cli_proven_only_switch(case, tmp_path):
         assert filecmp.cmp(os.path.join(ours, f), os.path.join(ref, f), shallow=False), f
     for c in (["c1.fq", "c2.fq"] if case[1] else ["c1.fq"]):
         assert _cat(os.path.join(ours, c)) == _cat(os.path.join(ref, c)), c
+
+
+@pytest.mark.first_contact
+def test_cli_sharded_gz_index(tmp_path):
+    """SNK_GZ_INDEX_DIR: the scout pass of a sharded run over `.gz` input -- one full decode in front of the run -- leaves its
+    borders (block header, window, record number per shard border) in a small index named after the input's size and modification time;
+    the next run over the same files reads them instead ("no decode in front of the run" in the log), a changed file is scouted again.
+    The reference binary's bytes each time."""
+    import torch
+    devs = "0,1" if torch.cuda.device_count() >= 2 else "0,0"
+    n, L = 24000, 150
+    d = synth.make_batch(n, L, paired=True, seed=68)
+    for m in range(2):
+        d["seq"][m][n // 2 + 100:n // 2 + 900] = d["seq"][m][0:800]
+    cli = ["-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J"]
+    case = ("gzindex", True, L, n, 2, 250, {}, {}, cli, ["rmdup"])
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    idx = os.path.join(work, "index dir")
+    os.makedirs(idx)
+    env = dict(os.environ, SNK_SHARDED="1", SNK_BATCH_PAIRS="4096", SNK_GZ_CHUNK="262144", SNK_GZ_INDEX_DIR=idx, SNK_SHARD_MIN_RECORDS="1000")
+
+    def run(tag):
+        ours = os.path.join(work, tag)
+        cmd = [CLI, "filter", "-1", os.path.join(work, "r1.fq.gz"), "-2", os.path.join(work, "r2.fq.gz"), "-C", "c1.fq", "-D", "c2.fq", "-o", ours, "-T", "2",
+               "--devices", devs, "-c", os.path.join(work, "cfg")] + cli
+        r = subprocess.run(cmd, capture_output=True, env=env, timeout=170)
+        assert r.returncode == 0, (r.stdout[-300:], r.stderr[-800:])
+        _compare_dirs(ours, ref, True)
+        return open(os.path.join(ours, "log"), "rb").read()
+    log = run("first")
+    assert b"scout pass over the .gz input" in log and b"sharded run: 2 shards" in log
+    made = sorted(os.listdir(idx))
+    assert len(made) == 2 and all(f.endswith(".snkidx") for f in made), made
+    log = run("second")
+    assert b"from the index in SNK_GZ_INDEX_DIR (no decode in front of the run)" in log and b"scout pass over" not in log and b"sharded run: 2 shards" in log
+    # a file that changed (here: only its modification time) is scouted again, and a cut-off index is not trusted
+    st = os.stat(os.path.join(work, "r1.fq.gz"))
+    os.utime(os.path.join(work, "r1.fq.gz"), ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000_000))
+    with open(os.path.join(idx, [f for f in made if f.startswith("r2")][0]), "r+b") as f:
+        f.truncate(40000)
+    log = run("third")
+    assert b"scout pass over the .gz input" in log
+    assert len(os.listdir(idx)) == 3                       # (r1's new index next to its old one, r2's rewritten)
