@@ -30,6 +30,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -280,6 +281,13 @@ public:
         return true;
     }
 
+    // Through rank 0, piece by piece (rank 0 used to hold every rank's whole payload plus one message per destination --
+    // tens of GB for the duplicate exchange of a run at the reference's 2^32-pair limit).  A peer first sends its counts, then its
+    // payload (already ordered by destination) from a THREAD of its own while its main thread receives; rank 0 walks the
+    // destinations in order and, for each, the sources in order: the next cnt[src][dst] * elem bytes of src's stream go straight on to
+    // dst in slabs of at most 4 MiB (its own pieces from / to its own buffers).  Rank 0 holds one slab, a peer its own two buffers.
+    // Why the thread: rank 0 reads a peer's stream in destination-major order, so a peer is still sending its pieces for later
+    // destinations while rank 0 already forwards other ranks' pieces TO it -- with a blocking send in its main thread both would wait.
     bool alltoallv(const void *d_send, const uint64_t *send_cnt, void *d_recv, const uint64_t *recv_cnt, size_t elem) override {
         uint64_t ns = 0, nr = 0;
         for (int p = 0; p < world; ++p) { ns += send_cnt[p]; nr += recv_cnt[p]; }
@@ -287,35 +295,49 @@ public:
         if (ns && hipMemcpy(out.data(), d_send, out.size(), hipMemcpyDeviceToHost) != hipSuccess) { err = "host wire: copy from the device failed"; return false; }
         if (world == 1) in = out;
         else if (rank == 0) {
-            // everybody's counts and payloads, then to every rank the pieces addressed to it in source order
             std::vector<std::vector<uint64_t>> cnt((size_t)world, std::vector<uint64_t>((size_t)world, 0));
-            std::vector<std::vector<char>> pay((size_t)world);
             cnt[0].assign(send_cnt, send_cnt + world);
-            pay[0] = out;
             for (int p = 1; p < world; ++p) {
                 std::vector<char> c;
-                if (!get_msg(fd_[(size_t)p], c) || c.size() != (size_t)world * 8 || !get_msg(fd_[(size_t)p], pay[(size_t)p])) { err = "host wire: a shard went away"; return false; }
+                uint64_t total = 0, said = 0;
+                if (!get_msg(fd_[(size_t)p], c) || c.size() != (size_t)world * 8 || !get(fd_[(size_t)p], &said, 8)) { err = "host wire: a shard went away"; return false; }
                 memcpy(cnt[(size_t)p].data(), c.data(), c.size());
-                uint64_t tot = 0;                            // (a peer's payload must be what its counts say: the slices below trust them)
-                for (int q = 0; q < world; ++q) tot += cnt[(size_t)p][(size_t)q];
-                if (pay[(size_t)p].size() != (size_t)(tot * elem)) { err = "host wire: a shard's payload does not match its counts"; return false; }
+                for (int q = 0; q < world; ++q) total += cnt[(size_t)p][(size_t)q];
+                if (said != total * elem) { err = "host wire: a shard's payload does not match its counts"; return false; }   // (the header of its payload message)
             }
+            std::vector<char> slab((size_t)4 << 20);
+            uint64_t own_off = 0;                            // rank 0's own pieces sit in `out` in destination order
             for (int dst = 0; dst < world; ++dst) {
-                std::vector<char> msg;
+                uint64_t total = 0;
+                for (int src = 0; src < world; ++src) total += cnt[(size_t)src][(size_t)dst];
+                if (dst == 0 ? total * elem != in.size() : false) { err = "host wire: counts do not match"; return false; }
+                if (dst != 0) { const uint64_t bytes = total * elem; if (!put(fd_[(size_t)dst], &bytes, 8)) { err = "host wire: a shard went away"; return false; } }
+                uint64_t in_off = 0;
                 for (int src = 0; src < world; ++src) {
-                    uint64_t off = 0;
-                    for (int q = 0; q < dst; ++q) off += cnt[(size_t)src][(size_t)q];
-                    const char *b = pay[(size_t)src].data() + off * elem;
-                    msg.insert(msg.end(), b, b + cnt[(size_t)src][(size_t)dst] * elem);
+                    uint64_t left = cnt[(size_t)src][(size_t)dst] * elem;
+                    if (src == 0) {
+                        if (dst == 0) memcpy(in.data() + in_off, out.data() + own_off, (size_t)left);
+                        else if (left && !put(fd_[(size_t)dst], out.data() + own_off, (size_t)left)) { err = "host wire: a shard went away"; return false; }
+                        own_off += left;
+                        in_off += left;
+                        continue;
+                    }
+                    while (left) {
+                        const size_t k = (size_t)std::min<uint64_t>(left, slab.size());
+                        char *to = dst == 0 ? in.data() + in_off : slab.data();
+                        if (!get(fd_[(size_t)src], to, k)) { err = "host wire: a shard went away"; return false; }
+                        if (dst != 0 && !put(fd_[(size_t)dst], slab.data(), k)) { err = "host wire: a shard went away"; return false; }
+                        left -= k;
+                        in_off += k;
+                    }
                 }
-                if (dst == 0) { if (msg.size() != in.size()) { err = "host wire: counts do not match"; return false; } in = msg; }
-                else if (!put_msg(fd_[(size_t)dst], msg.data(), msg.size())) { err = "host wire: a shard went away"; return false; }
             }
         } else {
-            if (!put_msg(fd_[0], send_cnt, (uint64_t)world * 8) || !put_msg(fd_[0], out.data(), out.size()) || !get_msg(fd_[0], in) || in.size() != (size_t)(nr * elem)) {
-                err = "host wire: rank 0 went away or the counts do not match";
-                return false;
-            }
+            bool sent = false;
+            std::thread sender([&] { sent = put_msg(fd_[0], send_cnt, (uint64_t)world * 8) && put_msg(fd_[0], out.data(), out.size()); });
+            const bool got = get_msg(fd_[0], in);
+            sender.join();
+            if (!sent || !got || in.size() != (size_t)(nr * elem)) { err = "host wire: rank 0 went away or the counts do not match"; return false; }
         }
         if (nr && hipMemcpy(d_recv, in.data(), in.size(), hipMemcpyHostToDevice) != hipSuccess) { err = "host wire: copy to the device failed"; return false; }
         return true;

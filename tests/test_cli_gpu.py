@@ -938,3 +938,39 @@ def test_cli_sharded_gz_index(tmp_path):
     log = run("third")
     assert b"scout pass over the .gz input" in log
     assert len(os.listdir(idx)) == 3                       # (r1's new index next to its old one, r2's rewritten)
+
+
+@pytest.mark.first_contact
+@pytest.mark.parametrize("G,paired,gz_in", [(3, True, True), (4, True, False), (5, False, True)])
+def test_cli_more_than_two_shards(G, paired, gz_in, tmp_path):
+    """Three, four and five shards (one device listed G times: the host wire carries the collectives -- since round 6 piece by piece
+    through rank 0, a peer sending from a thread of its own while it receives, host/snk_wire.h) with `rmdup`: duplicates across EVERY
+    shard border, owners = hash % G, the single-end flag shift across the borders; plain and `.gz` input (G - 1 scout borders).
+    Reports, clean FASTQ and the duplicate side files are the reference binary's."""
+    n, L, threads = 40000, 150, 3
+    d = synth.make_batch(n, L, paired=paired, seed=65)
+    for m in range(2 if paired else 1):
+        for g in range(1, G):
+            h = n * g // G
+            d["seq"][m][h + 200:h + 1200] = d["seq"][m][0:1000]
+            d["seq"][m][h - 3:h + 3] = d["seq"][m][100:106]
+    cli = ["-f", synth.ADAPTER1, "-J"] + (["-r", synth.ADAPTER2] if paired else [])
+    case = ("shards%d" % G, paired, L, n, threads, 250, {}, {}, cli, ["rmdup"])
+    work = str(tmp_path)
+    ref = R.run_reference_cli(case, d, work, gz_input=True)
+    ext = ".fq.gz" if gz_in else ".fq"
+    ours = os.path.join(work, "ours")
+    cmd = [CLI, "filter", "-1", os.path.join(work, "r1" + ext), "-C", "c1.fq", "-o", ours, "-T", str(threads), "--devices", ",".join(["0"] * G),
+           "-c", os.path.join(work, "cfg")]
+    if paired:
+        cmd += ["-2", os.path.join(work, "r2" + ext), "-D", "c2.fq"]
+    r = subprocess.run(cmd + cli, capture_output=True, timeout=170,
+                       env=dict(os.environ, SNK_SHARDED="1", SNK_BATCH_PAIRS="4096", SNK_GZ_CHUNK="131072", SNK_SHARD_MIN_RECORDS="1000"))
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-800:])
+    log = open(os.path.join(ours, "log"), "rb").read()
+    assert (b"sharded run: %d shards" % G) in log and (b"statistics merged over the host wire (%d shards)" % G) in log, log[-600:]
+    _compare_dirs(ours, ref, paired)
+    for t in range(threads):
+        for m in range(2 if paired else 1):
+            f = f"dupReads.{t}.{m + 1}.gz"
+            assert _cat(os.path.join(ours, f)) == _cat(os.path.join(ref, f)), f

@@ -14,7 +14,8 @@ import test_gunzip_gpu as GZ
 # what an ordinary run takes (substrings of the test ids); SNK_SIMT_FULL=1: everything (tests/conftest.py)
 CORE = ["test_cli_matches_reference_binary[se_trim_T2]", "test_cli_gz_in_gz_out", "test_cli_rmdup_one_pass_variants[small_batches]",
         "test_cli_sharded_ingest_emulated[True-True-True]", "test_cli_sharded_rmdup_and_wire_emulated[True-40000-True]",
-        "test_cli_proven_only_launches_no_rewritten_kernel", "test_cli_sharded_gz_index"]
+        "test_cli_proven_only_launches_no_rewritten_kernel", "test_cli_sharded_gz_index",
+        "test_cli_more_than_two_shards[4-True-False]"]
 
 
 @pytest.fixture(autouse=True)
