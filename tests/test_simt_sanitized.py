@@ -88,7 +88,7 @@ def test_asan_streaming(tmp_path):
     CG.test_cli_streaming(True, 2, 50, ["pe_info", "outQualSys=1"], tmp_path)
 
 
-@pytest.mark.parametrize("which", ["pe_full", "gz", "rmdup_small_batches", "streaming", "sharded", "sharded_rmdup_gz"])
+@pytest.mark.parametrize("which", ["pe_full", "gz", "rmdup_small_batches", "streaming", "sharded", "sharded_rmdup_gz", "four_shards_rmdup"])
 def test_tsan_cli_host_threads(which, tsan_cli, tmp_path):
     if which == "pe_full":
         CG.test_cli_matches_reference_binary(CG.R.REPORT_CASES[1], tmp_path)
@@ -98,6 +98,8 @@ def test_tsan_cli_host_threads(which, tsan_cli, tmp_path):
         CG.test_cli_rmdup_one_pass_variants("small_batches", tmp_path)
     elif which == "streaming":
         CG.test_cli_streaming(True, 2, 50, ["pe_info", "outQualSys=1"], tmp_path)
+    elif which == "four_shards_rmdup":         # round 6: the host wire's exchange piece by piece, a peer's sender thread next to its receiving main thread
+        CG.test_cli_more_than_two_shards(4, True, False, tmp_path)
     elif which == "sharded_rmdup_gz":          # the scout's two decoder threads, the shards' readers started mid-stream, the wire
         import torch
         os.environ["SIMT_DEVICES"] = "2"
