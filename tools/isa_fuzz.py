@@ -83,11 +83,20 @@ def one(seed):
     import test_simt_isa_interp as TI
     spec = context(seed)
     out = []
+    # SNK_ISA_FUZZ_SCHEDULE=skew|random|reverse: the waves of a workgroup take turns under that adversarial scheduler (tools/gfx950_interp.py
+    # run_launch) -- and the batch is made one where the barriers matter: ONE workgroup, several trips per wave, the LDS histograms flushed
+    # after every trip (the test hooks of csrc/snk_tiled.hip)
+    sched, env = os.environ.get("SNK_ISA_FUZZ_SCHEDULE"), {}
+    if sched:
+        env = {"SNK_TEST_MAX_WGS": "1", "SNK_TEST_FLUSH_EVERY": "1"}
+        if spec["L"] <= 256:
+            spec["n"] = 1500 if spec["L"] <= 150 else 1100
+        sched = sched if sched == "reverse" else "%s:%d" % (sched, seed)
     try:
         with tempfile.TemporaryDirectory(prefix="isafuzz_") as tmp:
-            launches = TI.capture(tmp, spec, kernels=("snk_tiled", "snk_long", "snk_contam"))
+            launches = TI.capture(tmp, spec, env, kernels=("snk_tiled", "snk_long", "snk_contam"))
             for k in launches:
-                info, diffs = G.replay(tmp, k, TI.BUILD, verbose=False, garbage=seed)
+                info, diffs = G.replay(tmp, k, TI.BUILD, verbose=False, garbage=seed, schedule=sched)
                 bad = bool(diffs) or bool(info["scalar_loads_of_words_written_in_this_launch"])
                 out.append((info["symbol"][22:62], info["instructions"], "DIFFERS %r" % (diffs[:2],) if bad else "ok"))
     except Exception as ex:              # noqa: BLE001 -- a capture the emulated tier rejects, a hazard, an unknown instruction: all findings
