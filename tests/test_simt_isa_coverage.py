@@ -204,6 +204,38 @@ def test_the_other_baseline_instances_are_executed_to_90_percent(which, tmp_path
     assert len(hit) / (b - a) >= floor, (which, len(hit), b - a, floor)
 
 
+@pytest.mark.parametrize("which", ["c3_pe150", "c2_pe250"])
+def test_mutation_score_of_two_more_instances(which, tmp_path):
+    """the same 32-mutant probe on the FULL instance of configs[2] and on the PE250 instance of configs[4], each on its own variant of the
+    capture list: >= 70 % killed asserted, 81 % / 75 % measured (SNK_SIMT_FULL=1 only; SNK_WRITE_PROFILES=1 adds the result to profiles/r06_isa_mutation.json)"""
+    full, L, pitch, pattern, _ = INSTANCES[which]
+    TI.simt_lib_path()
+    G.parse_file(TI.ASM)
+    jobs = [(n, _variant(s, full, L, pitch), e, str(tmp_path)) for n, (s, e) in HEADLINE_CAPTURES.items()]
+    with concurrent.futures.ProcessPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        got = dict(pool.map(_capture_and_replay, jobs))
+    _, labels, _ = G.parse_file(TI.ASM)
+    sym = [k for k in labels if pattern in k and "snk_tiled_kernel" in k][0]
+    reps = [r for rs in got.values() for r in rs if r["symbol"] == sym]
+    assert reps and all(r["identical"] for r in reps)
+    executed = set().union(*(set(r["lines"]) for r in reps))
+    muts, pool_size = IM.mutants(TI.ASM, sym, executed, 32, seed=6)
+    sets = [(set(r["lines"]), r) for r in sorted(reps, key=lambda r: r["instructions"])]
+    res = IM.run_mutants(TI.ASM, muts, lambda line: [(r["dump"], r["launch"]) for s_, r in sets if line in s_], cap=40 * max(r["instructions"] for r in reps) // 16)
+    real = [r for r in res if not r[3].startswith("not a mutant")]
+    survivors = [r for r in real if r[3] == "SURVIVED"]
+    if os.environ.get("SNK_WRITE_PROFILES"):
+        path = os.path.join(T.ROOT, "profiles", "r06_isa_mutation.json")
+        rep = json.load(open(path))
+        rep.setdefault("other_instances", {})[which] = {"kernel": sym, "pool_of_executed_mutable_instructions": pool_size, "mutants": len(real), "killed": len(real) - len(survivors),
+                                                        "results": [dict(line=r[0], was=r[1], mutant=r[2], verdict=r[3], replays_that_execute_it=r[4]) for r in res]}
+        json.dump(rep, open(path, "w"), indent=1)
+    # (measured in round 6: 26 of 32 and 24 of 32 -- the capture list was tuned on the headline instance, whose score is 31 of 32; the
+    # survivors here are exec-mask bookkeeping of the structurizer and arithmetic in paths that one or two of this instance's captures
+    # reach with data that does not tell the mutant apart: profiles/r06_isa_mutation.json "other_instances")
+    assert len(real) >= 30 and len(survivors) / len(real) <= 0.30, survivors
+
+
 # ---- the contaminant pass in front of the tiled kernel (snk_contam_kernel<5> for up to 160 positions, <8> for up to 256): one instance holds
 # five widths of the mismatch counters, the head / middle / tail alignments, the sequential matchers for what the bit planes cannot take and
 # the global contaminant's sliding window -- parameter space, not batch shape, is what reaches them
