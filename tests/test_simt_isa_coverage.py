@@ -137,8 +137,10 @@ def test_mutation_score_of_the_headline_instance(headline):
     real = [r for r in res if not r[3].startswith("not a mutant")]
     survivors = [r for r in real if r[3] == "SURVIVED"]
     if os.environ.get("SNK_WRITE_PROFILES"):             # (the run the committed profiles/r06_isa_mutation.json comes from)
-        with open(os.path.join(T.ROOT, "profiles", "r06_isa_mutation.json"), "w") as f:
-            json.dump({"kernel": "snk_tiled_kernel<5, false, true, 16, TileShape<160, 768, 4>>", "kernel_source_sha": IC.sources_sha(), "seed": 6, "pool_of_executed_mutable_instructions": pool_size,
+        path = os.path.join(T.ROOT, "profiles", "r06_isa_mutation.json")
+        keep = json.load(open(path)).get("other_instances", {}) if os.path.exists(path) else {}      # (written by the test of the two other instances)
+        with open(path, "w") as f:
+            json.dump({"other_instances": keep, "kernel": "snk_tiled_kernel<5, false, true, 16, TileShape<160, 768, 4>>", "kernel_source_sha": IC.sources_sha(), "seed": 6, "pool_of_executed_mutable_instructions": pool_size,
                        "captures": len(HEADLINE_CAPTURES), "mutants": len(real), "killed": len(real) - len(survivors),
                        "results": [dict(line=r[0], was=r[1], mutant=r[2], verdict=r[3], replays_that_execute_it=r[4]) for r in res]}, f, indent=1)
     assert len(real) >= 30, res
@@ -213,7 +215,7 @@ def test_the_other_baseline_instances_are_executed_to_90_percent(which, tmp_path
 @pytest.mark.parametrize("which", ["c3_pe150", "c2_pe250"])
 def test_mutation_score_of_two_more_instances(which, tmp_path):
     """the same 32-mutant probe on the FULL instance of configs[2] and on the PE250 instance of configs[4], each on its own variant of the
-    capture list: >= 70 % killed asserted, 81 % / 75 % measured (SNK_SIMT_FULL=1 only; SNK_WRITE_PROFILES=1 adds the result to profiles/r06_isa_mutation.json)"""
+    capture list: >= 70 % killed asserted, 72 % / 75 % measured (SNK_SIMT_FULL=1 only; SNK_WRITE_PROFILES=1 adds the result to profiles/r06_isa_mutation.json)"""
     full, L, pitch, pattern, _ = INSTANCES[which]
     TI.simt_lib_path()
     G.parse_file(TI.ASM)
@@ -236,7 +238,7 @@ def test_mutation_score_of_two_more_instances(which, tmp_path):
         rep.setdefault("other_instances", {})[which] = {"kernel": sym, "pool_of_executed_mutable_instructions": pool_size, "mutants": len(real), "killed": len(real) - len(survivors),
                                                         "results": [dict(line=r[0], was=r[1], mutant=r[2], verdict=r[3], replays_that_execute_it=r[4]) for r in res]}
         json.dump(rep, open(path, "w"), indent=1)
-    # (measured in round 6: 26 of 32 and 24 of 32 -- the capture list was tuned on the headline instance, whose score is 31 of 32; the
+    # (measured in round 6: 23 of 32 and 24 of 32 -- the capture list was tuned on the headline instance, whose score is 31 of 32; the
     # survivors here are exec-mask bookkeeping of the structurizer and arithmetic in paths that one or two of this instance's captures
     # reach with data that does not tell the mutant apart: profiles/r06_isa_mutation.json "other_instances")
     assert len(real) >= 30 and len(survivors) / len(real) <= 0.30, survivors
