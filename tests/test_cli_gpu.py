@@ -500,11 +500,26 @@ def test_cli_streaming_many_threads(tmp_path):
     open(os.path.join(work, "cfg"), "w").write("patch=8\n")            # T=4: blocks of 8 * 40 = 320 pairs
     tail = ["-C", "c1.fq.gz", "-D", "c2.fq.gz", "-T", "4", "-f", synth.ADAPTER1, "-r", synth.ADAPTER2, "-J", "-j", "-c", os.path.join(work, "cfg")]
     inp = ["-1", os.path.join(work, "r1.fq.gz"), "-2", os.path.join(work, "r2.fq.gz")]
-    ref = subprocess.run([T.REF_BIN, "filter"] + inp + ["-o", os.path.join(work, "ref")] + tail, capture_output=True, timeout=120)
     ours = subprocess.run([CLI, "filter"] + inp + ["-o", os.path.join(work, "ours")] + tail, capture_output=True)
-    assert ref.returncode == 0 and ours.returncode == 0, (ref.stderr[-200:], ours.stderr[-200:])
-    a, b = ours.stdout.split(b"\n"), ref.stdout.split(b"\n")
-    assert sorted(x for x in a if x.startswith(b">+")) == sorted(x for x in b if x.startswith(b">+"))
+    assert ours.returncode == 0, ours.stderr[-200:]
+    a = ours.stdout.split(b"\n")
+    mine = sorted(x for x in a if x.startswith(b">+"))
+    # The reference's four threads write to stdout without a lock: in about four runs of ten on the build container lines come out TORN
+    # (a read line cut by another thread's statistics row -- found in round 6, tools output in DESIGN 6.1: this CLI's lines are the same
+    # in every run, the reference's are not).  So the reference runs until one of its outputs is whole (eight tries: all torn ~ 0.1 %);
+    # a torn run still has to be a subset of ours line by line.
+    import collections
+    for attempt in range(8):
+        subprocess.call(["rm", "-rf", os.path.join(work, "ref")])
+        ref = subprocess.run([T.REF_BIN, "filter"] + inp + ["-o", os.path.join(work, "ref")] + tail, capture_output=True, timeout=120)
+        assert ref.returncode == 0, ref.stderr[-200:]
+        b = ref.stdout.split(b"\n")
+        theirs = sorted(x for x in b if x.startswith(b">+"))
+        if theirs == mine:
+            break
+        whole = [x for x in theirs if x.count(b"\t") == 4 and len(x.split(b"\t")[3]) == len(x.split(b"\t")[4])]
+        assert not (collections.Counter(whole) - collections.Counter(mine)), "a whole line of the reference that this CLI did not print"
+    assert theirs == mine, "the reference printed torn lines in eight runs out of eight"
     assert a.count(b"#Total_statistical_information") == b.count(b"#Total_statistical_information") == n // 8
     for f in R.REPORT_FILES_PE:
         assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
