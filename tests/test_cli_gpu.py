@@ -506,10 +506,10 @@ def test_cli_streaming_many_threads(tmp_path):
     mine = sorted(x for x in a if x.startswith(b">+"))
     # The reference's four threads write to stdout without a lock: in about four runs of ten on the build container lines come out TORN
     # (a read line cut by another thread's statistics row -- found in round 6, tools output in DESIGN 6.1: this CLI's lines are the same
-    # in every run, the reference's are not).  So the reference runs until one of its outputs is whole (eight tries: all torn ~ 0.1 %);
-    # a torn run still has to be a subset of ours line by line.
+    # in every run, the reference's are not).  So the reference runs until one of its outputs is whole (three tries), a torn
+    # run still has to be a subset of ours line by line, and when all three are torn its ONE-thread run -- deterministic -- decides the set.
     import collections
-    for attempt in range(8):
+    for attempt in range(3):
         subprocess.call(["rm", "-rf", os.path.join(work, "ref")])
         ref = subprocess.run([T.REF_BIN, "filter"] + inp + ["-o", os.path.join(work, "ref")] + tail, capture_output=True, timeout=120)
         assert ref.returncode == 0, ref.stderr[-200:]
@@ -519,7 +519,14 @@ def test_cli_streaming_many_threads(tmp_path):
             break
         whole = [x for x in theirs if x.count(b"\t") == 4 and len(x.split(b"\t")[3]) == len(x.split(b"\t")[4])]
         assert not (collections.Counter(whole) - collections.Counter(mine)), "a whole line of the reference that this CLI did not print"
-    assert theirs == mine, "the reference printed torn lines in eight runs out of eight"
+    if theirs != mine:
+        # torn three times out of three (a loaded box tears more): the SET of read lines does not depend on the reference's thread count, and
+        # with one thread its stdout is deterministic -- that run decides; the four-thread run above still supplies the reports and the
+        # number of statistics dumps
+        one = subprocess.run([T.REF_BIN, "filter"] + inp + ["-o", os.path.join(work, "ref1")] + [("1" if x == "4" and tail[i - 1] == "-T" else x) for i, x in enumerate(tail)],
+                             capture_output=True, timeout=120)
+        assert one.returncode == 0, one.stderr[-200:]
+        assert sorted(x for x in one.stdout.split(b"\n") if x.startswith(b">+")) == mine
     assert a.count(b"#Total_statistical_information") == b.count(b"#Total_statistical_information") == n // 8
     for f in R.REPORT_FILES_PE:
         assert filecmp.cmp(os.path.join(work, "ours", f), os.path.join(work, "ref", f), shallow=False), f
