@@ -41,5 +41,16 @@ d = json.loads(t); r = d.get('roofline') or {}
 print('$tag', '$wl', 'kernel_ms', r.get('kernel_ms'), 'frac', r.get('frac'), 'ms_per_step', d.get('ms_per_step'), d.get('error', ''))"
         done ) > gpurun_out/ab/$tag.txt 2>&1
       echo "== $tag"; cat gpurun_out/ab/$tag.txt
+    done
+    # ... and HEAD's own bench.py on each OLD library (SNK_LIB: soapnuke_amd/abi.py stubs the entry points an older library lacks): the same
+    # workload code and timing around the old kernels -- if the parameter block's struct_size is still accepted there
+    for d in abl/hw_d12b8ba abl/r03_5671319; do
+      [ -f $d/soapnuke_amd/libsnk_filter.so ] || continue
+      SNK_LIB=$ROOT/$d/soapnuke_amd/libsnk_filter.so timeout 300 python bench.py --no-cpu-baseline --no-traffic 2>/dev/null | tail -1 | python -c "
+import sys, json
+t = sys.stdin.read().strip()
+d = json.loads(t) if t.startswith('{') else {}
+r = d.get('roofline') or {}
+print('HEAD bench.py on the library of $(basename $d):', 'kernel_ms', r.get('kernel_ms'), 'frac', r.get('frac'), (d.get('error') or '')[:120])" | tee -a gpurun_out/ab/HEAD.txt
     done ;;
 esac
